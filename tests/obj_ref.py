@@ -1,0 +1,70 @@
+"""Independent, minimal Python restatement of the reference's scene ingest (main.cpp:28-58)
+used by the tests as the checker for the C++ host loader. Test infrastructure only.
+
+Semantics restated (tinyobjloader is not vendored in /root/reference):
+ * `v x y z`, `f a b c d ...` with 1-based or negative (relative) indices, `a/b/c` forms;
+ * polygons are fan-triangulated (0,1,2),(0,2,3),...; for this OBJ the shorter-diagonal
+   rule of newer tinyobjloader gives the same surface, only other prim ids;
+ * `usemtl` selects the material id of following faces; `mtllib` + `newmtl`/`Kd`/`Ke`;
+ * per mesh index: push (x, -y, z) and a running index (main.cpp:40-45);
+ * per face: push {Kd, Ke} of its material (main.cpp:47-56).
+"""
+import os
+
+import numpy as np
+
+
+def load_mtl(path):
+    mats, names, cur = [], {}, None
+    with open(path) as f:
+        for line in f:
+            line = line.split("#", 1)[0].split()
+            if not line:
+                continue
+            if line[0] == "newmtl":
+                cur = {"Kd": [0.6, 0.6, 0.6], "Ke": [0.0, 0.0, 0.0]}  # tinyobj defaults
+                names[line[1]] = len(mats)
+                mats.append(cur)
+            elif line[0] in ("Kd", "Ke") and cur is not None:
+                cur[line[0]] = [float(x) for x in line[1:4]]
+    return mats, names
+
+
+def load_obj(path):
+    base = os.path.dirname(path)
+    verts, tris, tri_mat = [], [], []
+    mats, names, mat = [], {}, -1
+    with open(path) as f:
+        for line in f:
+            tok = line.split("#", 1)[0].split()
+            if not tok:
+                continue
+            if tok[0] == "v":
+                verts.append([float(x) for x in tok[1:4]])
+            elif tok[0] == "mtllib":
+                mats, names = load_mtl(os.path.join(base, tok[1]))
+            elif tok[0] == "usemtl":
+                mat = names.get(tok[1], -1)
+            elif tok[0] == "f":
+                idx = []
+                for t in tok[1:]:
+                    i = int(t.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    tris.append((idx[0], idx[k], idx[k + 1]))
+                    tri_mat.append(mat)
+    v = np.array(verts, dtype=np.float32)
+    out_v = np.zeros((3 * len(tris), 3), dtype=np.float32)
+    for t, tri in enumerate(tris):
+        for c in range(3):
+            x, y, z = v[tri[c]]
+            out_v[3 * t + c] = (x, -y, z)
+    out_i = np.arange(3 * len(tris), dtype=np.uint32)
+    out_f = np.zeros((len(tris), 6), dtype=np.float32)
+    for t, m in enumerate(tri_mat):
+        if m >= 0:
+            out_f[t, :3] = mats[m]["Kd"]
+            out_f[t, 3:] = mats[m]["Ke"]
+        else:
+            out_f[t, :3] = (0.6, 0.6, 0.6)
+    return out_v.reshape(-1), out_i, out_f.reshape(-1)
