@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark: Mrays/s (and ms/frame) of the radiance loop on the Cornell
+box at 1920x1080, 8 bounces (BASELINE.json metric), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one frame = one reference launch (traceRaysKHR(W,H,1), main.cpp:659): 32 samples per
+pixel, <= 8 rays each, blended into the film (raygen.rgen:41-91).  K steps = 32*K spp; the
+default K=2 is exactly config C2 (64 spp).  The scene + LBVH are resident in HBM before the timed
+region; the timed region is the K frames (all kernels: generate, extend, shade/compact, resolve)
+plus, for N>1, the one RCCL reduce of the float film to rank 0.  Rank 0 prints ONE JSON line.
+
+N>1 shards the 8x8 pixel tiles of the SAME image over the ranks (config C3's decomposition), so
+the total work per step is fixed: "scaling": "strong".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+# algorithmic bytes per ray of the wavefront pipeline (SURVEY.md section 8d / DESIGN.md section 7)
+BYTES_EXTEND = 40.0    # read ray 28 (index-free dense queue: 24 + 4 slot id passed along), write hit 12
+BYTES_SHADE = 104.0
+BYTES_PER_PATH = 96.0
+
+
+def cpu_baseline(pt, width, height, depth):
+    """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
+    bounded sample of the same workload: the same image at 4 spp, all cores."""
+    from oracle import pt_oracle as orc
+    v, i, f = pt.load_obj(pt.ASSET_CORNELL)
+    osc = orc.Scene(v, i, f)
+    cores = os.cpu_count() or 1
+    spp = 4
+    p = orc.default_params(width=width, height=height, spp_per_frame=spp, max_depth=depth)
+    t0 = time.perf_counter()
+    _, rays, _, _ = osc.render_frame(p, mode=1, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"CornellBox-Original {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
+                      f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
+    ptd = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+
+    W, H = args.width, args.height
+    stream = torch.cuda.current_stream(dev)
+    ctx = pt.Context(local_rank, stream=stream.cuda_stream)
+    scene = pt.Scene.from_obj(ctx, pt.ASSET_CORNELL)          # upload + on-device LBVH build (untimed)
+    info = scene.info()
+    film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # torch owns the film: RCCL reduces it in place
+    film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
+    flags = 0 if args.no_kernel_events else pt.FLAG_PROFILE
+    common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
+                  frames_in_flight=args.frames_in_flight)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warmup: W untimed frames (also allocates the queues)
+    if args.warmup > 0:
+        pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, **common))
+        if world > 1:
+            tmp = film_t.clone()
+            ptd.reduce_film(tmp, dst=0)
+    film.clear()
+    ctx.reset_stats()
+
+    barrier()
+    t0 = time.perf_counter()
+    pt.render(scene, film, pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common))
+    ptd.reduce_film(film_t, dst=0)      # the one collective per presented image (no-op for N=1)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    st = ctx.stats()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    rays_total, paths_total = ptd.sum_counters([st.rays, st.paths], dev)
+    rays_minmax = None
+    if world > 1:
+        lo = torch.tensor([st.rays], dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rays_minmax = [int(lo.item()), int(hi.item())]
+
+    if rank == 0:
+        mean_len = rays_total / max(paths_total, 1)
+        out = {
+            "metric": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)",
+            "value": round(rays_total / dt / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "CornellBox-Original.obj (the reference's own scene, 36 triangles); rays are generated on device",
+            "config": {"workload": f"C2: CornellBox-Original.obj {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
+                                   f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
+                       "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" + (", RCCL reduce to rank 0" if world > 1 else ""),
+                       "frames_in_flight": args.frames_in_flight or "auto"},
+            "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
+            "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
+            "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
+                    "build_ms": round(info.build_ms, 3), "extend_variant": "lds-resident scene" if st.extend_variant == 0 else "hbm/l2 scene"},
+        }
+        if rays_minmax:
+            out["rays_per_rank_min_max"] = rays_minmax
+        if flags and st.launches_extend and st.ms_extend > 0:
+            # dominant kernel = k_extend (closest-hit traversal).  Algorithmic bytes: 40 B/ray; the
+            # 36-triangle scene + LBVH are LDS-resident so there is no scene-gather term.
+            gbs = BYTES_EXTEND * st.rays / (st.ms_extend * 1e-3) / 1e9
+            pipeline_bytes = (BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
+            traffic = None
+            prof = os.path.join(REPO, "profiles", "r01_pmc_extend.json")
+            if os.path.exists(prof):
+                try:
+                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_extend<16,lds>" if st.extend_variant == 0 else "k_extend<*,hbm>",
+                "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "launches": st.launches_extend,
+                "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
+                "algorithmic_bytes_per_launch": round(BYTES_EXTEND * st.rays / st.launches_extend, 1),
+                "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
+                "pipeline_algorithmic_GBps": round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2),
+                "note": "Cornell (<8 KB scene+BVH) is LDS-resident: extend is VALU/LDS-latency bound, HBM sees only "
+                        "queue I/O; the HBM fraction is physically meaningful on config C5 (1M triangles) only",
+            }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pt, W, H, args.depth)
+        print(json.dumps(out), flush=True)
+
+    film.close()
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

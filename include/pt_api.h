@@ -1,0 +1,146 @@
+/*
+ * pt_api.h -- C-ABI of the MI355X-native wavefront path tracer (libpt_amd.so).
+ *
+ * This is the drop-in boundary for the reference's per-pixel radiance loop.  The reference
+ * (yknishidate/single-file-vulkan-pathtracing) has no FFI layer: its operator boundary is the
+ * Vulkan dispatch itself, so every entry point below names the Vulkan-side interface it
+ * replaces (file:line in the reference).  Plain pointers and sizes only; no C++/torch types;
+ * no exceptions or aborts cross this boundary -- every call returns a pt_status and
+ * pt_last_error() gives the text (the reference throws std::runtime_error, main.cpp:35, 118,
+ * 151, 221, 594, 612, 681).
+ *
+ * Threading: calls on one context are serialised by the caller, as in the reference (single
+ * host thread, single queue, main.cpp:224-238, 683).  One context per GPU; multi-GPU runs use
+ * one process (or thread) per GPU, each rendering its interleaved pixel tiles.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API_VERSION 1
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = 1,
+    PT_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime unusable (replaces main.cpp:105,118) */
+    PT_ERR_HIP = 3,         /* a HIP call failed; see pt_last_error                            */
+    PT_ERR_OOM = 4,
+    PT_ERR_UNSUPPORTED = 5
+} pt_status;
+
+typedef struct pt_ctx pt_ctx;     /* replaces Context (main.cpp:74-267): device + queue      */
+typedef struct pt_scene pt_scene; /* replaces vertex/index/face Buffers + BLAS + TLAS        */
+typedef struct pt_film pt_film;   /* replaces the storage Image (main.cpp:481-484)            */
+
+/* ---- context ------------------------------------------------------------------------- */
+/* device: HIP ordinal (the reference takes physical device 0, main.cpp:105).
+ * stream: a hipStream_t to launch on, or NULL for the library's own stream.  The caller
+ *         keeps ownership of a stream it passes in.                                        */
+pt_status pt_ctx_create(int device, void *stream, pt_ctx **out);
+void pt_ctx_destroy(pt_ctx *ctx);
+/* Last error text of this context (ctx may be NULL: text of the last failed pt_ctx_create). */
+const char *pt_last_error(const pt_ctx *ctx);
+/* Blocks until everything queued on the context's stream is done (queue.waitIdle, main.cpp:683). */
+pt_status pt_sync(pt_ctx *ctx);
+
+/* ---- scene: descriptor bindings 0,2,3,4 (main.cpp:561-567, 628-641) -------------------- */
+/* Takes the exact arrays the reference uploads (main.cpp:492-494):
+ *   vertices f32[3*n_verts]  (closesthit.rchit:6, stride 3, closesthit.rchit:24-31)
+ *   indices  u32[3*n_tris]   (closesthit.rchit:7)
+ *   faces    f32[6*n_tris]   (closesthit.rchit:8: Kd.rgb, Ke.rgb, stride 6, :33-41)
+ * Inputs are copied (main.cpp:321-325); the caller keeps its arrays.  Builds the LBVH on the
+ * device (Morton keys + radix sort + Karras hierarchy + refit): the replacement of the BLAS/
+ * TLAS builds at main.cpp:496-538 (one identity instance, opaque, no culling).              */
+pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts,
+                          const uint32_t *indices, uint32_t n_tris, const float *faces,
+                          pt_scene **out);
+void pt_scene_destroy(pt_scene *scene);
+
+typedef struct pt_scene_info {
+    uint32_t n_tris, n_nodes, bvh_height;
+    float    bbox_min[3], bbox_max[3];
+    float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
+    uint64_t device_bytes;    /* resident scene + BVH bytes                                     */
+} pt_scene_info;
+pt_status pt_scene_get_info(const pt_scene *scene, pt_scene_info *info);
+
+/* Debug/parity read-back of the device-built LBVH.  keys/prim_of_pos: n_tris entries each;
+ * nodes16: n_nodes x 16 dwords {lmin[3] lmax[3] rmin[3] rmax[3] left right 0 0}, child bit31 =
+ * leaf (sorted position).  Any pointer may be NULL.                                         */
+pt_status pt_scene_read_bvh(const pt_scene *scene, uint64_t *keys, uint32_t *prim_of_pos,
+                            uint32_t *nodes16);
+
+/* ---- film: descriptor binding 1 (raygen.rgen:7, main.cpp:481-484) ---------------------- */
+/* float32 running-mean radiance (the canonical result) plus the reference's rgba8 display
+ * image (B,G,R,A bytes, clamped + quantised on every frame like raygen.rgen:88-90).         */
+pt_status pt_film_create(pt_ctx *ctx, uint32_t width, uint32_t height, pt_film **out);
+/* Same, but the float film lives in caller-owned DEVICE memory (width*height*3 floats), e.g.
+ * a torch tensor's data_ptr(), so a collective can reduce it in place.                      */
+pt_status pt_film_create_external(pt_ctx *ctx, uint32_t width, uint32_t height,
+                                  void *device_rgb_f32, pt_film **out);
+pt_status pt_film_clear(pt_film *film);
+/* rgb: width*height*3 floats, row-major, linear radiance mean over all frames so far.       */
+pt_status pt_film_read_f32(pt_film *film, float *rgb);
+/* bgra: width*height*4 bytes = what main.cpp:661-667 copies to the swapchain.               */
+pt_status pt_film_read_bgra8(pt_film *film, uint8_t *bgra);
+void pt_film_destroy(pt_film *film);
+
+/* ---- dispatch: pushConstants + traceRaysKHR (main.cpp:656-659) ------------------------- */
+enum { PT_PIPELINE_WAVEFRONT = 0 /* generate / extend / shade queues */ };
+enum { PT_FLAG_PROFILE = 1u /* hipEvent-time every extend/shade launch (adds events to the stream) */ };
+
+typedef struct pt_params {
+    int32_t  frame;            /* push constant `frame` (main.cpp:658, raygen.rgen:8-10): first frame */
+    uint32_t frame_count;      /* consecutive frames rendered by this call (reference: 1 per dispatch) */
+    uint32_t width, height;    /* launch size (main.cpp:659); must equal the film's                   */
+    uint32_t spp_per_frame;    /* maxSamples, 32 (raygen.rgen:43)                                      */
+    uint32_t max_depth;        /* 8 (raygen.rgen:62)                                                   */
+    float    tmin, tmax;       /* 0.001, 10000 (raygen.rgen:71,73)                                     */
+    float    cam_origin[3];    /* (0,-1,5) (raygen.rgen:55)                                            */
+    float    cam_target[3];    /* target = (d.x+tx, d.y+ty, tz); (0,-1,2) (raygen.rgen:56)             */
+    float    env[3];           /* (0.7,0.6,0.5) (miss.rmiss:10)                                        */
+    uint32_t rank, world;      /* this call renders the 8x8 pixel tiles (tx+ty) % world == rank        */
+    uint32_t pipeline;         /* PT_PIPELINE_*                                                        */
+    uint32_t frames_in_flight; /* frames traced concurrently (0 = auto); results do not depend on it   */
+    uint32_t flags;            /* PT_FLAG_*                                                            */
+} pt_params;
+void pt_params_default(pt_params *p); /* the reference's compile-time constants, 1024x1024, world 1 */
+
+/* Renders frames [frame, frame+frame_count) into the film: each frame is one reference launch
+ * (spp_per_frame samples/pixel, <= max_depth rays each) blended by raygen.rgen:88-90.
+ * Blocking (returns after the device is done), like submit + waitIdle (main.cpp:672-683).   */
+pt_status pt_render(pt_scene *scene, pt_film *film, const pt_params *params);
+
+/* ---- closest-hit query alone: traceRayEXT (raygen.rgen:63-75) -------------------------- */
+typedef struct pt_hit {
+    uint32_t prim;  /* gl_PrimitiveID, 0xFFFFFFFF = miss                                   */
+    float    t;     /* hit distance (0 on miss)                                             */
+    float    u, v;  /* hitAttributeEXT attribs.xy: weights of v1, v2 (closesthit.rchit:56)  */
+} pt_hit;
+/* rays6: host array n x {origin.xyz, direction.xyz}; hits: host array of n.  Runs the same
+ * extend kernel the renderer uses (opaque, no culling, tmin < t < tmax).                   */
+pt_status pt_trace(pt_scene *scene, const float *rays6, uint32_t n, float tmin, float tmax,
+                   pt_hit *hits);
+
+/* ---- statistics ------------------------------------------------------------------------ */
+typedef struct pt_stats {
+    uint64_t rays;             /* closest-hit queries (= traceRayEXT calls) since last reset, exact */
+    uint64_t paths;            /* samples started                                                   */
+    uint32_t rounds;           /* wavefront rounds executed                                         */
+    uint32_t launches_extend, launches_shade, launches_other;
+    float    ms_total;         /* device time of pt_render calls (first kernel .. last kernel)      */
+    float    ms_extend, ms_shade; /* summed kernel times; only with PT_FLAG_PROFILE                 */
+    uint32_t extend_variant;   /* 0 = BVH+triangles staged in LDS, 1 = read through L1/L2 from HBM */
+} pt_stats;
+pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
+pt_status pt_reset_stats(pt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

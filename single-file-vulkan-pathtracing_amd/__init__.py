@@ -1,0 +1,318 @@
+"""MI355X-native wavefront path tracer -- Python mirror of the C-ABI (include/pt_api.h, pt_host.h).
+
+The package directory name contains '-', so import it with
+    importlib.import_module("single-file-vulkan-pathtracing_amd")
+(`__graft_entry__.py`, `bench.py` and the tests do exactly that).
+
+This module only loads the in-tree shared libraries and forwards to them:
+    libpt_amd.so   hand-written HIP kernels for gfx950 + the pt_* entry points
+    libpt_host.so  C++20 host code: OBJ/MTL ingest (reference loadFromFile, main.cpp:28-58), image output
+There is NO CPU fallback: without the HIP library, or without a GPU, every compute call raises.
+Names follow the reference: Scene = vertex/index/face buffers + acceleration structure
+(main.cpp:492-538), Film = the storage image (main.cpp:481-484), render() = pushConstants +
+traceRaysKHR (main.cpp:656-659).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+ASSET_CORNELL = os.path.join(REPO, "assets", "CornellBox-Original.obj")
+
+PT_OK = 0
+STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_OOM",
+                5: "PT_ERR_UNSUPPORTED"}
+PIPELINE_WAVEFRONT = 0
+FLAG_PROFILE = 1
+MISS = 0xFFFFFFFF
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("frame", C.c_int32), ("frame_count", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+        ("spp_per_frame", C.c_uint32), ("max_depth", C.c_uint32), ("tmin", C.c_float), ("tmax", C.c_float),
+        ("cam_origin", C.c_float * 3), ("cam_target", C.c_float * 3), ("env", C.c_float * 3),
+        ("rank", C.c_uint32), ("world", C.c_uint32), ("pipeline", C.c_uint32),
+        ("frames_in_flight", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_height", C.c_uint32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
+                ("device_bytes", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rounds", C.c_uint32),
+                ("launches_extend", C.c_uint32), ("launches_shade", C.c_uint32), ("launches_other", C.c_uint32),
+                ("ms_total", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float),
+                ("extend_variant", C.c_uint32)]
+
+
+class HostScene(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_verts", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
+                ("n_tris", C.c_uint32), ("faces", C.POINTER(C.c_float))]
+
+
+HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+
+# every symbol include/pt_api.h and include/pt_host.h declare
+API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "pt_scene_create", "pt_scene_destroy",
+               "pt_scene_get_info", "pt_scene_read_bvh", "pt_film_create", "pt_film_create_external", "pt_film_clear",
+               "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render", "pt_trace",
+               "pt_get_stats", "pt_reset_stats"]
+HOST_SYMBOLS = ["pth_load_obj", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj"]
+
+_amd = None
+_host = None
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 and the host library/driver, in-tree."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=out)
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "host")], stdout=out)
+
+
+def lib_amd():
+    global _amd
+    if _amd is None:
+        path = os.path.join(_HERE, "libpt_amd.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                              "there is no CPU fallback")
+        L = C.CDLL(path)
+        vp = C.c_void_p
+        L.pt_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+        L.pt_ctx_destroy.argtypes = [vp]
+        L.pt_ctx_destroy.restype = None
+        L.pt_last_error.argtypes = [vp]
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_sync.argtypes = [vp]
+        L.pt_scene_create.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(vp)]
+        L.pt_scene_destroy.argtypes = [vp]
+        L.pt_scene_destroy.restype = None
+        L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+        L.pt_scene_read_bvh.argtypes = [vp, vp, vp, vp]
+        L.pt_film_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.pt_film_create_external.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(vp)]
+        L.pt_film_clear.argtypes = [vp]
+        L.pt_film_read_f32.argtypes = [vp, vp]
+        L.pt_film_read_bgra8.argtypes = [vp, vp]
+        L.pt_film_destroy.argtypes = [vp]
+        L.pt_film_destroy.restype = None
+        L.pt_params_default.argtypes = [C.POINTER(Params)]
+        L.pt_params_default.restype = None
+        L.pt_render.argtypes = [vp, vp, C.POINTER(Params)]
+        L.pt_trace.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, vp]
+        L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.pt_reset_stats.argtypes = [vp]
+        _amd = L
+    return _amd
+
+
+def lib_host():
+    global _host
+    if _host is None:
+        path = os.path.join(_HERE, "libpt_host.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: run __graft_entry__.build()")
+        L = C.CDLL(path)
+        L.pth_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(HostScene), C.c_char_p, C.c_size_t]
+        L.pth_free_scene.argtypes = [C.POINTER(HostScene)]
+        L.pth_free_scene.restype = None
+        L.pth_write_ppm_bgra8.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pth_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pth_write_soup_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
+        _host = L
+    return _host
+
+
+# ---- host side: scene ingest / image output ---------------------------------------------------
+def load_obj(path, mtl_dir=None):
+    """-> (vertices f32[3*nv], indices u32[3*nt], faces f32[6*nt]) exactly as the reference's
+    loadFromFile fills them (main.cpp:28-58)."""
+    hs = HostScene()
+    err = C.create_string_buffer(512)
+    rc = lib_host().pth_load_obj(os.fsencode(path), os.fsencode(mtl_dir) if mtl_dir else None, C.byref(hs), err, 512)
+    if rc != 0:
+        raise RuntimeError(f"load_obj({path}): {err.value.decode()}")  # reference: throw std::runtime_error (main.cpp:35)
+    try:
+        v = np.ctypeslib.as_array(hs.vertices, shape=(3 * hs.n_verts,)).copy()
+        i = np.ctypeslib.as_array(hs.indices, shape=(3 * hs.n_tris,)).copy()
+        f = np.ctypeslib.as_array(hs.faces, shape=(6 * hs.n_tris,)).copy()
+    finally:
+        lib_host().pth_free_scene(C.byref(hs))
+    return v, i, f
+
+
+def write_ppm(path, bgra):
+    h, w = bgra.shape[:2]
+    a = np.ascontiguousarray(bgra, dtype=np.uint8)
+    if lib_host().pth_write_ppm_bgra8(os.fsencode(path), a.ctypes.data, w, h) != 0:
+        raise RuntimeError(f"cannot write {path}")
+
+
+def write_pfm(path, rgb):
+    h, w = rgb.shape[:2]
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    if lib_host().pth_write_pfm(os.fsencode(path), a.ctypes.data, w, h) != 0:
+        raise RuntimeError(f"cannot write {path}")
+
+
+def write_soup_obj(path, n_tris, seed=1):
+    if lib_host().pth_write_soup_obj(os.fsencode(path), n_tris, seed) != 0:
+        raise RuntimeError(f"cannot write {path}")
+
+
+# ---- device side --------------------------------------------------------------------------------
+def default_params(**kw):
+    p = Params()
+    lib_amd().pt_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k in ("cam_origin", "cam_target", "env"):
+            setattr(p, k, (C.c_float * 3)(*v))
+        else:
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One GPU + one stream (reference: Context, main.cpp:74-267)."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        rc = lib_amd().pt_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h))
+        if rc != PT_OK:
+            raise PtError(rc, lib_amd().pt_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc != PT_OK:
+            raise PtError(rc, lib_amd().pt_last_error(self.h).decode())
+
+    def sync(self):
+        self._check(lib_amd().pt_sync(self.h))
+
+    def stats(self):
+        s = Stats()
+        self._check(lib_amd().pt_get_stats(self.h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(lib_amd().pt_reset_stats(self.h))
+
+    def close(self):
+        if self.h:
+            lib_amd().pt_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """Vertex/index/face buffers + the device-built LBVH (reference: main.cpp:492-538)."""
+
+    def __init__(self, ctx, vertices, indices, faces):
+        self.ctx = ctx
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1)
+        i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        f = np.ascontiguousarray(faces, dtype=np.float32).reshape(-1)
+        if v.size % 3 or i.size % 3 or f.size != 2 * i.size:
+            raise ValueError("vertices must be 3*nv, indices 3*nt, faces 6*nt")
+        self.h = C.c_void_p()
+        ctx._check(lib_amd().pt_scene_create(ctx.h, v.ctypes.data, v.size // 3, i.ctypes.data, i.size // 3,
+                                             f.ctypes.data, C.byref(self.h)))
+
+    @classmethod
+    def from_obj(cls, ctx, path=ASSET_CORNELL):
+        return cls(ctx, *load_obj(path))
+
+    def info(self):
+        i = SceneInfo()
+        self.ctx._check(lib_amd().pt_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def read_bvh(self):
+        i = self.info()
+        keys = np.zeros(i.n_tris, dtype=np.uint64)
+        prim = np.zeros(i.n_tris, dtype=np.uint32)
+        nodes = np.zeros((i.n_nodes, 16), dtype=np.uint32)
+        self.ctx._check(lib_amd().pt_scene_read_bvh(self.h, keys.ctypes.data, prim.ctypes.data, nodes.ctypes.data))
+        return keys, prim, nodes
+
+    def trace(self, rays6, tmin=0.001, tmax=10000.0):
+        """Closest-hit query alone (traceRayEXT, raygen.rgen:63-75)."""
+        r = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
+        hits = np.zeros(r.shape[0], dtype=HIT_DTYPE)
+        self.ctx._check(lib_amd().pt_trace(self.h, r.ctypes.data, r.shape[0], tmin, tmax, hits.ctypes.data))
+        return hits
+
+    def close(self):
+        if self.h:
+            lib_amd().pt_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Film:
+    """The storage image (main.cpp:481-484): float running mean + the reference's rgba8 image."""
+
+    def __init__(self, ctx, width, height, device_ptr=None):
+        self.ctx, self.width, self.height = ctx, width, height
+        self.h = C.c_void_p()
+        if device_ptr is None:
+            rc = lib_amd().pt_film_create(ctx.h, width, height, C.byref(self.h))
+        else:
+            rc = lib_amd().pt_film_create_external(ctx.h, width, height, C.c_void_p(device_ptr), C.byref(self.h))
+        ctx._check(rc)
+
+    def clear(self):
+        self.ctx._check(lib_amd().pt_film_clear(self.h))
+
+    def read_f32(self):
+        a = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        self.ctx._check(lib_amd().pt_film_read_f32(self.h, a.ctypes.data))
+        return a
+
+    def read_bgra8(self):
+        a = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self.ctx._check(lib_amd().pt_film_read_bgra8(self.h, a.ctypes.data))
+        return a
+
+    def close(self):
+        if self.h:
+            lib_amd().pt_film_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render(scene, film, params):
+    """pushConstants(frame) + traceRaysKHR(W,H,1) + waitIdle (main.cpp:656-659, 683), for
+    params.frame_count consecutive frames."""
+    scene.ctx._check(lib_amd().pt_render(scene.h, film.h, C.byref(params)))

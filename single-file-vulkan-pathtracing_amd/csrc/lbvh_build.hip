@@ -1,0 +1,447 @@
+// lbvh_build.hip -- on-device LBVH construction (gfx950).
+//
+// Replaces the driver's acceleration-structure build of the reference (Accel::Accel,
+// main.cpp:414-455, called for the BLAS at main.cpp:497-512 and the one-instance TLAS at
+// main.cpp:515-538).  Pipeline, all on the GPU:
+//   1. k_gather    de-index triangles (closesthit.rchit:52-54 semantics), per-triangle AABB,
+//                  scene AABB by wave/block reduction + ordered-int atomics
+//   2. k_morton    63-bit Morton key of the AABB centre (21 bits/axis, x most significant)
+//   3. radix sort  LSD, 8 passes x 8-bit digits, stable (ties keep prim-id order)
+//   4. k_karras    Karras 2012 hierarchy (duplicate keys disambiguated by position)
+//   5. k_refit     bottom-up boxes with one arrival counter per node
+//   6. k_pack      leaf-ordered triangle + shading records for the traversal / shade kernels
+// The tree is fully determined by the input, so a CPU builder following the same rules yields
+// bit-identical keys, order, topology and boxes (tests compare them).
+#include "pt_internal.h"
+#include "pt_math.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int TB = 256;
+
+// ---- float <-> order-preserving uint (for atomicMin/Max on floats) --------------------------
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t u)
+{
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 1. gather + bounds.  tri_orig: 3 float4 per triangle in prim-id order.
+__global__ __launch_bounds__(TB) void k_gather(const float *__restrict__ vertices, const uint32_t *__restrict__ indices,
+                                               uint32_t n_tris, float4 *__restrict__ tri_orig,
+                                               float4 *__restrict__ tlo, float4 *__restrict__ thi,
+                                               uint32_t *__restrict__ scene_ord /*[6]: min xyz, max xyz*/)
+{
+    const uint32_t t = blockIdx.x * TB + threadIdx.x;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (t < n_tris) {
+        float v[3][3];
+        for (int c = 0; c < 3; c++) {
+            const uint32_t vi = indices[3 * (size_t)t + c];
+            for (int k = 0; k < 3; k++) v[c][k] = vertices[3 * (size_t)vi + k];
+        }
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(fminf(v[0][k], v[1][k]), v[2][k]);
+            mx[k] = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]);
+        }
+        tri_orig[3 * (size_t)t + 0] = make_float4(v[0][0], v[0][1], v[0][2], __uint_as_float(t));
+        tri_orig[3 * (size_t)t + 1] = make_float4(v[1][0], v[1][1], v[1][2], 0.f);
+        tri_orig[3 * (size_t)t + 2] = make_float4(v[2][0], v[2][1], v[2][2], 0.f);
+        tlo[t] = make_float4(mn[0], mn[1], mn[2], 0.f);
+        thi[t] = make_float4(mx[0], mx[1], mx[2], 0.f);
+    }
+    for (int k = 0; k < 3; k++) {
+        const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&scene_ord[k], f2ord(a));
+            atomicMax(&scene_ord[3 + k], f2ord(b));
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long expand21(uint32_t v)
+{
+    unsigned long long x = v & 0x1FFFFFu;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t quant21(float c, float lo, float ext)
+{
+    const float n = ext > 0.0f ? ptm::fdiv(c - lo, ext) : 0.0f;
+    float q = n * 2097152.0f;
+    if (!(q >= 0.0f)) q = 0.0f;
+    if (q > 2097151.0f) q = 2097151.0f;
+    return (uint32_t)q;
+}
+
+// 2. Morton keys
+__global__ __launch_bounds__(TB) void k_morton(const float4 *__restrict__ tlo, const float4 *__restrict__ thi,
+                                               uint32_t n_tris, const uint32_t *__restrict__ scene_ord,
+                                               unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t t = blockIdx.x * TB + threadIdx.x;
+    if (t >= n_tris) return;
+    const float lo[3] = { ord2f(scene_ord[0]), ord2f(scene_ord[1]), ord2f(scene_ord[2]) };
+    const float hi[3] = { ord2f(scene_ord[3]), ord2f(scene_ord[4]), ord2f(scene_ord[5]) };
+    const float4 a = tlo[t], b = thi[t];
+    const uint32_t qx = quant21((a.x + b.x) * 0.5f, lo[0], hi[0] - lo[0]);
+    const uint32_t qy = quant21((a.y + b.y) * 0.5f, lo[1], hi[1] - lo[1]);
+    const uint32_t qz = quant21((a.z + b.z) * 0.5f, lo[2], hi[2] - lo[2]);
+    keys[t] = (expand21(qx) << 2) | (expand21(qy) << 1) | expand21(qz);
+    vals[t] = t;
+}
+
+// 3. radix sort: one pass = hist -> scan -> scatter.  A block owns a tile of 2048 keys, each of
+// its 4 waves a contiguous 512-key run (so (wave, item, lane) order == index order == stable).
+constexpr int RS_KPT = 8;
+constexpr int RS_TILE = TB * RS_KPT;
+
+__global__ __launch_bounds__(TB) void k_rs_hist(const unsigned long long *__restrict__ keys, uint32_t n, int shift,
+                                                uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    for (int k = 0; k < RS_KPT; k++) {
+        const uint32_t i = base + k * TB + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of `total` counters in place, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *__restrict__ hist, uint32_t total)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (total + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = min(b + per, total);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= (uint32_t)o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t v = hist[i];
+        hist[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_rs_scatter(const unsigned long long *__restrict__ kin,
+                                                   const uint32_t *__restrict__ vin,
+                                                   unsigned long long *__restrict__ kout, uint32_t *__restrict__ vout,
+                                                   uint32_t n, int shift, const uint32_t *__restrict__ offs,
+                                                   uint32_t nblocks)
+{
+    __shared__ uint32_t wh[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int w = 0; w < 4; w++) wh[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE + wave * (RS_TILE / 4);
+    unsigned long long key[RS_KPT];
+    uint32_t val[RS_KPT];
+    for (int k = 0; k < RS_KPT; k++) {
+        const uint32_t i = base + k * 64 + lane;
+        const bool ok = i < n;
+        key[k] = ok ? kin[i] : 0ull;
+        val[k] = ok ? vin[i] : 0u;
+        if (ok) atomicAdd(&wh[wave][(uint32_t)(key[k] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {
+        const int d = threadIdx.x;
+        uint32_t run = offs[(size_t)d * nblocks + blockIdx.x];
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = wh[w][d];
+            wh[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int k = 0; k < RS_KPT; k++) {
+        const uint32_t i = base + k * 64 + lane;
+        const bool ok = i < n;
+        const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+        unsigned long long m = __ballot(ok);
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        const uint32_t rank = __popcll(m & lt);
+        uint32_t pos = 0;
+        if (ok) pos = wh[wave][d] + rank;
+        __syncthreads();
+        if (ok && rank == 0) wh[wave][d] += __popcll(m);
+        __syncthreads();
+        if (ok) {
+            kout[pos] = key[k];
+            vout[pos] = val[k];
+        }
+    }
+}
+
+// 4. Karras 2012
+__device__ __forceinline__ int kdelta(const unsigned long long *__restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll(a ^ b);
+}
+
+__global__ __launch_bounds__(TB) void k_karras(const unsigned long long *__restrict__ keys, int n,
+                                               uint2 *__restrict__ topo, uint32_t *__restrict__ parent_int,
+                                               uint32_t *__restrict__ parent_leaf)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (kdelta(keys, n, i, i + 1) - kdelta(keys, n, i, i - 1)) < 0 ? -1 : 1;
+    const int dmin = kdelta(keys, n, i, i - d);
+    int lmax = 2;
+    while (kdelta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (kdelta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = kdelta(keys, n, i, j);
+    int sp = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (kdelta(keys, n, i, i + (sp + t) * d) > dnode) sp += t;
+    } while (t > 1);
+    const int gamma = i + sp * d + (d < 0 ? -1 : 0);
+    const int lo = min(i, j), hi = max(i, j);
+    uint32_t left, right;
+    if (lo == gamma) { left = PT_LEAF | (uint32_t)gamma; parent_leaf[gamma] = (uint32_t)i; }
+    else { left = (uint32_t)gamma; parent_int[gamma] = (uint32_t)i; }
+    if (hi == gamma + 1) { right = PT_LEAF | (uint32_t)(gamma + 1); parent_leaf[gamma + 1] = (uint32_t)i; }
+    else { right = (uint32_t)(gamma + 1); parent_int[gamma + 1] = (uint32_t)i; }
+    topo[i] = make_uint2(left, right);
+}
+
+// leaf pad = 2^-18 of the scene scale: keeps the slab test conservative w.r.t. the rounded
+// watertight triangle test
+__device__ __forceinline__ float leaf_pad(const uint32_t *__restrict__ scene_ord)
+{
+    float scale = 0.f;
+    for (int k = 0; k < 6; k++) scale = fmaxf(scale, fabsf(ord2f(scene_ord[k])));
+    return scale * 3.814697265625e-06f;
+}
+
+// 5. refit.  box arrays: index pos for leaves, n + node for internal nodes; .w of lo = height bits
+__global__ __launch_bounds__(TB) void k_refit(const float4 *__restrict__ tlo, const float4 *__restrict__ thi,
+                                              const uint32_t *__restrict__ prim_of, int n,
+                                              const uint2 *__restrict__ topo, const uint32_t *__restrict__ parent_int,
+                                              const uint32_t *__restrict__ parent_leaf, float4 *box_lo, float4 *box_hi,
+                                              uint32_t *flags, const uint32_t *__restrict__ scene_ord,
+                                              float4 *__restrict__ nodes, uint32_t *__restrict__ height_out)
+{
+    const int pos = blockIdx.x * TB + threadIdx.x;
+    if (pos >= n) return;
+    {
+        const float pad = leaf_pad(scene_ord);
+        const uint32_t prim = prim_of[pos];
+        const float4 a = tlo[prim], b = thi[prim];
+        box_lo[pos] = make_float4(a.x - pad, a.y - pad, a.z - pad, __uint_as_float(0u));
+        box_hi[pos] = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.f);
+    }
+    uint32_t node = parent_leaf[pos];
+    for (;;) {
+        // publish my subtree's box, then arrive (agent-scope release; the explicit vmcnt wait
+        // keeps the arrival from overtaking the write-back)
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = atomicAdd(&flags[node], 1u);
+        if (old == 0u) return;  // sibling subtree not finished: its last thread continues
+        __threadfence();        // acquire the sibling's box
+        const uint2 ch = topo[node];
+        const size_t li = (ch.x & PT_LEAF) ? (size_t)(ch.x & ~PT_LEAF) : (size_t)n + ch.x;
+        const size_t ri = (ch.y & PT_LEAF) ? (size_t)(ch.y & ~PT_LEAF) : (size_t)n + ch.y;
+        const float4 llo = box_lo[li], lhi = box_hi[li], rlo = box_lo[ri], rhi = box_hi[ri];
+        const uint32_t h = 1u + max(__float_as_uint(llo.w), __float_as_uint(rlo.w));
+        nodes[4 * (size_t)node + 0] = make_float4(llo.x, llo.y, llo.z, lhi.x);
+        nodes[4 * (size_t)node + 1] = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
+        nodes[4 * (size_t)node + 2] = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
+        nodes[4 * (size_t)node + 3] = make_float4(__uint_as_float(ch.x), __uint_as_float(ch.y), 0.f, 0.f);
+        box_lo[(size_t)n + node] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z),
+                                               __uint_as_float(h));
+        box_hi[(size_t)n + node] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.f);
+        if (node == 0u) { *height_out = h; return; }
+        node = parent_int[node];
+    }
+}
+
+// n == 1: a root whose two children are the same leaf (tested twice, same result)
+__global__ void k_single(const float4 *__restrict__ tlo, const float4 *__restrict__ thi,
+                         const uint32_t *__restrict__ scene_ord, float4 *__restrict__ nodes,
+                         uint32_t *__restrict__ height_out)
+{
+    const float pad = leaf_pad(scene_ord);
+    const float4 a = tlo[0], b = thi[0];
+    const float lx = a.x - pad, ly = a.y - pad, lz = a.z - pad, hx = b.x + pad, hy = b.y + pad, hz = b.z + pad;
+    nodes[0] = make_float4(lx, ly, lz, hx);
+    nodes[1] = make_float4(hy, hz, lx, ly);
+    nodes[2] = make_float4(lz, hx, hy, hz);
+    nodes[3] = make_float4(__uint_as_float(PT_LEAF), __uint_as_float(PT_LEAF), 0.f, 0.f);
+    *height_out = 1u;
+}
+
+// 6. leaf-ordered records
+__global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig, const float *__restrict__ faces,
+                                             const uint32_t *__restrict__ prim_of, uint32_t n,
+                                             float4 *__restrict__ tri4, float4 *__restrict__ shade4)
+{
+    const uint32_t pos = blockIdx.x * TB + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t prim = prim_of[pos];
+    const float4 a = tri_orig[3 * (size_t)prim + 0], b = tri_orig[3 * (size_t)prim + 1],
+                 c = tri_orig[3 * (size_t)prim + 2];
+    tri4[3 * (size_t)pos + 0] = a;  // .w = bits(prim)
+    tri4[3 * (size_t)pos + 1] = b;
+    tri4[3 * (size_t)pos + 2] = c;
+    // closesthit.rchit:43-48 normal (never flipped), :60 brdf = Kd / pi (true divide), :61 emission
+    const ptm::f3 nrm = ptm::tri_normal({ a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z });
+    const float *f = faces + 6 * (size_t)prim;
+    const float br = ptm::fdiv(f[0], 3.1415927410125732f), bg = ptm::fdiv(f[1], 3.1415927410125732f),
+                bb = ptm::fdiv(f[2], 3.1415927410125732f);
+    shade4[3 * (size_t)pos + 0] = make_float4(nrm.x, nrm.y, nrm.z, br);
+    shade4[3 * (size_t)pos + 1] = make_float4(bg, bb, f[3], f[4]);
+    shade4[3 * (size_t)pos + 2] = make_float4(f[5], 0.f, 0.f, 0.f);
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)); }
+};
+
+}  // namespace
+
+pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
+                          uint32_t n_tris, const float *h_faces)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = n_tris;
+    const uint32_t gt = (n + TB - 1) / TB;
+
+    DevBuf<float> d_vert, d_faces;
+    DevBuf<uint32_t> d_idx, d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height;
+    DevBuf<float4> d_tri_orig, d_tlo, d_thi, d_blo, d_bhi;
+    DevBuf<unsigned long long> d_keys[2];
+    DevBuf<uint2> d_topo;
+    const uint32_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+
+    PT_HIP(ctx, d_vert.alloc(3 * (size_t)n_verts));
+    PT_HIP(ctx, d_idx.alloc(3 * (size_t)n));
+    PT_HIP(ctx, d_faces.alloc(6 * (size_t)n));
+    PT_HIP(ctx, d_scene.alloc(6));
+    PT_HIP(ctx, d_tri_orig.alloc(3 * (size_t)n));
+    PT_HIP(ctx, d_tlo.alloc(n));
+    PT_HIP(ctx, d_thi.alloc(n));
+    for (int i = 0; i < 2; i++) {
+        PT_HIP(ctx, d_keys[i].alloc(n));
+        PT_HIP(ctx, d_vals[i].alloc(n));
+    }
+    PT_HIP(ctx, d_hist.alloc(256 * (size_t)nblocks));
+    PT_HIP(ctx, d_topo.alloc(n));
+    PT_HIP(ctx, d_pint.alloc(n));
+    PT_HIP(ctx, d_pleaf.alloc(n));
+    PT_HIP(ctx, d_flags.alloc(n));
+    PT_HIP(ctx, d_height.alloc(1));
+    PT_HIP(ctx, d_blo.alloc(2 * (size_t)n));
+    PT_HIP(ctx, d_bhi.alloc(2 * (size_t)n));
+
+    s->n_tris = n;
+    s->n_nodes = n > 1 ? n - 1 : 1;
+    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * 3 * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_nodes, sizeof(float4) * 4 * (size_t)s->n_nodes));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_keys, sizeof(unsigned long long) * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of, sizeof(uint32_t) * (size_t)n));
+    s->device_bytes = (sizeof(float4) * 6 + 12) * (uint64_t)n + sizeof(float4) * 4 * (uint64_t)s->n_nodes;
+
+    PT_HIP(ctx, hipMemcpyAsync(d_vert.p, h_vertices, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_idx.p, h_indices, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_faces.p, h_faces, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st));
+    const uint32_t ord_init[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
+    PT_HIP(ctx, hipMemcpyAsync(d_scene.p, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t) * (size_t)n, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));  // pageable host sources are done with
+
+    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p, d_scene.p);
+    k_morton<<<gt, TB, 0, st>>>(d_tlo.p, d_thi.p, n, d_scene.p, d_keys[0].p, d_vals[0].p);
+    int cur = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 8 * pass;
+        k_rs_hist<<<nblocks, TB, 0, st>>>(d_keys[cur].p, n, shift, d_hist.p, nblocks);
+        k_rs_scan<<<1, 1024, 0, st>>>(d_hist.p, 256u * nblocks);
+        k_rs_scatter<<<nblocks, TB, 0, st>>>(d_keys[cur].p, d_vals[cur].p, d_keys[cur ^ 1].p, d_vals[cur ^ 1].p, n, shift,
+                                             d_hist.p, nblocks);
+        cur ^= 1;
+    }
+    PT_HIP(ctx, hipMemcpyAsync(s->d_keys, d_keys[cur].p, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(s->d_prim_of, d_vals[cur].p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+
+    if (n > 1) {
+        k_karras<<<(n - 1 + TB - 1) / TB, TB, 0, st>>>(s->d_keys, (int)n, d_topo.p, d_pint.p, d_pleaf.p);
+        k_refit<<<gt, TB, 0, st>>>(d_tlo.p, d_thi.p, s->d_prim_of, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_blo.p, d_bhi.p,
+                                   d_flags.p, d_scene.p, s->d_nodes, d_height.p);
+    } else {
+        k_single<<<1, 1, 0, st>>>(d_tlo.p, d_thi.p, d_scene.p, s->d_nodes, d_height.p);
+    }
+    k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4);
+    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    uint32_t ord[6];
+    PT_HIP(ctx, hipMemcpyAsync(ord, d_scene.p, sizeof(ord), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipMemcpyAsync(&s->height, d_height.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < 3; k++) {
+        s->bmin[k] = ord2f(ord[k]);
+        s->bmax[k] = ord2f(ord[3 + k]);
+    }
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
+    return PT_OK;
+}

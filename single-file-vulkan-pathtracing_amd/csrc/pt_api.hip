@@ -1,0 +1,240 @@
+// pt_api.hip -- the C-ABI (include/pt_api.h) over the HIP kernels.  No exception leaves this file.
+#include "pt_internal.h"
+
+#include <cstring>
+#include <new>
+
+static thread_local std::string g_create_err;
+
+extern "C" {
+
+pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
+{
+    if (!out) return PT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_err = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        (void)hipGetLastError();
+        return PT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_create_err = "device ordinal out of range";
+        return PT_ERR_INVALID_ARG;
+    }
+    pt_ctx *ctx = new (std::nothrow) pt_ctx();
+    if (!ctx) return PT_ERR_OOM;
+    ctx->device = device;
+    auto fail = [&](const char *what, hipError_t err) {
+        g_create_err = std::string(what) + ": " + hipGetErrorString(err);
+        pt_ctx_destroy(ctx);
+        return PT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->lds_bytes = (int)prop.sharedMemPerBlock;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+        ctx->own_stream = true;
+    }
+    if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * 4)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 4)) != hipSuccess) return fail("hipMemset", e);
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_ctx_destroy(pt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+pt_status pt_sync(pt_ctx *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts, const uint32_t *indices, uint32_t n_tris,
+                          const float *faces, pt_scene **out)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!out || !vertices || !indices || !faces) { ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (n_tris == 0 || n_verts == 0) { ctx->err = "empty scene"; return PT_ERR_INVALID_ARG; }
+    if (n_tris >= 0x7FFFFFFFu / 4u) { ctx->err = "too many triangles"; return PT_ERR_INVALID_ARG; }
+    for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
+        if (indices[i] >= n_verts) { ctx->err = "vertex index out of range"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    pt_scene *s = new (std::nothrow) pt_scene();
+    if (!s) return PT_ERR_OOM;
+    s->ctx = ctx;
+    pt_status rc = ptb_build_scene(s, vertices, n_verts, indices, n_tris, faces);
+    if (rc != PT_OK) { pt_scene_destroy(s); return rc; }
+    *out = s;
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene *s)
+{
+    if (!s) return;
+    (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
+    delete s;
+}
+
+pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
+{
+    if (!s || !info) return PT_ERR_INVALID_ARG;
+    info->n_tris = s->n_tris; info->n_nodes = s->n_nodes; info->bvh_height = s->height;
+    for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
+    info->build_ms = s->build_ms;
+    info->device_bytes = s->device_bytes;
+    return PT_OK;
+}
+
+pt_status pt_scene_read_bvh(const pt_scene *s, uint64_t *keys, uint32_t *prim_of_pos, uint32_t *nodes16)
+{
+    if (!s) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = s->ctx;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (keys) PT_HIP(ctx, hipMemcpy(keys, s->d_keys, sizeof(uint64_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
+    if (prim_of_pos) PT_HIP(ctx, hipMemcpy(prim_of_pos, s->d_prim_of, sizeof(uint32_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
+    if (nodes16) PT_HIP(ctx, hipMemcpy(nodes16, s->d_nodes, 64 * (size_t)s->n_nodes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+static pt_status film_create(pt_ctx *ctx, uint32_t w, uint32_t h, void *ext, pt_film **out)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!out || w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 28)) { ctx->err = "bad film size"; return PT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    pt_film *f = new (std::nothrow) pt_film();
+    if (!f) return PT_ERR_OOM;
+    f->ctx = ctx; f->w = w; f->h = h;
+    hipError_t e = hipSuccess;
+    if (ext) { f->d_rgb = static_cast<float *>(ext); f->own_rgb = false; }
+    else e = hipMalloc((void **)&f->d_rgb, sizeof(float) * 3 * (size_t)w * h);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_bgra, 4 * (size_t)w * h);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); pt_film_destroy(f); return PT_ERR_OOM; }
+    pt_status rc = pt_film_clear(f);
+    if (rc != PT_OK) { pt_film_destroy(f); return rc; }
+    *out = f;
+    return PT_OK;
+}
+
+pt_status pt_film_create(pt_ctx *ctx, uint32_t w, uint32_t h, pt_film **out) { return film_create(ctx, w, h, nullptr, out); }
+
+pt_status pt_film_create_external(pt_ctx *ctx, uint32_t w, uint32_t h, void *device_rgb_f32, pt_film **out)
+{
+    if (ctx && !device_rgb_f32) { ctx->err = "null device buffer"; return PT_ERR_INVALID_ARG; }
+    return film_create(ctx, w, h, device_rgb_f32, out);
+}
+
+pt_status pt_film_clear(pt_film *f)
+{
+    if (!f) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = f->ctx;
+    PT_HIP(ctx, hipMemsetAsync(f->d_rgb, 0, sizeof(float) * 3 * (size_t)f->w * f->h, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(f->d_bgra, 0, 4 * (size_t)f->w * f->h, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+pt_status pt_film_read_f32(pt_film *f, float *rgb)
+{
+    if (!f || !rgb) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = f->ctx;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(rgb, f->d_rgb, sizeof(float) * 3 * (size_t)f->w * f->h, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_film_read_bgra8(pt_film *f, uint8_t *bgra)
+{
+    if (!f || !bgra) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = f->ctx;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(bgra, f->d_bgra, 4 * (size_t)f->w * f->h, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+void pt_film_destroy(pt_film *f)
+{
+    if (!f) return;
+    ptw_free_work(f);
+    if (f->own_rgb) (void)hipFree(f->d_rgb);
+    (void)hipFree(f->d_bgra);
+    delete f;
+}
+
+void pt_params_default(pt_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->frame = 0; p->frame_count = 1;
+    p->width = 1024; p->height = 1024;          // main.cpp:16-17
+    p->spp_per_frame = 32; p->max_depth = 8;    // raygen.rgen:43, 62
+    p->tmin = 0.001f; p->tmax = 10000.0f;       // raygen.rgen:71, 73
+    p->cam_origin[0] = 0.f; p->cam_origin[1] = -1.f; p->cam_origin[2] = 5.f;  // raygen.rgen:55
+    p->cam_target[0] = 0.f; p->cam_target[1] = -1.f; p->cam_target[2] = 2.f;  // raygen.rgen:56
+    p->env[0] = 0.7f; p->env[1] = 0.6f; p->env[2] = 0.5f;                     // miss.rmiss:10
+    p->rank = 0; p->world = 1;
+    p->pipeline = PT_PIPELINE_WAVEFRONT;
+    p->frames_in_flight = 0;
+    p->flags = 0;
+}
+
+pt_status pt_render(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    if (!s || !f || !p) return PT_ERR_INVALID_ARG;
+    if (s->ctx != f->ctx) { s->ctx->err = "scene and film belong to different contexts"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return ptw_render(s, f, p);
+}
+
+pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, pt_hit *hits)
+{
+    if (!s) return PT_ERR_INVALID_ARG;
+    if (n && (!rays6 || !hits)) { s->ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return ptw_trace(s, rays6, n, tmin, tmax, hits);
+}
+
+pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
+{
+    if (!ctx || !out) return PT_ERR_INVALID_ARG;
+    unsigned long long h[4];
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    ctx->stats.rays = h[0];
+    *out = ctx->stats;
+    return PT_OK;
+}
+
+pt_status pt_reset_stats(pt_ctx *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 4));
+    ctx->stats = pt_stats{};
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// pt_internal.h -- host-side objects behind the opaque C-ABI handles, and the HBM data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/pt_api.h"
+
+// ---- HBM layout of a scene --------------------------------------------
+// All per-triangle arrays are in LBVH leaf order (sorted Morton position), so neighbouring
+// leaves are neighbouring memory.
+//   tri4   : 3 x float4 per triangle  {v0.xyz, bits(prim id)} {v1.xyz, 0} {v2.xyz, 0}       48 B
+//   shade4 : 3 x float4 per triangle  {n.xyz, brdf.r} {brdf.gb, emission.rg} {emission.b,0,0,0} 48 B
+//   nodes  : 4 x float4 per internal node {lmin.xyz,lmax.x} {lmax.yz,rmin.xy} {rmin.z,rmax.xyz}
+//            {bits(left), bits(right), 0, 0}; child bit31 set = leaf at that sorted position    64 B
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    int lds_bytes = 65536;
+    std::string err;
+    // statistics block in device memory: [0] rays (u64), [1] paths (u64)
+    unsigned long long *d_stats = nullptr;
+    pt_stats stats{};
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+};
+
+struct pt_scene {
+    pt_ctx *ctx = nullptr;
+    uint32_t n_tris = 0, n_nodes = 0, height = 0;
+    float bmin[3]{}, bmax[3]{};
+    float build_ms = 0.f;
+    float4 *d_tri4 = nullptr;
+    float4 *d_shade4 = nullptr;
+    float4 *d_nodes = nullptr;
+    unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
+    uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
+    uint64_t device_bytes = 0;
+};
+
+struct pt_film {
+    pt_ctx *ctx = nullptr;
+    uint32_t w = 0, h = 0;
+    float *d_rgb = nullptr;   // w*h*3 running mean (canonical float film)
+    bool own_rgb = true;
+    uint8_t *d_bgra = nullptr;  // w*h*4 reference-display image
+    // wavefront workspace, (re)allocated by pt_render for (rank, world, frames_in_flight)
+    struct Work {
+        uint32_t rank = 0, world = 0, lanes = 0;  // lanes = frames in flight
+        uint32_t n_tiles = 0;                     // local 8x8 tiles
+        uint32_t n_slots = 0;                     // lanes * n_tiles * 64
+        uint32_t *d_tiles = nullptr;              // local tile -> global tile id
+        float4 *d_color = nullptr;                // per slot: frame colour accumulator rgb + pad
+        // double-buffered dense queues (index = queue position)
+        uint32_t *d_qslot[2] = { nullptr, nullptr };
+        uint32_t *d_qctr[2] = { nullptr, nullptr };   // sample | depth<<16
+        float4 *d_qstate[2] = { nullptr, nullptr };   // {bits(seed), weight.rgb}
+        float4 *d_qrayA[2] = { nullptr, nullptr };    // {org.xyz, dir.x}
+        float2 *d_qrayB[2] = { nullptr, nullptr };    // {dir.y, dir.z}
+        float4 *d_hit = nullptr;                      // {bits(pos), t, u, v}
+        uint32_t *d_count = nullptr;                  // [2] queue sizes
+    } work;
+};
+
+#define PT_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return PT_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+// lbvh_build.hip
+pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
+                          uint32_t n_tris, const float *h_faces);
+// wavefront.hip
+pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);
+pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, pt_hit *hits);
+void ptw_free_work(pt_film *f);

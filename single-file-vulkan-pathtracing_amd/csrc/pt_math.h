@@ -1,0 +1,230 @@
+// pt_math.h -- device-side arithmetic of the radiance loop (gfx950, wave64).
+//
+// Every function here follows the project's canonical arithmetic: IEEE
+// binary32, round-to-nearest-even, no FMA contraction (the whole library is compiled with
+// -ffp-contract=off), correctly rounded divide and sqrt, denormals kept.  That is what makes
+// the GPU radiance bit-comparable with a CPU restatement of the reference shaders.
+//
+// Reference anchors (paths relative to the reference repo):
+//   pcg / pcg2d / rand        shaders/common.glsl:13-37
+//   seed                      shaders/raygen.rgen:47-48
+//   primary ray               shaders/raygen.rgen:51-57
+//   sampleDirection           shaders/raygen.rgen:14-39
+//   hit position / normal     shaders/closesthit.rchit:43-58
+//   closest-hit semantics     shaders/raygen.rgen:63-75, main.cpp:497-538 (opaque, no culling)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_MISS 0xFFFFFFFFu
+#define PT_LEAF 0x80000000u
+
+namespace ptm {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+
+// ---- RNG ------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pcg(uint32_t &state)  // common.glsl:13-19
+{
+    const uint32_t prev = state * 747796405u + 2891336453u;
+    const uint32_t word = ((prev >> ((prev >> 28u) + 4u)) ^ prev) * 277803737u;
+    state = prev;
+    return (word >> 22u) ^ word;
+}
+
+__device__ __forceinline__ uint2 pcg2d(uint2 v)  // common.glsl:21-31
+{
+    v.x = v.x * 1664525u + 1013904223u;
+    v.y = v.y * 1664525u + 1013904223u;
+    v.x += v.y * 1664525u;
+    v.y += v.x * 1664525u;
+    v.x ^= v.x >> 16u;
+    v.y ^= v.y >> 16u;
+    v.x += v.y * 1664525u;
+    v.y += v.x * 1664525u;
+    v.x ^= v.x >> 16u;
+    v.y ^= v.y >> 16u;
+    return v;
+}
+
+__device__ __forceinline__ float rnd(uint32_t &seed)  // common.glsl:33-37
+{
+    // float(val) is v_cvt_f32_u32 = round-to-nearest-even; the constant is 2^-32
+    return __uint2float_rn(pcg(seed)) * 2.3283064365386963e-10f;
+}
+
+__device__ __forceinline__ uint32_t make_seed(uint32_t px, uint32_t py, uint32_t sample, int32_t frame,
+                                              uint32_t spp)  // raygen.rgen:47-48
+{
+    const uint32_t m = sample + (uint32_t)((int32_t)spp * frame) + 1u;
+    const uint2 s = pcg2d(make_uint2(px * m, py * m));
+    return s.x + s.y;
+}
+
+// ---- sin/cos of a in [0, 2*pi] ---------------------------------------------------------
+// Quadrant reduction (Cody-Waite, three-part pi/2) + cephes-style minimax polynomials on
+// |r| <= pi/4, Horner form.  Fully specified so host and device agree to the bit; accuracy
+// ~1e-7 absolute, far inside what GLSL.std.450 Sin/Cos guarantee (2^-11).
+__device__ __forceinline__ void sincos_2pi(float a, float &s, float &c)
+{
+    const int j = (int)(a * 0.636619772f + 0.5f);
+    const float fj = (float)j;
+    float r = a - fj * 1.5703125f;
+    r = r - fj * 4.837512969970703125e-4f;
+    r = r - fj * 7.54978995489188e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    ps = ps * z;
+    ps = ps * r + r;
+    float pc = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    pc = pc * z;
+    pc = pc * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    const bool swap = j & 1;
+    const float s0 = swap ? pc : ps;
+    const float c0 = swap ? ps : pc;
+    s = (j & 2) ? -s0 : s0;           // j&3: 0 (s,c) 1 (c,-s) 2 (-s,-c) 3 (-c,s)
+    c = ((j + 1) & 2) ? -c0 : c0;
+}
+
+// ---- camera ----------------------------------------------------------------------------
+struct Camera {
+    float ox, oy, oz;   // raygen.rgen:55
+    float tx, ty, tz;   // raygen.rgen:56: target = (d.x + tx, d.y + ty, tz)
+    float w, h;         // float(gl_LaunchSizeEXT.xy)
+};
+
+__device__ __forceinline__ void primary_ray(const Camera &cam, uint32_t px, uint32_t py, uint32_t &seed,
+                                            f3 &org, f3 &dir)  // raygen.rgen:51-57
+{
+    const float jx = rnd(seed);  // x first, then y
+    const float jy = rnd(seed);
+    const float sx = (float)px + jx;
+    const float sy = (float)py + jy;
+    const float dx = fdiv(sx, cam.w) * 2.0f - 1.0f;  // no aspect-ratio correction (kept)
+    const float dy = fdiv(sy, cam.h) * 2.0f - 1.0f;
+    const float vx = (dx + cam.tx) - cam.ox;
+    const float vy = (dy + cam.ty) - cam.oy;
+    const float vz = cam.tz - cam.oz;
+    const float len = fsqrt((vx * vx + vy * vy) + vz * vz);
+    org = { cam.ox, cam.oy, cam.oz };
+    dir = { fdiv(vx, len), fdiv(vy, len), fdiv(vz, len) };
+}
+
+// ---- bounce: raygen.rgen:14-39 ---------------------------------------------------------
+__device__ __forceinline__ f3 sample_direction(float r1, float r2, const f3 n)
+{
+    f3 T;
+    if (fabsf(n.x) > fabsf(n.y)) {  // createCoordinateSystem, strict >
+        const float l = fsqrt(n.x * n.x + n.z * n.z);
+        T = { fdiv(n.z, l), fdiv(0.0f, l), fdiv(-n.x, l) };
+    } else {
+        const float l = fsqrt(n.y * n.y + n.z * n.z);
+        T = { fdiv(0.0f, l), fdiv(-n.z, l), fdiv(n.y, l) };
+    }
+    const f3 B = { n.y * T.z - n.z * T.y, n.z * T.x - n.x * T.z, n.x * T.y - n.y * T.x };
+    const float sq = fsqrt(1.0f - r1 * r1);  // uniform hemisphere, pdf 1/(2*pi)
+    const float phi = 6.2831854820251465f * r2;
+    float sn, cs;
+    sincos_2pi(phi, sn, cs);
+    const float dx = cs * sq, dy = sn * sq, dz = r1;
+    return { (T.x * dx + B.x * dy) + n.x * dz, (T.y * dx + B.y * dy) + n.y * dz,
+             (T.z * dx + B.z * dy) + n.z * dz };
+}
+
+// ---- geometric normal: closesthit.rchit:43-48 -------------------------------------------
+__device__ __forceinline__ f3 tri_normal(const f3 v0, const f3 v1, const f3 v2)
+{
+    const f3 a = { v1.x - v0.x, v1.y - v0.y, v1.z - v0.z };
+    const f3 b = { v2.x - v0.x, v2.y - v0.y, v2.z - v0.z };
+    const float cx = a.y * b.z - a.z * b.y;
+    const float cy = a.z * b.x - a.x * b.z;
+    const float cz = a.x * b.y - a.y * b.x;
+    const float len = fsqrt((cx * cx + cy * cy) + cz * cz);
+    return { -fdiv(cx, len), -fdiv(cy, len), -fdiv(cz, len) };
+}
+
+// ---- closest-hit query: watertight ray/triangle (Woop, Benthin, Wald, JCGT 2013) --------
+struct RayPre {
+    f3 org;
+    float Sx, Sy, Sz;
+    int kz;  // dominant axis; kx = (kz+1)%3, ky = (kz+2)%3 (winding swap omitted: no culling)
+};
+
+__device__ __forceinline__ float sel3(int k, float x, float y, float z) { return k == 0 ? x : (k == 1 ? y : z); }
+
+__device__ __forceinline__ RayPre ray_setup(const f3 org, const f3 dir)
+{
+    RayPre r;
+    int kz = 0;
+    if (fabsf(dir.y) > fabsf(dir.x)) kz = 1;
+    if (fabsf(dir.z) > fabsf(sel3(kz, dir.x, dir.y, dir.z))) kz = 2;
+    // permuted components: (kx,ky,kz) = (1,2,0) (2,0,1) (0,1,2)
+    const float dkx = sel3(kz, dir.y, dir.z, dir.x);
+    const float dky = sel3(kz, dir.z, dir.x, dir.y);
+    const float dkz = sel3(kz, dir.x, dir.y, dir.z);
+    r.Sx = fdiv(dkx, dkz);
+    r.Sy = fdiv(dky, dkz);
+    r.Sz = fdiv(1.0f, dkz);
+    r.kz = kz;
+    r.org = org;
+    return r;
+}
+
+// Tests one triangle; on a hit inside (tmin, tmax) returns true with t,u,v.
+__device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 v1, const f3 v2, float tmin,
+                                         float tmax, float &t, float &u, float &v)
+{
+    const f3 A = { v0.x - r.org.x, v0.y - r.org.y, v0.z - r.org.z };
+    const f3 B = { v1.x - r.org.x, v1.y - r.org.y, v1.z - r.org.z };
+    const f3 C = { v2.x - r.org.x, v2.y - r.org.y, v2.z - r.org.z };
+    const int kz = r.kz;
+    const float Akx = sel3(kz, A.y, A.z, A.x), Aky = sel3(kz, A.z, A.x, A.y), Akz = sel3(kz, A.x, A.y, A.z);
+    const float Bkx = sel3(kz, B.y, B.z, B.x), Bky = sel3(kz, B.z, B.x, B.y), Bkz = sel3(kz, B.x, B.y, B.z);
+    const float Ckx = sel3(kz, C.y, C.z, C.x), Cky = sel3(kz, C.z, C.x, C.y), Ckz = sel3(kz, C.x, C.y, C.z);
+    const float Ax = Akx - r.Sx * Akz, Ay = Aky - r.Sy * Akz;
+    const float Bx = Bkx - r.Sx * Bkz, By = Bky - r.Sy * Bkz;
+    const float Cx = Ckx - r.Sx * Ckz, Cy = Cky - r.Sy * Ckz;
+    const float U = Cx * By - Cy * Bx;
+    const float V = Ax * Cy - Ay * Cx;
+    const float W = Bx * Ay - By * Ax;
+    // a zero edge function counts as inside: shared edges stay watertight
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+    const float T = (U * Az + V * Bz) + W * Cz;
+    const float tt = fdiv(T, det);
+    if (!(tt > tmin && tt < tmax)) return false;  // tMin < t < tMax, NaN rejects
+    t = tt;
+    u = fdiv(V, det);  // weight of v1 = attribs.x
+    v = fdiv(W, det);  // weight of v2 = attribs.y
+    return true;
+}
+
+__device__ __forceinline__ float safe_inv(float d)
+{
+    if (fabsf(d) < 1e-20f) d = copysignf(1e-20f, d);
+    return fdiv(1.0f, d);
+}
+
+// Conservative slab test against [tmin, tbest]; only has to never cull a real hit.
+__device__ __forceinline__ bool box_test(const f3 mn, const f3 mx, const f3 org, const f3 inv, float tmin,
+                                         float tbest, float &tnear)
+{
+    const float x0 = (mn.x - org.x) * inv.x, x1 = (mx.x - org.x) * inv.x;
+    const float y0 = (mn.y - org.y) * inv.y, y1 = (mx.y - org.y) * inv.y;
+    const float z0 = (mn.z - org.z) * inv.z, z1 = (mx.z - org.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tbest));
+    tnear = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+}  // namespace ptm

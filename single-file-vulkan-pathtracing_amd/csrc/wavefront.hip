@@ -1,0 +1,650 @@
+// wavefront.hip -- the per-pixel radiance loop as a wavefront path tracer on gfx950.
+//
+// Replaces what runs behind vkCmdTraceRaysKHR (main.cpp:659): raygen.rgen:41-91 with its
+// traceRayEXT (raygen.rgen:63-75), closesthit.rchit:50-65 and miss.rmiss:8-12.
+//
+// Structure.  A *slot* is one (frame, pixel) pair; it runs that pixel's
+// spp_per_frame samples one after the other, so the reference's single `color` accumulator
+// (raygen.rgen:42,76) is reproduced add-for-add.  Live paths sit in dense, double-buffered
+// queues (index = queue position, all accesses coalesced):
+//     qslot, qctr (sample | depth<<16), qstate {seed, weight}, qray {origin, direction}
+// One round = two kernels over the live queue:
+//     k_extend  : closest hit of ray[q] -> hit[q]      (persistent grid, LDS short stack,
+//                                                        BVH + triangles staged in LDS when small)
+//     k_shade   : hit[q] -> emission/environment into color[slot], bounce, or start the next
+//                 sample of the same pixel ("regeneration"); survivors are compacted into the
+//                 other queue with wave ballots + one atomic per 1024-path chunk
+// k_generate fills the queue for a batch of frames, k_resolve applies raygen.rgen:86-90.
+#include "pt_internal.h"
+#include "pt_math.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int TB = 256;
+constexpr uint32_t SENTINEL = 0xFFFFFFFFu;
+
+struct RenderConst {
+    ptm::Camera cam;
+    float env[3];
+    float tmin, tmax;
+    uint32_t width, height, tiles_x;
+    uint32_t spp, max_depth;
+    int32_t frame_base;        // frame index of lane 0 of this batch
+    uint32_t lanes_active;     // frames in this batch
+    uint32_t slots_per_lane;   // n_tiles * 64
+};
+
+struct QueueView {
+    uint32_t *slot;
+    uint32_t *ctr;
+    float4 *state;
+    float4 *rayA;
+    float2 *rayB;
+};
+
+__device__ __forceinline__ void slot_pixel(const RenderConst &rc, const uint32_t *__restrict__ tiles, uint32_t slot,
+                                           uint32_t &lane_f, uint32_t &px, uint32_t &py)
+{
+    lane_f = slot / rc.slots_per_lane;
+    const uint32_t local = slot - lane_f * rc.slots_per_lane;
+    const uint32_t g = tiles[local >> 6];
+    const uint32_t ty = g / rc.tiles_x, tx = g - ty * rc.tiles_x;
+    px = tx * 8u + (local & 7u);
+    py = ty * 8u + ((local >> 3) & 7u);
+}
+
+// Block-wide ordered compaction of up to ITEMS x 256 survivors: wave ballots for the in-wave
+// rank, LDS for the cross-wave prefix, ONE device-scope atomic per chunk for the queue tail.
+template <int ITEMS>
+__device__ __forceinline__ void chunk_offsets(const bool (&alive)[ITEMS], uint32_t (&dst)[ITEMS], uint32_t *count_out,
+                                              uint32_t (*s_wcnt)[4], uint32_t *s_base)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const unsigned long long m = __ballot(alive[it]);
+        rank[it] = __popcll(m & lt);
+        if (lane == 0) s_wcnt[it][wave] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++)
+            for (int w = 0; w < 4; w++) total += s_wcnt[it][w];
+        *s_base = total ? atomicAdd(count_out, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t run = *s_base;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        for (int w = 0; w < 4; w++) {
+            if (w == wave) dst[it] = run + rank[it];
+            run += s_wcnt[it][w];
+        }
+    }
+    __syncthreads();  // s_wcnt / s_base are reused by the next chunk
+}
+
+// ---- generate: sample 0 of every (frame, pixel) slot of the batch ----------------------------
+__global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t *__restrict__ tiles, uint32_t n_slots,
+                                                 float4 *__restrict__ color, QueueView out, uint32_t *count_out)
+{
+    __shared__ uint32_t s_wcnt[1][4];
+    __shared__ uint32_t s_base;
+    for (uint32_t base = blockIdx.x * TB; base < n_slots; base += gridDim.x * TB) {
+        const uint32_t slot = base + threadIdx.x;
+        bool alive[1] = { false };
+        uint32_t seed = 0;
+        ptm::f3 org{}, dir{};
+        if (slot < n_slots) {
+            uint32_t f, px, py;
+            slot_pixel(rc, tiles, slot, f, px, py);
+            color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
+            if (px < rc.width && py < rc.height && f < rc.lanes_active) {
+                alive[0] = true;
+                seed = ptm::make_seed(px, py, 0u, rc.frame_base + (int32_t)f, rc.spp);
+                ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+            }
+        }
+        uint32_t dst[1];
+        chunk_offsets<1>(alive, dst, count_out, s_wcnt, &s_base);
+        if (alive[0]) {
+            out.slot[dst[0]] = slot;
+            out.ctr[dst[0]] = 0u;
+            out.state[dst[0]] = make_float4(__uint_as_float(seed), 1.f, 1.f, 1.f);  // raygen.rgen:59
+            out.rayA[dst[0]] = make_float4(org.x, org.y, org.z, dir.x);
+            out.rayB[dst[0]] = make_float2(dir.y, dir.z);
+        }
+    }
+}
+
+// ---- extend: closest hit for every queued ray (traceRayEXT, raygen.rgen:63-75) ---------------
+// Persistent grid (gridDim = CUs x resident blocks); each block walks 256-ray chunks of the
+// dense queue.  Per-lane traversal stack lives in LDS as stack[level][thread] (bank = thread, so
+// pushes/pops never conflict).  LDS_SCENE: the whole BVH + triangle array is staged into LDS
+// once per block, traversal then touches no HBM at all.
+template <int STACK, bool LDS_SCENE>
+__global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_nodes, const float4 *__restrict__ g_tri4,
+                                               uint32_t n_nodes, uint32_t n_tris, const float4 *__restrict__ rayA,
+                                               const float2 *__restrict__ rayB, float4 *__restrict__ hit,
+                                               const uint32_t *__restrict__ count_in, uint32_t *count_zero,
+                                               unsigned long long *stats, float tmin, float tmax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *stack = reinterpret_cast<uint32_t *>(smem);
+    const float4 *nodes = g_nodes;
+    const float4 *tri4 = g_tri4;
+    if (LDS_SCENE) {
+        float4 *s_nodes = reinterpret_cast<float4 *>(smem + (size_t)STACK * TB * 4);
+        float4 *s_tri = s_nodes + 4 * (size_t)n_nodes;
+        for (uint32_t i = threadIdx.x; i < 4 * n_nodes; i += TB) s_nodes[i] = g_nodes[i];
+        for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) s_tri[i] = g_tri4[i];
+        __syncthreads();
+        nodes = s_nodes;
+        tri4 = s_tri;
+    }
+    const uint32_t n = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (count_zero) *count_zero = 0u;  // the queue the coming shade pass appends to
+        if (stats) atomicAdd(stats, (unsigned long long)n);  // exact ray count
+    }
+    uint32_t *my_stack = stack + threadIdx.x;
+
+    for (uint32_t base = blockIdx.x * TB; base < n; base += gridDim.x * TB) {
+        const uint32_t q = base + threadIdx.x;
+        if (q >= n) continue;
+        const float4 ra = rayA[q];
+        const float2 rb = rayB[q];
+        const ptm::f3 org = { ra.x, ra.y, ra.z };
+        const ptm::f3 dir = { ra.w, rb.x, rb.y };
+        const ptm::RayPre pre = ptm::ray_setup(org, dir);
+        const ptm::f3 inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
+
+        float best_t = tmax, best_u = 0.f, best_v = 0.f;
+        uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
+        uint32_t ref = 0u;  // root
+        int sp = 0;
+        for (;;) {
+            while (!(ref & PT_LEAF)) {  // descend through internal nodes
+                const float4 n0 = nodes[4 * ref + 0], n1 = nodes[4 * ref + 1], n2 = nodes[4 * ref + 2],
+                             n3 = nodes[4 * ref + 3];
+                float tl, tr;
+                const bool hl = ptm::box_test({ n0.x, n0.y, n0.z }, { n0.w, n1.x, n1.y }, org, inv, tmin, best_t, tl);
+                const bool hr = ptm::box_test({ n1.z, n1.w, n2.x }, { n2.y, n2.z, n2.w }, org, inv, tmin, best_t, tr);
+                const uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
+                if (hl && hr) {
+                    const bool swap = tr < tl;
+                    my_stack[sp * TB] = swap ? cl : cr;
+                    sp++;
+                    ref = swap ? cr : cl;
+                } else if (hl) {
+                    ref = cl;
+                } else if (hr) {
+                    ref = cr;
+                } else if (sp > 0) {
+                    sp--;
+                    ref = my_stack[sp * TB];
+                } else {
+                    ref = SENTINEL;
+                }
+            }
+            if (ref == SENTINEL) break;
+            const uint32_t pos = ref & ~PT_LEAF;
+            const float4 a = tri4[3 * pos + 0], b = tri4[3 * pos + 1], c = tri4[3 * pos + 2];
+            float t, u, v;
+            if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, u, v)) {
+                const uint32_t prim = __float_as_uint(a.w);
+                // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
+                if (t < best_t || (t == best_t && prim < best_prim)) {
+                    best_t = t; best_u = u; best_v = v; best_pos = pos; best_prim = prim;
+                }
+            }
+            if (sp == 0) break;
+            sp--;
+            ref = my_stack[sp * TB];
+        }
+        hit[q] = make_float4(__uint_as_float(best_pos), best_pos == PT_MISS ? 0.f : best_t, best_u, best_v);
+    }
+}
+
+// ---- shade: closesthit / miss + the bounce logic of raygen.rgen:76-83, regeneration, compaction
+constexpr int SH_ITEMS = 4;
+
+__global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
+                                              const float4 *__restrict__ tri4, const float4 *__restrict__ shade4,
+                                              const float4 *__restrict__ hit, float4 *__restrict__ color, QueueView in,
+                                              QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out)
+{
+    __shared__ uint32_t s_wcnt[SH_ITEMS][4];
+    __shared__ uint32_t s_base;
+    const uint32_t n = *count_in;
+    constexpr uint32_t CHUNK = TB * SH_ITEMS;
+    for (uint32_t base = blockIdx.x * CHUNK; base < n; base += gridDim.x * CHUNK) {
+        bool alive[SH_ITEMS];
+        uint32_t o_slot[SH_ITEMS], o_ctr[SH_ITEMS];
+        float4 o_state[SH_ITEMS], o_rayA[SH_ITEMS];
+        float2 o_rayB[SH_ITEMS];
+#pragma unroll
+        for (int it = 0; it < SH_ITEMS; it++) {
+            const uint32_t q = base + it * TB + threadIdx.x;
+            alive[it] = false;
+            if (q >= n) continue;
+            const uint32_t slot = in.slot[q];
+            const uint32_t ctr = in.ctr[q];
+            const float4 st = in.state[q];
+            const float4 h = hit[q];
+            uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
+            uint32_t seed = __float_as_uint(st.x);
+            float wr = st.y, wg = st.z, wb = st.w;
+            const uint32_t pos = __float_as_uint(h.x);
+            bool terminated;
+            ptm::f3 org{}, dir{};
+            if (pos == PT_MISS) {
+                // miss.rmiss:10-11 then raygen.rgen:76: color += weight * (0.7,0.6,0.5); break
+                float4 c = color[slot];
+                c.x = c.x + wr * rc.env[0];
+                c.y = c.y + wg * rc.env[1];
+                c.z = c.z + wb * rc.env[2];
+                color[slot] = c;
+                terminated = true;
+            } else {
+                const float4 s0 = shade4[3 * pos + 0], s1 = shade4[3 * pos + 1], s2 = shade4[3 * pos + 2];
+                // raygen.rgen:76: color += weight * emission.  Adding +0 changes no bit of a
+                // non-negative accumulator, so the read-modify-write is skipped for non-emitters
+                // (NaN compares false and still takes the add).
+                const float er = wr * s1.z, eg = wg * s1.w, eb = wb * s2.x;
+                if (!(er == 0.f && eg == 0.f && eb == 0.f)) {
+                    float4 c = color[slot];
+                    c.x = c.x + er;
+                    c.y = c.y + eg;
+                    c.z = c.z + eb;
+                    color[slot] = c;
+                }
+                depth++;
+                terminated = depth >= rc.max_depth;  // raygen.rgen:62 loop bound
+                if (!terminated) {
+                    const float4 a = tri4[3 * pos + 0], b = tri4[3 * pos + 1], c = tri4[3 * pos + 2];
+                    // closesthit.rchit:56-57: position from barycentrics, (v0*b0 + v1*b1) + v2*b2
+                    const float b0 = (1.0f - h.z) - h.w;
+                    org = { (a.x * b0 + b.x * h.z) + c.x * h.w, (a.y * b0 + b.y * h.z) + c.y * h.w,
+                            (a.z * b0 + b.z * h.z) + c.z * h.w };
+                    const ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                    const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
+                    const float r2 = ptm::rnd(seed);
+                    dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
+                    const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
+                    // raygen.rgen:79-80: weight *= brdf * dot / pdf, pdf = 1/(2*pi) as a true divide
+                    wr = wr * ptm::fdiv(s0.w * dt, 0.15915493667125702f);
+                    wg = wg * ptm::fdiv(s1.x * dt, 0.15915493667125702f);
+                    wb = wb * ptm::fdiv(s1.y * dt, 0.15915493667125702f);
+                }
+            }
+            if (terminated) {
+                sample++;
+                if (sample < rc.spp) {  // next sample of the same pixel: raygen.rgen:45-60
+                    uint32_t f, px, py;
+                    slot_pixel(rc, tiles, slot, f, px, py);
+                    seed = ptm::make_seed(px, py, sample, rc.frame_base + (int32_t)f, rc.spp);
+                    ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                    wr = wg = wb = 1.0f;
+                    depth = 0;
+                    alive[it] = true;
+                }
+            } else {
+                alive[it] = true;
+            }
+            o_slot[it] = slot;
+            o_ctr[it] = sample | (depth << 16);
+            o_state[it] = make_float4(__uint_as_float(seed), wr, wg, wb);
+            o_rayA[it] = make_float4(org.x, org.y, org.z, dir.x);
+            o_rayB[it] = make_float2(dir.y, dir.z);
+        }
+        uint32_t dst[SH_ITEMS];
+        chunk_offsets<SH_ITEMS>(alive, dst, count_out, s_wcnt, &s_base);
+#pragma unroll
+        for (int it = 0; it < SH_ITEMS; it++) {
+            if (alive[it]) {
+                out.slot[dst[it]] = o_slot[it];
+                out.ctr[dst[it]] = o_ctr[it];
+                out.state[dst[it]] = o_state[it];
+                out.rayA[dst[it]] = o_rayA[it];
+                out.rayB[dst[it]] = o_rayB[it];
+            }
+        }
+    }
+}
+
+// ---- resolve: raygen.rgen:86-90 for every frame of the batch, in frame order -------------------
+__device__ __forceinline__ uint8_t to_unorm8(float c)
+{
+    if (!(c > 0.0f)) return 0;
+    if (c > 1.0f) c = 1.0f;
+    return (uint8_t)(c * 255.0f + 0.5f);
+}
+
+__global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *__restrict__ tiles,
+                                                const float4 *__restrict__ color, float *__restrict__ film,
+                                                uint8_t *__restrict__ bgra)
+{
+    const uint32_t local = blockIdx.x * TB + threadIdx.x;
+    if (local >= rc.slots_per_lane) return;
+    uint32_t f0, px, py;
+    slot_pixel(rc, tiles, local, f0, px, py);
+    if (px >= rc.width || py >= rc.height) return;
+    const size_t pix = (size_t)py * rc.width + px;
+    float fr = film[3 * pix + 0], fg = film[3 * pix + 1], fb = film[3 * pix + 2];
+    uchar4 img = reinterpret_cast<uchar4 *>(bgra)[pix];  // bytes B,G,R,A
+    const float spp = (float)rc.spp;
+    for (uint32_t f = 0; f < rc.lanes_active; f++) {
+        const float4 c = color[(size_t)f * rc.slots_per_lane + local];
+        const float cr = ptm::fdiv(c.x, spp), cg = ptm::fdiv(c.y, spp), cb = ptm::fdiv(c.z, spp);  // :86
+        const int32_t frame = rc.frame_base + (int32_t)f;
+        const float ff = (float)frame, f1 = (float)(frame + 1);
+        const bool first = frame == 0;  // old * 0: never read the uninitialised image
+        // float film (canonical): new = (color + old*frame) / (frame+1)
+        fr = ptm::fdiv(cr + (first ? 0.f : fr) * ff, f1);
+        fg = ptm::fdiv(cg + (first ? 0.f : fg) * ff, f1);
+        fb = ptm::fdiv(cb + (first ? 0.f : fb) * ff, f1);
+        // reference display image: rgba8 load -> blend -> clamp + quantise on store
+        const float orr = first ? 0.f : ptm::fdiv((float)img.z, 255.0f);
+        const float og = first ? 0.f : ptm::fdiv((float)img.y, 255.0f);
+        const float ob = first ? 0.f : ptm::fdiv((float)img.x, 255.0f);
+        const float oa = first ? 0.f : ptm::fdiv((float)img.w, 255.0f);
+        img.z = to_unorm8(ptm::fdiv(cr + orr * ff, f1));
+        img.y = to_unorm8(ptm::fdiv(cg + og * ff, f1));
+        img.x = to_unorm8(ptm::fdiv(cb + ob * ff, f1));
+        img.w = to_unorm8(ptm::fdiv(1.0f + oa * ff, f1));
+    }
+    film[3 * pix + 0] = fr;
+    film[3 * pix + 1] = fg;
+    film[3 * pix + 2] = fb;
+    reinterpret_cast<uchar4 *>(bgra)[pix] = img;
+}
+
+// hit records of the internal layout (sorted position) -> API layout (gl_PrimitiveID)
+__global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ hit, const float4 *__restrict__ tri4,
+                                                    uint32_t n, pt_hit *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = hit[i];
+    const uint32_t pos = __float_as_uint(h.x);
+    pt_hit o;
+    o.prim = pos == PT_MISS ? PT_MISS : __float_as_uint(tri4[3 * (size_t)pos].w);
+    o.t = h.y; o.u = h.z; o.v = h.w;
+    out[i] = o;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct ExtendPlan {
+    int stack = 16;
+    bool lds_scene = false;
+    size_t smem = 0;
+    int grid = 0;
+};
+
+using ExtendFn = void (*)(const float4 *, const float4 *, uint32_t, uint32_t, const float4 *, const float2 *, float4 *,
+                          const uint32_t *, uint32_t *, unsigned long long *, float, float);
+
+ExtendFn extend_fn(int stack, bool lds)
+{
+    if (stack == 16) return lds ? k_extend<16, true> : k_extend<16, false>;
+    if (stack == 32) return lds ? k_extend<32, true> : k_extend<32, false>;
+    return lds ? k_extend<64, true> : k_extend<64, false>;
+}
+
+pt_status plan_extend(pt_scene *s, ExtendPlan &pl)
+{
+    pt_ctx *ctx = s->ctx;
+    if (s->height > 64) {
+        ctx->err = "LBVH height " + std::to_string(s->height) + " exceeds the 64-entry traversal stack";
+        return PT_ERR_UNSUPPORTED;
+    }
+    pl.stack = s->height <= 16 ? 16 : (s->height <= 32 ? 32 : 64);
+    const size_t scene_bytes = sizeof(float4) * (4 * (size_t)s->n_nodes + 3 * (size_t)s->n_tris);
+    pl.lds_scene = scene_bytes <= 24 * 1024;
+    pl.smem = (size_t)pl.stack * TB * 4 + (pl.lds_scene ? scene_bytes : 0);
+    ExtendFn fn = extend_fn(pl.stack, pl.lds_scene);
+    if (pl.smem > 48 * 1024)
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)pl.smem));
+    int per_cu = 0;
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), TB, pl.smem));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    pl.grid = ctx->num_cus * per_cu;
+    return PT_OK;
+}
+
+void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
+                   const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats, float tmin, float tmax,
+                   hipStream_t st)
+{
+    ExtendFn fn = extend_fn(pl.stack, pl.lds_scene);
+    hipLaunchKernelGGL(fn, dim3(pl.grid), dim3(TB), pl.smem, st, s->d_nodes, s->d_tri4, s->n_nodes, s->n_tris, rayA, rayB,
+                       hit, count_in, count_zero, stats, tmin, tmax);
+}
+
+pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes)
+{
+    pt_ctx *ctx = f->ctx;
+    pt_film::Work &w = f->work;
+    if (w.d_tiles && w.rank == rank && w.world == world && w.lanes == lanes) return PT_OK;
+    ptw_free_work(f);
+    const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
+    std::vector<uint32_t> tiles;
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++)
+            if ((tx + ty) % world == rank) tiles.push_back(ty * tiles_x + tx);
+    w.rank = rank; w.world = world; w.lanes = lanes;
+    w.n_tiles = (uint32_t)tiles.size();
+    const uint64_t n_slots64 = (uint64_t)lanes * w.n_tiles * 64ull;
+    if (n_slots64 >= (1ull << 31)) {
+        ctx->err = "too many path slots (frames_in_flight x pixels >= 2^31)";
+        return PT_ERR_INVALID_ARG;
+    }
+    w.n_slots = (uint32_t)n_slots64;
+    const size_t ns = std::max<size_t>(w.n_slots, 1);
+    PT_HIP(ctx, hipMalloc((void **)&w.d_tiles, sizeof(uint32_t) * std::max<size_t>(tiles.size(), 1)));
+    if (!tiles.empty())
+        PT_HIP(ctx, hipMemcpy(w.d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMalloc((void **)&w.d_color, sizeof(float4) * ns));
+    for (int i = 0; i < 2; i++) {
+        PT_HIP(ctx, hipMalloc((void **)&w.d_qslot[i], sizeof(uint32_t) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_qctr[i], sizeof(uint32_t) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_qstate[i], sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_qrayA[i], sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_qrayB[i], sizeof(float2) * ns));
+    }
+    PT_HIP(ctx, hipMalloc((void **)&w.d_hit, sizeof(float4) * ns));
+    PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2));
+    return PT_OK;
+}
+
+}  // namespace
+
+void ptw_free_work(pt_film *f)
+{
+    pt_film::Work &w = f->work;
+    (void)hipFree(w.d_tiles);
+    (void)hipFree(w.d_color);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(w.d_qslot[i]);
+        (void)hipFree(w.d_qctr[i]);
+        (void)hipFree(w.d_qstate[i]);
+        (void)hipFree(w.d_qrayA[i]);
+        (void)hipFree(w.d_qrayB[i]);
+    }
+    (void)hipFree(w.d_hit);
+    (void)hipFree(w.d_count);
+    w = pt_film::Work{};
+}
+
+pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    if (p->width != f->w || p->height != f->h) { ctx->err = "params width/height differ from the film's"; return PT_ERR_INVALID_ARG; }
+    if (p->world == 0 || p->rank >= p->world) { ctx->err = "rank/world invalid"; return PT_ERR_INVALID_ARG; }
+    if (p->spp_per_frame == 0 || p->spp_per_frame > 0xFFFFu || p->max_depth == 0 || p->max_depth > 0xFFFFu) {
+        ctx->err = "spp_per_frame and max_depth must be in 1..65535";
+        return PT_ERR_INVALID_ARG;
+    }
+    if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
+    if (p->pipeline != PT_PIPELINE_WAVEFRONT) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+
+    ExtendPlan pl;
+    pt_status rc_ = plan_extend(s, pl);
+    if (rc_ != PT_OK) return rc_;
+
+    // frames in flight: enough slots to fill the chip several times over, bounded by memory
+    const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
+    uint32_t lanes = p->frames_in_flight;
+    if (lanes == 0) {
+        const uint64_t target = 4ull << 20;  // ~4M live paths
+        lanes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, target / std::max<uint64_t>(pixels_local, 1)));
+    }
+    lanes = std::min(lanes, p->frame_count);
+    rc_ = ensure_work(f, p->rank, p->world, lanes);
+    if (rc_ != PT_OK) return rc_;
+    pt_film::Work &w = f->work;
+
+    RenderConst rc{};
+    rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
+               (float)p->width, (float)p->height };
+    for (int k = 0; k < 3; k++) rc.env[k] = p->env[k];
+    rc.tmin = p->tmin; rc.tmax = p->tmax;
+    rc.width = p->width; rc.height = p->height; rc.tiles_x = (p->width + 7) / 8;
+    rc.spp = p->spp_per_frame; rc.max_depth = p->max_depth;
+    rc.slots_per_lane = w.n_tiles * 64u;
+
+    const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
+    std::vector<hipEvent_t> evs;
+    auto new_event = [&]() -> hipEvent_t {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        evs.push_back(e);
+        (void)hipEventRecord(e, st);
+        return e;
+    };
+
+    const int shade_grid = ctx->num_cus * 8;
+    QueueView qv[2];
+    for (int i = 0; i < 2; i++) qv[i] = { w.d_qslot[i], w.d_qctr[i], w.d_qstate[i], w.d_qrayA[i], w.d_qrayB[i] };
+
+    ctx->stats.extend_variant = pl.lds_scene ? 0u : 1u;
+    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    if (w.n_slots > 0) {
+        for (uint32_t done = 0; done < p->frame_count; done += lanes) {
+            rc.frame_base = p->frame + (int32_t)done;
+            rc.lanes_active = std::min(lanes, p->frame_count - done);
+            PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 2, st));
+            const uint32_t gen_slots = rc.lanes_active * rc.slots_per_lane;
+            const int gen_grid = (int)std::min<uint32_t>((gen_slots + TB - 1) / TB, (uint32_t)ctx->num_cus * 16u);
+            k_generate<<<gen_grid, TB, 0, st>>>(rc, w.d_tiles, gen_slots, w.d_color, qv[0], &w.d_count[0]);
+            ctx->stats.launches_other++;
+            int cur = 0;
+            const uint32_t max_rounds = p->spp_per_frame * p->max_depth;  // every sample at full depth
+            uint32_t h_count = 1;
+            for (uint32_t round = 0; round < max_rounds; round++) {
+                hipEvent_t e0 = profile ? new_event() : nullptr;
+                launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, &w.d_count[cur], &w.d_count[cur ^ 1], ctx->d_stats,
+                              p->tmin, p->tmax, st);
+                hipEvent_t e1 = profile ? new_event() : nullptr;
+                k_shade<<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, w.d_color, qv[cur], qv[cur ^ 1],
+                                                   &w.d_count[cur], &w.d_count[cur ^ 1]);
+                hipEvent_t e2 = profile ? new_event() : nullptr;
+                (void)e0; (void)e1; (void)e2;
+                ctx->stats.launches_extend++;
+                ctx->stats.launches_shade++;
+                ctx->stats.rounds++;
+                cur ^= 1;
+                // every pixel needs >= spp rounds; after that poll the live count now and then
+                if (round + 1 >= p->spp_per_frame && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
+                    PT_HIP(ctx, hipMemcpyAsync(&h_count, &w.d_count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    PT_HIP(ctx, hipStreamSynchronize(st));
+                    if (h_count == 0) break;
+                }
+            }
+            k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, w.d_color, f->d_rgb, f->d_bgra);
+            ctx->stats.launches_other++;
+        }
+    }
+    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    float ms = 0.f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+    ctx->stats.ms_total += ms;
+    {
+        // samples started = valid local pixels x spp x frames
+        uint64_t valid = 0;
+        const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
+        for (uint32_t ty = 0; ty < tiles_y; ty++)
+            for (uint32_t tx = 0; tx < tiles_x; tx++)
+                if ((tx + ty) % p->world == p->rank)
+                    valid += (uint64_t)std::min(8u, f->w - tx * 8) * std::min(8u, f->h - ty * 8);
+        ctx->stats.paths += valid * p->spp_per_frame * p->frame_count;
+    }
+    if (profile) {
+        for (size_t i = 0; i + 2 < evs.size(); i += 3) {
+            float a = 0.f, b = 0.f;
+            (void)hipEventElapsedTime(&a, evs[i], evs[i + 1]);
+            (void)hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]);
+            ctx->stats.ms_extend += a;
+            ctx->stats.ms_shade += b;
+        }
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    return PT_OK;
+}
+
+pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, pt_hit *hits)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    if (n == 0) return PT_OK;
+    ExtendPlan pl;
+    pt_status rc_ = plan_extend(s, pl);
+    if (rc_ != PT_OK) return rc_;
+    std::vector<float4> a(n);
+    std::vector<float2> b(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *r = rays6 + 6 * (size_t)i;
+        a[i] = make_float4(r[0], r[1], r[2], r[3]);
+        b[i] = make_float2(r[4], r[5]);
+    }
+    float4 *d_a = nullptr, *d_hit = nullptr;
+    float2 *d_b = nullptr;
+    uint32_t *d_cnt = nullptr;
+    pt_hit *d_out = nullptr;
+    pt_status ret = PT_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        ret = PT_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_a, sizeof(float4) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_b, sizeof(float2) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_hit, sizeof(float4) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_out, sizeof(pt_hit) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_cnt, sizeof(uint32_t))) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK) {
+        (void)hipMemcpyAsync(d_a, a.data(), sizeof(float4) * n, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_b, b.data(), sizeof(float2) * n, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_cnt, &n, sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        launch_extend(pl, s, d_a, d_b, d_hit, d_cnt, nullptr, ctx->d_stats, tmin, tmax, st);
+        k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, s->d_tri4, n, d_out);
+        (void)hipMemcpyAsync(hits, d_out, sizeof(pt_hit) * n, hipMemcpyDeviceToHost, st);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) fail(e, "pt_trace");
+        else if ((e = hipGetLastError()) != hipSuccess) fail(e, "pt_trace");
+        ctx->stats.launches_extend++;
+    }
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_hit); (void)hipFree(d_out); (void)hipFree(d_cnt);
+    return ret;
+}

@@ -1,0 +1,140 @@
+"""CPU tests of the host side (OBJ/MTL ingest, image output) and of the C-ABI surface."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import obj_ref
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_loader_matches_independent_restatement(pt):
+    v, i, f = pt.load_obj(pt.ASSET_CORNELL)
+    rv, ri, rf = obj_ref.load_obj(pt.ASSET_CORNELL)
+    assert v.dtype == np.float32 and i.dtype == np.uint32 and f.dtype == np.float32
+    assert v.tobytes() == rv.tobytes() and i.tobytes() == ri.tobytes() and f.tobytes() == rf.tobytes()
+    # main.cpp:42: Y negated; main.cpp:45: running indices
+    assert (i == np.arange(108)).all()
+    assert v.reshape(-1, 3)[:, 1].max() <= 0.0
+
+
+def test_loader_ragged_inputs(pt, tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.1 0.2 0.3\nKe 1 2 3\nnewmtl grey\nKd 0.5\n")
+    obj = tmp_path / "t.obj"
+    obj.write_text(
+        "# comment\nmtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0 # trailing comment\n"
+        "f 1 2 3\n"                 # no material yet -> default grey 0.6
+        "usemtl a\nf 1/1/1 2/2/2 3/3/3 4/4/4 5/5/5\n"   # pentagon, v/vt/vn form -> 3 fan triangles
+        "usemtl grey\nf -5//1 -4//1 -3//1\n"             # negative indices, v//vn form
+        "usemtl nosuch\nf 1 2 3\n")                      # unknown material -> default
+    v, i, f = pt.load_obj(str(obj))
+    rv, ri, rf = obj_ref.load_obj(str(obj))
+    assert v.tobytes() == rv.tobytes() and f.tobytes() == rf.tobytes()
+    faces = f.reshape(-1, 6)
+    assert faces.shape[0] == 6
+    np.testing.assert_allclose(faces[0], [0.6, 0.6, 0.6, 0, 0, 0])
+    np.testing.assert_allclose(faces[1], [0.1, 0.2, 0.3, 1, 2, 3])
+    np.testing.assert_allclose(faces[4], [0.5, 0.5, 0.5, 0, 0, 0])
+    np.testing.assert_allclose(faces[5], [0.6, 0.6, 0.6, 0, 0, 0])
+    tri = v.reshape(-1, 3, 3)
+    np.testing.assert_allclose(tri[3], [[0, 0, 0], [0, -1, 0], [0.5, -2, 0]])  # fan (0,3,4), y flipped
+
+
+def test_loader_errors(pt, tmp_path):
+    with pytest.raises(RuntimeError):
+        pt.load_obj(str(tmp_path / "missing.obj"))
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
+    with pytest.raises(RuntimeError, match="out of range"):
+        pt.load_obj(str(bad))
+    empty = tmp_path / "empty.obj"
+    empty.write_text("v 0 0 0\n")
+    with pytest.raises(RuntimeError, match="no faces"):
+        pt.load_obj(str(empty))
+    # missing MTL is only a warning in tinyobjloader: faces get the default material
+    nomtl = tmp_path / "nomtl.obj"
+    nomtl.write_text("mtllib nothere.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl x\nf 1 2 3\n")
+    _, _, f = pt.load_obj(str(nomtl))
+    np.testing.assert_allclose(f, [0.6, 0.6, 0.6, 0, 0, 0])
+
+
+def test_soup_generator_roundtrip(pt, tmp_path):
+    path = str(tmp_path / "soup.obj")
+    pt.write_soup_obj(path, 2000, 1)
+    v, i, f = pt.load_obj(path)
+    rv, ri, rf = obj_ref.load_obj(path)
+    assert v.tobytes() == rv.tobytes() and f.tobytes() == rf.tobytes()
+    assert i.size == 6000
+    tri = v.reshape(-1, 3, 3)
+    assert tri[..., 0].min() > -1.02 and tri[..., 0].max() < 1.02
+    assert tri[..., 1].min() > -2.02 and tri[..., 1].max() < 0.02     # Y negated at load
+    faces = f.reshape(-1, 6)
+    emit = faces[:, 3:].sum(1) > 0
+    assert (np.nonzero(emit)[0] % 64 == 7).all() and emit.sum() == len(range(7, 2000, 64))
+    pt.write_soup_obj(str(tmp_path / "soup2.obj"), 2000, 1)          # deterministic
+    body = lambda fn: [l for l in open(fn) if not l.startswith(("#", "mtllib"))]
+    assert body(path) == body(str(tmp_path / "soup2.obj"))
+
+
+def test_image_writers(pt, tmp_path):
+    bgra = np.zeros((2, 3, 4), np.uint8)
+    bgra[..., 0], bgra[..., 1], bgra[..., 2], bgra[..., 3] = 10, 20, 30, 255
+    pt.write_ppm(str(tmp_path / "a.ppm"), bgra)
+    raw = open(tmp_path / "a.ppm", "rb").read()
+    assert raw.startswith(b"P6\n3 2\n255\n") and raw[-3:] == bytes([30, 20, 10])
+    rgb = np.arange(18, dtype=np.float32).reshape(2, 3, 3)
+    pt.write_pfm(str(tmp_path / "a.pfm"), rgb)
+    raw = open(tmp_path / "a.pfm", "rb").read()
+    body = np.frombuffer(raw[len(b"PF\n3 2\n-1.0\n"):], np.float32).reshape(2, 3, 3)
+    assert (body[::-1] == rgb).all()
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(REPO, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s_\w+)\s*\(" % prefix, text)))
+
+
+def test_abi_exports_every_declared_symbol(pt):
+    api = _declared("pt_api.h", "pt")
+    host = _declared("pt_host.h", "pth")
+    assert sorted(pt.API_SYMBOLS) == api
+    assert sorted(pt.HOST_SYMBOLS) == host
+    La, Lh = pt.lib_amd(), pt.lib_host()
+    for s in api:
+        assert hasattr(La, s), s
+    for s in host:
+        assert hasattr(Lh, s), s
+
+
+def test_struct_layouts_match_header(pt):
+    import ctypes as C
+    assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 5
+    assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4
+    assert C.sizeof(pt.SceneInfo) == 4 * 3 + 4 * 6 + 4 + 8
+    p = pt.default_params()
+    assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
+    assert list(p.cam_origin) == [0.0, -1.0, 5.0] and list(p.cam_target) == [0.0, -1.0, 2.0]
+    assert [round(x, 6) for x in p.env] == [0.7, 0.6, 0.5]
+    assert abs(p.tmin - 0.001) < 1e-9 and p.tmax == 10000.0
+
+
+def test_no_cpu_fallback(pt):
+    """Without a GPU the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pt.PtError) as e:
+        pt.Context(0)
+    assert e.value.status == 2  # PT_ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(REPO, "single-file-vulkan-pathtracing_amd")
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(root, fn), errors="ignore").read()
+                assert "pt_oracle" not in text and "oracle/" not in text, os.path.join(root, fn)
