@@ -24,7 +24,10 @@ namespace ptm {
 struct f3 { float x, y, z; };
 
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+// NOTE: __fsqrt_rn() lowers to the bare 1-ulp v_sqrt_f32 on gfx950 (ROCm 7.2); __builtin_sqrtf
+// gets the correctly rounded expansion (v_sqrt_f32 + two fma corrections), which is what the
+// canonical arithmetic requires.
+__device__ __forceinline__ float fsqrt(float a) { return __builtin_sqrtf(a); }
 
 // ---- RNG ------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pcg(uint32_t &state)  // common.glsl:13-19
