@@ -506,7 +506,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
     uint32_t lanes = p->frames_in_flight;
     if (lanes == 0) {
-        const uint64_t target = 4ull << 20;  // ~4M live paths
+        const uint64_t target = 8ull << 20;  // ~8M live paths
         lanes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, target / std::max<uint64_t>(pixels_local, 1)));
     }
     lanes = std::min(lanes, p->frame_count);
@@ -524,7 +524,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     rc.slots_per_lane = w.n_tiles * 64u;
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
-    std::vector<hipEvent_t> evs;
+    std::vector<hipEvent_t> evs, ev_triples;
     auto new_event = [&]() -> hipEvent_t {
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
@@ -551,15 +551,20 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
             int cur = 0;
             const uint32_t max_rounds = p->spp_per_frame * p->max_depth;  // every sample at full depth
             uint32_t h_count = 1;
+            hipEvent_t e_prev = profile ? new_event() : nullptr;  // one event between consecutive kernels
             for (uint32_t round = 0; round < max_rounds; round++) {
-                hipEvent_t e0 = profile ? new_event() : nullptr;
                 launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, &w.d_count[cur], &w.d_count[cur ^ 1], ctx->d_stats,
                               p->tmin, p->tmax, st);
                 hipEvent_t e1 = profile ? new_event() : nullptr;
                 k_shade<<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, w.d_color, qv[cur], qv[cur ^ 1],
                                                    &w.d_count[cur], &w.d_count[cur ^ 1]);
                 hipEvent_t e2 = profile ? new_event() : nullptr;
-                (void)e0; (void)e1; (void)e2;
+                if (profile) {
+                    ev_triples.push_back(e_prev);
+                    ev_triples.push_back(e1);
+                    ev_triples.push_back(e2);
+                    e_prev = e2;
+                }
                 ctx->stats.launches_extend++;
                 ctx->stats.launches_shade++;
                 ctx->stats.rounds++;
@@ -592,10 +597,10 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
         ctx->stats.paths += valid * p->spp_per_frame * p->frame_count;
     }
     if (profile) {
-        for (size_t i = 0; i + 2 < evs.size(); i += 3) {
+        for (size_t i = 0; i + 2 < ev_triples.size(); i += 3) {
             float a = 0.f, b = 0.f;
-            (void)hipEventElapsedTime(&a, evs[i], evs[i + 1]);
-            (void)hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]);
+            (void)hipEventElapsedTime(&a, ev_triples[i], ev_triples[i + 1]);
+            (void)hipEventElapsedTime(&b, ev_triples[i + 1], ev_triples[i + 2]);
             ctx->stats.ms_extend += a;
             ctx->stats.ms_shade += b;
         }
