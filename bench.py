@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm"], default="auto", help="closest-hit kernel variant")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -94,7 +95,8 @@ def main():
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
     flags = 0 if args.no_kernel_events else pt.FLAG_PROFILE
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
-                  frames_in_flight=args.frames_in_flight)
+                  frames_in_flight=args.frames_in_flight,
+                  extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM}[args.extend])
 
     def barrier():
         if world > 1:
@@ -151,7 +153,7 @@ def main():
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
-                    "build_ms": round(info.build_ms, 3), "extend_variant": "lds-resident scene" if st.extend_variant == 0 else "hbm/l2 scene"},
+                    "build_ms": round(info.build_ms, 3), "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant, str(st.extend_variant))},
         }
         if rays_minmax:
             out["rays_per_rank_min_max"] = rays_minmax
@@ -168,7 +170,7 @@ def main():
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_extend<16,lds>" if st.extend_variant == 0 else "k_extend<*,hbm>",
+                "bound": "hbm", "kernel": {1: "k_extend_flat", 2: "k_extend<STACK,lds>", 3: "k_extend<STACK,hbm>"}.get(st.extend_variant, "?"),
                 "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "launches": st.launches_extend,

@@ -93,6 +93,14 @@ void pt_film_destroy(pt_film *film);
 /* ---- dispatch: pushConstants + traceRaysKHR (main.cpp:656-659) ------------------------- */
 enum { PT_PIPELINE_WAVEFRONT = 0 /* generate / extend / shade queues */ };
 enum { PT_FLAG_PROFILE = 1u /* hipEvent-time every extend/shade launch (adds events to the stream) */ };
+/* Which closest-hit kernel runs.  All variants implement the same closest-hit definition and
+ * return identical bits; AUTO picks by scene size. */
+enum {
+    PT_EXTEND_AUTO = 0,
+    PT_EXTEND_FLAT = 1, /* <= 64 triangles: the scene is one wide leaf, scanned wave-uniformly (SGPR stream) */
+    PT_EXTEND_LDS = 2,  /* LBVH + triangles staged in LDS, per-lane short stack in LDS                      */
+    PT_EXTEND_HBM = 3   /* LBVH + triangles read through L1/L2/MALL from HBM, short stack in LDS            */
+};
 
 typedef struct pt_params {
     int32_t  frame;            /* push constant `frame` (main.cpp:658, raygen.rgen:8-10): first frame */
@@ -108,6 +116,7 @@ typedef struct pt_params {
     uint32_t pipeline;         /* PT_PIPELINE_*                                                        */
     uint32_t frames_in_flight; /* frames traced concurrently (0 = auto); results do not depend on it   */
     uint32_t flags;            /* PT_FLAG_*                                                            */
+    uint32_t extend;           /* PT_EXTEND_*                                                          */
 } pt_params;
 void pt_params_default(pt_params *p); /* the reference's compile-time constants, 1024x1024, world 1 */
 
@@ -125,7 +134,7 @@ typedef struct pt_hit {
 /* rays6: host array n x {origin.xyz, direction.xyz}; hits: host array of n.  Runs the same
  * extend kernel the renderer uses (opaque, no culling, tmin < t < tmax).                   */
 pt_status pt_trace(pt_scene *scene, const float *rays6, uint32_t n, float tmin, float tmax,
-                   pt_hit *hits);
+                   uint32_t extend /* PT_EXTEND_* */, pt_hit *hits);
 
 /* ---- statistics ------------------------------------------------------------------------ */
 typedef struct pt_stats {
@@ -135,7 +144,7 @@ typedef struct pt_stats {
     uint32_t launches_extend, launches_shade, launches_other;
     float    ms_total;         /* device time of pt_render calls (first kernel .. last kernel)      */
     float    ms_extend, ms_shade; /* summed kernel times; only with PT_FLAG_PROFILE                 */
-    uint32_t extend_variant;   /* 0 = BVH+triangles staged in LDS, 1 = read through L1/L2 from HBM */
+    uint32_t extend_variant;   /* PT_EXTEND_* that actually ran                                     */
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

@@ -27,6 +27,8 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "
                 5: "PT_ERR_UNSUPPORTED"}
 PIPELINE_WAVEFRONT = 0
 FLAG_PROFILE = 1
+EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM = 0, 1, 2, 3
+EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "LBVH, scene staged in LDS", 3: "LBVH, scene in HBM/L2"}
 MISS = 0xFFFFFFFF
 
 
@@ -42,7 +44,7 @@ class Params(C.Structure):
         ("spp_per_frame", C.c_uint32), ("max_depth", C.c_uint32), ("tmin", C.c_float), ("tmax", C.c_float),
         ("cam_origin", C.c_float * 3), ("cam_target", C.c_float * 3), ("env", C.c_float * 3),
         ("rank", C.c_uint32), ("world", C.c_uint32), ("pipeline", C.c_uint32),
-        ("frames_in_flight", C.c_uint32), ("flags", C.c_uint32),
+        ("frames_in_flight", C.c_uint32), ("flags", C.c_uint32), ("extend", C.c_uint32),
     ]
 
 
@@ -114,7 +116,7 @@ def lib_amd():
         L.pt_params_default.argtypes = [C.POINTER(Params)]
         L.pt_params_default.restype = None
         L.pt_render.argtypes = [vp, vp, C.POINTER(Params)]
-        L.pt_trace.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, vp]
+        L.pt_trace.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, vp]
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_reset_stats.argtypes = [vp]
         _amd = L
@@ -256,11 +258,11 @@ class Scene:
         self.ctx._check(lib_amd().pt_scene_read_bvh(self.h, keys.ctypes.data, prim.ctypes.data, nodes.ctypes.data))
         return keys, prim, nodes
 
-    def trace(self, rays6, tmin=0.001, tmax=10000.0):
+    def trace(self, rays6, tmin=0.001, tmax=10000.0, extend=EXTEND_AUTO):
         """Closest-hit query alone (traceRayEXT, raygen.rgen:63-75)."""
         r = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
         hits = np.zeros(r.shape[0], dtype=HIT_DTYPE)
-        self.ctx._check(lib_amd().pt_trace(self.h, r.ctypes.data, r.shape[0], tmin, tmax, hits.ctypes.data))
+        self.ctx._check(lib_amd().pt_trace(self.h, r.ctypes.data, r.shape[0], tmin, tmax, extend, hits.ctypes.data))
         return hits
 
     def close(self):

@@ -199,6 +199,7 @@ void pt_params_default(pt_params *p)
     p->pipeline = PT_PIPELINE_WAVEFRONT;
     p->frames_in_flight = 0;
     p->flags = 0;
+    p->extend = PT_EXTEND_AUTO;
 }
 
 pt_status pt_render(pt_scene *s, pt_film *f, const pt_params *p)
@@ -209,12 +210,12 @@ pt_status pt_render(pt_scene *s, pt_film *f, const pt_params *p)
     return ptw_render(s, f, p);
 }
 
-pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, pt_hit *hits)
+pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits)
 {
     if (!s) return PT_ERR_INVALID_ARG;
     if (n && (!rays6 || !hits)) { s->ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    return ptw_trace(s, rays6, n, tmin, tmax, hits);
+    return ptw_trace(s, rays6, n, tmin, tmax, extend, hits);
 }
 
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)

@@ -78,5 +78,5 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
                           uint32_t n_tris, const float *h_faces);
 // wavefront.hip
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);
-pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, pt_hit *hits);
+pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits);
 void ptw_free_work(pt_film *f);

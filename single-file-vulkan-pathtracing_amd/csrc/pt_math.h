@@ -180,9 +180,12 @@ __device__ __forceinline__ RayPre ray_setup(const f3 org, const f3 dir)
     return r;
 }
 
-// Tests one triangle; on a hit inside (tmin, tmax) returns true with t,u,v.
+// Tests one triangle; on a hit inside (tmin, tmax) returns true with t and the UNDIVIDED
+// barycentric numerators V, W and det: u = V/det (weight of v1 = attribs.x), v = W/det (weight of
+// v2 = attribs.y).  The two divides are deferred to the hit that finally wins (same operands,
+// same bits, fewer IEEE divides).
 __device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 v1, const f3 v2, float tmin,
-                                         float tmax, float &t, float &u, float &v)
+                                         float tmax, float &t, float &Vn, float &Wn, float &detn)
 {
     const f3 A = { v0.x - r.org.x, v0.y - r.org.y, v0.z - r.org.z };
     const f3 B = { v1.x - r.org.x, v1.y - r.org.y, v1.z - r.org.z };
@@ -206,8 +209,9 @@ __device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 
     const float tt = fdiv(T, det);
     if (!(tt > tmin && tt < tmax)) return false;  // tMin < t < tMax, NaN rejects
     t = tt;
-    u = fdiv(V, det);  // weight of v1 = attribs.x
-    v = fdiv(W, det);  // weight of v2 = attribs.y
+    Vn = V;
+    Wn = W;
+    detn = det;
     return true;
 }
 

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_node
         const ptm::RayPre pre = ptm::ray_setup(org, dir);
         const ptm::f3 inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
 
-        float best_t = tmax, best_u = 0.f, best_v = 0.f;
+        float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
         uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
         uint32_t ref = 0u;  // root
         int sp = 0;
@@ -197,19 +197,61 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_node
             if (ref == SENTINEL) break;
             const uint32_t pos = ref & ~PT_LEAF;
             const float4 a = tri4[3 * pos + 0], b = tri4[3 * pos + 1], c = tri4[3 * pos + 2];
-            float t, u, v;
-            if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, u, v)) {
+            float t, V, W, det;
+            if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
                 const uint32_t prim = __float_as_uint(a.w);
                 // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
                 if (t < best_t || (t == best_t && prim < best_prim)) {
-                    best_t = t; best_u = u; best_v = v; best_pos = pos; best_prim = prim;
+                    best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
                 }
             }
             if (sp == 0) break;
             sp--;
             ref = my_stack[sp * TB];
         }
-        hit[q] = make_float4(__uint_as_float(best_pos), best_pos == PT_MISS ? 0.f : best_t, best_u, best_v);
+        const bool miss = best_pos == PT_MISS;
+        hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t, miss ? 0.f : ptm::fdiv(best_V, best_det),
+                             miss ? 0.f : ptm::fdiv(best_W, best_det));
+    }
+}
+
+// ---- extend, flat variant: the whole scene is ONE wide leaf ------------------------------------
+// For scenes of a few dozen triangles (the Cornell box has 36) a tree only adds divergence: rays
+// of a wave take different branches and the wave pays for the union.  Here every lane tests every
+// triangle in the same order, so the triangle stream is wave-uniform: it comes through the scalar
+// cache into SGPRs (s_load), there is no stack, no LDS traffic and no divergent control flow
+// except the rare "some lane passed the edge test" tail.  Same closest-hit definition, same bits.
+__global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ tri4, uint32_t n_tris,
+                                                    const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
+                                                    float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
+                                                    uint32_t *count_zero, unsigned long long *stats, float tmin,
+                                                    float tmax)
+{
+    const uint32_t n = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (count_zero) *count_zero = 0u;
+        if (stats) atomicAdd(stats, (unsigned long long)n);
+    }
+    for (uint32_t base = blockIdx.x * TB; base < n; base += gridDim.x * TB) {
+        const uint32_t q = min(base + threadIdx.x, n - 1u);  // tail lanes redo the last ray (same value stored)
+        const float4 ra = rayA[q];
+        const float2 rb = rayB[q];
+        const ptm::RayPre pre = ptm::ray_setup({ ra.x, ra.y, ra.z }, { ra.w, rb.x, rb.y });
+        float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
+        uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
+        for (uint32_t i = 0; i < n_tris; i++) {
+            const float4 a = tri4[3 * i + 0], b = tri4[3 * i + 1], c = tri4[3 * i + 2];  // uniform address
+            float t, V, W, det;
+            if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
+                const uint32_t prim = __float_as_uint(a.w);
+                if (t < best_t || (t == best_t && prim < best_prim)) {
+                    best_t = t; best_V = V; best_W = W; best_det = det; best_pos = i; best_prim = prim;
+                }
+            }
+        }
+        const bool miss = best_pos == PT_MISS;
+        hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t, miss ? 0.f : ptm::fdiv(best_V, best_det),
+                             miss ? 0.f : ptm::fdiv(best_W, best_det));
     }
 }
 
@@ -383,6 +425,7 @@ __global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ h
 
 // ---- host side ------------------------------------------------------------------------------
 struct ExtendPlan {
+    uint32_t variant = PT_EXTEND_LDS;  // PT_EXTEND_FLAT / _LDS / _HBM
     int stack = 16;
     bool lds_scene = false;
     size_t smem = 0;
@@ -399,16 +442,28 @@ ExtendFn extend_fn(int stack, bool lds)
     return lds ? k_extend<64, true> : k_extend<64, false>;
 }
 
-pt_status plan_extend(pt_scene *s, ExtendPlan &pl)
+pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
+    if (want > PT_EXTEND_HBM) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
+    if (want == PT_EXTEND_FLAT && s->n_tris > 1024) { ctx->err = "flat extend variant needs <= 1024 triangles"; return PT_ERR_UNSUPPORTED; }
+    if (want == PT_EXTEND_FLAT || (want == PT_EXTEND_AUTO && s->n_tris <= 64)) {
+        pl.variant = PT_EXTEND_FLAT;
+        pl.smem = 0;
+        int per_cu = 0;
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_extend_flat), TB, 0));
+        pl.grid = ctx->num_cus * std::max(1, std::min(per_cu, 8));
+        return PT_OK;
+    }
     if (s->height > 64) {
         ctx->err = "LBVH height " + std::to_string(s->height) + " exceeds the 64-entry traversal stack";
         return PT_ERR_UNSUPPORTED;
     }
     pl.stack = s->height <= 16 ? 16 : (s->height <= 32 ? 32 : 64);
     const size_t scene_bytes = sizeof(float4) * (4 * (size_t)s->n_nodes + 3 * (size_t)s->n_tris);
-    pl.lds_scene = scene_bytes <= 24 * 1024;
+    if (want == PT_EXTEND_LDS && scene_bytes > 96 * 1024) { ctx->err = "scene does not fit LDS"; return PT_ERR_UNSUPPORTED; }
+    pl.lds_scene = want == PT_EXTEND_LDS || (want == PT_EXTEND_AUTO && scene_bytes <= 24 * 1024);
+    pl.variant = pl.lds_scene ? PT_EXTEND_LDS : PT_EXTEND_HBM;
     pl.smem = (size_t)pl.stack * TB * 4 + (pl.lds_scene ? scene_bytes : 0);
     ExtendFn fn = extend_fn(pl.stack, pl.lds_scene);
     if (pl.smem > 48 * 1024)
@@ -425,6 +480,10 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
                    const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats, float tmin, float tmax,
                    hipStream_t st)
 {
+    if (pl.variant == PT_EXTEND_FLAT) {
+        k_extend_flat<<<pl.grid, TB, 0, st>>>(s->d_tri4, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, tmin, tmax);
+        return;
+    }
     ExtendFn fn = extend_fn(pl.stack, pl.lds_scene);
     hipLaunchKernelGGL(fn, dim3(pl.grid), dim3(TB), pl.smem, st, s->d_nodes, s->d_tri4, s->n_nodes, s->n_tris, rayA, rayB,
                        hit, count_in, count_zero, stats, tmin, tmax);
@@ -499,7 +558,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     if (p->pipeline != PT_PIPELINE_WAVEFRONT) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
 
     ExtendPlan pl;
-    pt_status rc_ = plan_extend(s, pl);
+    pt_status rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
 
     // frames in flight: enough slots to fill the chip several times over, bounded by memory
@@ -537,7 +596,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     QueueView qv[2];
     for (int i = 0; i < 2; i++) qv[i] = { w.d_qslot[i], w.d_qctr[i], w.d_qstate[i], w.d_qrayA[i], w.d_qrayB[i] };
 
-    ctx->stats.extend_variant = pl.lds_scene ? 0u : 1u;
+    ctx->stats.extend_variant = pl.variant;
     PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     if (w.n_slots > 0) {
         for (uint32_t done = 0; done < p->frame_count; done += lanes) {
@@ -609,13 +668,13 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     return PT_OK;
 }
 
-pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, pt_hit *hits)
+pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits)
 {
     pt_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
     if (n == 0) return PT_OK;
     ExtendPlan pl;
-    pt_status rc_ = plan_extend(s, pl);
+    pt_status rc_ = plan_extend(s, extend, pl);
     if (rc_ != PT_OK) return rc_;
     std::vector<float4> a(n);
     std::vector<float2> b(n);

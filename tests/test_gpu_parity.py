@@ -71,9 +71,10 @@ def test_trace_primary_rays_bit_exact(pt, orc, cornell_gpu, cornell_oracle):
         for x in range(256):
             o, d, _ = orc.primary_ray(p, x, y, orc.seed(x, y, 0, 0))
             rays[y * 256 + x] = np.concatenate([o, d])
-    hits = cornell_gpu.trace(rays)
     ohits, _ = cornell_oracle.trace(rays, mode=0)
-    assert hits.tobytes() == ohits.tobytes()
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_FLAT, pt.EXTEND_LDS, pt.EXTEND_HBM):
+        hits = cornell_gpu.trace(rays, extend=variant)
+        assert hits.tobytes() == ohits.tobytes(), variant
     prim = hits["prim"].astype(np.int64)
     prim[prim == pt.MISS] = 255
     assert (prim.reshape(256, 256) == g["first_prim"]).all()
@@ -92,9 +93,12 @@ def test_trace_random_rays_soup_bit_exact(pt, orc, gpu_ctx):
     d[np.arange(30), np.arange(30) % 3] = np.where(np.arange(30) % 2, 1, -1)  # axis-aligned
     d[30] = np.nan
     rays = np.concatenate([org, d.astype(np.float32)], 1)
-    hits = gs.trace(rays)
     ohits, _ = osc.trace(rays, mode=1)
-    assert hits.tobytes() == ohits.tobytes()
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_HBM):
+        hits = gs.trace(rays, extend=variant)
+        assert hits.tobytes() == ohits.tobytes()
+    with pytest.raises(pt.PtError):
+        gs.trace(rays, extend=pt.EXTEND_FLAT)      # 20000 triangles are not "one leaf"
     assert 0.2 < (hits["prim"] != pt.MISS).mean() < 1.0
     assert gs.trace(rays[:0]).size == 0  # empty batch
     gs.close()
@@ -127,6 +131,21 @@ def test_progressive_render_bit_exact(pt, orc, gpu_ctx, cornell_gpu, cornell_ora
     st = gpu_ctx.stats()
     assert st.rays == orays
     assert st.paths == w * h * spp * frames
+    assert film.read_f32().tobytes() == ofilm.tobytes()
+    assert film.read_bgra8().tobytes() == obgra.tobytes()
+    film.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_every_extend_variant_renders_the_same_bits(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle, variant):
+    kw = dict(width=72, height=56, spp_per_frame=6, max_depth=8)
+    film = pt.Film(gpu_ctx, 72, 56)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, extend=variant, **kw))
+    st = gpu_ctx.stats()
+    assert st.extend_variant == variant
+    ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 2, **kw)
+    assert st.rays == orays
     assert film.read_f32().tobytes() == ofilm.tobytes()
     assert film.read_bgra8().tobytes() == obgra.tobytes()
     film.close()
@@ -183,7 +202,7 @@ def test_soup_render_bit_exact_global_memory_variant(pt, orc, gpu_ctx):
     gpu_ctx.reset_stats()
     pt.render(gs, film, pt.default_params(width=96, height=96, spp_per_frame=4, max_depth=6, frame_count=2))
     st = gpu_ctx.stats()
-    assert st.extend_variant == 1
+    assert st.extend_variant == pt.EXTEND_HBM
     ofilm, obgra, orays = _render_oracle(orc, osc, 2, width=96, height=96, spp_per_frame=4, max_depth=6)
     assert st.rays == orays
     assert film.read_f32().tobytes() == ofilm.tobytes()

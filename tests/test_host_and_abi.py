@@ -111,7 +111,7 @@ def test_abi_exports_every_declared_symbol(pt):
 
 def test_struct_layouts_match_header(pt):
     import ctypes as C
-    assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 5
+    assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 6
     assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4
     assert C.sizeof(pt.SceneInfo) == 4 * 3 + 4 * 6 + 4 + 8
     p = pt.default_params()
