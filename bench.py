@@ -33,21 +33,22 @@ BYTES_SHADE = 104.0
 BYTES_PER_PATH = 96.0
 
 
-def cpu_baseline(pt, width, height, depth):
+def cpu_baseline(arrays, name, width, height, spp, depth):
     """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
-    bounded sample of the same workload: the same image at 4 spp, all cores."""
+    bounded sample of the same workload: the same image at a few spp, all cores.  Also returns
+    the instrumented traversal counts (child boxes tested, triangles tested per ray) of the
+    same LBVH the GPU builds -- the input of the scene-gather term of the algorithmic bytes."""
     from oracle import pt_oracle as orc
-    v, i, f = pt.load_obj(pt.ASSET_CORNELL)
-    osc = orc.Scene(v, i, f)
+    osc = orc.Scene(*arrays)
     cores = os.cpu_count() or 1
-    spp = 4
     p = orc.default_params(width=width, height=height, spp_per_frame=spp, max_depth=depth)
     t0 = time.perf_counter()
-    _, rays, _, _ = osc.render_frame(p, mode=1, nthreads=cores)
+    _, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"CornellBox-Original {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
+    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
                       f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads"}
+    return base, cnt.nodes_visited / max(rays, 1), cnt.tris_tested / max(rays, 1)
 
 
 def main():
@@ -57,8 +58,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=32)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--config", choices=["c2", "c5"], default="c2",
+                    help="c2 = Cornell box (the headline), c5 = 1M-triangle soup, 16 spp/frame, depth 16")
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--soup-tris", type=int, default=1000000)
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm"], default="auto", help="closest-hit kernel variant")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
@@ -87,9 +91,27 @@ def main():
     ptd = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
 
     W, H = args.width, args.height
+    if args.config == "c5":
+        args.spp = args.spp or 16
+        args.depth = args.depth or 16
+        obj = f"/tmp/pt_soup_{args.soup_tris}_rank{rank}.obj"     # generated, not committed (139 MB of text)
+        t0 = time.perf_counter()
+        pt.write_soup_obj(obj, args.soup_tris, 1)
+        t1 = time.perf_counter()
+        arrays = pt.load_obj(obj)
+        ingest = {"generate_s": round(t1 - t0, 3), "load_obj_s": round(time.perf_counter() - t1, 3),
+                  "obj_bytes": os.path.getsize(obj)}
+        os.remove(obj)
+        scene_name = f"soup {args.soup_tris} triangles (PCG seed 1)"
+    else:
+        args.spp = args.spp or 32
+        args.depth = args.depth or 8
+        arrays = pt.load_obj(pt.ASSET_CORNELL)
+        ingest = None
+        scene_name = "CornellBox-Original.obj"
     stream = torch.cuda.current_stream(dev)
     ctx = pt.Context(local_rank, stream=stream.cuda_stream)
-    scene = pt.Scene.from_obj(ctx, pt.ASSET_CORNELL)          # upload + on-device LBVH build (untimed)
+    scene = pt.Scene(ctx, *arrays)          # upload + on-device LBVH build (untimed, reported apart)
     info = scene.info()
     film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # torch owns the film: RCCL reduces it in place
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
@@ -136,7 +158,8 @@ def main():
     if rank == 0:
         mean_len = rays_total / max(paths_total, 1)
         out = {
-            "metric": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)",
+            "metric": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)" if args.config == "c2"
+                      else "Mrays/s, 1M-triangle soup 1920x1080 @ 16 bounces (BASELINE config C5)",
             "value": round(rays_total / dt / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,8 +168,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "CornellBox-Original.obj (the reference's own scene, 36 triangles); rays are generated on device",
-            "config": {"workload": f"C2: CornellBox-Original.obj {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
+            "data": ("CornellBox-Original.obj (the reference's own scene, 36 triangles)" if args.config == "c2" else
+                     "synthetic triangle soup (generator pth_write_soup_obj, seed 1), written as OBJ+MTL and parsed by the host loader")
+                    + "; rays are generated on device",
+            "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
                                    f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" + (", RCCL reduce to rank 0" if world > 1 else ""),
                        "frames_in_flight": args.frames_in_flight or "auto"},
@@ -157,13 +182,26 @@ def main():
         }
         if rays_minmax:
             out["rays_per_rank_min_max"] = rays_minmax
+        if ingest:
+            out["ingest"] = ingest
+        base = None
+        nodes_per_ray = tris_per_ray = 0.0
+        if (not args.no_cpu_baseline and world == 1) or args.config == "c5":
+            if args.config == "c2":
+                base, nodes_per_ray, tris_per_ray = cpu_baseline(arrays, scene_name, W, H, 4, args.depth)
+            else:   # 1/16 of the image area, 1 spp: ~0.5 M rays through the 1M-triangle LBVH
+                base, nodes_per_ray, tris_per_ray = cpu_baseline(arrays, scene_name, W // 4, H // 4, 1, args.depth)
         if flags and st.launches_extend and st.ms_extend > 0:
             # dominant kernel = k_extend (closest-hit traversal).  Algorithmic bytes: 40 B/ray; the
             # 36-triangle scene + LBVH are LDS-resident so there is no scene-gather term.
-            gbs = BYTES_EXTEND * st.rays / (st.ms_extend * 1e-3) / 1e9
-            pipeline_bytes = (BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
+            # scene gather: counted only when the scene exceeds the 32 MiB of L2
+            scene_bytes = info.device_bytes
+            gather = (nodes_per_ray * 32.0 + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
+            bytes_extend = BYTES_EXTEND + gather
+            gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
+            pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
             traffic = None
-            prof = os.path.join(REPO, "profiles", "r01_pmc_extend.json")
+            prof = os.path.join(REPO, "profiles", "r01_pmc_extend.json" if args.config == "c2" else "r01_pmc_extend_c5.json")
             if os.path.exists(prof):
                 try:
                     traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
@@ -175,14 +213,20 @@ def main():
                 "traffic": traffic,
                 "launches": st.launches_extend,
                 "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
-                "algorithmic_bytes_per_launch": round(BYTES_EXTEND * st.rays / st.launches_extend, 1),
+                "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
+                "algorithmic_bytes_per_ray": round(bytes_extend, 1),
+                "gather": {"child_boxes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                           "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
+                           "source": "instrumented oracle on the identical LBVH, sample of the same image"},
                 "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
                 "pipeline_algorithmic_GBps": round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2),
-                "note": "Cornell (<8 KB scene+BVH) is LDS-resident: extend is VALU/LDS-latency bound, HBM sees only "
-                        "queue I/O; the HBM fraction is physically meaningful on config C5 (1M triangles) only",
+                "note": ("Cornell (<8 KB scene+BVH) never leaves SGPRs/LDS: extend is VALU-issue bound, HBM sees only "
+                         "queue I/O; the HBM fraction is physically meaningful on config C5 (1M triangles) only")
+                        if args.config == "c2" else
+                        "scene + LBVH = 160 MB > L2: every node/triangle fetch is a 64/48-B gather through L2/MALL/HBM",
             }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pt, W, H, args.depth)
+        if base and not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
 
     film.close()

@@ -62,7 +62,8 @@ pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts,
 void pt_scene_destroy(pt_scene *scene);
 
 typedef struct pt_scene_info {
-    uint32_t n_tris, n_nodes, bvh_height;
+    uint32_t n_tris, n_nodes /* binary LBVH */, bvh_height /* of the binary LBVH */;
+    uint32_t n_wide_nodes;    /* BVH4 nodes (128 B each) the traversal kernels walk               */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
     uint64_t device_bytes;    /* resident scene + BVH bytes                                     */
@@ -74,6 +75,10 @@ pt_status pt_scene_get_info(const pt_scene *scene, pt_scene_info *info);
  * leaf (sorted position).  Any pointer may be NULL.                                         */
 pt_status pt_scene_read_bvh(const pt_scene *scene, uint64_t *keys, uint32_t *prim_of_pos,
                             uint32_t *nodes16);
+/* The BVH4 collapsed from it: n_wide_nodes x 32 dwords {lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
+ * hi.z[4] child[4] 0[4]}; child = 0xFFFFFFFF empty | node index | bit31: leaf,
+ * (count-1)<<28 | first sorted position.                                                     */
+pt_status pt_scene_read_bvh4(const pt_scene *scene, uint32_t *nodes32);
 
 /* ---- film: descriptor binding 1 (raygen.rgen:7, main.cpp:481-484) ---------------------- */
 /* float32 running-mean radiance (the canonical result) plus the reference's rgba8 display

@@ -50,7 +50,7 @@ class Params(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_height", C.c_uint32),
-                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
+                ("n_wide_nodes", C.c_uint32), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
                 ("device_bytes", C.c_uint64)]
 
 
@@ -70,7 +70,7 @@ HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")]
 
 # every symbol include/pt_api.h and include/pt_host.h declare
 API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "pt_scene_create", "pt_scene_destroy",
-               "pt_scene_get_info", "pt_scene_read_bvh", "pt_film_create", "pt_film_create_external", "pt_film_clear",
+               "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_film_create", "pt_film_create_external", "pt_film_clear",
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render", "pt_trace",
                "pt_get_stats", "pt_reset_stats"]
 HOST_SYMBOLS = ["pth_load_obj", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj"]
@@ -106,6 +106,7 @@ def lib_amd():
         L.pt_scene_destroy.restype = None
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.pt_scene_read_bvh.argtypes = [vp, vp, vp, vp]
+        L.pt_scene_read_bvh4.argtypes = [vp, vp]
         L.pt_film_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.pt_film_create_external.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(vp)]
         L.pt_film_clear.argtypes = [vp]
@@ -257,6 +258,11 @@ class Scene:
         nodes = np.zeros((i.n_nodes, 16), dtype=np.uint32)
         self.ctx._check(lib_amd().pt_scene_read_bvh(self.h, keys.ctypes.data, prim.ctypes.data, nodes.ctypes.data))
         return keys, prim, nodes
+
+    def read_bvh4(self):
+        nodes = np.zeros((self.info().n_wide_nodes, 32), dtype=np.uint32)
+        self.ctx._check(lib_amd().pt_scene_read_bvh4(self.h, nodes.ctypes.data))
+        return nodes
 
     def trace(self, rays6, tmin=0.001, tmax=10000.0, extend=EXTEND_AUTO):
         """Closest-hit query alone (traceRayEXT, raygen.rgen:63-75)."""

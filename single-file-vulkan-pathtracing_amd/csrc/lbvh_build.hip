@@ -230,7 +230,7 @@ __device__ __forceinline__ int kdelta(const unsigned long long *__restrict__ key
 
 __global__ __launch_bounds__(TB) void k_karras(const unsigned long long *__restrict__ keys, int n,
                                                uint2 *__restrict__ topo, uint32_t *__restrict__ parent_int,
-                                               uint32_t *__restrict__ parent_leaf)
+                                               uint32_t *__restrict__ parent_leaf, uint2 *__restrict__ range)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
     if (i >= n - 1) return;
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(TB) void k_karras(const unsigned long long *__restr
     if (hi == gamma + 1) { right = PT_LEAF | (uint32_t)(gamma + 1); parent_leaf[gamma + 1] = (uint32_t)i; }
     else { right = (uint32_t)(gamma + 1); parent_int[gamma + 1] = (uint32_t)i; }
     topo[i] = make_uint2(left, right);
+    range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);  // sorted positions covered by this node
 }
 
 // leaf pad = 2^-18 of the scene scale: keeps the slab test conservative w.r.t. the rounded
@@ -325,6 +326,111 @@ __global__ void k_single(const float4 *__restrict__ tlo, const float4 *__restric
     *height_out = 1u;
 }
 
+
+// 7. BVH4 collapse.  Binary nodes at even depth whose subtree holds more than PT_LEAF_MAX triangles
+// become wide nodes; their internal children (odd depth) are absorbed, so a wide node holds the
+// up-to-4 grandchildren.  Any binary subtree with <= PT_LEAF_MAX triangles becomes ONE leaf child
+// (its triangles are contiguous in sorted order): child word = LEAF | (count-1)<<28 | first.
+// Wide node = 128 B = one gfx950 L2 line: 6 float4 {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]}
+// {hi.z[4]}, 1 uint4 children (0xFFFFFFFF = empty slot, box lo = hi = +inf: never hit), 1 spare.
+__device__ __forceinline__ bool leaf_like(uint32_t ref, const uint2 *__restrict__ range)
+{
+    if (ref & PT_LEAF) return true;
+    const uint2 r = range[ref];
+    return r.y - r.x + 1u <= PT_LEAF_MAX;
+}
+
+__global__ __launch_bounds__(TB) void k_wide_flag(int n_int, const uint32_t *__restrict__ parent_int,
+                                                  const uint2 *__restrict__ range, uint32_t *__restrict__ flag)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n_int) return;
+    uint32_t depth = 0;
+    for (uint32_t a = (uint32_t)i; a != 0u; a = parent_int[a]) depth++;
+    const uint2 r = range[i];
+    const bool big = r.y - r.x + 1u > PT_LEAF_MAX;
+    flag[i] = (i == 0 || (big && (depth & 1u) == 0u)) ? 1u : 0u;
+}
+
+__device__ __forceinline__ void wide_child(uint32_t ref, int n, const uint2 *__restrict__ range,
+                                           const uint32_t *__restrict__ widx, const float4 *__restrict__ box_lo,
+                                           const float4 *__restrict__ box_hi, uint32_t &word, float4 &lo, float4 &hi)
+{
+    if (ref & PT_LEAF) {
+        const uint32_t pos = ref & ~PT_LEAF;
+        word = PT_LEAF | pos;  // count 1
+        lo = box_lo[pos];
+        hi = box_hi[pos];
+        return;
+    }
+    const uint2 r = range[ref];
+    const uint32_t cnt = r.y - r.x + 1u;
+    word = cnt <= PT_LEAF_MAX ? (PT_LEAF | ((cnt - 1u) << 28) | r.x) : widx[ref];
+    lo = box_lo[(size_t)n + ref];
+    hi = box_hi[(size_t)n + ref];
+}
+
+__global__ __launch_bounds__(TB) void k_wide_emit(int n, int n_int, const uint2 *__restrict__ topo,
+                                                  const uint2 *__restrict__ range, const uint32_t *__restrict__ flag,
+                                                  const uint32_t *__restrict__ widx, const float4 *__restrict__ box_lo,
+                                                  const float4 *__restrict__ box_hi, float4 *__restrict__ wide)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n_int || !flag[i]) return;
+    uint32_t word[4] = { PT_MISS, PT_MISS, PT_MISS, PT_MISS };
+    float4 lo[4], hi[4];
+    for (int k = 0; k < 4; k++) {
+        lo[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);  // empty slot: lo = hi = +inf, every slab
+        hi[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);  // test sees an empty interval
+    }
+    int m = 0;
+    if (leaf_like((uint32_t)i, range)) {  // tiny scene: the root itself is one leaf
+        wide_child((uint32_t)i, n, range, widx, box_lo, box_hi, word[0], lo[0], hi[0]);
+        m = 1;
+    } else {
+        const uint2 ch = topo[i];
+        const uint32_t c2[2] = { ch.x, ch.y };
+        for (int a = 0; a < 2; a++) {
+            if (leaf_like(c2[a], range)) {
+                wide_child(c2[a], n, range, widx, box_lo, box_hi, word[m], lo[m], hi[m]);
+                m++;
+            } else {  // absorbed odd-depth node: its two children move up
+                const uint2 g = topo[c2[a]];
+                wide_child(g.x, n, range, widx, box_lo, box_hi, word[m], lo[m], hi[m]);
+                m++;
+                wide_child(g.y, n, range, widx, box_lo, box_hi, word[m], lo[m], hi[m]);
+                m++;
+            }
+        }
+    }
+    float4 *dst = wide + 8 * (size_t)widx[i];
+    dst[0] = make_float4(lo[0].x, lo[1].x, lo[2].x, lo[3].x);
+    dst[1] = make_float4(lo[0].y, lo[1].y, lo[2].y, lo[3].y);
+    dst[2] = make_float4(lo[0].z, lo[1].z, lo[2].z, lo[3].z);
+    dst[3] = make_float4(hi[0].x, hi[1].x, hi[2].x, hi[3].x);
+    dst[4] = make_float4(hi[0].y, hi[1].y, hi[2].y, hi[3].y);
+    dst[5] = make_float4(hi[0].z, hi[1].z, hi[2].z, hi[3].z);
+    dst[6] = make_float4(__uint_as_float(word[0]), __uint_as_float(word[1]), __uint_as_float(word[2]),
+                         __uint_as_float(word[3]));
+    dst[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// n == 1: one wide node with a single one-triangle leaf
+__global__ void k_wide_single(const float4 *__restrict__ nodes, float4 *__restrict__ wide)
+{
+    const float4 n0 = nodes[0], n1 = nodes[1];
+    const float inf = INFINITY;
+    wide[0] = make_float4(n0.x, inf, inf, inf);
+    wide[1] = make_float4(n0.y, inf, inf, inf);
+    wide[2] = make_float4(n0.z, inf, inf, inf);
+    wide[3] = make_float4(n0.w, inf, inf, inf);
+    wide[4] = make_float4(n1.x, inf, inf, inf);
+    wide[5] = make_float4(n1.y, inf, inf, inf);
+    wide[6] = make_float4(__uint_as_float(PT_LEAF | 0u), __uint_as_float(PT_MISS), __uint_as_float(PT_MISS),
+                          __uint_as_float(PT_MISS));
+    wide[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // 6. leaf-ordered records
 __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig, const float *__restrict__ faces,
                                              const uint32_t *__restrict__ prim_of, uint32_t n,
@@ -369,7 +475,8 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     DevBuf<uint32_t> d_idx, d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height;
     DevBuf<float4> d_tri_orig, d_tlo, d_thi, d_blo, d_bhi;
     DevBuf<unsigned long long> d_keys[2];
-    DevBuf<uint2> d_topo;
+    DevBuf<uint2> d_topo, d_range;
+    DevBuf<uint32_t> d_wflag, d_widx;
     const uint32_t nblocks = (n + RS_TILE - 1) / RS_TILE;
 
     PT_HIP(ctx, d_vert.alloc(3 * (size_t)n_verts));
@@ -385,6 +492,9 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     }
     PT_HIP(ctx, d_hist.alloc(256 * (size_t)nblocks));
     PT_HIP(ctx, d_topo.alloc(n));
+    PT_HIP(ctx, d_range.alloc(n));
+    PT_HIP(ctx, d_wflag.alloc(n));
+    PT_HIP(ctx, d_widx.alloc(n));
     PT_HIP(ctx, d_pint.alloc(n));
     PT_HIP(ctx, d_pleaf.alloc(n));
     PT_HIP(ctx, d_flags.alloc(n));
@@ -399,7 +509,6 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipMalloc((void **)&s->d_nodes, sizeof(float4) * 4 * (size_t)s->n_nodes));
     PT_HIP(ctx, hipMalloc((void **)&s->d_keys, sizeof(unsigned long long) * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of, sizeof(uint32_t) * (size_t)n));
-    s->device_bytes = (sizeof(float4) * 6 + 12) * (uint64_t)n + sizeof(float4) * 4 * (uint64_t)s->n_nodes;
 
     PT_HIP(ctx, hipMemcpyAsync(d_vert.p, h_vertices, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d_idx.p, h_indices, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -425,13 +534,34 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipMemcpyAsync(s->d_prim_of, d_vals[cur].p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
 
     if (n > 1) {
-        k_karras<<<(n - 1 + TB - 1) / TB, TB, 0, st>>>(s->d_keys, (int)n, d_topo.p, d_pint.p, d_pleaf.p);
+        k_karras<<<(n - 1 + TB - 1) / TB, TB, 0, st>>>(s->d_keys, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_range.p);
         k_refit<<<gt, TB, 0, st>>>(d_tlo.p, d_thi.p, s->d_prim_of, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_blo.p, d_bhi.p,
                                    d_flags.p, d_scene.p, s->d_nodes, d_height.p);
     } else {
         k_single<<<1, 1, 0, st>>>(d_tlo.p, d_thi.p, d_scene.p, s->d_nodes, d_height.p);
     }
     k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4);
+    // BVH4 collapse: flag wide roots, number them (exclusive scan), emit 128-B nodes
+    uint32_t n_wide = 1;
+    if (n > 1) {
+        const int n_int = (int)n - 1;
+        const uint32_t gi = (uint32_t)(n_int + TB - 1) / TB;
+        k_wide_flag<<<gi, TB, 0, st>>>(n_int, d_pint.p, d_range.p, d_wflag.p);
+        PT_HIP(ctx, hipMemcpyAsync(d_widx.p, d_wflag.p, sizeof(uint32_t) * (size_t)n_int, hipMemcpyDeviceToDevice, st));
+        k_rs_scan<<<1, 1024, 0, st>>>(d_widx.p, (uint32_t)n_int);
+        uint32_t last_idx = 0, last_flag = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&last_idx, d_widx.p + (n_int - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(&last_flag, d_wflag.p + (n_int - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        n_wide = last_idx + last_flag;
+        PT_HIP(ctx, hipMalloc((void **)&s->d_wide, 128 * (size_t)n_wide));
+        k_wide_emit<<<gi, TB, 0, st>>>((int)n, n_int, d_topo.p, d_range.p, d_wflag.p, d_widx.p, d_blo.p, d_bhi.p, s->d_wide);
+    } else {
+        PT_HIP(ctx, hipMalloc((void **)&s->d_wide, 128));
+        k_wide_single<<<1, 1, 0, st>>>(s->d_nodes, s->d_wide);
+    }
+    s->n_wide = n_wide;
+    s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * n_wide;
     PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     uint32_t ord[6];
     PT_HIP(ctx, hipMemcpyAsync(ord, d_scene.p, sizeof(ord), hipMemcpyDeviceToHost, st));

@@ -55,6 +55,7 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -93,7 +94,7 @@ pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts, 
 void pt_scene_destroy(pt_scene *s)
 {
     if (!s) return;
-    (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes); (void)hipFree(s->d_wide);
     (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
     delete s;
 }
@@ -102,6 +103,7 @@ pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
 {
     if (!s || !info) return PT_ERR_INVALID_ARG;
     info->n_tris = s->n_tris; info->n_nodes = s->n_nodes; info->bvh_height = s->height;
+    info->n_wide_nodes = s->n_wide;
     for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
     info->build_ms = s->build_ms;
     info->device_bytes = s->device_bytes;
@@ -116,6 +118,15 @@ pt_status pt_scene_read_bvh(const pt_scene *s, uint64_t *keys, uint32_t *prim_of
     if (keys) PT_HIP(ctx, hipMemcpy(keys, s->d_keys, sizeof(uint64_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
     if (prim_of_pos) PT_HIP(ctx, hipMemcpy(prim_of_pos, s->d_prim_of, sizeof(uint32_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
     if (nodes16) PT_HIP(ctx, hipMemcpy(nodes16, s->d_nodes, 64 * (size_t)s->n_nodes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_scene_read_bvh4(const pt_scene *s, uint32_t *nodes32)
+{
+    if (!s || !nodes32) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = s->ctx;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide, 128 * (size_t)s->n_wide, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -12,8 +12,10 @@
 // leaves are neighbouring memory.
 //   tri4   : 3 x float4 per triangle  {v0.xyz, bits(prim id)} {v1.xyz, 0} {v2.xyz, 0}       48 B
 //   shade4 : 3 x float4 per triangle  {n.xyz, brdf.r} {brdf.gb, emission.rg} {emission.b,0,0,0} 48 B
-//   nodes  : 4 x float4 per internal node {lmin.xyz,lmax.x} {lmax.yz,rmin.xy} {rmin.z,rmax.xyz}
-//            {bits(left), bits(right), 0, 0}; child bit31 set = leaf at that sorted position    64 B
+//   nodes  : binary LBVH, 4 x float4 per internal node {lmin.xyz,lmax.x} {lmax.yz,rmin.xy}
+//            {rmin.z,rmax.xyz} {bits(left), bits(right), 0, 0}; child bit31 = leaf position       64 B
+//   wide   : BVH4 collapsed from it, 8 x float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
+//            hi.z[4] child[4] spare; leaf child = LEAF | (count-1)<<28 | first sorted position     128 B
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -25,6 +27,8 @@ struct pt_ctx {
     unsigned long long *d_stats = nullptr;
     pt_stats stats{};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    void *d_spill = nullptr;   // HBM overflow of the traversal short stack: [level][thread] uint2
+    size_t spill_bytes = 0;
 };
 
 struct pt_scene {
@@ -34,7 +38,9 @@ struct pt_scene {
     float build_ms = 0.f;
     float4 *d_tri4 = nullptr;
     float4 *d_shade4 = nullptr;
-    float4 *d_nodes = nullptr;
+    float4 *d_nodes = nullptr;            // binary LBVH (parity read-back; the collapse reads it)
+    float4 *d_wide = nullptr;             // BVH4, 8 x float4 = 128 B per node: what traversal walks
+    uint32_t n_wide = 0;
     unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
     uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
     uint64_t device_bytes = 0;

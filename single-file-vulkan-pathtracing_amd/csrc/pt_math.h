@@ -18,6 +18,7 @@
 
 #define PT_MISS 0xFFFFFFFFu
 #define PT_LEAF 0x80000000u
+#define PT_LEAF_MAX 4u  // triangles per BVH4 leaf (count-1 lives in bits 28..30 of a leaf word)
 
 namespace ptm {
 

@@ -126,27 +126,37 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
 
 // ---- extend: closest hit for every queued ray (traceRayEXT, raygen.rgen:63-75) ---------------
 // Persistent grid (gridDim = CUs x resident blocks); each block walks 256-ray chunks of the
-// dense queue.  Per-lane traversal stack lives in LDS as stack[level][thread] (bank = thread, so
-// pushes/pops never conflict).  LDS_SCENE: the whole BVH + triangle array is staged into LDS
-// once per block, traversal then touches no HBM at all.
-template <int STACK, bool LDS_SCENE>
-__global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_nodes, const float4 *__restrict__ g_tri4,
-                                               uint32_t n_nodes, uint32_t n_tris, const float4 *__restrict__ rayA,
+// dense queue, one ray per lane, over the BVH4 (128-B nodes = one L2 line per visit).
+//  * children are visited nearest-first (4-element sorting network on the entry distances);
+//  * stack entries are (child word, entry distance): a popped subtree that now starts behind the
+//    best hit is dropped without touching memory (culling uses <= so equal-t candidates survive
+//    for the deterministic lowest-primitive-id tie-break);
+//  * short stack: the first LDS_STACK entries of every lane live in LDS as stack[level][thread]
+//    (conflict-free), deeper entries spill to a per-thread column in HBM -- LDS use is constant
+//    whatever the tree height, so occupancy is not capped by the scene;
+//  * LDS_SCENE: nodes + triangles are staged into LDS once per persistent block and traversal
+//    touches no HBM at all (scenes up to ~24 KB).
+constexpr int LDS_STACK = 8;
+
+template <bool LDS_SCENE>
+__global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
+                                               uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
-                                               unsigned long long *stats, float tmin, float tmax)
+                                               unsigned long long *stats, uint2 *__restrict__ spill,
+                                               uint32_t spill_stride, float tmin, float tmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *stack = reinterpret_cast<uint32_t *>(smem);
-    const float4 *nodes = g_nodes;
+    uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
+    const float4 *wide = g_wide;
     const float4 *tri4 = g_tri4;
     if (LDS_SCENE) {
-        float4 *s_nodes = reinterpret_cast<float4 *>(smem + (size_t)STACK * TB * 4);
-        float4 *s_tri = s_nodes + 4 * (size_t)n_nodes;
-        for (uint32_t i = threadIdx.x; i < 4 * n_nodes; i += TB) s_nodes[i] = g_nodes[i];
+        float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)LDS_STACK * TB * sizeof(uint2));
+        float4 *s_tri = s_wide + 8 * (size_t)n_wide;
+        for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) s_wide[i] = g_wide[i];
         for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) s_tri[i] = g_tri4[i];
         __syncthreads();
-        nodes = s_nodes;
+        wide = s_wide;
         tri4 = s_tri;
     }
     const uint32_t n = *count_in;
@@ -154,7 +164,9 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_node
         if (count_zero) *count_zero = 0u;  // the queue the coming shade pass appends to
         if (stats) atomicAdd(stats, (unsigned long long)n);  // exact ray count
     }
-    uint32_t *my_stack = stack + threadIdx.x;
+    uint2 *my_stack = stack + threadIdx.x;
+    uint2 *my_spill = spill + (size_t)blockIdx.x * TB + threadIdx.x;
+    const float INF = __builtin_inff();
 
     for (uint32_t base = blockIdx.x * TB; base < n; base += gridDim.x * TB) {
         const uint32_t q = base + threadIdx.x;
@@ -168,46 +180,75 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_node
 
         float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
         uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
-        uint32_t ref = 0u;  // root
+        uint32_t cur = 0u;  // wide root
         int sp = 0;
+        auto push = [&](uint32_t w, float t) {
+            const uint2 e = make_uint2(w, __float_as_uint(t));
+            if (sp < LDS_STACK) my_stack[sp * TB] = e;
+            else my_spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
+            sp++;
+        };
+        auto pop = [&]() -> uint32_t {  // next subtree that can still contain the closest hit
+            while (sp > 0) {
+                sp--;
+                const uint2 e = sp < LDS_STACK ? my_stack[sp * TB] : my_spill[(size_t)(sp - LDS_STACK) * spill_stride];
+                if (__uint_as_float(e.y) <= best_t) return e.x;
+            }
+            return SENTINEL;
+        };
         for (;;) {
-            while (!(ref & PT_LEAF)) {  // descend through internal nodes
-                const float4 n0 = nodes[4 * ref + 0], n1 = nodes[4 * ref + 1], n2 = nodes[4 * ref + 2],
-                             n3 = nodes[4 * ref + 3];
-                float tl, tr;
-                const bool hl = ptm::box_test({ n0.x, n0.y, n0.z }, { n0.w, n1.x, n1.y }, org, inv, tmin, best_t, tl);
-                const bool hr = ptm::box_test({ n1.z, n1.w, n2.x }, { n2.y, n2.z, n2.w }, org, inv, tmin, best_t, tr);
-                const uint32_t cl = __float_as_uint(n3.x), cr = __float_as_uint(n3.y);
-                if (hl && hr) {
-                    const bool swap = tr < tl;
-                    my_stack[sp * TB] = swap ? cl : cr;
-                    sp++;
-                    ref = swap ? cr : cl;
-                } else if (hl) {
-                    ref = cl;
-                } else if (hr) {
-                    ref = cr;
-                } else if (sp > 0) {
-                    sp--;
-                    ref = my_stack[sp * TB];
-                } else {
-                    ref = SENTINEL;
+            while (!(cur & PT_LEAF)) {  // internal nodes
+                const float4 *nd = wide + 8 * (size_t)cur;
+                const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+                const float4 cw = nd[6];
+                float t0, t1, t2, t3;
+                uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
+                         w3 = __float_as_uint(cw.w);
+#define PT_SLAB(T, LX, LY, LZ, HX, HY, HZ)                                                                      \
+    {                                                                                                          \
+        float tn;                                                                                              \
+        const bool h = ptm::box_test({ LX, LY, LZ }, { HX, HY, HZ }, org, inv, tmin, best_t, tn);              \
+        T = h ? tn : INF;                                                                                      \
+    }
+                PT_SLAB(t0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x)
+                PT_SLAB(t1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y)
+                PT_SLAB(t2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z)
+                PT_SLAB(t3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w)
+#undef PT_SLAB
+#define PT_CSWAP(TA, WA, TB_, WB)                     \
+    {                                                 \
+        const bool sw = TB_ < TA;                     \
+        const float ta = sw ? TB_ : TA, tb = sw ? TA : TB_; \
+        const uint32_t wa = sw ? WB : WA, wb = sw ? WA : WB; \
+        TA = ta; TB_ = tb; WA = wa; WB = wb;          \
+    }
+                PT_CSWAP(t0, w0, t1, w1)
+                PT_CSWAP(t2, w2, t3, w3)
+                PT_CSWAP(t0, w0, t2, w2)
+                PT_CSWAP(t1, w1, t3, w3)
+                PT_CSWAP(t1, w1, t2, w2)
+#undef PT_CSWAP
+                if (t3 < INF) push(w3, t3);  // farthest first, so the nearest pending pops first
+                if (t2 < INF) push(w2, t2);
+                if (t1 < INF) push(w1, t1);
+                cur = t0 < INF ? w0 : pop();
+            }
+            if (cur == SENTINEL) break;
+            const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t pos = first + k;
+                const float4 a = tri4[3 * (size_t)pos + 0], b = tri4[3 * (size_t)pos + 1], c = tri4[3 * (size_t)pos + 2];
+                float t, V, W, det;
+                if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
+                    const uint32_t prim = __float_as_uint(a.w);
+                    // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
+                    if (t < best_t || (t == best_t && prim < best_prim)) {
+                        best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                    }
                 }
             }
-            if (ref == SENTINEL) break;
-            const uint32_t pos = ref & ~PT_LEAF;
-            const float4 a = tri4[3 * pos + 0], b = tri4[3 * pos + 1], c = tri4[3 * pos + 2];
-            float t, V, W, det;
-            if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
-                const uint32_t prim = __float_as_uint(a.w);
-                // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
-                if (t < best_t || (t == best_t && prim < best_prim)) {
-                    best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
-                }
-            }
-            if (sp == 0) break;
-            sp--;
-            ref = my_stack[sp * TB];
+            cur = pop();
+            if (cur == SENTINEL) break;
         }
         const bool miss = best_pos == PT_MISS;
         hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t, miss ? 0.f : ptm::fdiv(best_V, best_det),
@@ -426,21 +467,11 @@ __global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ h
 // ---- host side ------------------------------------------------------------------------------
 struct ExtendPlan {
     uint32_t variant = PT_EXTEND_LDS;  // PT_EXTEND_FLAT / _LDS / _HBM
-    int stack = 16;
     bool lds_scene = false;
     size_t smem = 0;
     int grid = 0;
+    uint32_t spill_levels = 0;
 };
-
-using ExtendFn = void (*)(const float4 *, const float4 *, uint32_t, uint32_t, const float4 *, const float2 *, float4 *,
-                          const uint32_t *, uint32_t *, unsigned long long *, float, float);
-
-ExtendFn extend_fn(int stack, bool lds)
-{
-    if (stack == 16) return lds ? k_extend<16, true> : k_extend<16, false>;
-    if (stack == 32) return lds ? k_extend<32, true> : k_extend<32, false>;
-    return lds ? k_extend<64, true> : k_extend<64, false>;
-}
 
 pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
@@ -455,24 +486,28 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         pl.grid = ctx->num_cus * std::max(1, std::min(per_cu, 8));
         return PT_OK;
     }
-    if (s->height > 64) {
-        ctx->err = "LBVH height " + std::to_string(s->height) + " exceeds the 64-entry traversal stack";
-        return PT_ERR_UNSUPPORTED;
-    }
-    pl.stack = s->height <= 16 ? 16 : (s->height <= 32 ? 32 : 64);
-    const size_t scene_bytes = sizeof(float4) * (4 * (size_t)s->n_nodes + 3 * (size_t)s->n_tris);
+    const size_t scene_bytes = 128 * (size_t)s->n_wide + sizeof(float4) * 3 * (size_t)s->n_tris;
     if (want == PT_EXTEND_LDS && scene_bytes > 96 * 1024) { ctx->err = "scene does not fit LDS"; return PT_ERR_UNSUPPORTED; }
     pl.lds_scene = want == PT_EXTEND_LDS || (want == PT_EXTEND_AUTO && scene_bytes <= 24 * 1024);
     pl.variant = pl.lds_scene ? PT_EXTEND_LDS : PT_EXTEND_HBM;
-    pl.smem = (size_t)pl.stack * TB * 4 + (pl.lds_scene ? scene_bytes : 0);
-    ExtendFn fn = extend_fn(pl.stack, pl.lds_scene);
-    if (pl.smem > 48 * 1024)
-        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)pl.smem));
+    pl.smem = (size_t)LDS_STACK * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
+    const void *fn = pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true>) : reinterpret_cast<const void *>(k_extend<false>);
+    if (pl.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
     int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), TB, pl.smem));
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TB, pl.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
     pl.grid = ctx->num_cus * per_cu;
+    // stack bound: a BVH4 node pushes <= 3 entries per level; wide height <= binary height/2 + 1
+    const uint32_t bound = 3u * (s->height / 2u + 1u) + 1u;
+    pl.spill_levels = bound > (uint32_t)LDS_STACK ? bound - (uint32_t)LDS_STACK : 0u;
+    const size_t need = (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
+    if (need > ctx->spill_bytes) {
+        (void)hipFree(ctx->d_spill);
+        ctx->d_spill = nullptr;
+        ctx->spill_bytes = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_spill, need));
+        ctx->spill_bytes = need;
+    }
     return PT_OK;
 }
 
@@ -484,9 +519,14 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         k_extend_flat<<<pl.grid, TB, 0, st>>>(s->d_tri4, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, tmin, tmax);
         return;
     }
-    ExtendFn fn = extend_fn(pl.stack, pl.lds_scene);
-    hipLaunchKernelGGL(fn, dim3(pl.grid), dim3(TB), pl.smem, st, s->d_nodes, s->d_tri4, s->n_nodes, s->n_tris, rayA, rayB,
-                       hit, count_in, count_zero, stats, tmin, tmax);
+    uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill);
+    const uint32_t stride = (uint32_t)pl.grid * TB;
+    if (pl.lds_scene)
+        k_extend<true><<<pl.grid, TB, pl.smem, st>>>(s->d_wide, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in,
+                                                     count_zero, stats, spill, stride, tmin, tmax);
+    else
+        k_extend<false><<<pl.grid, TB, pl.smem, st>>>(s->d_wide, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in,
+                                                      count_zero, stats, spill, stride, tmin, tmax);
 }
 
 pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes)

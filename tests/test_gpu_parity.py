@@ -63,6 +63,112 @@ def test_lbvh_build_matches_oracle_soup(pt, orc, gpu_ctx, n, seed):
     gs.close()
 
 
+def _collapse_reference(nodes, n_tris, leaf_max=4):
+    """Python restatement of the BVH4 collapse rule (csrc/lbvh_build.hip, step 7) applied to the
+    ORACLE's binary LBVH: even-depth nodes with > leaf_max triangles become wide nodes, odd-depth
+    internal children are absorbed, subtrees with <= leaf_max triangles become one leaf child."""
+    LEAF = 0x80000000
+    n_int = nodes.shape[0]
+    fl = nodes.view(np.float32)
+    left, right = nodes[:, 12].astype(np.int64), nodes[:, 13].astype(np.int64)
+    rng, depth = {}, {0: 0}
+
+    def walk(i, d):
+        stack = [(i, d, 0)]
+        while stack:
+            i, d, st = stack.pop()
+            if st == 0:
+                depth[i] = d
+                stack.append((i, d, 1))
+                for c in (left[i], right[i]):
+                    if not c & LEAF:
+                        stack.append((int(c), d + 1, 0))
+            else:
+                lo, hi = [], []
+                for c in (left[i], right[i]):
+                    if c & LEAF:
+                        lo.append(int(c & ~LEAF)); hi.append(int(c & ~LEAF))
+                    else:
+                        lo.append(rng[int(c)][0]); hi.append(rng[int(c)][1])
+                rng[i] = (min(lo), max(hi))
+    walk(0, 0)
+    cnt = lambda i: rng[i][1] - rng[i][0] + 1
+    flag = [i == 0 or (cnt(i) > leaf_max and depth[i] % 2 == 0) for i in range(n_int)]
+    widx = np.cumsum([0] + flag[:-1])
+
+    def box_of(parent, side):      # child box as stored in the binary parent
+        o = 0 if side == 0 else 6
+        return fl[parent, o:o + 3], fl[parent, o + 3:o + 6]
+
+    def child(parent, side):
+        c = int(left[parent] if side == 0 else right[parent])
+        lo, hi = box_of(parent, side)
+        if c & LEAF:
+            return LEAF | (c & ~LEAF), lo, hi
+        if cnt(c) <= leaf_max:
+            return LEAF | ((cnt(c) - 1) << 28) | rng[c][0], lo, hi
+        return None, lo, hi        # internal, not leaf-like
+
+    out = np.zeros((int(sum(flag)), 32), np.uint32)
+    of = out.view(np.float32)
+    for i in range(n_int):
+        if not flag[i]:
+            continue
+        slots = []
+        if cnt(i) <= leaf_max:     # tiny scene: root is one leaf; its box = union of its children
+            lo = np.minimum(fl[i, 0:3], fl[i, 6:9]); hi = np.maximum(fl[i, 3:6], fl[i, 9:12])
+            slots.append((LEAF | ((cnt(i) - 1) << 28) | rng[i][0], lo, hi))
+        else:
+            for side in (0, 1):
+                w, lo, hi = child(i, side)
+                c = int(left[i] if side == 0 else right[i])
+                if w is not None:
+                    slots.append((w, lo, hi))
+                else:
+                    for s2 in (0, 1):
+                        w2, lo2, hi2 = child(c, s2)
+                        g = int(left[c] if s2 == 0 else right[c])
+                        slots.append((w2 if w2 is not None else int(widx[g]), lo2, hi2))
+        row = int(widx[i])
+        of[row, 0:12] = np.inf
+        of[row, 12:24] = np.inf
+        out[row, 24:28] = 0xFFFFFFFF
+        for k, (w, lo, hi) in enumerate(slots):
+            for ax in range(3):
+                of[row, 4 * ax + k] = lo[ax]
+                of[row, 12 + 4 * ax + k] = hi[ax]
+            out[row, 24 + k] = w
+    return out
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (4, 3), (5, 4), (37, 5), (3000, 6), (60000, 7)])
+def test_bvh4_collapse_matches_reference_rule(pt, orc, gpu_ctx, n, seed):
+    v, i, f = _soup(n, seed)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    wide = gs.read_bvh4()
+    if n == 1:
+        assert wide.shape[0] == 1 and wide[0, 24] == 0x80000000 and (wide[0, 25:28] == 0xFFFFFFFF).all()
+    else:
+        ref = _collapse_reference(osc.bvh_nodes(), n)
+        assert wide.shape == ref.shape
+        assert wide.tobytes() == ref.tobytes()
+    # every sorted position sits in exactly one leaf
+    words = wide[:, 24:28].ravel()
+    leaves = words[(words != 0xFFFFFFFF) & (words & 0x80000000 != 0)]
+    seen = np.zeros(n, np.int64)
+    for w in leaves:
+        first, cnt = int(w & 0x0FFFFFFF), int((w >> 28) & 7) + 1
+        seen[first:first + cnt] += 1
+    assert (seen == 1).all()
+    gs.close()
+
+
+def test_bvh4_cornell(pt, orc, cornell_gpu, cornell_oracle):
+    wide = cornell_gpu.read_bvh4()
+    assert wide.tobytes() == _collapse_reference(cornell_oracle.bvh_nodes(), 36).tobytes()
+    assert cornell_gpu.info().n_wide_nodes == wide.shape[0] <= 12
+
+
 def test_trace_primary_rays_bit_exact(pt, orc, cornell_gpu, cornell_oracle):
     g = np.load(os.path.join(HERE, "golden", "c1_256_1spp_d4.npz"))
     p = orc.default_params(width=256, height=256)
