@@ -7,8 +7,8 @@ box at 1920x1080, 8 bounces (BASELINE.json metric), on N GPUs of one node.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A *step* is one frame = one reference launch (traceRaysKHR(W,H,1), main.cpp:659): 32 samples per
-pixel, <= 8 rays each, blended into the film (raygen.rgen:41-91).  K steps = 32*K spp; the
-default K=2 is exactly config C2 (64 spp).  The scene + LBVH are resident in HBM before the timed
+pixel, <= 8 rays each, blended into the film (raygen.rgen:41-91).  K steps = 32*K spp; K=2 is
+exactly config C2 (64 spp); the default K=16 (512 spp) lets the device keep 16 frames in flight.  The scene + LBVH are resident in HBM before the timed
 region; the timed region is the K frames (all kernels: generate, extend, shade/compact, resolve)
 plus, for N>1, the one RCCL reduce of the float film to rank 0.  Rank 0 prints ONE JSON line.
 
@@ -54,8 +54,8 @@ def cpu_baseline(arrays, name, width, height, spp, depth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--config", choices=["c2", "c5"], default="c2",
@@ -185,39 +185,50 @@ def main():
         if ingest:
             out["ingest"] = ingest
         base = None
-        nodes_per_ray = tris_per_ray = 0.0
-        if (not args.no_cpu_baseline and world == 1) or args.config == "c5":
+        if not args.no_cpu_baseline and world == 1:
             if args.config == "c2":
-                base, nodes_per_ray, tris_per_ray = cpu_baseline(arrays, scene_name, W, H, 4, args.depth)
+                base, _, _ = cpu_baseline(arrays, scene_name, W, H, 4, args.depth)
             else:   # 1/16 of the image area, 1 spp: ~0.5 M rays through the 1M-triangle LBVH
-                base, nodes_per_ray, tris_per_ray = cpu_baseline(arrays, scene_name, W // 4, H // 4, 1, args.depth)
+                base, _, _ = cpu_baseline(arrays, scene_name, W // 4, H // 4, 1, args.depth)
+        # traversal work per ray, counted by an instrumented build of the same kernel on the same
+        # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
+        nodes_per_ray = tris_per_ray = 0.0
+        if st.extend_variant != pt.EXTEND_FLAT:
+            ctx.reset_stats()
+            scratch = pt.Film(ctx, W, H)
+            pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, flags=pt.FLAG_COUNT_VISITS, **common))
+            cst = ctx.stats()
+            nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
+            tris_per_ray = cst.tris_tested / max(cst.rays, 1)
+            scratch.close()
         if flags and st.launches_extend and st.ms_extend > 0:
             # dominant kernel = k_extend (closest-hit traversal).  Algorithmic bytes: 40 B/ray; the
             # 36-triangle scene + LBVH are LDS-resident so there is no scene-gather term.
             # scene gather: counted only when the scene exceeds the 32 MiB of L2
             scene_bytes = info.device_bytes
-            gather = (nodes_per_ray * 32.0 + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
+            # one BVH4 node visit = 4 child boxes x 32 B = 128 B; one triangle = 36 B of positions
+            gather = (nodes_per_ray * 128.0 + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
             bytes_extend = BYTES_EXTEND + gather
             gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
             pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
             traffic = None
             prof = os.path.join(REPO, "profiles", "r01_pmc_extend.json" if args.config == "c2" else "r01_pmc_extend_c5.json")
             if os.path.exists(prof):
-                try:
-                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                try:   # PMC HBM bytes per ray of the same kernel (committed rocprofv3 run) x this run's rays per launch
+                    traffic = round(json.load(open(prof))["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "bound": "hbm", "kernel": {1: "k_extend_flat", 2: "k_extend<STACK,lds>", 3: "k_extend<STACK,hbm>"}.get(st.extend_variant, "?"),
+                "bound": "hbm", "kernel": {1: "k_extend_flat", 2: "k_extend<lds>", 3: "k_extend<hbm>"}.get(st.extend_variant, "?"),
                 "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "launches": st.launches_extend,
                 "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
                 "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
                 "algorithmic_bytes_per_ray": round(bytes_extend, 1),
-                "gather": {"child_boxes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                "gather": {"bvh4_nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
                            "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
-                           "source": "instrumented oracle on the identical LBVH, sample of the same image"},
+                           "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
                 "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
                 "pipeline_algorithmic_GBps": round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2),
                 "note": ("Cornell (<8 KB scene+BVH) never leaves SGPRs/LDS: extend is VALU-issue bound, HBM sees only "

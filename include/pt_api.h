@@ -97,14 +97,17 @@ void pt_film_destroy(pt_film *film);
 
 /* ---- dispatch: pushConstants + traceRaysKHR (main.cpp:656-659) ------------------------- */
 enum { PT_PIPELINE_WAVEFRONT = 0 /* generate / extend / shade queues */ };
-enum { PT_FLAG_PROFILE = 1u /* hipEvent-time every extend/shade launch (adds events to the stream) */ };
+enum {
+    PT_FLAG_PROFILE = 1u,      /* hipEvent-time every extend/shade launch (adds events to the stream)       */
+    PT_FLAG_COUNT_VISITS = 2u  /* instrumented traversal: count BVH4 nodes / triangles visited (slower)      */
+};
 /* Which closest-hit kernel runs.  All variants implement the same closest-hit definition and
  * return identical bits; AUTO picks by scene size. */
 enum {
     PT_EXTEND_AUTO = 0,
-    PT_EXTEND_FLAT = 1, /* <= 64 triangles: the scene is one wide leaf, scanned wave-uniformly (SGPR stream) */
-    PT_EXTEND_LDS = 2,  /* LBVH + triangles staged in LDS, per-lane short stack in LDS                      */
-    PT_EXTEND_HBM = 3   /* LBVH + triangles read through L1/L2/MALL from HBM, short stack in LDS            */
+    PT_EXTEND_FLAT = 1, /* <= 1024 triangles: one wide leaf scanned wave-uniformly (SGPR stream); never AUTO  */
+    PT_EXTEND_LDS = 2,  /* BVH4 + triangles staged in LDS (scenes <= 24 KB by AUTO), lane refill             */
+    PT_EXTEND_HBM = 3   /* BVH4 + triangles read through L1/L2/MALL from HBM, LDS short stack + HBM spill    */
 };
 
 typedef struct pt_params {
@@ -150,6 +153,8 @@ typedef struct pt_stats {
     float    ms_total;         /* device time of pt_render calls (first kernel .. last kernel)      */
     float    ms_extend, ms_shade; /* summed kernel times; only with PT_FLAG_PROFILE                 */
     uint32_t extend_variant;   /* PT_EXTEND_* that actually ran                                     */
+    uint64_t nodes_visited;    /* BVH4 nodes fetched (128 B each) -- only with PT_FLAG_COUNT_VISITS  */
+    uint64_t tris_tested;      /* triangles tested                -- only with PT_FLAG_COUNT_VISITS  */
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

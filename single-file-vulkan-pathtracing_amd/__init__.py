@@ -27,8 +27,9 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "
                 5: "PT_ERR_UNSUPPORTED"}
 PIPELINE_WAVEFRONT = 0
 FLAG_PROFILE = 1
+FLAG_COUNT_VISITS = 2
 EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM = 0, 1, 2, 3
-EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "LBVH, scene staged in LDS", 3: "LBVH, scene in HBM/L2"}
+EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4 (collapsed LBVH), scene staged in LDS", 3: "BVH4 (collapsed LBVH), scene in HBM/L2"}
 MISS = 0xFFFFFFFF
 
 
@@ -58,7 +59,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rounds", C.c_uint32),
                 ("launches_extend", C.c_uint32), ("launches_shade", C.c_uint32), ("launches_other", C.c_uint32),
                 ("ms_total", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float),
-                ("extend_variant", C.c_uint32)]
+                ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
 
 
 class HostScene(C.Structure):

@@ -236,6 +236,8 @@ pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     ctx->stats.rays = h[0];
+    ctx->stats.nodes_visited = h[2];
+    ctx->stats.tris_tested = h[3];
     *out = ctx->stats;
     return PT_OK;
 }
