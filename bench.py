@@ -58,8 +58,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--config", choices=["c2", "c5"], default="c2",
-                    help="c2 = Cornell box (the headline), c5 = 1M-triangle soup, 16 spp/frame, depth 16")
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+                    help="c2 = Cornell box (the headline), c4 = Cornell x 10 000 instances (two-level BVH), "
+                         "c5 = 1M-triangle soup, 16 spp/frame, depth 16")
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--soup-tris", type=int, default=1000000)
@@ -112,6 +113,12 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = pt.Context(local_rank, stream=stream.cuda_stream)
     scene = pt.Scene(ctx, *arrays)          # upload + on-device LBVH build (untimed, reported apart)
+    if args.config == "c4":
+        t0 = time.perf_counter()
+        scene.set_instances(pt.cornell_grid_instances())      # TLAS build on device
+        ctx.sync()
+        tlas_ms = (time.perf_counter() - t0) * 1e3
+        scene_name = "CornellBox-Original.obj x 10 000 instances (100x100 grid, scale 0.009)"
     info = scene.info()
     film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # torch owns the film: RCCL reduces it in place
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
@@ -158,8 +165,9 @@ def main():
     if rank == 0:
         mean_len = rays_total / max(paths_total, 1)
         out = {
-            "metric": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)" if args.config == "c2"
-                      else "Mrays/s, 1M-triangle soup 1920x1080 @ 16 bounces (BASELINE config C5)",
+            "metric": {"c2": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)",
+                       "c4": "Mrays/s, Cornell Box x 10k instances (two-level BVH) 1920x1080 @ 8 bounces (BASELINE config C4)",
+                       "c5": "Mrays/s, 1M-triangle soup 1920x1080 @ 16 bounces (BASELINE config C5)"}[args.config],
             "value": round(rays_total / dt / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +176,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("CornellBox-Original.obj (the reference's own scene, 36 triangles)" if args.config == "c2" else
+            "data": ("CornellBox-Original.obj (the reference's own scene, 36 triangles)" if args.config in ("c2", "c4") else
                      "synthetic triangle soup (generator pth_write_soup_obj, seed 1), written as OBJ+MTL and parsed by the host loader")
                     + "; rays are generated on device",
             "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
@@ -184,9 +192,13 @@ def main():
             out["rays_per_rank_min_max"] = rays_minmax
         if ingest:
             out["ingest"] = ingest
+        if args.config == "c4":
+            out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
         base = None
         if not args.no_cpu_baseline and world == 1:
-            if args.config == "c2":
+            if args.config == "c4":
+                base = None        # the oracle binding used here has no instance set-up in cpu_baseline: skipped for C4
+            elif args.config == "c2":
                 base, _, _ = cpu_baseline(arrays, scene_name, W, H, 4, args.depth)
             else:   # 1/16 of the image area, 1 spp: ~0.5 M rays through the 1M-triangle LBVH
                 base, _, _ = cpu_baseline(arrays, scene_name, W // 4, H // 4, 1, args.depth)
@@ -234,7 +246,9 @@ def main():
                 "note": ("Cornell (<8 KB scene+BVH) never leaves SGPRs/LDS: extend is VALU-issue bound, HBM sees only "
                          "queue I/O; the HBM fraction is physically meaningful on config C5 (1M triangles) only")
                         if args.config == "c2" else
-                        "scene + LBVH = 160 MB > L2: every node/triangle fetch is a 64/48-B gather through L2/MALL/HBM",
+                        ("TLAS (10k instances) + BLAS fit in L2: traversal is VALU/latency bound, HBM sees queue I/O only"
+                         if args.config == "c4" else
+                         "scene + BVH4 = 118 MB > L2: every node/triangle fetch is a 128/48-B gather through L2/MALL/HBM"),
             }
         if base and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = base

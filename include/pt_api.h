@@ -61,9 +61,21 @@ pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts,
                           pt_scene **out);
 void pt_scene_destroy(pt_scene *scene);
 
+/* Two-level scenes (BASELINE config C4).  The reference builds exactly ONE identity instance
+ * (main.cpp:515-538: VkAccelerationStructureInstanceKHR with an identity 3x4, mask 0xFF,
+ * TriangleFacingCullDisable); this sets n instances of the scene's geometry instead.
+ * xforms3x4: n object->world matrices, 3x4 row major (VkTransformMatrixKHR layout), copied.
+ * n = 0 restores the single-level scene.  A TLAS (BVH4 over the instances' world boxes) is built
+ * on the device.  Hits report gl_InstanceID in pt_hit.inst; ties in t go to the lowest
+ * (instance, primitive).  Shading transforms the hit position by the matrix and the normal by the
+ * inverse transpose (renormalised); materials are per primitive, shared by all instances.      */
+pt_status pt_scene_set_instances(pt_scene *scene, const float *xforms3x4, uint32_t n);
+
 typedef struct pt_scene_info {
     uint32_t n_tris, n_nodes /* binary LBVH */, bvh_height /* of the binary LBVH */;
     uint32_t n_wide_nodes;    /* BVH4 nodes (128 B each) the traversal kernels walk               */
+    uint32_t n_instances;     /* 0 = single-level scene                                           */
+    uint32_t n_tlas_nodes;    /* BVH4 nodes of the TLAS                                           */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
     uint64_t device_bytes;    /* resident scene + BVH bytes                                     */
@@ -138,6 +150,7 @@ typedef struct pt_hit {
     uint32_t prim;  /* gl_PrimitiveID, 0xFFFFFFFF = miss                                   */
     float    t;     /* hit distance (0 on miss)                                             */
     float    u, v;  /* hitAttributeEXT attribs.xy: weights of v1, v2 (closesthit.rchit:56)  */
+    uint32_t inst;  /* gl_InstanceID (0 without instances), 0xFFFFFFFF = miss              */
 } pt_hit;
 /* rays6: host array n x {origin.xyz, direction.xyz}; hits: host array of n.  Runs the same
  * extend kernel the renderer uses (opaque, no culling, tmin < t < tmax).                   */

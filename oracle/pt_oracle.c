@@ -121,16 +121,30 @@ typedef struct orc_node {
     uint32_t left, right, pad0, pad1;
 } orc_node;
 
+/* one LBVH over n boxes (triangles of the BLAS, or instances of the TLAS) */
+typedef struct orc_bvh {
+    uint32_t n;
+    uint64_t *keys;      /* sorted */
+    uint32_t *prim_of;   /* sorted position -> box id */
+    orc_node *nodes;     /* n-1 internal nodes (>=1) */
+    uint32_t n_nodes, height;
+    float bmin[3], bmax[3];
+} orc_bvh;
+
+typedef struct orc_instance {
+    float m[12];     /* object -> world, 3x4 row major (VkTransformMatrixKHR layout)       */
+    float inv[12];   /* world -> object, 3x4 row major: rows of A^-1 with -A^-1 t in column 3 */
+} orc_instance;
+
 struct orc_scene {
     uint32_t n_tris;
     float *tri;    /* 9 floats per triangle, original (prim id) order: v0 v1 v2          */
     float *face;   /* 6 floats per triangle: Kd, Ke                                      */
-    /* LBVH */
-    uint64_t *keys;      /* sorted */
-    uint32_t *prim_of;   /* sorted position -> prim id */
-    orc_node *nodes;     /* n_tris-1 internal nodes (>=1) */
-    uint32_t n_nodes, height;
-    float bmin[3], bmax[3];
+    orc_bvh blas;  /* LBVH over the triangles */
+    /* two-level scenes (config C4; the reference has one identity instance, main.cpp:515-538) */
+    uint32_t n_inst;
+    orc_instance *inst;
+    orc_bvh tlas;  /* LBVH over the instances' world boxes */
 };
 
 static inline uint64_t expand21(uint32_t v)
@@ -178,17 +192,17 @@ static void tri_bounds(const float *t, float mn[3], float mx[3])
 }
 
 /* box of child reference (leaf or internal) written into mn/mx; returns subtree height */
-static uint32_t build_boxes(orc_scene *s, uint32_t ref, float pad, float mn[3], float mx[3])
+static uint32_t build_boxes(orc_bvh *b, const float *blo, const float *bhi, uint32_t ref, float pad,
+                            float mn[3], float mx[3])
 {
     if (ref & ORC_LEAF) {
-        uint32_t pos = ref & ~ORC_LEAF;
-        tri_bounds(s->tri + 9 * (size_t)s->prim_of[pos], mn, mx);
-        for (int k = 0; k < 3; k++) { mn[k] = mn[k] - pad; mx[k] = mx[k] + pad; }
+        uint32_t id = b->prim_of[ref & ~ORC_LEAF];
+        for (int k = 0; k < 3; k++) { mn[k] = blo[3 * (size_t)id + k] - pad; mx[k] = bhi[3 * (size_t)id + k] + pad; }
         return 0;
     }
-    orc_node *nd = &s->nodes[ref];
-    uint32_t hl = build_boxes(s, nd->left, pad, nd->lmin, nd->lmax);
-    uint32_t hr = build_boxes(s, nd->right, pad, nd->rmin, nd->rmax);
+    orc_node *nd = &b->nodes[ref];
+    uint32_t hl = build_boxes(b, blo, bhi, nd->left, pad, nd->lmin, nd->lmax);
+    uint32_t hr = build_boxes(b, blo, bhi, nd->right, pad, nd->rmin, nd->rmax);
     for (int k = 0; k < 3; k++) {
         mn[k] = fminf(nd->lmin[k], nd->rmin[k]);
         mx[k] = fmaxf(nd->lmax[k], nd->rmax[k]);
@@ -196,46 +210,50 @@ static uint32_t build_boxes(orc_scene *s, uint32_t ref, float pad, float mn[3], 
     return 1 + (hl > hr ? hl : hr);
 }
 
-static void build_lbvh(orc_scene *s)
+static void bvh_free(orc_bvh *b)
 {
-    const int n = (int)s->n_tris;
-    /* scene bounds over all triangle vertices */
-    for (int k = 0; k < 3; k++) { s->bmin[k] = INFINITY; s->bmax[k] = -INFINITY; }
-    for (int i = 0; i < n; i++) {
-        float mn[3], mx[3];
-        tri_bounds(s->tri + 9 * (size_t)i, mn, mx);
+    free(b->keys); free(b->prim_of); free(b->nodes);
+    memset(b, 0, sizeof(*b));
+}
+
+/* LBVH over n boxes blo/bhi (3 floats each): Morton keys of the box centres, stable sort,
+ * Karras 2012 hierarchy, leaf boxes padded by 2^-18 of the scene scale. */
+static void build_lbvh(orc_bvh *b, const float *blo, const float *bhi, uint32_t n_boxes)
+{
+    const int n = (int)n_boxes;
+    b->n = n_boxes;
+    for (int k = 0; k < 3; k++) { b->bmin[k] = INFINITY; b->bmax[k] = -INFINITY; }
+    for (int i = 0; i < n; i++)
         for (int k = 0; k < 3; k++) {
-            s->bmin[k] = fminf(s->bmin[k], mn[k]);
-            s->bmax[k] = fmaxf(s->bmax[k], mx[k]);
+            b->bmin[k] = fminf(b->bmin[k], blo[3 * (size_t)i + k]);
+            b->bmax[k] = fmaxf(b->bmax[k], bhi[3 * (size_t)i + k]);
         }
-    }
     float ext[3];
-    for (int k = 0; k < 3; k++) ext[k] = s->bmax[k] - s->bmin[k];
-    /* Morton keys of triangle-AABB centres, 21 bits per axis, x most significant */
+    for (int k = 0; k < 3; k++) ext[k] = b->bmax[k] - b->bmin[k];
+    /* Morton keys of box centres, 21 bits per axis, x most significant */
     keyprim *kp = malloc(sizeof(keyprim) * (size_t)n);
     for (int i = 0; i < n; i++) {
-        float mn[3], mx[3];
-        tri_bounds(s->tri + 9 * (size_t)i, mn, mx);
         uint32_t q[3];
-        for (int k = 0; k < 3; k++) q[k] = quant21((mn[k] + mx[k]) * 0.5f, s->bmin[k], ext[k]);
+        for (int k = 0; k < 3; k++)
+            q[k] = quant21((blo[3 * (size_t)i + k] + bhi[3 * (size_t)i + k]) * 0.5f, b->bmin[k], ext[k]);
         kp[i].key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
         kp[i].prim = (uint32_t)i;
     }
-    qsort(kp, (size_t)n, sizeof(keyprim), cmp_keyprim); /* (key, prim) order == stable sort */
-    s->keys = malloc(sizeof(uint64_t) * (size_t)n);
-    s->prim_of = malloc(sizeof(uint32_t) * (size_t)n);
-    for (int i = 0; i < n; i++) { s->keys[i] = kp[i].key; s->prim_of[i] = kp[i].prim; }
+    qsort(kp, (size_t)n, sizeof(keyprim), cmp_keyprim); /* (key, id) order == stable sort */
+    b->keys = malloc(sizeof(uint64_t) * (size_t)n);
+    b->prim_of = malloc(sizeof(uint32_t) * (size_t)n);
+    for (int i = 0; i < n; i++) { b->keys[i] = kp[i].key; b->prim_of[i] = kp[i].prim; }
     free(kp);
 
-    s->n_nodes = n > 1 ? (uint32_t)(n - 1) : 1u;
-    s->nodes = calloc(s->n_nodes, sizeof(orc_node));
+    b->n_nodes = n > 1 ? (uint32_t)(n - 1) : 1u;
+    b->nodes = calloc(b->n_nodes, sizeof(orc_node));
     if (n == 1) {
-        s->nodes[0].left = ORC_LEAF | 0u;
-        s->nodes[0].right = ORC_LEAF | 0u;
+        b->nodes[0].left = ORC_LEAF | 0u;
+        b->nodes[0].right = ORC_LEAF | 0u;
     }
     /* Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees" */
     for (int i = 0; i < n - 1; i++) {
-        const uint64_t *K = s->keys;
+        const uint64_t *K = b->keys;
         int d = (delta(K, n, i, i + 1) - delta(K, n, i, i - 1)) < 0 ? -1 : 1;
         int dmin = delta(K, n, i, i - d);
         int lmax = 2;
@@ -253,16 +271,84 @@ static void build_lbvh(orc_scene *s)
         } while (t > 1);
         int gamma = i + sp * d + (d < 0 ? -1 : 0);
         int lo = i < j ? i : j, hi = i < j ? j : i;
-        s->nodes[i].left = (lo == gamma) ? (ORC_LEAF | (uint32_t)gamma) : (uint32_t)gamma;
-        s->nodes[i].right = (hi == gamma + 1) ? (ORC_LEAF | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+        b->nodes[i].left = (lo == gamma) ? (ORC_LEAF | (uint32_t)gamma) : (uint32_t)gamma;
+        b->nodes[i].right = (hi == gamma + 1) ? (ORC_LEAF | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
     }
     /* leaf boxes are padded by 2^-18 * scene scale so the slab test is conservative w.r.t.
      * the (rounded) watertight triangle test */
     float scale = 0.0f;
-    for (int k = 0; k < 3; k++) scale = fmaxf(scale, fmaxf(fabsf(s->bmin[k]), fabsf(s->bmax[k])));
+    for (int k = 0; k < 3; k++) scale = fmaxf(scale, fmaxf(fabsf(b->bmin[k]), fabsf(b->bmax[k])));
     float pad = scale * 3.814697265625e-06f;
     float mn[3], mx[3];
-    s->height = build_boxes(s, 0u, pad, mn, mx);
+    b->height = build_boxes(b, blo, bhi, 0u, pad, mn, mx);
+}
+
+static void build_blas(orc_scene *s)
+{
+    const size_t n = s->n_tris;
+    float *blo = malloc(sizeof(float) * 3 * n), *bhi = malloc(sizeof(float) * 3 * n);
+    for (size_t i = 0; i < n; i++) tri_bounds(s->tri + 9 * i, blo + 3 * i, bhi + 3 * i);
+    build_lbvh(&s->blas, blo, bhi, s->n_tris);
+    free(blo); free(bhi);
+}
+
+/* ---- instances (beyond the reference: it has exactly one identity instance) --------------- */
+/* world -> object matrix: adjugate / determinant in binary64, rounded once to float */
+static void invert_3x4(const float m[12], float inv[12])
+{
+    const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9],
+                 a22 = m[10];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+    const double det = (a00 * c00 + a01 * c01) + a02 * c02;
+    const double i00 = c00 / det, i01 = (a02 * a21 - a01 * a22) / det, i02 = (a01 * a12 - a02 * a11) / det;
+    const double i10 = c01 / det, i11 = (a00 * a22 - a02 * a20) / det, i12 = (a02 * a10 - a00 * a12) / det;
+    const double i20 = c02 / det, i21 = (a01 * a20 - a00 * a21) / det, i22 = (a00 * a11 - a01 * a10) / det;
+    const double tx = m[3], ty = m[7], tz = m[11];
+    inv[0] = (float)i00; inv[1] = (float)i01; inv[2] = (float)i02;  inv[3] = (float)(-((i00 * tx + i01 * ty) + i02 * tz));
+    inv[4] = (float)i10; inv[5] = (float)i11; inv[6] = (float)i12;  inv[7] = (float)(-((i10 * tx + i11 * ty) + i12 * tz));
+    inv[8] = (float)i20; inv[9] = (float)i21; inv[10] = (float)i22; inv[11] = (float)(-((i20 * tx + i21 * ty) + i22 * tz));
+}
+
+static inline void xform_point(const float m[12], const float p[3], float out[3])
+{
+    for (int k = 0; k < 3; k++) out[k] = ((m[4 * k] * p[0] + m[4 * k + 1] * p[1]) + m[4 * k + 2] * p[2]) + m[4 * k + 3];
+}
+static inline void xform_vector(const float m[12], const float v[3], float out[3])
+{
+    for (int k = 0; k < 3; k++) out[k] = (m[4 * k] * v[0] + m[4 * k + 1] * v[1]) + m[4 * k + 2] * v[2];
+}
+
+int orc_scene_set_instances(orc_scene *s, const float *xforms3x4, uint32_t n)
+{
+    if (!s || (n && !xforms3x4)) return 1;
+    free(s->inst); s->inst = NULL; s->n_inst = 0;
+    bvh_free(&s->tlas);
+    if (n == 0) return 0;
+    s->inst = malloc(sizeof(orc_instance) * (size_t)n);
+    s->n_inst = n;
+    float *blo = malloc(sizeof(float) * 3 * (size_t)n), *bhi = malloc(sizeof(float) * 3 * (size_t)n);
+    /* object box = the BLAS root box (children of node 0, already padded) */
+    float omin[3], omax[3];
+    for (int k = 0; k < 3; k++) {
+        omin[k] = fminf(s->blas.nodes[0].lmin[k], s->blas.nodes[0].rmin[k]);
+        omax[k] = fmaxf(s->blas.nodes[0].lmax[k], s->blas.nodes[0].rmax[k]);
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        memcpy(s->inst[i].m, xforms3x4 + 12 * (size_t)i, sizeof(float) * 12);
+        invert_3x4(s->inst[i].m, s->inst[i].inv);
+        for (int k = 0; k < 3; k++) { blo[3 * (size_t)i + k] = INFINITY; bhi[3 * (size_t)i + k] = -INFINITY; }
+        for (int c = 0; c < 8; c++) { /* world box of the 8 transformed corners */
+            float p[3] = { (c & 1) ? omax[0] : omin[0], (c & 2) ? omax[1] : omin[1], (c & 4) ? omax[2] : omin[2] }, w[3];
+            xform_point(s->inst[i].m, p, w);
+            for (int k = 0; k < 3; k++) {
+                blo[3 * (size_t)i + k] = fminf(blo[3 * (size_t)i + k], w[k]);
+                bhi[3 * (size_t)i + k] = fmaxf(bhi[3 * (size_t)i + k], w[k]);
+            }
+        }
+    }
+    build_lbvh(&s->tlas, blo, bhi, n);
+    free(blo); free(bhi);
+    return 0;
 }
 
 orc_scene *orc_scene_create(const float *vertices, uint32_t n_verts, const uint32_t *indices,
@@ -280,29 +366,29 @@ orc_scene *orc_scene_create(const float *vertices, uint32_t n_verts, const uint3
             for (int k = 0; k < 3; k++)
                 s->tri[9 * (size_t)t + 3 * c + k] = vertices[3 * (size_t)indices[3 * (size_t)t + c] + k];
     memcpy(s->face, faces, sizeof(float) * 6 * (size_t)n_tris);
-    build_lbvh(s);
+    build_blas(s);
     return s;
 }
 
 void orc_scene_destroy(orc_scene *s)
 {
     if (!s) return;
-    free(s->tri); free(s->face); free(s->keys); free(s->prim_of); free(s->nodes); free(s);
+    free(s->tri); free(s->face); free(s->inst); bvh_free(&s->blas); bvh_free(&s->tlas); free(s);
 }
 
 void orc_scene_bvh_info(const orc_scene *s, orc_bvh_info *info)
 {
-    info->n_tris = s->n_tris; info->n_nodes = s->n_nodes; info->height = s->height;
-    for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
+    info->n_tris = s->n_tris; info->n_nodes = s->blas.n_nodes; info->height = s->blas.height;
+    for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->blas.bmin[k]; info->bbox_max[k] = s->blas.bmax[k]; }
 }
 void orc_scene_bvh_keys(const orc_scene *s, uint64_t *keys, uint32_t *prim_of_pos)
 {
-    memcpy(keys, s->keys, sizeof(uint64_t) * s->n_tris);
-    memcpy(prim_of_pos, s->prim_of, sizeof(uint32_t) * s->n_tris);
+    memcpy(keys, s->blas.keys, sizeof(uint64_t) * s->n_tris);
+    memcpy(prim_of_pos, s->blas.prim_of, sizeof(uint32_t) * s->n_tris);
 }
 void orc_scene_bvh_nodes(const orc_scene *s, uint32_t *nodes16)
 {
-    memcpy(nodes16, s->nodes, sizeof(orc_node) * s->n_nodes);
+    memcpy(nodes16, s->blas.nodes, sizeof(orc_node) * s->blas.n_nodes);
 }
 
 /* ===== closest hit =================================================================== */
@@ -367,11 +453,12 @@ static inline int tri_test(const ray_pre *r, const float *tv, float tmax, float 
     return 1;
 }
 
-static inline void hit_consider(orc_hit *h, uint32_t prim, float t, float u, float v)
+static inline void hit_consider(orc_hit *h, uint32_t inst, uint32_t prim, float t, float u, float v)
 {
-    /* closest t; equal t -> lowest primitive id (deterministic for the OBJ's duplicated quads) */
-    if (t < h->t || (t == h->t && prim < h->prim)) {
-        h->t = t; h->u = u; h->v = v; h->prim = prim;
+    /* closest t; equal t -> lowest (instance id, primitive id): deterministic for the OBJ's
+     * duplicated quads and for coincident instances */
+    if (t < h->t || (t == h->t && (inst < h->inst || (inst == h->inst && prim < h->prim)))) {
+        h->t = t; h->u = u; h->v = v; h->prim = prim; h->inst = inst;
     }
 }
 
@@ -395,33 +482,83 @@ static inline int box_test(const float mn[3], const float mx[3], const float org
     return tn <= tf * 1.0000004f;
 }
 
-void orc_trace(const orc_scene *s, int mode, const float org[3], const float dir[3], float tmin,
-               float tmax, orc_hit *hit, orc_counters *cnt)
+/* closest hit against the triangles of one BLAS copy; inst = id recorded with the hit */
+static void trace_blas(const orc_scene *s, int mode, uint32_t inst, const float org[3], const float dir[3],
+                       float tmin, float tmax, orc_hit *h, uint64_t *nodes, uint64_t *tris)
 {
     ray_pre r;
     ray_setup(&r, org, dir, tmin);
-    orc_hit h; h.prim = ORC_MISS; h.t = tmax; h.u = 0.0f; h.v = 0.0f;
-    /* h.t starts at tmax: candidates need t < tmax strictly; (t == h.t && prim < MISS) can
-     * not fire for t == tmax because tri_test already rejected t >= tmax. */
-    uint64_t nodes = 0, tris = 0;
     float t, u, v;
     if (mode == 0) {
         for (uint32_t p = 0; p < s->n_tris; p++) {
-            tris++;
-            if (tri_test(&r, s->tri + 9 * (size_t)p, tmax, &t, &u, &v)) hit_consider(&h, p, t, u, v);
+            (*tris)++;
+            if (tri_test(&r, s->tri + 9 * (size_t)p, tmax, &t, &u, &v)) hit_consider(h, inst, p, t, u, v);
         }
+        return;
+    }
+    const orc_bvh *b = &s->blas;
+    float inv[3] = { safe_inv(dir[0]), safe_inv(dir[1]), safe_inv(dir[2]) };
+    uint32_t stack[128];
+    int sp = 0;
+    uint32_t ref = 0; /* root internal node */
+    for (;;) {
+        if (ref & ORC_LEAF) {
+            uint32_t prim = b->prim_of[ref & ~ORC_LEAF];
+            (*tris)++;
+            if (tri_test(&r, s->tri + 9 * (size_t)prim, tmax, &t, &u, &v)) hit_consider(h, inst, prim, t, u, v);
+        } else {
+            const orc_node *nd = &b->nodes[ref];
+            float tl, tr;
+            *nodes += 2;
+            int hl = box_test(nd->lmin, nd->lmax, org, inv, tmin, h->t, &tl);
+            int hr = box_test(nd->rmin, nd->rmax, org, inv, tmin, h->t, &tr);
+            if (hl && hr) {
+                uint32_t nearc = nd->left, farc = nd->right;
+                if (tr < tl) { nearc = nd->right; farc = nd->left; }
+                stack[sp++] = farc;
+                ref = nearc;
+                continue;
+            } else if (hl) { ref = nd->left; continue; }
+            else if (hr) { ref = nd->right; continue; }
+        }
+        if (sp == 0) break;
+        ref = stack[--sp];
+    }
+}
+
+/* one instance: ray into object space (direction NOT renormalised, so t is the same parameter
+ * in both spaces, as in Vulkan), then the BLAS */
+static void trace_instance(const orc_scene *s, int mode, uint32_t inst, const float org[3], const float dir[3],
+                           float tmin, float tmax, orc_hit *h, uint64_t *nodes, uint64_t *tris)
+{
+    float oo[3], od[3];
+    xform_point(s->inst[inst].inv, org, oo);
+    xform_vector(s->inst[inst].inv, dir, od);
+    trace_blas(s, mode, inst, oo, od, tmin, tmax, h, nodes, tris);
+}
+
+void orc_trace(const orc_scene *s, int mode, const float org[3], const float dir[3], float tmin,
+               float tmax, orc_hit *hit, orc_counters *cnt)
+{
+    orc_hit h; h.prim = ORC_MISS; h.inst = ORC_MISS; h.t = tmax; h.u = 0.0f; h.v = 0.0f;
+    /* h.t starts at tmax: candidates need t < tmax strictly; the tie-break can not fire for
+     * t == tmax because tri_test already rejected t >= tmax. */
+    uint64_t nodes = 0, tris = 0;
+    if (s->n_inst == 0) {
+        trace_blas(s, mode, 0u, org, dir, tmin, tmax, &h, &nodes, &tris);
+    } else if (mode == 0) {
+        for (uint32_t i = 0; i < s->n_inst; i++) trace_instance(s, 0, i, org, dir, tmin, tmax, &h, &nodes, &tris);
     } else {
+        const orc_bvh *b = &s->tlas;
         float inv[3] = { safe_inv(dir[0]), safe_inv(dir[1]), safe_inv(dir[2]) };
         uint32_t stack[128];
         int sp = 0;
-        uint32_t ref = 0; /* root internal node */
+        uint32_t ref = 0;
         for (;;) {
             if (ref & ORC_LEAF) {
-                uint32_t prim = s->prim_of[ref & ~ORC_LEAF];
-                tris++;
-                if (tri_test(&r, s->tri + 9 * (size_t)prim, tmax, &t, &u, &v)) hit_consider(&h, prim, t, u, v);
+                trace_instance(s, 1, b->prim_of[ref & ~ORC_LEAF], org, dir, tmin, tmax, &h, &nodes, &tris);
             } else {
-                const orc_node *nd = &s->nodes[ref];
+                const orc_node *nd = &b->nodes[ref];
                 float tl, tr;
                 nodes += 2;
                 int hl = box_test(nd->lmin, nd->lmax, org, inv, tmin, h.t, &tl);
@@ -439,7 +576,8 @@ void orc_trace(const orc_scene *s, int mode, const float org[3], const float dir
             ref = stack[--sp];
         }
     }
-    if (h.prim == ORC_MISS) { h.t = 0.0f; }
+    if (h.prim == ORC_MISS) { h.t = 0.0f; h.inst = ORC_MISS; }
+    else if (s->n_inst == 0) h.inst = 0u;
     *hit = h;
     if (cnt) { cnt->rays += 1; cnt->nodes_visited += nodes; cnt->tris_tested += tris; }
 }
@@ -495,6 +633,18 @@ void orc_shade_hit(const orc_scene *s, const orc_hit *h, float position[3], floa
     for (int k = 0; k < 3; k++) {
         brdf[k] = f[k] / 3.1415927410125732f; /* true divide by float(pi), closesthit.rchit:60 */
         emission[k] = f[3 + k];
+    }
+    if (s->n_inst) {
+        /* instanced scenes (not in the reference, whose closesthit uses object-space vertices
+         * with one identity instance): position by the object->world matrix, normal by the
+         * inverse transpose, renormalised */
+        const orc_instance *in = &s->inst[h->inst];
+        float pw[3], nw[3];
+        xform_point(in->m, position, pw);
+        for (int k = 0; k < 3; k++)
+            nw[k] = (in->inv[k] * normal[0] + in->inv[4 + k] * normal[1]) + in->inv[8 + k] * normal[2];
+        float l = sqrtf((nw[0] * nw[0] + nw[1] * nw[1]) + nw[2] * nw[2]);
+        for (int k = 0; k < 3; k++) { position[k] = pw[k]; normal[k] = nw[k] / l; }
     }
 }
 

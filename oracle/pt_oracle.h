@@ -62,6 +62,13 @@ typedef struct orc_scene orc_scene;
 orc_scene *orc_scene_create(const float *vertices, uint32_t n_verts,
                             const uint32_t *indices, uint32_t n_tris, const float *faces);
 void orc_scene_destroy(orc_scene *s);
+/* Two-level scenes (BASELINE config C4; the reference builds ONE identity instance,
+ * main.cpp:515-538): n object->world matrices, 3x4 row major like VkTransformMatrixKHR.
+ * n = 0 returns to the single-level scene.  Semantics: world->object
+ * matrix = adjugate/determinant in binary64 rounded to float; the ray goes to object space
+ * un-normalised (t is shared by both spaces); closest t, ties -> lowest (instance, primitive);
+ * hit position by the matrix, normal by the inverse transpose, renormalised.              */
+int orc_scene_set_instances(orc_scene *s, const float *xforms3x4, uint32_t n);
 
 /* LBVH facts (Morton 63-bit keys of triangle-AABB centres, stable sort, Karras 2012).  */
 typedef struct orc_bvh_info {
@@ -79,6 +86,7 @@ void orc_scene_bvh_nodes(const orc_scene *s, uint32_t *nodes16);
 typedef struct orc_hit {
     uint32_t prim;   /* 0xFFFFFFFF = miss */
     float    t, u, v; /* u -> weight of v1 (attribs.x), v -> weight of v2 (attribs.y) */
+    uint32_t inst;   /* gl_InstanceID: 0 without instances, 0xFFFFFFFF on a miss */
 } orc_hit;
 typedef struct orc_counters {
     uint64_t rays, nodes_visited /* child boxes tested */, tris_tested;

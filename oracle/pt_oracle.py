@@ -34,7 +34,7 @@ class Counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
 
 
-HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("inst", "<u4")])
 
 
 def build(force=False):
@@ -63,6 +63,7 @@ def lib():
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_set_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_scene_bvh_info.argtypes = [C.c_void_p, C.POINTER(BvhInfo)]
         L.orc_scene_bvh_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_scene_bvh_nodes.argtypes = [C.c_void_p, C.c_void_p]
@@ -137,6 +138,12 @@ class Scene:
         if getattr(self, "h", None):
             lib().orc_scene_destroy(self.h)
             self.h = None
+
+    def set_instances(self, xforms3x4):
+        """n object->world matrices [n,3,4] (VkTransformMatrixKHR layout); empty = single level."""
+        x = np.ascontiguousarray(xforms3x4, dtype=np.float32).reshape(-1, 12)
+        if lib().orc_scene_set_instances(self.h, x.ctypes.data if len(x) else None, len(x)):
+            raise ValueError("orc_scene_set_instances failed")
 
     def bvh_info(self):
         i = BvhInfo()

@@ -51,7 +51,8 @@ class Params(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_height", C.c_uint32),
-                ("n_wide_nodes", C.c_uint32), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
+                ("n_wide_nodes", C.c_uint32), ("n_instances", C.c_uint32), ("n_tlas_nodes", C.c_uint32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
                 ("device_bytes", C.c_uint64)]
 
 
@@ -67,10 +68,11 @@ class HostScene(C.Structure):
                 ("n_tris", C.c_uint32), ("faces", C.POINTER(C.c_float))]
 
 
-HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("inst", "<u4")])
 
 # every symbol include/pt_api.h and include/pt_host.h declare
 API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "pt_scene_create", "pt_scene_destroy",
+               "pt_scene_set_instances",
                "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_film_create", "pt_film_create_external", "pt_film_clear",
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render", "pt_trace",
                "pt_get_stats", "pt_reset_stats"]
@@ -105,6 +107,7 @@ def lib_amd():
         L.pt_scene_create.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(vp)]
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None
+        L.pt_scene_set_instances.argtypes = [vp, vp, C.c_uint32]
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.pt_scene_read_bvh.argtypes = [vp, vp, vp, vp]
         L.pt_scene_read_bvh4.argtypes = [vp, vp]
@@ -179,6 +182,20 @@ def write_soup_obj(path, n_tris, seed=1):
         raise RuntimeError(f"cannot write {path}")
 
 
+def cornell_grid_instances(n=100, cell=0.02, scale=0.009):
+    """BASELINE config C4 (frozen recipe): n x n instances of the scene in the
+    z = 0 plane filling x in [-1,1], y in [-2,0]: uniform scale `scale`, translation
+    (-1 + (i+1/2) cell, -2 + (j+1/2) cell + scale, 0); row-major 3x4, instance id = j*n + i."""
+    m = np.zeros((n * n, 3, 4), dtype=np.float32)
+    i = np.arange(n, dtype=np.float32)
+    tx = (np.float32(-1.0) + (i + np.float32(0.5)) * np.float32(cell)).astype(np.float32)
+    ty = (np.float32(-2.0) + (i + np.float32(0.5)) * np.float32(cell) + np.float32(scale)).astype(np.float32)
+    m[:, 0, 0] = m[:, 1, 1] = m[:, 2, 2] = np.float32(scale)
+    m[:, 0, 3] = np.tile(tx, n)
+    m[:, 1, 3] = np.repeat(ty, n)
+    return m
+
+
 # ---- device side --------------------------------------------------------------------------------
 def default_params(**kw):
     p = Params()
@@ -246,6 +263,12 @@ class Scene:
     @classmethod
     def from_obj(cls, ctx, path=ASSET_CORNELL):
         return cls(ctx, *load_obj(path))
+
+    def set_instances(self, xforms3x4):
+        """n object->world 3x4 matrices (VkTransformMatrixKHR layout); empty = the reference's
+        single identity instance (main.cpp:515-538)."""
+        x = np.ascontiguousarray(xforms3x4, dtype=np.float32).reshape(-1, 12)
+        self.ctx._check(lib_amd().pt_scene_set_instances(self.h, x.ctypes.data if len(x) else None, len(x)))
 
     def info(self):
         i = SceneInfo()

@@ -50,11 +50,10 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// 1. gather + bounds.  tri_orig: 3 float4 per triangle in prim-id order.
+// 1. gather: de-indexed triangles + their boxes.  tri_orig: 3 float4 per triangle in prim-id order.
 __global__ __launch_bounds__(TB) void k_gather(const float *__restrict__ vertices, const uint32_t *__restrict__ indices,
                                                uint32_t n_tris, float4 *__restrict__ tri_orig,
-                                               float4 *__restrict__ tlo, float4 *__restrict__ thi,
-                                               uint32_t *__restrict__ scene_ord /*[6]: min xyz, max xyz*/)
+                                               float4 *__restrict__ tlo, float4 *__restrict__ thi)
 {
     const uint32_t t = blockIdx.x * TB + threadIdx.x;
     float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -73,13 +72,6 @@ __global__ __launch_bounds__(TB) void k_gather(const float *__restrict__ vertice
         tri_orig[3 * (size_t)t + 2] = make_float4(v[2][0], v[2][1], v[2][2], 0.f);
         tlo[t] = make_float4(mn[0], mn[1], mn[2], 0.f);
         thi[t] = make_float4(mx[0], mx[1], mx[2], 0.f);
-    }
-    for (int k = 0; k < 3; k++) {
-        const float a = wave_min(mn[k]), b = wave_max(mx[k]);
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&scene_ord[k], f2ord(a));
-            atomicMax(&scene_ord[3 + k], f2ord(b));
-        }
     }
 }
 
@@ -463,29 +455,45 @@ struct DevBuf {
 
 }  // namespace
 
-pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
-                          uint32_t n_tris, const float *h_faces)
-{
-    pt_ctx *ctx = s->ctx;
-    hipStream_t st = ctx->stream;
-    const uint32_t n = n_tris;
-    const uint32_t gt = (n + TB - 1) / TB;
+// ---- generic part: n boxes (tlo/thi on the device) -> sorted order, binary LBVH, BVH4 ----------
+struct BvhOut {
+    unsigned long long *d_keys = nullptr;  // sorted Morton keys           (caller owns)
+    uint32_t *d_prim_of = nullptr;         // sorted position -> box id
+    float4 *d_nodes = nullptr;             // binary nodes, 64 B
+    float4 *d_wide = nullptr;              // BVH4 nodes, 128 B
+    uint32_t n_nodes = 0, n_wide = 0, height = 0;
+    float bmin[3]{}, bmax[3]{};
+};
 
-    DevBuf<float> d_vert, d_faces;
-    DevBuf<uint32_t> d_idx, d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height;
-    DevBuf<float4> d_tri_orig, d_tlo, d_thi, d_blo, d_bhi;
+__global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n,
+                                               uint32_t *__restrict__ scene_ord)
+{
+    const uint32_t t = blockIdx.x * TB + threadIdx.x;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (t < n) {
+        const float4 a = tlo[t], b = thi[t];
+        mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
+        mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
+    }
+    for (int k = 0; k < 3; k++) {
+        const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&scene_ord[k], f2ord(a));
+            atomicMax(&scene_ord[3 + k], f2ord(b));
+        }
+    }
+}
+
+static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, BvhOut &out)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t gt = (n + TB - 1) / TB;
+    DevBuf<uint32_t> d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height, d_wflag, d_widx;
+    DevBuf<float4> d_blo, d_bhi;
     DevBuf<unsigned long long> d_keys[2];
     DevBuf<uint2> d_topo, d_range;
-    DevBuf<uint32_t> d_wflag, d_widx;
     const uint32_t nblocks = (n + RS_TILE - 1) / RS_TILE;
-
-    PT_HIP(ctx, d_vert.alloc(3 * (size_t)n_verts));
-    PT_HIP(ctx, d_idx.alloc(3 * (size_t)n));
-    PT_HIP(ctx, d_faces.alloc(6 * (size_t)n));
     PT_HIP(ctx, d_scene.alloc(6));
-    PT_HIP(ctx, d_tri_orig.alloc(3 * (size_t)n));
-    PT_HIP(ctx, d_tlo.alloc(n));
-    PT_HIP(ctx, d_thi.alloc(n));
     for (int i = 0; i < 2; i++) {
         PT_HIP(ctx, d_keys[i].alloc(n));
         PT_HIP(ctx, d_vals[i].alloc(n));
@@ -501,26 +509,18 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, d_height.alloc(1));
     PT_HIP(ctx, d_blo.alloc(2 * (size_t)n));
     PT_HIP(ctx, d_bhi.alloc(2 * (size_t)n));
+    out.n_nodes = n > 1 ? n - 1 : 1;
+    PT_HIP(ctx, hipMalloc((void **)&out.d_nodes, sizeof(float4) * 4 * (size_t)out.n_nodes));
+    PT_HIP(ctx, hipMalloc((void **)&out.d_keys, sizeof(unsigned long long) * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&out.d_prim_of, sizeof(uint32_t) * (size_t)n));
 
-    s->n_tris = n;
-    s->n_nodes = n > 1 ? n - 1 : 1;
-    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * 3 * (size_t)n));
-    PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
-    PT_HIP(ctx, hipMalloc((void **)&s->d_nodes, sizeof(float4) * 4 * (size_t)s->n_nodes));
-    PT_HIP(ctx, hipMalloc((void **)&s->d_keys, sizeof(unsigned long long) * (size_t)n));
-    PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of, sizeof(uint32_t) * (size_t)n));
-
-    PT_HIP(ctx, hipMemcpyAsync(d_vert.p, h_vertices, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemcpyAsync(d_idx.p, h_indices, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemcpyAsync(d_faces.p, h_faces, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st));
     const uint32_t ord_init[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
     PT_HIP(ctx, hipMemcpyAsync(d_scene.p, ord_init, sizeof(ord_init), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t) * (size_t)n, st));
-    PT_HIP(ctx, hipStreamSynchronize(st));  // pageable host sources are done with
+    PT_HIP(ctx, hipStreamSynchronize(st));  // ord_init is a stack array
 
-    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
-    k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p, d_scene.p);
-    k_morton<<<gt, TB, 0, st>>>(d_tlo.p, d_thi.p, n, d_scene.p, d_keys[0].p, d_vals[0].p);
+    k_bounds<<<gt, TB, 0, st>>>(d_tlo, d_thi, n, d_scene.p);
+    k_morton<<<gt, TB, 0, st>>>(d_tlo, d_thi, n, d_scene.p, d_keys[0].p, d_vals[0].p);
     int cur = 0;
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 8 * pass;
@@ -530,17 +530,16 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
                                              d_hist.p, nblocks);
         cur ^= 1;
     }
-    PT_HIP(ctx, hipMemcpyAsync(s->d_keys, d_keys[cur].p, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    PT_HIP(ctx, hipMemcpyAsync(s->d_prim_of, d_vals[cur].p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(out.d_keys, d_keys[cur].p, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(out.d_prim_of, d_vals[cur].p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
 
     if (n > 1) {
-        k_karras<<<(n - 1 + TB - 1) / TB, TB, 0, st>>>(s->d_keys, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_range.p);
-        k_refit<<<gt, TB, 0, st>>>(d_tlo.p, d_thi.p, s->d_prim_of, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_blo.p, d_bhi.p,
-                                   d_flags.p, d_scene.p, s->d_nodes, d_height.p);
+        k_karras<<<(n - 1 + TB - 1) / TB, TB, 0, st>>>(out.d_keys, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_range.p);
+        k_refit<<<gt, TB, 0, st>>>(d_tlo, d_thi, out.d_prim_of, (int)n, d_topo.p, d_pint.p, d_pleaf.p, d_blo.p, d_bhi.p,
+                                   d_flags.p, d_scene.p, out.d_nodes, d_height.p);
     } else {
-        k_single<<<1, 1, 0, st>>>(d_tlo.p, d_thi.p, d_scene.p, s->d_nodes, d_height.p);
+        k_single<<<1, 1, 0, st>>>(d_tlo, d_thi, d_scene.p, out.d_nodes, d_height.p);
     }
-    k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4);
     // BVH4 collapse: flag wide roots, number them (exclusive scan), emit 128-B nodes
     uint32_t n_wide = 1;
     if (n > 1) {
@@ -554,24 +553,169 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
         PT_HIP(ctx, hipMemcpyAsync(&last_flag, d_wflag.p + (n_int - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
         n_wide = last_idx + last_flag;
-        PT_HIP(ctx, hipMalloc((void **)&s->d_wide, 128 * (size_t)n_wide));
-        k_wide_emit<<<gi, TB, 0, st>>>((int)n, n_int, d_topo.p, d_range.p, d_wflag.p, d_widx.p, d_blo.p, d_bhi.p, s->d_wide);
+        PT_HIP(ctx, hipMalloc((void **)&out.d_wide, 128 * (size_t)n_wide));
+        k_wide_emit<<<gi, TB, 0, st>>>((int)n, n_int, d_topo.p, d_range.p, d_wflag.p, d_widx.p, d_blo.p, d_bhi.p, out.d_wide);
     } else {
-        PT_HIP(ctx, hipMalloc((void **)&s->d_wide, 128));
-        k_wide_single<<<1, 1, 0, st>>>(s->d_nodes, s->d_wide);
+        PT_HIP(ctx, hipMalloc((void **)&out.d_wide, 128));
+        k_wide_single<<<1, 1, 0, st>>>(out.d_nodes, out.d_wide);
     }
-    s->n_wide = n_wide;
-    s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * n_wide;
-    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    out.n_wide = n_wide;
     uint32_t ord[6];
     PT_HIP(ctx, hipMemcpyAsync(ord, d_scene.p, sizeof(ord), hipMemcpyDeviceToHost, st));
-    PT_HIP(ctx, hipMemcpyAsync(&s->height, d_height.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipMemcpyAsync(&out.height, d_height.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipStreamSynchronize(st));
     for (int k = 0; k < 3; k++) {
-        s->bmin[k] = ord2f(ord[k]);
-        s->bmax[k] = ord2f(ord[3 + k]);
+        out.bmin[k] = ord2f(ord[k]);
+        out.bmax[k] = ord2f(ord[3 + k]);
     }
     PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
+                          uint32_t n_tris, const float *h_faces)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = n_tris;
+    const uint32_t gt = (n + TB - 1) / TB;
+    DevBuf<float> d_vert, d_faces;
+    DevBuf<uint32_t> d_idx;
+    DevBuf<float4> d_tri_orig, d_tlo, d_thi;
+    PT_HIP(ctx, d_vert.alloc(3 * (size_t)n_verts));
+    PT_HIP(ctx, d_idx.alloc(3 * (size_t)n));
+    PT_HIP(ctx, d_faces.alloc(6 * (size_t)n));
+    PT_HIP(ctx, d_tri_orig.alloc(3 * (size_t)n));
+    PT_HIP(ctx, d_tlo.alloc(n));
+    PT_HIP(ctx, d_thi.alloc(n));
+    s->n_tris = n;
+    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * 3 * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
+    PT_HIP(ctx, hipMemcpyAsync(d_vert.p, h_vertices, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_idx.p, h_indices, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_faces.p, h_faces, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));  // pageable host sources are done with
+
+    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p);
+    BvhOut o;
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, o);
+    s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
+    if (rc != PT_OK) return rc;
+    s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height;
+    for (int k = 0; k < 3; k++) { s->bmin[k] = o.bmin[k]; s->bmax[k] = o.bmax[k]; }
+    k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4);
+    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
+    s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
+    return PT_OK;
+}
+
+// ---- instances: TLAS over world boxes of the transformed BLAS root box --------------------------
+// (beyond the reference, which builds ONE identity instance, main.cpp:515-538)
+__global__ __launch_bounds__(TB) void k_inst_boxes(const float4 *__restrict__ blas_wide, const float4 *__restrict__ inst6,
+                                                   uint32_t n, float4 *__restrict__ tlo, float4 *__restrict__ thi)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    // object box = union of the (padded) child boxes of the BLAS root
+    float omin[3] = { INFINITY, INFINITY, INFINITY }, omax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    const float4 lx = blas_wide[0], ly = blas_wide[1], lz = blas_wide[2], hx = blas_wide[3], hy = blas_wide[4], hz = blas_wide[5];
+    const float4 cw = blas_wide[6];
+    const float l[3][4] = { { lx.x, lx.y, lx.z, lx.w }, { ly.x, ly.y, ly.z, ly.w }, { lz.x, lz.y, lz.z, lz.w } };
+    const float h[3][4] = { { hx.x, hx.y, hx.z, hx.w }, { hy.x, hy.y, hy.z, hy.w }, { hz.x, hz.y, hz.z, hz.w } };
+    const uint32_t w[4] = { __float_as_uint(cw.x), __float_as_uint(cw.y), __float_as_uint(cw.z), __float_as_uint(cw.w) };
+    for (int c = 0; c < 4; c++)
+        if (w[c] != PT_MISS)
+            for (int k = 0; k < 3; k++) { omin[k] = fminf(omin[k], l[k][c]); omax[k] = fmaxf(omax[k], h[k][c]); }
+    const float4 m0 = inst6[6 * (size_t)i + 0], m1 = inst6[6 * (size_t)i + 1], m2 = inst6[6 * (size_t)i + 2];
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int c = 0; c < 8; c++) {
+        const float px = (c & 1) ? omax[0] : omin[0], py = (c & 2) ? omax[1] : omin[1], pz = (c & 4) ? omax[2] : omin[2];
+        const float wx = ((m0.x * px + m0.y * py) + m0.z * pz) + m0.w;
+        const float wy = ((m1.x * px + m1.y * py) + m1.z * pz) + m1.w;
+        const float wz = ((m2.x * px + m2.y * py) + m2.z * pz) + m2.w;
+        mn[0] = fminf(mn[0], wx); mn[1] = fminf(mn[1], wy); mn[2] = fminf(mn[2], wz);
+        mx[0] = fmaxf(mx[0], wx); mx[1] = fmaxf(mx[1], wy); mx[2] = fmaxf(mx[2], wz);
+    }
+    tlo[i] = make_float4(mn[0], mn[1], mn[2], 0.f);
+    thi[i] = make_float4(mx[0], mx[1], mx[2], 0.f);
+}
+
+__global__ __launch_bounds__(TB) void k_inst_sort(const float4 *__restrict__ inst6, const uint32_t *__restrict__ prim_of,
+                                                  uint32_t n, float4 *__restrict__ sorted6)
+{
+    const uint32_t pos = blockIdx.x * TB + threadIdx.x;
+    if (pos >= n) return;
+    const uint32_t id = prim_of[pos];
+    for (int k = 0; k < 6; k++) sorted6[6 * (size_t)pos + k] = inst6[6 * (size_t)id + k];
+}
+
+// world -> object matrix: adjugate / determinant in binary64, rounded once to float
+static void invert_3x4(const float m[12], float inv[12])
+{
+    const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+    const double det = (a00 * c00 + a01 * c01) + a02 * c02;
+    const double i00 = c00 / det, i01 = (a02 * a21 - a01 * a22) / det, i02 = (a01 * a12 - a02 * a11) / det;
+    const double i10 = c01 / det, i11 = (a00 * a22 - a02 * a20) / det, i12 = (a02 * a10 - a00 * a12) / det;
+    const double i20 = c02 / det, i21 = (a01 * a20 - a00 * a21) / det, i22 = (a00 * a11 - a01 * a10) / det;
+    const double tx = m[3], ty = m[7], tz = m[11];
+    inv[0] = (float)i00; inv[1] = (float)i01; inv[2] = (float)i02;  inv[3] = (float)(-((i00 * tx + i01 * ty) + i02 * tz));
+    inv[4] = (float)i10; inv[5] = (float)i11; inv[6] = (float)i12;  inv[7] = (float)(-((i10 * tx + i11 * ty) + i12 * tz));
+    inv[8] = (float)i20; inv[9] = (float)i21; inv[10] = (float)i22; inv[11] = (float)(-((i20 * tx + i21 * ty) + i22 * tz));
+}
+
+void ptb_free_instances(pt_scene *s)
+{
+    (void)hipFree(s->d_inst6); (void)hipFree(s->d_tlas_wide); (void)hipFree(s->d_tlas_prim_of);
+    s->d_inst6 = nullptr; s->d_tlas_wide = nullptr; s->d_tlas_prim_of = nullptr;
+    s->n_inst = 0; s->n_tlas_wide = 0; s->tlas_height = 0;
+}
+
+pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    ptb_free_instances(s);
+    if (n == 0) return PT_OK;
+    std::vector<float> rec(24 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *m = xforms3x4 + 12 * (size_t)i;
+        for (int k = 0; k < 12; k++) {
+            if (!(m[k] == m[k]) || __builtin_isinf(m[k])) { ctx->err = "instance matrix has a NaN/Inf"; return PT_ERR_INVALID_ARG; }
+            rec[24 * (size_t)i + k] = m[k];
+        }
+        invert_3x4(m, &rec[24 * (size_t)i + 12]);
+        for (int k = 12; k < 24; k++)
+            if (!(rec[24 * (size_t)i + k] == rec[24 * (size_t)i + k]) || __builtin_isinf(rec[24 * (size_t)i + k])) {
+                ctx->err = "instance matrix is singular";
+                return PT_ERR_INVALID_ARG;
+            }
+    }
+    DevBuf<float4> d_in, d_tlo, d_thi;
+    PT_HIP(ctx, d_in.alloc(6 * (size_t)n));
+    PT_HIP(ctx, d_tlo.alloc(n));
+    PT_HIP(ctx, d_thi.alloc(n));
+    PT_HIP(ctx, hipMemcpy(d_in.p, rec.data(), sizeof(float) * 24 * (size_t)n, hipMemcpyHostToDevice));
+    const uint32_t g = (n + TB - 1) / TB;
+    k_inst_boxes<<<g, TB, 0, st>>>(s->d_wide, d_in.p, n, d_tlo.p, d_thi.p);
+    BvhOut o;
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, o);
+    (void)hipFree(o.d_keys);
+    (void)hipFree(o.d_nodes);
+    s->d_tlas_wide = o.d_wide;
+    s->d_tlas_prim_of = o.d_prim_of;
+    if (rc != PT_OK) { ptb_free_instances(s); return rc; }
+    PT_HIP(ctx, hipMalloc((void **)&s->d_inst6, sizeof(float4) * 6 * (size_t)n));
+    k_inst_sort<<<g, TB, 0, st>>>(d_in.p, s->d_tlas_prim_of, n, s->d_inst6);
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    s->n_inst = n;
+    s->n_tlas_wide = o.n_wide;
+    s->tlas_height = o.height;
     return PT_OK;
 }

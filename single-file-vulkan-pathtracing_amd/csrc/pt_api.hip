@@ -91,9 +91,19 @@ pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts, 
     return PT_OK;
 }
 
+pt_status pt_scene_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
+{
+    if (!s) return PT_ERR_INVALID_ARG;
+    if (n && !xforms3x4) { s->ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
+    if (n >= (1u << 28)) { s->ctx->err = "too many instances"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return ptb_set_instances(s, xforms3x4, n);
+}
+
 void pt_scene_destroy(pt_scene *s)
 {
     if (!s) return;
+    ptb_free_instances(s);
     (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes); (void)hipFree(s->d_wide);
     (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
     delete s;
@@ -104,6 +114,8 @@ pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
     if (!s || !info) return PT_ERR_INVALID_ARG;
     info->n_tris = s->n_tris; info->n_nodes = s->n_nodes; info->bvh_height = s->height;
     info->n_wide_nodes = s->n_wide;
+    info->n_instances = s->n_inst;
+    info->n_tlas_nodes = s->n_tlas_wide;
     for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
     info->build_ms = s->build_ms;
     info->device_bytes = s->device_bytes;

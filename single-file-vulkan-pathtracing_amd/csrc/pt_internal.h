@@ -44,6 +44,11 @@ struct pt_scene {
     unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
     uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
     uint64_t device_bytes = 0;
+    // two-level scenes: instances in TLAS leaf order, 6 float4 each {object->world rows, world->object rows}
+    uint32_t n_inst = 0, n_tlas_wide = 0, tlas_height = 0;
+    float4 *d_inst6 = nullptr;
+    float4 *d_tlas_wide = nullptr;        // BVH4 over the instances' world boxes
+    uint32_t *d_tlas_prim_of = nullptr;   // sorted position -> instance id (gl_InstanceID)
 };
 
 struct pt_film {
@@ -66,6 +71,7 @@ struct pt_film {
         float4 *d_qrayA[2] = { nullptr, nullptr };    // {org.xyz, dir.x}
         float2 *d_qrayB[2] = { nullptr, nullptr };    // {dir.y, dir.z}
         float4 *d_hit = nullptr;                      // {bits(pos), t, u, v}
+        uint32_t *d_hit_inst = nullptr;               // instance (TLAS sorted position); only for two-level scenes
         uint32_t *d_count = nullptr;                  // [2] queue sizes
     } work;
 };
@@ -82,6 +88,8 @@ struct pt_film {
 // lbvh_build.hip
 pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
                           uint32_t n_tris, const float *h_faces);
+pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
+void ptb_free_instances(pt_scene *s);
 // wavefront.hip
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);
 pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits);

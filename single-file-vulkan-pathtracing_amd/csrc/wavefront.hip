@@ -315,6 +315,211 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     }
 }
 
+// ---- extend, two-level variant (BASELINE config C4: instanced scenes) ----------------------------
+// TLAS = BVH4 over the instances' world boxes, BLAS = the scene's BVH4 in object space.  Same
+// persistent-thread structure; one stack serves both levels: entering an instance pushes an EXIT
+// marker, everything above it belongs to the BLAS walk, popping it restores the world-space ray.
+// The ray goes to object space un-normalised (Vulkan semantics: t is the same parameter in both
+// spaces), so entry distances and the best hit compare across levels.  Not in the reference
+// (one identity instance, main.cpp:515-538); semantics in DESIGN.md section 3.
+constexpr uint32_t EXIT_MARK = 0x7FFFFFFFu;
+
+template <bool COUNT>
+__global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ tlas, const float4 *__restrict__ blas,
+                                                    const float4 *__restrict__ tri4, const float4 *__restrict__ inst6,
+                                                    const uint32_t *__restrict__ inst_id, const float4 *__restrict__ rayA,
+                                                    const float2 *__restrict__ rayB, float4 *__restrict__ hit,
+                                                    uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
+                                                    uint32_t *count_zero, unsigned long long *stats,
+                                                    uint2 *__restrict__ spill, uint32_t spill_stride, int refill_min_idle,
+                                                    float tmin, float tmax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
+    const uint32_t n = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (count_zero) *count_zero = 0u;
+        if (stats) atomicAdd(stats, (unsigned long long)n);
+    }
+    uint2 *my_stack = stack + threadIdx.x;
+    uint2 *my_spill = spill + (size_t)blockIdx.x * TB + threadIdx.x;
+    const float INF = __builtin_inff();
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    bool have = false, exhausted = false, in_blas = false;
+    uint32_t q = 0;
+    ptm::f3 org_w{}, dir_w{}, inv_w{};   // world-space ray
+    ptm::f3 org{}, inv{};                 // ray of the level being walked
+    ptm::RayPre pre{};
+    float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
+    uint32_t best_pos = PT_MISS, best_prim = PT_MISS, best_ipos = PT_MISS, best_iid = PT_MISS;
+    uint32_t cur = SENTINEL, cur_ipos = 0, cur_iid = 0;
+    float cur_t = 0.f;
+    int sp = 0;
+    unsigned long long c_nodes = 0, c_tris = 0;
+    const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
+    const uint32_t wave_stride = gridDim.x * TB;
+    uint32_t cursor = 0;
+
+    auto push = [&](uint32_t w, float t) {
+        const uint2 e = make_uint2(w, __float_as_uint(t));
+        if (sp < LDS_STACK) my_stack[sp * TB] = e;
+        else my_spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
+        sp++;
+    };
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            sp--;
+            const uint2 e = sp < LDS_STACK ? my_stack[sp * TB] : my_spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            if (e.x == EXIT_MARK) {  // the instance is done: back to the world-space ray and the TLAS
+                org = org_w;
+                inv = inv_w;
+                in_blas = false;
+                continue;
+            }
+            if (__uint_as_float(e.y) <= best_t) {
+                cur_t = __uint_as_float(e.y);
+                return e.x;
+            }
+        }
+        return SENTINEL;
+    };
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= refill_min_idle) {
+            if (!have) {
+                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
+                const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
+                if (qq < n) {
+                    q = qq;
+                    const float4 ra = rayA[q];
+                    const float2 rb = rayB[q];
+                    org_w = { ra.x, ra.y, ra.z };
+                    dir_w = { ra.w, rb.x, rb.y };
+                    inv_w = { ptm::safe_inv(dir_w.x), ptm::safe_inv(dir_w.y), ptm::safe_inv(dir_w.z) };
+                    org = org_w;
+                    inv = inv_w;
+                    in_blas = false;
+                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
+                    cur = 0u;  // TLAS root
+                    cur_t = tmin;
+                    sp = 0;
+                    have = true;
+                }
+            }
+            cursor += (uint32_t)n_idle;
+            exhausted = (cursor >> 6) * wave_stride + wave_base >= n;
+        }
+        if (__ballot(have) == 0ull) break;
+
+        // ---- node phase (either level)
+        while (have && !(cur & PT_LEAF)) {
+            const float4 *nd = (in_blas ? blas : tlas) + 8 * (size_t)cur;
+            const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+            const float4 cw = nd[6];
+            if (COUNT) c_nodes++;
+            float t0, t1, t2, t3;
+            uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
+                     w3 = __float_as_uint(cw.w);
+#define PT_SLAB(T, LX, LY, LZ, HX, HY, HZ)                                                         \
+    {                                                                                             \
+        float tn;                                                                                 \
+        const bool h = ptm::box_test({ LX, LY, LZ }, { HX, HY, HZ }, org, inv, tmin, best_t, tn); \
+        T = h ? tn : INF;                                                                         \
+    }
+            PT_SLAB(t0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x)
+            PT_SLAB(t1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y)
+            PT_SLAB(t2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z)
+            PT_SLAB(t3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w)
+#undef PT_SLAB
+#define PT_CSWAP(TA, WA, TB_, WB)                            \
+    {                                                        \
+        const bool sw = TB_ < TA;                            \
+        const float ta = sw ? TB_ : TA, tb = sw ? TA : TB_;  \
+        const uint32_t wa = sw ? WB : WA, wb = sw ? WA : WB; \
+        TA = ta; TB_ = tb; WA = wa; WB = wb;                 \
+    }
+            PT_CSWAP(t0, w0, t1, w1)
+            PT_CSWAP(t2, w2, t3, w3)
+            PT_CSWAP(t0, w0, t2, w2)
+            PT_CSWAP(t1, w1, t3, w3)
+            PT_CSWAP(t1, w1, t2, w2)
+#undef PT_CSWAP
+            if (t3 < INF) push(w3, t3);
+            if (t2 < INF) push(w2, t2);
+            if (t1 < INF) push(w1, t1);
+            if (t0 < INF) { cur = w0; cur_t = t0; }
+            else cur = pop();
+        }
+        // ---- leaf phase
+        if (have) {
+            if (cur != SENTINEL) {
+                const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+                if (in_blas) {
+                    if (COUNT) c_tris += cnt;
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const uint32_t pos = first + k;
+                        const float4 a = tri4[3 * (size_t)pos + 0], b = tri4[3 * (size_t)pos + 1],
+                                     c = tri4[3 * (size_t)pos + 2];
+                        float t, V, W, det;
+                        if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
+                            const uint32_t prim = __float_as_uint(a.w);
+                            // closest t; equal t -> lowest (gl_InstanceID, gl_PrimitiveID)
+                            if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
+                                best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                                best_ipos = cur_ipos; best_iid = cur_iid;
+                            }
+                        }
+                    }
+                    cur = pop();
+                } else {
+                    // TLAS leaf: up to 4 instances; all but the first go back on the stack as
+                    // single-instance leaves, the first is entered now
+                    for (uint32_t k = cnt - 1u; k >= 1u; k--) push(PT_LEAF | (first + k), cur_t);
+                    cur_ipos = first;
+                    cur_iid = inst_id[first];
+                    const float4 r0 = inst6[6 * (size_t)first + 3], r1 = inst6[6 * (size_t)first + 4],
+                                 r2 = inst6[6 * (size_t)first + 5];
+                    const ptm::f3 oo = { ((r0.x * org_w.x + r0.y * org_w.y) + r0.z * org_w.z) + r0.w,
+                                         ((r1.x * org_w.x + r1.y * org_w.y) + r1.z * org_w.z) + r1.w,
+                                         ((r2.x * org_w.x + r2.y * org_w.y) + r2.z * org_w.z) + r2.w };
+                    const ptm::f3 od = { (r0.x * dir_w.x + r0.y * dir_w.y) + r0.z * dir_w.z,
+                                         (r1.x * dir_w.x + r1.y * dir_w.y) + r1.z * dir_w.z,
+                                         (r2.x * dir_w.x + r2.y * dir_w.y) + r2.z * dir_w.z };
+                    org = oo;
+                    inv = { ptm::safe_inv(od.x), ptm::safe_inv(od.y), ptm::safe_inv(od.z) };
+                    pre = ptm::ray_setup(oo, od);
+                    push(EXIT_MARK, 0.f);
+                    in_blas = true;
+                    cur = 0u;  // BLAS root
+                    cur_t = tmin;
+                }
+            }
+            if (cur == SENTINEL) {
+                const bool miss = best_pos == PT_MISS;
+                hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
+                                     miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                hit_inst[q] = best_ipos;
+                have = false;
+            }
+        }
+    }
+    if (COUNT) {
+        for (int o = 32; o > 0; o >>= 1) {
+            c_nodes += __shfl_xor(c_nodes, o, 64);
+            c_tris += __shfl_xor(c_tris, o, 64);
+        }
+        if (lane == 0 && stats) {
+            atomicAdd(stats + 2, c_nodes);
+            atomicAdd(stats + 3, c_tris);
+        }
+    }
+}
+
 // ---- extend, flat variant: the whole scene is ONE wide leaf ------------------------------------
 // For scenes of a few dozen triangles (the Cornell box has 36) a tree only adds divergence: rays
 // of a wave take different branches and the wave pays for the union.  Here every lane tests every
@@ -361,7 +566,8 @@ constexpr int SH_ITEMS = 4;
 __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ tri4, const float4 *__restrict__ shade4,
                                               const float4 *__restrict__ hit, float4 *__restrict__ color, QueueView in,
-                                              QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out)
+                                              QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out,
+                                              const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst)
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
@@ -416,7 +622,23 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
                     const float b0 = (1.0f - h.z) - h.w;
                     org = { (a.x * b0 + b.x * h.z) + c.x * h.w, (a.y * b0 + b.y * h.z) + c.y * h.w,
                             (a.z * b0 + b.z * h.z) + c.z * h.w };
-                    const ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                    ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                    if (inst6) {
+                        // instanced scene: position by the object->world matrix, normal by the inverse
+                        // transpose, renormalised (the reference's closesthit has one identity instance)
+                        const uint32_t ip = hit_inst[q];
+                        const float4 m0 = inst6[6 * (size_t)ip + 0], m1 = inst6[6 * (size_t)ip + 1], m2 = inst6[6 * (size_t)ip + 2];
+                        const float4 i0 = inst6[6 * (size_t)ip + 3], i1 = inst6[6 * (size_t)ip + 4], i2 = inst6[6 * (size_t)ip + 5];
+                        const ptm::f3 pw = { ((m0.x * org.x + m0.y * org.y) + m0.z * org.z) + m0.w,
+                                             ((m1.x * org.x + m1.y * org.y) + m1.z * org.z) + m1.w,
+                                             ((m2.x * org.x + m2.y * org.y) + m2.z * org.z) + m2.w };
+                        const float nx = (i0.x * nrm.x + i1.x * nrm.y) + i2.x * nrm.z;
+                        const float ny = (i0.y * nrm.x + i1.y * nrm.y) + i2.y * nrm.z;
+                        const float nz = (i0.z * nrm.x + i1.z * nrm.y) + i2.z * nrm.z;
+                        const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
+                        org = pw;
+                        nrm = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
+                    }
                     const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
                     const float r2 = ptm::rnd(seed);
                     dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
@@ -511,7 +733,9 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
 
 // hit records of the internal layout (sorted position) -> API layout (gl_PrimitiveID)
 __global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ hit, const float4 *__restrict__ tri4,
-                                                    uint32_t n, pt_hit *__restrict__ out)
+                                                    const uint32_t *__restrict__ hit_inst,
+                                                    const uint32_t *__restrict__ inst_id, uint32_t n,
+                                                    pt_hit *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
@@ -520,6 +744,7 @@ __global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ h
     pt_hit o;
     o.prim = pos == PT_MISS ? PT_MISS : __float_as_uint(tri4[3 * (size_t)pos].w);
     o.t = h.y; o.u = h.z; o.v = h.w;
+    o.inst = pos == PT_MISS ? PT_MISS : (hit_inst ? inst_id[hit_inst[i]] : 0u);
     out[i] = o;
 }
 
@@ -537,6 +762,29 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
     if (want > PT_EXTEND_HBM) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
+    if (s->n_inst) {  // two-level scenes: one kernel variant (BVH4s read through L1/L2)
+        if (want == PT_EXTEND_FLAT || want == PT_EXTEND_LDS) { ctx->err = "instanced scenes only have the HBM extend variant"; return PT_ERR_UNSUPPORTED; }
+        pl.variant = PT_EXTEND_HBM;
+        pl.lds_scene = false;
+        pl.smem = (size_t)LDS_STACK * TB * sizeof(uint2);
+        int per_cu_i = 0;
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_i, reinterpret_cast<const void *>(k_extend_inst<false>), TB, pl.smem));
+        per_cu_i = std::max(1, std::min(per_cu_i, 8));
+        if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+        pl.grid = ctx->num_cus * per_cu_i;
+        // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk
+        const uint32_t bound_i = 3u * (s->tlas_height / 2u + 1u) + 4u + 3u * (s->height / 2u + 1u) + 2u;
+        pl.spill_levels = bound_i > (uint32_t)LDS_STACK ? bound_i - (uint32_t)LDS_STACK : 0u;
+        const size_t need_i = (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
+        if (need_i > ctx->spill_bytes) {
+            (void)hipFree(ctx->d_spill);
+            ctx->d_spill = nullptr;
+            ctx->spill_bytes = 0;
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_spill, need_i));
+            ctx->spill_bytes = need_i;
+        }
+        return PT_OK;
+    }
     if (want == PT_EXTEND_FLAT && s->n_tris > 1024) { ctx->err = "flat extend variant needs <= 1024 triangles"; return PT_ERR_UNSUPPORTED; }
     if (want == PT_EXTEND_FLAT) {  // never chosen by AUTO: the LDS BVH4 with lane refill measured faster even at 36 triangles
         pl.variant = PT_EXTEND_FLAT;
@@ -579,9 +827,22 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 }
 
 void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
-                   const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats, float tmin, float tmax,
-                   bool count, hipStream_t st)
+                   uint32_t *hit_inst, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
+                   float tmin, float tmax, bool count, hipStream_t st)
 {
+    if (s->n_inst) {
+        uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill);
+        const uint32_t str = (uint32_t)pl.grid * TB;
+        if (count)
+            k_extend_inst<true><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->d_inst6, s->d_tlas_prim_of,
+                                                               rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp, str,
+                                                               pl.refill, tmin, tmax);
+        else
+            k_extend_inst<false><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->d_inst6, s->d_tlas_prim_of,
+                                                                rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp, str,
+                                                                pl.refill, tmin, tmax);
+        return;
+    }
     if (pl.variant == PT_EXTEND_FLAT) {
         k_extend_flat<<<pl.grid, TB, 0, st>>>(s->d_tri4, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, tmin, tmax);
         return;
@@ -631,6 +892,7 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes)
         PT_HIP(ctx, hipMalloc((void **)&w.d_qrayB[i], sizeof(float2) * ns));
     }
     PT_HIP(ctx, hipMalloc((void **)&w.d_hit, sizeof(float4) * ns));
+    PT_HIP(ctx, hipMalloc((void **)&w.d_hit_inst, sizeof(uint32_t) * ns));
     PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 4));  // [0],[1] queue sizes
     return PT_OK;
 }
@@ -650,6 +912,7 @@ void ptw_free_work(pt_film *f)
         (void)hipFree(w.d_qrayB[i]);
     }
     (void)hipFree(w.d_hit);
+    (void)hipFree(w.d_hit_inst);
     (void)hipFree(w.d_count);
     w = pt_film::Work{};
 }
@@ -723,11 +986,12 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
             uint32_t h_count = 1;
             hipEvent_t e_prev = profile ? new_event() : nullptr;  // one event between consecutive kernels
             for (uint32_t round = 0; round < max_rounds; round++) {
-                launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, &w.d_count[cur], &w.d_count[cur ^ 1], ctx->d_stats,
-                              p->tmin, p->tmax, count_visits, st);
+                launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, w.d_hit_inst, &w.d_count[cur], &w.d_count[cur ^ 1],
+                              ctx->d_stats, p->tmin, p->tmax, count_visits, st);
                 hipEvent_t e1 = profile ? new_event() : nullptr;
                 k_shade<<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, w.d_color, qv[cur], qv[cur ^ 1],
-                                                   &w.d_count[cur], &w.d_count[cur ^ 1]);
+                                                   &w.d_count[cur], &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,
+                                                   w.d_hit_inst);
                 hipEvent_t e2 = profile ? new_event() : nullptr;
                 if (profile) {
                     ev_triples.push_back(e_prev);
@@ -796,7 +1060,7 @@ pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, flo
     }
     float4 *d_a = nullptr, *d_hit = nullptr;
     float2 *d_b = nullptr;
-    uint32_t *d_cnt = nullptr;
+    uint32_t *d_cnt = nullptr, *d_hi = nullptr;
     pt_hit *d_out = nullptr;
     pt_status ret = PT_OK;
     auto fail = [&](hipError_t e, const char *what) {
@@ -809,18 +1073,19 @@ pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, flo
     if (ret == PT_OK && (e = hipMalloc((void **)&d_hit, sizeof(float4) * n)) != hipSuccess) fail(e, "hipMalloc");
     if (ret == PT_OK && (e = hipMalloc((void **)&d_out, sizeof(pt_hit) * n)) != hipSuccess) fail(e, "hipMalloc");
     if (ret == PT_OK && (e = hipMalloc((void **)&d_cnt, sizeof(uint32_t) * 2)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_hi, sizeof(uint32_t) * n)) != hipSuccess) fail(e, "hipMalloc");
     if (ret == PT_OK) {
         (void)hipMemcpyAsync(d_a, a.data(), sizeof(float4) * n, hipMemcpyHostToDevice, st);
         (void)hipMemcpyAsync(d_b, b.data(), sizeof(float2) * n, hipMemcpyHostToDevice, st);
         const uint32_t cnt_head[2] = { n, 0u };
         (void)hipMemcpyAsync(d_cnt, cnt_head, sizeof(cnt_head), hipMemcpyHostToDevice, st);
-        launch_extend(pl, s, d_a, d_b, d_hit, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, st);
-        k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, s->d_tri4, n, d_out);
+        launch_extend(pl, s, d_a, d_b, d_hit, d_hi, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, st);
+        k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, s->d_tri4, s->n_inst ? d_hi : nullptr, s->d_tlas_prim_of, n, d_out);
         (void)hipMemcpyAsync(hits, d_out, sizeof(pt_hit) * n, hipMemcpyDeviceToHost, st);
         if ((e = hipStreamSynchronize(st)) != hipSuccess) fail(e, "pt_trace");
         else if ((e = hipGetLastError()) != hipSuccess) fail(e, "pt_trace");
         ctx->stats.launches_extend++;
     }
-    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_hit); (void)hipFree(d_out); (void)hipFree(d_cnt);
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_hit); (void)hipFree(d_out); (void)hipFree(d_cnt); (void)hipFree(d_hi);
     return ret;
 }

@@ -350,6 +350,83 @@ def test_c2_size_properties(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
     film.close()
 
 
+def _random_instances(n, seed):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((n, 3, 4), np.float32)
+    for k in range(n):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        m[k, :, :3] = (q * rng.uniform(0.2, 0.6)).astype(np.float32)
+        m[k, :, 3] = rng.uniform(-1.5, 1.5, 3).astype(np.float32) + np.float32([0, -1, 0])
+    return m
+
+
+@pytest.mark.parametrize("n_inst,seed", [(1, 1), (2, 2), (5, 3), (60, 4), (1500, 5)])
+def test_instanced_trace_and_render_bit_exact(pt, orc, gpu_ctx, cornell_arrays, n_inst, seed):
+    """Two-level scenes (config C4's mechanism) with rotated + scaled instances."""
+    inst = _random_instances(n_inst, seed)
+    gs, osc = pt.Scene(gpu_ctx, *cornell_arrays), orc.Scene(*cornell_arrays)
+    gs.set_instances(inst)
+    osc.set_instances(inst)
+    info = gs.info()
+    assert info.n_instances == n_inst and info.n_tlas_nodes >= 1
+    rng = np.random.default_rng(seed + 100)
+    n = 20000
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32) + np.float32([0, -1, 0])
+    tgt = inst[rng.integers(0, n_inst, n), :, 3] + rng.uniform(-0.4, 0.4, (n, 3)).astype(np.float32)
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d.astype(np.float32)], 1)
+    hits = gs.trace(rays)
+    ohits, _ = osc.trace(rays, mode=1)
+    assert hits.tobytes() == ohits.tobytes()
+    assert (hits["prim"] != pt.MISS).mean() > 0.2
+    kw = dict(width=80, height=64, spp_per_frame=3, max_depth=6)
+    film = pt.Film(gpu_ctx, 80, 64)
+    gpu_ctx.reset_stats()
+    pt.render(gs, film, pt.default_params(frame=0, frame_count=2, **kw))
+    ofilm, obgra, orays = _render_oracle(orc, osc, 2, **kw)
+    assert gpu_ctx.stats().rays == orays
+    assert film.read_f32().tobytes() == ofilm.tobytes()
+    assert film.read_bgra8().tobytes() == obgra.tobytes()
+    # dropping the instances restores the reference's single-instance scene
+    gs.set_instances(np.zeros((0, 3, 4), np.float32))
+    film.clear()
+    pt.render(gs, film, pt.default_params(frame=0, frame_count=1, **kw))
+    single = orc.Scene(*cornell_arrays)
+    sfilm, _, _ = _render_oracle(orc, single, 1, **kw)
+    assert film.read_f32().tobytes() == sfilm.tobytes()
+    film.close(); gs.close()
+
+
+def test_c4_grid_of_10000_instances(pt, orc, gpu_ctx, cornell_arrays):
+    """BASELINE.json config 4: Cornell BLAS x 10 000 instances (100 x 100 grid), two-level BVH."""
+    inst = pt.cornell_grid_instances()
+    assert inst.shape == (10000, 3, 4)
+    gs, osc = pt.Scene(gpu_ctx, *cornell_arrays), orc.Scene(*cornell_arrays)
+    gs.set_instances(inst)
+    osc.set_instances(inst)
+    kw = dict(width=320, height=180, spp_per_frame=2, max_depth=8)
+    film = pt.Film(gpu_ctx, 320, 180)
+    gpu_ctx.reset_stats()
+    pt.render(gs, film, pt.default_params(frame=0, frame_count=1, **kw))
+    ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
+    assert gpu_ctx.stats().rays == orays
+    img = film.read_f32()
+    assert img.tobytes() == ofilm.tobytes()
+    # first hits at full resolution geometry: every primary ray inside the grid hits some instance
+    p = orc.default_params(width=1920, height=1080)
+    rays = np.array([np.concatenate(orc.primary_ray(p, x, y, orc.seed(x, y, 0, 0))[:2])
+                     for y in range(300, 800, 23) for x in range(500, 1400, 29)], np.float32)
+    h = gs.trace(rays)
+    oh, _ = osc.trace(rays, mode=1)
+    assert h.tobytes() == oh.tobytes()
+    hit = h["prim"] != pt.MISS          # rays can slip through the 2 mm gaps between the mini boxes
+    assert hit.mean() > 0.8 and len(np.unique(h["inst"][hit])) > 100
+    film.close(); gs.close()
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):
@@ -362,4 +439,7 @@ def test_error_paths(pt, gpu_ctx, cornell_gpu):
         pt.Scene(gpu_ctx, np.zeros(9, np.float32), np.array([0, 1, 7], np.uint32), np.zeros(6, np.float32))
     with pytest.raises(pt.PtError):
         pt.Film(gpu_ctx, 0, 10)
+    with pytest.raises(pt.PtError):
+        cornell_gpu.set_instances(np.zeros((1, 3, 4), np.float32))       # singular matrix
+    assert cornell_gpu.info().n_instances == 0
     film.close()

@@ -69,7 +69,7 @@ def test_scene_facts(orc, cornell_oracle, cornell_arrays):
     np.testing.assert_allclose(faces[6, :3], sc["right_wall_kd"], rtol=1e-7)
     # all 36 geometric normals point into the room / out of the boxes: light faces down (+y)
     hit = np.zeros(1, dtype=orc.HIT_DTYPE)
-    hit[0] = (35, 1.0, 0.3, 0.3)
+    hit[0] = (35, 1.0, 0.3, 0.3, 0)
     _, n, _, emi = cornell_oracle.shade_hit(hit[0])
     assert list(n) == [0.0, 1.0, 0.0] and list(emi) == [17.0, 12.0, 4.0]
 
@@ -207,3 +207,62 @@ def test_accumulate_float_and_unorm8(orc):
         assert film.tobytes() == ref.tobytes()
         assert (img[..., [2, 1, 0, 3]] == q).all()  # memory order is B,G,R,A
     assert (img[..., 3] == 255).all()
+
+
+# ---- two-level scenes (BASELINE config C4; beyond the reference's single identity instance) ----
+def _random_instances(n, seed):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((n, 3, 4), np.float32)
+    for k in range(n):
+        a = rng.normal(size=(3, 3))
+        q, _ = np.linalg.qr(a)
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        m[k, :, :3] = (q * rng.uniform(0.2, 0.6)).astype(np.float32)
+        m[k, :, 3] = rng.uniform(-1.5, 1.5, 3).astype(np.float32) + np.float32([0, -1, 0])
+    return m
+
+
+def test_identity_instance_gives_the_single_level_hits(orc, cornell_arrays):
+    a, b = orc.Scene(*cornell_arrays), orc.Scene(*cornell_arrays)
+    b.set_instances(np.eye(3, 4, dtype=np.float32)[None])
+    p = orc.default_params(width=64, height=64)
+    rays = np.array([np.concatenate(orc.primary_ray(p, x, y, orc.seed(x, y, 0, 0))[:2])
+                     for y in range(0, 64, 3) for x in range(0, 64, 3)], np.float32)
+    for mode in (0, 1):
+        ha, _ = a.trace(rays, mode=mode)
+        hb, _ = b.trace(rays, mode=mode)
+        assert ha.tobytes() == hb.tobytes()
+        assert set(np.unique(hb["inst"])) <= {0, orc.MISS}
+    b.set_instances(np.zeros((0, 3, 4), np.float32))   # back to single level
+    hb, _ = b.trace(rays)
+    assert hb.tobytes() == ha.tobytes()
+
+
+def test_instances_brute_equals_tlas_and_hits_are_consistent(orc, cornell_arrays):
+    sc = orc.Scene(*cornell_arrays)
+    inst = _random_instances(40, 3)
+    sc.set_instances(inst)
+    rng = np.random.default_rng(4)
+    n = 3000
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32) + np.float32([0, -1, 0])
+    tgt = inst[rng.integers(0, 40, n), :, 3] + rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d.astype(np.float32)], 1)
+    hb, cb = sc.trace(rays, mode=0)
+    hv, cv = sc.trace(rays, mode=1)
+    assert hb.tobytes() == hv.tobytes()
+    hit = hb["prim"] != orc.MISS
+    assert 0.3 < hit.mean() < 1.0 and len(np.unique(hb["inst"][hit])) > 10
+    assert cv.tris_tested < cb.tris_tested / 10
+    # world-space hit point o + t d lies on the transformed triangle's barycentric point
+    k = np.nonzero(hit)[0][0]
+    pos, nrm, _, _ = sc.shade_hit(hb[k])
+    np.testing.assert_allclose(org[k] + hb[k]["t"] * d[k], pos, atol=2e-5)
+    assert abs(np.linalg.norm(nrm) - 1) < 1e-6
+    # rendering through both traversals gives the same bits
+    p = orc.default_params(width=48, height=48, spp_per_frame=2, max_depth=5)
+    a, ra, _, _ = sc.render_frame(p, mode=0)
+    b, rb, _, _ = sc.render_frame(p, mode=1)
+    assert ra == rb and a.tobytes() == b.tobytes()
