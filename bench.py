@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--soup-tris", type=int, default=1000000)
     ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--sample-groups", type=int, default=0)
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm"], default="auto", help="closest-hit kernel variant")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,7 +125,7 @@ def main():
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
     flags = 0 if args.no_kernel_events else pt.FLAG_PROFILE
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
-                  frames_in_flight=args.frames_in_flight,
+                  frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
                   extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM}[args.extend])
 
     def barrier():
@@ -132,7 +133,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # warmup: W untimed frames (also allocates the queues)
+    # the workspace is sized once for the timed call's shape (frames in flight x sample groups) ...
+    timed = pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common)
+    pt.render_prepare(scene, film, timed)
+    shape = ctx.stats()
+    common.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups)
+    timed = pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common)
+    # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
         pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, **common))
         if world > 1:
@@ -143,7 +150,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    pt.render(scene, film, pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common))
+    pt.render(scene, film, timed)
     ptd.reduce_film(film_t, dst=0)      # the one collective per presented image (no-op for N=1)
     barrier()
     dt = time.perf_counter() - t0
@@ -182,7 +189,7 @@ def main():
             "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
                                    f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" + (", RCCL reduce to rank 0" if world > 1 else ""),
-                       "frames_in_flight": args.frames_in_flight or "auto"},
+                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups},
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,

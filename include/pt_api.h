@@ -137,6 +137,8 @@ typedef struct pt_params {
     uint32_t frames_in_flight; /* frames traced concurrently (0 = auto); results do not depend on it   */
     uint32_t flags;            /* PT_FLAG_*                                                            */
     uint32_t extend;           /* PT_EXTEND_*                                                          */
+    uint32_t sample_groups;    /* slots per (frame, pixel) tracing disjoint sample ranges concurrently  */
+                               /* (0 = auto); results do not depend on it                              */
 } pt_params;
 void pt_params_default(pt_params *p); /* the reference's compile-time constants, 1024x1024, world 1 */
 
@@ -144,6 +146,11 @@ void pt_params_default(pt_params *p); /* the reference's compile-time constants,
  * (spp_per_frame samples/pixel, <= max_depth rays each) blended by raygen.rgen:88-90.
  * Blocking (returns after the device is done), like submit + waitIdle (main.cpp:672-683).   */
 pt_status pt_render(pt_scene *scene, pt_film *film, const pt_params *params);
+/* Allocates (or grows) the film's wavefront workspace for exactly the shape pt_render would pick
+ * for these params, without rendering -- so the first timed pt_render does not pay for hipMalloc
+ * (the pipeline / descriptor set-up of main.cpp:540-641 plays this role in the reference).
+ * pt_get_stats afterwards reports the chosen frames_in_flight / sample_groups.              */
+pt_status pt_render_prepare(pt_scene *scene, pt_film *film, const pt_params *params);
 
 /* ---- closest-hit query alone: traceRayEXT (raygen.rgen:63-75) -------------------------- */
 typedef struct pt_hit {
@@ -168,6 +175,8 @@ typedef struct pt_stats {
     uint32_t extend_variant;   /* PT_EXTEND_* that actually ran                                     */
     uint64_t nodes_visited;    /* BVH4 nodes fetched (128 B each) -- only with PT_FLAG_COUNT_VISITS  */
     uint64_t tris_tested;      /* triangles tested                -- only with PT_FLAG_COUNT_VISITS  */
+    uint32_t frames_in_flight; /* shape of the last pt_render / pt_render_prepare                    */
+    uint32_t sample_groups;
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

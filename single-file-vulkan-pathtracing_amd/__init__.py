@@ -46,6 +46,7 @@ class Params(C.Structure):
         ("cam_origin", C.c_float * 3), ("cam_target", C.c_float * 3), ("env", C.c_float * 3),
         ("rank", C.c_uint32), ("world", C.c_uint32), ("pipeline", C.c_uint32),
         ("frames_in_flight", C.c_uint32), ("flags", C.c_uint32), ("extend", C.c_uint32),
+        ("sample_groups", C.c_uint32),
     ]
 
 
@@ -60,7 +61,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rounds", C.c_uint32),
                 ("launches_extend", C.c_uint32), ("launches_shade", C.c_uint32), ("launches_other", C.c_uint32),
                 ("ms_total", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float),
-                ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
+                ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+                ("frames_in_flight", C.c_uint32), ("sample_groups", C.c_uint32)]
 
 
 class HostScene(C.Structure):
@@ -74,7 +76,8 @@ HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"),
 API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "pt_scene_create", "pt_scene_destroy",
                "pt_scene_set_instances",
                "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_film_create", "pt_film_create_external", "pt_film_clear",
-               "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render", "pt_trace",
+               "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render",
+               "pt_render_prepare", "pt_trace",
                "pt_get_stats", "pt_reset_stats"]
 HOST_SYMBOLS = ["pth_load_obj", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj"]
 
@@ -121,6 +124,7 @@ def lib_amd():
         L.pt_params_default.argtypes = [C.POINTER(Params)]
         L.pt_params_default.restype = None
         L.pt_render.argtypes = [vp, vp, C.POINTER(Params)]
+        L.pt_render_prepare.argtypes = [vp, vp, C.POINTER(Params)]
         L.pt_trace.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, vp]
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_reset_stats.argtypes = [vp]
@@ -348,3 +352,8 @@ def render(scene, film, params):
     """pushConstants(frame) + traceRaysKHR(W,H,1) + waitIdle (main.cpp:656-659, 683), for
     params.frame_count consecutive frames."""
     scene.ctx._check(lib_amd().pt_render(scene.h, film.h, C.byref(params)))
+
+
+def render_prepare(scene, film, params):
+    """Allocate the workspace pt_render would use for these params (no rendering)."""
+    scene.ctx._check(lib_amd().pt_render_prepare(scene.h, film.h, C.byref(params)))

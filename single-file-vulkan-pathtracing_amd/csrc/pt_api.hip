@@ -223,6 +223,7 @@ void pt_params_default(pt_params *p)
     p->frames_in_flight = 0;
     p->flags = 0;
     p->extend = PT_EXTEND_AUTO;
+    p->sample_groups = 0;
 }
 
 pt_status pt_render(pt_scene *s, pt_film *f, const pt_params *p)
@@ -231,6 +232,14 @@ pt_status pt_render(pt_scene *s, pt_film *f, const pt_params *p)
     if (s->ctx != f->ctx) { s->ctx->err = "scene and film belong to different contexts"; return PT_ERR_INVALID_ARG; }
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
     return ptw_render(s, f, p);
+}
+
+pt_status pt_render_prepare(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    if (!s || !f || !p) return PT_ERR_INVALID_ARG;
+    if (s->ctx != f->ctx) { s->ctx->err = "scene and film belong to different contexts"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return ptw_prepare(s, f, p);
 }
 
 pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits)

@@ -60,10 +60,13 @@ struct pt_film {
     // wavefront workspace, (re)allocated by pt_render for (rank, world, frames_in_flight)
     struct Work {
         uint32_t rank = 0, world = 0, lanes = 0;  // lanes = frames in flight
+        uint32_t groups = 0, term_cap = 0;        // sample groups per pixel, radiance-term log capacity per slot
         uint32_t n_tiles = 0;                     // local 8x8 tiles
         uint32_t n_slots = 0;                     // lanes * n_tiles * 64
         uint32_t *d_tiles = nullptr;              // local tile -> global tile id
-        float4 *d_color = nullptr;                // per slot: frame colour accumulator rgb + pad
+        float4 *d_color = nullptr;                // per slot: frame colour accumulator rgb + pad (groups == 1)
+        float *d_terms = nullptr;                 // per slot: ordered radiance terms [term_cap][3]  (groups > 1)
+        uint32_t *d_nterm = nullptr;              // per slot: number of logged terms               (groups > 1)
         // double-buffered dense queues (index = queue position)
         uint32_t *d_qslot[2] = { nullptr, nullptr };
         uint32_t *d_qctr[2] = { nullptr, nullptr };   // sample | depth<<16
@@ -73,6 +76,7 @@ struct pt_film {
         float4 *d_hit = nullptr;                      // {bits(pos), t, u, v}
         uint32_t *d_hit_inst = nullptr;               // instance (TLAS sorted position); only for two-level scenes
         uint32_t *d_count = nullptr;                  // [2] queue sizes
+        size_t cap_slots = 0, cap_color = 0, cap_terms = 0;  // allocated capacities (buffers only grow)
     } work;
 };
 
@@ -92,5 +96,6 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
 void ptb_free_instances(pt_scene *s);
 // wavefront.hip
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);
+pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p);
 pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits);
 void ptw_free_work(pt_film *f);

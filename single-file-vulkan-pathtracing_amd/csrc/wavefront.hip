@@ -36,7 +36,37 @@ struct RenderConst {
     int32_t frame_base;        // frame index of lane 0 of this batch
     uint32_t lanes_active;     // frames in this batch
     uint32_t slots_per_lane;   // n_tiles * 64
+    uint32_t groups;           // sample groups per (frame, pixel): slot lane = frame_lane * groups + group
+    uint32_t group_size;       // samples per group: group g runs samples [g*group_size, min(spp, (g+1)*group_size))
+    uint32_t term_cap;         // radiance-term log capacity per slot = group_size * max_depth (groups > 1)
 };
+
+// Where a slot's radiance goes.  groups == 1: one accumulator per slot, added to in path order
+// (raygen.rgen:76).  groups > 1: the samples of a pixel are traced by several slots at once, so
+// every slot LOGS its non-zero terms in order and k_resolve replays the logs group by group --
+// the same float adds in the same order as the reference's single `color`, still bit-exact.
+struct Radiance {
+    float4 *color;     // [n_slots]              (groups == 1)
+    float *terms;      // [n_slots][term_cap][3] (groups > 1)
+    uint32_t *nterm;   // [n_slots]              (groups > 1)
+};
+
+__device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radiance &rad, uint32_t slot, float r, float g,
+                                             float b)
+{
+    if (rc.groups == 1u) {
+        float4 c = rad.color[slot];
+        c.x = c.x + r;
+        c.y = c.y + g;
+        c.z = c.z + b;
+        rad.color[slot] = c;
+    } else {
+        const uint32_t k = rad.nterm[slot];
+        float *t = rad.terms + ((size_t)slot * rc.term_cap + k) * 3u;
+        t[0] = r; t[1] = g; t[2] = b;
+        rad.nterm[slot] = k + 1u;
+    }
+}
 
 struct QueueView {
     uint32_t *slot;
@@ -47,10 +77,12 @@ struct QueueView {
 };
 
 __device__ __forceinline__ void slot_pixel(const RenderConst &rc, const uint32_t *__restrict__ tiles, uint32_t slot,
-                                           uint32_t &lane_f, uint32_t &px, uint32_t &py)
+                                           uint32_t &lane_f, uint32_t &group, uint32_t &px, uint32_t &py)
 {
-    lane_f = slot / rc.slots_per_lane;
-    const uint32_t local = slot - lane_f * rc.slots_per_lane;
+    const uint32_t lane = slot / rc.slots_per_lane;
+    lane_f = lane / rc.groups;
+    group = lane - lane_f * rc.groups;
+    const uint32_t local = slot - lane * rc.slots_per_lane;
     const uint32_t g = tiles[local >> 6];
     const uint32_t ty = g / rc.tiles_x, tx = g - ty * rc.tiles_x;
     px = tx * 8u + (local & 7u);
@@ -94,22 +126,24 @@ __device__ __forceinline__ void chunk_offsets(const bool (&alive)[ITEMS], uint32
 
 // ---- generate: sample 0 of every (frame, pixel) slot of the batch ----------------------------
 __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t *__restrict__ tiles, uint32_t n_slots,
-                                                 float4 *__restrict__ color, QueueView out, uint32_t *count_out)
+                                                 Radiance rad, QueueView out, uint32_t *count_out)
 {
     __shared__ uint32_t s_wcnt[1][4];
     __shared__ uint32_t s_base;
     for (uint32_t base = blockIdx.x * TB; base < n_slots; base += gridDim.x * TB) {
         const uint32_t slot = base + threadIdx.x;
         bool alive[1] = { false };
-        uint32_t seed = 0;
+        uint32_t seed = 0, sample0 = 0;
         ptm::f3 org{}, dir{};
         if (slot < n_slots) {
-            uint32_t f, px, py;
-            slot_pixel(rc, tiles, slot, f, px, py);
-            color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
-            if (px < rc.width && py < rc.height && f < rc.lanes_active) {
+            uint32_t f, g, px, py;
+            slot_pixel(rc, tiles, slot, f, g, px, py);
+            if (rc.groups == 1u) rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
+            else rad.nterm[slot] = 0u;
+            sample0 = g * rc.group_size;
+            if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
                 alive[0] = true;
-                seed = ptm::make_seed(px, py, 0u, rc.frame_base + (int32_t)f, rc.spp);
+                seed = ptm::make_seed(px, py, sample0, rc.frame_base + (int32_t)f, rc.spp);
                 ptm::primary_ray(rc.cam, px, py, seed, org, dir);
             }
         }
@@ -117,7 +151,7 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
         chunk_offsets<1>(alive, dst, count_out, s_wcnt, &s_base);
         if (alive[0]) {
             out.slot[dst[0]] = slot;
-            out.ctr[dst[0]] = 0u;
+            out.ctr[dst[0]] = sample0;
             out.state[dst[0]] = make_float4(__uint_as_float(seed), 1.f, 1.f, 1.f);  // raygen.rgen:59
             out.rayA[dst[0]] = make_float4(org.x, org.y, org.z, dir.x);
             out.rayB[dst[0]] = make_float2(dir.y, dir.z);
@@ -565,7 +599,7 @@ constexpr int SH_ITEMS = 4;
 
 __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ tri4, const float4 *__restrict__ shade4,
-                                              const float4 *__restrict__ hit, float4 *__restrict__ color, QueueView in,
+                                              const float4 *__restrict__ hit, Radiance rad, QueueView in,
                                               QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out,
                                               const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst)
 {
@@ -595,11 +629,7 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
             ptm::f3 org{}, dir{};
             if (pos == PT_MISS) {
                 // miss.rmiss:10-11 then raygen.rgen:76: color += weight * (0.7,0.6,0.5); break
-                float4 c = color[slot];
-                c.x = c.x + wr * rc.env[0];
-                c.y = c.y + wg * rc.env[1];
-                c.z = c.z + wb * rc.env[2];
-                color[slot] = c;
+                add_radiance(rc, rad, slot, wr * rc.env[0], wg * rc.env[1], wb * rc.env[2]);
                 terminated = true;
             } else {
                 const float4 s0 = shade4[3 * pos + 0], s1 = shade4[3 * pos + 1], s2 = shade4[3 * pos + 2];
@@ -607,13 +637,7 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
                 // non-negative accumulator, so the read-modify-write is skipped for non-emitters
                 // (NaN compares false and still takes the add).
                 const float er = wr * s1.z, eg = wg * s1.w, eb = wb * s2.x;
-                if (!(er == 0.f && eg == 0.f && eb == 0.f)) {
-                    float4 c = color[slot];
-                    c.x = c.x + er;
-                    c.y = c.y + eg;
-                    c.z = c.z + eb;
-                    color[slot] = c;
-                }
+                if (!(er == 0.f && eg == 0.f && eb == 0.f)) add_radiance(rc, rad, slot, er, eg, eb);
                 depth++;
                 terminated = depth >= rc.max_depth;  // raygen.rgen:62 loop bound
                 if (!terminated) {
@@ -651,9 +675,9 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
             }
             if (terminated) {
                 sample++;
-                if (sample < rc.spp) {  // next sample of the same pixel: raygen.rgen:45-60
-                    uint32_t f, px, py;
-                    slot_pixel(rc, tiles, slot, f, px, py);
+                uint32_t f, g, px, py;
+                slot_pixel(rc, tiles, slot, f, g, px, py);
+                if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {  // next sample of this slot: raygen.rgen:45-60
                     seed = ptm::make_seed(px, py, sample, rc.frame_base + (int32_t)f, rc.spp);
                     ptm::primary_ray(rc.cam, px, py, seed, org, dir);
                     wr = wg = wb = 1.0f;
@@ -692,21 +716,34 @@ __device__ __forceinline__ uint8_t to_unorm8(float c)
     return (uint8_t)(c * 255.0f + 0.5f);
 }
 
-__global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *__restrict__ tiles,
-                                                const float4 *__restrict__ color, float *__restrict__ film,
-                                                uint8_t *__restrict__ bgra)
+__global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+                                                float *__restrict__ film, uint8_t *__restrict__ bgra)
 {
     const uint32_t local = blockIdx.x * TB + threadIdx.x;
     if (local >= rc.slots_per_lane) return;
-    uint32_t f0, px, py;
-    slot_pixel(rc, tiles, local, f0, px, py);
+    uint32_t f0, g0, px, py;
+    slot_pixel(rc, tiles, local, f0, g0, px, py);
     if (px >= rc.width || py >= rc.height) return;
     const size_t pix = (size_t)py * rc.width + px;
     float fr = film[3 * pix + 0], fg = film[3 * pix + 1], fb = film[3 * pix + 2];
     uchar4 img = reinterpret_cast<uchar4 *>(bgra)[pix];  // bytes B,G,R,A
     const float spp = (float)rc.spp;
     for (uint32_t f = 0; f < rc.lanes_active; f++) {
-        const float4 c = color[(size_t)f * rc.slots_per_lane + local];
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rc.groups == 1u) {
+            c = rad.color[(size_t)f * rc.slots_per_lane + local];
+        } else {  // replay the groups' term logs in sample order: the reference's sequence of adds
+            for (uint32_t g = 0; g < rc.groups; g++) {
+                const size_t slot = ((size_t)f * rc.groups + g) * rc.slots_per_lane + local;
+                const uint32_t nt = rad.nterm[slot];
+                const float *t = rad.terms + slot * rc.term_cap * 3u;
+                for (uint32_t k = 0; k < nt; k++) {
+                    c.x = c.x + t[3 * k + 0];
+                    c.y = c.y + t[3 * k + 1];
+                    c.z = c.z + t[3 * k + 2];
+                }
+            }
+        }
         const float cr = ptm::fdiv(c.x, spp), cg = ptm::fdiv(c.y, spp), cb = ptm::fdiv(c.z, spp);  // :86
         const int32_t frame = rc.frame_base + (int32_t)f;
         const float ff = (float)frame, f1 = (float)(frame + 1);
@@ -860,40 +897,117 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 #undef PT_LAUNCH_EXTEND
 }
 
-pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes)
+// Workspace for (rank, world) tiles, `lanes` frames in flight and `groups` sample groups.  Buffers only
+// ever grow: a later call with a smaller shape reuses them (hipMalloc of tens of GB costs 100s of ms).
+pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap)
 {
     pt_ctx *ctx = f->ctx;
     pt_film::Work &w = f->work;
-    if (w.d_tiles && w.rank == rank && w.world == world && w.lanes == lanes) return PT_OK;
-    ptw_free_work(f);
-    const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
-    std::vector<uint32_t> tiles;
-    for (uint32_t ty = 0; ty < tiles_y; ty++)
-        for (uint32_t tx = 0; tx < tiles_x; tx++)
-            if ((tx + ty) % world == rank) tiles.push_back(ty * tiles_x + tx);
-    w.rank = rank; w.world = world; w.lanes = lanes;
-    w.n_tiles = (uint32_t)tiles.size();
-    const uint64_t n_slots64 = (uint64_t)lanes * w.n_tiles * 64ull;
+    if (!w.d_tiles || w.rank != rank || w.world != world) {
+        (void)hipFree(w.d_tiles);
+        w.d_tiles = nullptr;
+        const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
+        std::vector<uint32_t> tiles;
+        for (uint32_t ty = 0; ty < tiles_y; ty++)
+            for (uint32_t tx = 0; tx < tiles_x; tx++)
+                if ((tx + ty) % world == rank) tiles.push_back(ty * tiles_x + tx);
+        w.rank = rank; w.world = world;
+        w.n_tiles = (uint32_t)tiles.size();
+        PT_HIP(ctx, hipMalloc((void **)&w.d_tiles, sizeof(uint32_t) * std::max<size_t>(tiles.size(), 1)));
+        if (!tiles.empty())
+            PT_HIP(ctx, hipMemcpy(w.d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice));
+    }
+    const uint64_t n_slots64 = (uint64_t)lanes * groups * w.n_tiles * 64ull;
     if (n_slots64 >= (1ull << 31)) {
-        ctx->err = "too many path slots (frames_in_flight x pixels >= 2^31)";
+        ctx->err = "too many path slots (frames_in_flight x sample_groups x pixels >= 2^31)";
         return PT_ERR_INVALID_ARG;
     }
+    w.lanes = lanes; w.groups = groups; w.term_cap = term_cap;
     w.n_slots = (uint32_t)n_slots64;
     const size_t ns = std::max<size_t>(w.n_slots, 1);
-    PT_HIP(ctx, hipMalloc((void **)&w.d_tiles, sizeof(uint32_t) * std::max<size_t>(tiles.size(), 1)));
-    if (!tiles.empty())
-        PT_HIP(ctx, hipMemcpy(w.d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice));
-    PT_HIP(ctx, hipMalloc((void **)&w.d_color, sizeof(float4) * ns));
-    for (int i = 0; i < 2; i++) {
-        PT_HIP(ctx, hipMalloc((void **)&w.d_qslot[i], sizeof(uint32_t) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_qctr[i], sizeof(uint32_t) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_qstate[i], sizeof(float4) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_qrayA[i], sizeof(float4) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_qrayB[i], sizeof(float2) * ns));
+    if (ns > w.cap_slots) {
+        for (int i = 0; i < 2; i++) {
+            (void)hipFree(w.d_qslot[i]); (void)hipFree(w.d_qctr[i]); (void)hipFree(w.d_qstate[i]);
+            (void)hipFree(w.d_qrayA[i]); (void)hipFree(w.d_qrayB[i]);
+            w.d_qslot[i] = w.d_qctr[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
+        }
+        (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst); (void)hipFree(w.d_nterm);
+        w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr;
+        w.cap_slots = 0;
+        for (int i = 0; i < 2; i++) {
+            PT_HIP(ctx, hipMalloc((void **)&w.d_qslot[i], sizeof(uint32_t) * ns));
+            PT_HIP(ctx, hipMalloc((void **)&w.d_qctr[i], sizeof(uint32_t) * ns));
+            PT_HIP(ctx, hipMalloc((void **)&w.d_qstate[i], sizeof(float4) * ns));
+            PT_HIP(ctx, hipMalloc((void **)&w.d_qrayA[i], sizeof(float4) * ns));
+            PT_HIP(ctx, hipMalloc((void **)&w.d_qrayB[i], sizeof(float2) * ns));
+        }
+        PT_HIP(ctx, hipMalloc((void **)&w.d_hit, sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_hit_inst, sizeof(uint32_t) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_nterm, sizeof(uint32_t) * ns));
+        w.cap_slots = ns;
     }
-    PT_HIP(ctx, hipMalloc((void **)&w.d_hit, sizeof(float4) * ns));
-    PT_HIP(ctx, hipMalloc((void **)&w.d_hit_inst, sizeof(uint32_t) * ns));
-    PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 4));  // [0],[1] queue sizes
+    if (groups == 1 && ns > w.cap_color) {
+        (void)hipFree(w.d_color);
+        w.d_color = nullptr; w.cap_color = 0;
+        PT_HIP(ctx, hipMalloc((void **)&w.d_color, sizeof(float4) * ns));
+        w.cap_color = ns;
+    }
+    const size_t nterms = groups > 1 ? ns * (size_t)term_cap : 0;
+    if (nterms > w.cap_terms) {
+        (void)hipFree(w.d_terms);
+        w.d_terms = nullptr; w.cap_terms = 0;
+        PT_HIP(ctx, hipMalloc((void **)&w.d_terms, sizeof(float) * 3 * nterms));
+        w.cap_terms = nterms;
+    }
+    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 4));  // [0],[1] queue sizes
+    return PT_OK;
+}
+
+struct RenderShape {
+    uint32_t lanes = 1, groups = 1, group_size = 1, term_cap = 0;
+};
+
+// frames in flight x sample groups: enough live paths (~32M) to fill the chip several times over
+RenderShape choose_shape(const pt_film *f, const pt_params *p)
+{
+    RenderShape sh;
+    const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
+    const uint64_t target = 32ull << 20;  // 128 B of queue state per live path
+    uint32_t lanes = p->frames_in_flight;
+    if (lanes == 0) lanes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, target / std::max<uint64_t>(pixels_local, 1)));
+    lanes = std::max(1u, std::min(lanes, p->frame_count));
+    // sample groups: when the frames in flight alone cannot fill the chip (few frames asked for),
+    // split each pixel's samples over several slots; the term logs keep the sum order exact.
+    uint32_t groups = p->sample_groups;
+    if (groups == 0) {
+        groups = 1;
+        const uint64_t have = std::max<uint64_t>((uint64_t)lanes * pixels_local, 1);
+        if (have * 2 <= target) {
+            const uint32_t g = (uint32_t)std::min<uint64_t>(p->spp_per_frame, (target + have - 1) / have);
+            // worst-case log: one 12-B term per ray
+            const uint64_t log_bytes = (uint64_t)lanes * pixels_local * p->spp_per_frame * p->max_depth * 12ull;
+            if (g > 1 && log_bytes <= (32ull << 30)) groups = g;
+        }
+    }
+    groups = std::max(1u, std::min(groups, p->spp_per_frame));
+    sh.group_size = (p->spp_per_frame + groups - 1) / groups;
+    sh.groups = (p->spp_per_frame + sh.group_size - 1) / sh.group_size;  // no empty groups
+    sh.term_cap = sh.groups > 1 ? sh.group_size * p->max_depth : 0u;
+    sh.lanes = lanes;
+    return sh;
+}
+
+pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    pt_ctx *ctx = s->ctx;
+    if (p->width != f->w || p->height != f->h) { ctx->err = "params width/height differ from the film's"; return PT_ERR_INVALID_ARG; }
+    if (p->world == 0 || p->rank >= p->world) { ctx->err = "rank/world invalid"; return PT_ERR_INVALID_ARG; }
+    if (p->spp_per_frame == 0 || p->spp_per_frame > 0xFFFFu || p->max_depth == 0 || p->max_depth > 0xFFFFu) {
+        ctx->err = "spp_per_frame and max_depth must be in 1..65535";
+        return PT_ERR_INVALID_ARG;
+    }
+    if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
+    if (p->pipeline != PT_PIPELINE_WAVEFRONT) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
     return PT_OK;
 }
 
@@ -904,6 +1018,8 @@ void ptw_free_work(pt_film *f)
     pt_film::Work &w = f->work;
     (void)hipFree(w.d_tiles);
     (void)hipFree(w.d_color);
+    (void)hipFree(w.d_terms);
+    (void)hipFree(w.d_nterm);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(w.d_qslot[i]);
         (void)hipFree(w.d_qctr[i]);
@@ -917,34 +1033,37 @@ void ptw_free_work(pt_film *f)
     w = pt_film::Work{};
 }
 
+pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    pt_status rc_ = check_params(s, f, p);
+    if (rc_ != PT_OK) return rc_;
+    ExtendPlan pl;
+    rc_ = plan_extend(s, p->extend, pl);
+    if (rc_ != PT_OK) return rc_;
+    const RenderShape sh = choose_shape(f, p);
+    rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap);
+    s->ctx->stats.frames_in_flight = sh.lanes;
+    s->ctx->stats.sample_groups = sh.groups;
+    return rc_;
+}
+
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
 {
     pt_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    if (p->width != f->w || p->height != f->h) { ctx->err = "params width/height differ from the film's"; return PT_ERR_INVALID_ARG; }
-    if (p->world == 0 || p->rank >= p->world) { ctx->err = "rank/world invalid"; return PT_ERR_INVALID_ARG; }
-    if (p->spp_per_frame == 0 || p->spp_per_frame > 0xFFFFu || p->max_depth == 0 || p->max_depth > 0xFFFFu) {
-        ctx->err = "spp_per_frame and max_depth must be in 1..65535";
-        return PT_ERR_INVALID_ARG;
-    }
-    if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
-    if (p->pipeline != PT_PIPELINE_WAVEFRONT) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
-
+    pt_status rc_ = check_params(s, f, p);
+    if (rc_ != PT_OK) return rc_;
     ExtendPlan pl;
-    pt_status rc_ = plan_extend(s, p->extend, pl);
+    rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
-
-    // frames in flight: enough slots to fill the chip several times over, bounded by memory
-    const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
-    uint32_t lanes = p->frames_in_flight;
-    if (lanes == 0) {
-        const uint64_t target = 32ull << 20;  // ~32M live paths (128 B of queue state each)
-        lanes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, target / std::max<uint64_t>(pixels_local, 1)));
-    }
-    lanes = std::min(lanes, p->frame_count);
-    rc_ = ensure_work(f, p->rank, p->world, lanes);
+    const RenderShape sh = choose_shape(f, p);
+    const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
+    rc_ = ensure_work(f, p->rank, p->world, lanes, groups, term_cap);
     if (rc_ != PT_OK) return rc_;
+    ctx->stats.frames_in_flight = lanes;
+    ctx->stats.sample_groups = groups;
     pt_film::Work &w = f->work;
+    const Radiance rad = { w.d_color, w.d_terms, w.d_nterm };
 
     RenderConst rc{};
     rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
@@ -954,6 +1073,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     rc.width = p->width; rc.height = p->height; rc.tiles_x = (p->width + 7) / 8;
     rc.spp = p->spp_per_frame; rc.max_depth = p->max_depth;
     rc.slots_per_lane = w.n_tiles * 64u;
+    rc.groups = groups; rc.group_size = group_size; rc.term_cap = term_cap;
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
@@ -977,19 +1097,19 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
             rc.frame_base = p->frame + (int32_t)done;
             rc.lanes_active = std::min(lanes, p->frame_count - done);
             PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 4, st));
-            const uint32_t gen_slots = rc.lanes_active * rc.slots_per_lane;
+            const uint32_t gen_slots = rc.lanes_active * groups * rc.slots_per_lane;
             const int gen_grid = (int)std::min<uint32_t>((gen_slots + TB - 1) / TB, (uint32_t)ctx->num_cus * 16u);
-            k_generate<<<gen_grid, TB, 0, st>>>(rc, w.d_tiles, gen_slots, w.d_color, qv[0], &w.d_count[0]);
+            k_generate<<<gen_grid, TB, 0, st>>>(rc, w.d_tiles, gen_slots, rad, qv[0], &w.d_count[0]);
             ctx->stats.launches_other++;
             int cur = 0;
-            const uint32_t max_rounds = p->spp_per_frame * p->max_depth;  // every sample at full depth
+            const uint32_t max_rounds = group_size * p->max_depth;  // every sample of a slot at full depth
             uint32_t h_count = 1;
             hipEvent_t e_prev = profile ? new_event() : nullptr;  // one event between consecutive kernels
             for (uint32_t round = 0; round < max_rounds; round++) {
                 launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, w.d_hit_inst, &w.d_count[cur], &w.d_count[cur ^ 1],
                               ctx->d_stats, p->tmin, p->tmax, count_visits, st);
                 hipEvent_t e1 = profile ? new_event() : nullptr;
-                k_shade<<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, w.d_color, qv[cur], qv[cur ^ 1],
+                k_shade<<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, rad, qv[cur], qv[cur ^ 1],
                                                    &w.d_count[cur], &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,
                                                    w.d_hit_inst);
                 hipEvent_t e2 = profile ? new_event() : nullptr;
@@ -1004,13 +1124,13 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 ctx->stats.rounds++;
                 cur ^= 1;
                 // every pixel needs >= spp rounds; after that poll the live count now and then
-                if (round + 1 >= p->spp_per_frame && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
+                if (round + 1 >= group_size && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
                     PT_HIP(ctx, hipMemcpyAsync(&h_count, &w.d_count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     PT_HIP(ctx, hipStreamSynchronize(st));
                     if (h_count == 0) break;
                 }
             }
-            k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, w.d_color, f->d_rgb, f->d_bgra);
+            k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra);
             ctx->stats.launches_other++;
         }
     }

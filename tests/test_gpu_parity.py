@@ -242,6 +242,22 @@ def test_progressive_render_bit_exact(pt, orc, gpu_ctx, cornell_gpu, cornell_ora
     film.close()
 
 
+@pytest.mark.parametrize("groups,fif", [(1, 1), (2, 1), (3, 2), (5, 1), (8, 3), (32, 1), (0, 0)])
+def test_sample_groups_keep_the_sum_order_bit_exact(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle, groups, fif):
+    """Samples of a pixel traced concurrently by several slots (term logs replayed in order) must
+    reproduce the reference's single sequential accumulator bit for bit."""
+    kw = dict(width=88, height=40, spp_per_frame=32, max_depth=8)
+    film = pt.Film(gpu_ctx, 88, 40)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=3, sample_groups=groups, frames_in_flight=fif, **kw))
+    ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 3, **kw)
+    st = gpu_ctx.stats()
+    assert st.rays == orays and st.paths == 88 * 40 * 32 * 3
+    assert film.read_f32().tobytes() == ofilm.tobytes()
+    assert film.read_bgra8().tobytes() == obgra.tobytes()
+    film.close()
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_every_extend_variant_renders_the_same_bits(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle, variant):
     kw = dict(width=72, height=56, spp_per_frame=6, max_depth=8)
