@@ -216,10 +216,41 @@ __device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 
     return true;
 }
 
+// Reciprocal for the slab tests only (traversal is not part of the numerical contract: boxes are
+// padded by 2^-18 of the scene scale and the far distance by 4e-7, far more than v_rcp_f32's 1 ulp).
 __device__ __forceinline__ float safe_inv(float d)
 {
     if (fabsf(d) < 1e-20f) d = copysignf(1e-20f, d);
-    return fdiv(1.0f, d);
+    return __builtin_amdgcn_rcpf(d);
+}
+
+// Triangle test on vertices whose components were permuted to (kx, ky, kz) at build time and a ray
+// origin permuted the same way: the per-vertex component selects of tri_test() disappear, every
+// remaining operation has the same operands, so the result is bit-identical.
+__device__ __forceinline__ bool tri_test_perm(const RayPre &r, const f3 orgp, const f3 v0, const f3 v1, const f3 v2,
+                                              float tmin, float tmax, float &t, float &Vn, float &Wn, float &detn)
+{
+    const f3 A = { v0.x - orgp.x, v0.y - orgp.y, v0.z - orgp.z };
+    const f3 B = { v1.x - orgp.x, v1.y - orgp.y, v1.z - orgp.z };
+    const f3 C = { v2.x - orgp.x, v2.y - orgp.y, v2.z - orgp.z };
+    const float Ax = A.x - r.Sx * A.z, Ay = A.y - r.Sy * A.z;
+    const float Bx = B.x - r.Sx * B.z, By = B.y - r.Sy * B.z;
+    const float Cx = C.x - r.Sx * C.z, Cy = C.y - r.Sy * C.z;
+    const float U = Cx * By - Cy * Bx;
+    const float V = Ax * Cy - Ay * Cx;
+    const float W = Bx * Ay - By * Ax;
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * A.z, Bz = r.Sz * B.z, Cz = r.Sz * C.z;
+    const float T = (U * Az + V * Bz) + W * Cz;
+    const float tt = fdiv(T, det);
+    if (!(tt > tmin && tt < tmax)) return false;
+    t = tt;
+    Vn = V;
+    Wn = W;
+    detn = det;
+    return true;
 }
 
 // Conservative slab test against [tmin, tbest]; only has to never cull a real hit.

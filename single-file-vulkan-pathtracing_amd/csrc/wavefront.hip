@@ -172,6 +172,21 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
 //  * LDS_SCENE: nodes + triangles are staged into LDS once per persistent block and traversal
 //    touches no HBM at all (scenes up to ~24 KB).
 constexpr int LDS_STACK = 8;
+
+// Slab test of the 4 children of a BVH4 node with the near/far planes picked by the ray's direction
+// signs THROUGH THE LOAD ADDRESS (ixn/iyn/izn = float4 index of the near planes: 0|3, 1|4, 2|5), so no
+// per-child min/max of the two plane distances is needed.  Conservative like ptm::box_test.
+#define PT_NODE_LOAD(ND)                                                                                 \
+    const float4 nx = (ND)[ixn], fx = (ND)[3 - ixn], ny = (ND)[iyn], fy = (ND)[5 - iyn], nz = (ND)[izn], \
+                 fz = (ND)[7 - izn], cw = (ND)[6];
+#define PT_SLAB4(T, C)                                                                                           \
+    {                                                                                                            \
+        const float tn = fmaxf(fmaxf((nx.C - org.x) * inv.x, (ny.C - org.y) * inv.y),                            \
+                               fmaxf((nz.C - org.z) * inv.z, tmin));                                             \
+        const float tf = fminf(fminf((fx.C - org.x) * inv.x, (fy.C - org.y) * inv.y),                            \
+                               fminf((fz.C - org.z) * inv.z, best_t));                                           \
+        T = tn <= tf * 1.0000004f ? tn : INF;                                                                    \
+    }
 constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the wave pulls new rays
 
 // Persistent threads with dynamic ray fetch (Aila & Laine 2009, re-tiled for wave64): a lane whose
@@ -198,7 +213,14 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)LDS_STACK * TB * sizeof(uint2));
         float4 *s_tri = s_wide + 8 * (size_t)n_wide;
         for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) s_wide[i] = g_wide[i];
-        for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) s_tri[i] = g_tri4[i];
+        // three copies of the triangles with components permuted to (kx,ky,kz) for kz = 0,1,2:
+        // the triangle test then needs no per-lane component selects (ptm::tri_test_perm)
+        for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
+            const float4 v = g_tri4[i];
+            s_tri[i] = make_float4(v.y, v.z, v.x, v.w);                    // kz = 0: (kx,ky,kz) = (1,2,0)
+            s_tri[3 * n_tris + i] = make_float4(v.z, v.x, v.y, v.w);       // kz = 1: (2,0,1)
+            s_tri[6 * n_tris + i] = v;                                     // kz = 2: (0,1,2)
+        }
         __syncthreads();
         wide = s_wide;
         tri4 = s_tri;
@@ -220,8 +242,10 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
     const uint32_t wave_stride = gridDim.x * TB;
     uint32_t cursor = 0;
-    ptm::f3 org{}, inv{};
+    ptm::f3 org{}, inv{}, orgp{};
     ptm::RayPre pre{};
+    int ixn = 0, iyn = 1, izn = 2;  // float4 index of the near planes inside a node
+    uint32_t tri_base = 0;           // LDS_SCENE: start of the triangle copy for this ray's kz
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
     uint32_t cur = SENTINEL;
@@ -259,6 +283,14 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup(org, dir);
                     inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
+                    ixn = inv.x < 0.f ? 3 : 0;
+                    iyn = inv.y < 0.f ? 4 : 1;
+                    izn = inv.z < 0.f ? 5 : 2;
+                    if (LDS_SCENE) {
+                        tri_base = (uint32_t)pre.kz * 3u * n_tris;
+                        orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y),
+                                 ptm::sel3(pre.kz, org.x, org.y, org.z) };
+                    }
                     best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS;
                     cur = 0u;  // wide root
@@ -274,23 +306,15 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         // ---- node phase: every lane descends until it holds a leaf (or runs out of nodes)
         while (have && !(cur & PT_LEAF)) {
             const float4 *nd = wide + 8 * (size_t)cur;
-            const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-            const float4 cw = nd[6];
+            PT_NODE_LOAD(nd)
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
             uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
                      w3 = __float_as_uint(cw.w);
-#define PT_SLAB(T, LX, LY, LZ, HX, HY, HZ)                                                         \
-    {                                                                                             \
-        float tn;                                                                                 \
-        const bool h = ptm::box_test({ LX, LY, LZ }, { HX, HY, HZ }, org, inv, tmin, best_t, tn); \
-        T = h ? tn : INF;                                                                         \
-    }
-            PT_SLAB(t0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x)
-            PT_SLAB(t1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y)
-            PT_SLAB(t2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z)
-            PT_SLAB(t3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w)
-#undef PT_SLAB
+            PT_SLAB4(t0, x)
+            PT_SLAB4(t1, y)
+            PT_SLAB4(t2, z)
+            PT_SLAB4(t3, w)
 #define PT_CSWAP(TA, WA, TB_, WB)                            \
     {                                                        \
         const bool sw = TB_ < TA;                            \
@@ -316,10 +340,13 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                 if (COUNT) c_tris += cnt;
                 for (uint32_t k = 0; k < cnt; k++) {
                     const uint32_t pos = first + k;
-                    const float4 a = tri4[3 * (size_t)pos + 0], b = tri4[3 * (size_t)pos + 1],
-                                 c = tri4[3 * (size_t)pos + 2];
+                    const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : 3 * (size_t)pos;
+                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
                     float t, V, W, det;
-                    if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
+                    const bool th = LDS_SCENE
+                        ? ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)
+                        : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det);
+                    if (th) {
                         const uint32_t prim = __float_as_uint(a.w);
                         // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
                         if (t < best_t || (t == best_t && prim < best_prim)) {
@@ -385,6 +412,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
     uint32_t q = 0;
     ptm::f3 org_w{}, dir_w{}, inv_w{};   // world-space ray
     ptm::f3 org{}, inv{};                 // ray of the level being walked
+    int ixn = 0, iyn = 1, izn = 2;        // near-plane float4 indices for the level being walked
     ptm::RayPre pre{};
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS, best_ipos = PT_MISS, best_iid = PT_MISS;
@@ -409,6 +437,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
             if (e.x == EXIT_MARK) {  // the instance is done: back to the world-space ray and the TLAS
                 org = org_w;
                 inv = inv_w;
+                ixn = inv.x < 0.f ? 3 : 0;
+                iyn = inv.y < 0.f ? 4 : 1;
+                izn = inv.z < 0.f ? 5 : 2;
                 in_blas = false;
                 continue;
             }
@@ -436,6 +467,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                     inv_w = { ptm::safe_inv(dir_w.x), ptm::safe_inv(dir_w.y), ptm::safe_inv(dir_w.z) };
                     org = org_w;
                     inv = inv_w;
+                    ixn = inv.x < 0.f ? 3 : 0;
+                    iyn = inv.y < 0.f ? 4 : 1;
+                    izn = inv.z < 0.f ? 5 : 2;
                     in_blas = false;
                     best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
@@ -453,23 +487,15 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
         // ---- node phase (either level)
         while (have && !(cur & PT_LEAF)) {
             const float4 *nd = (in_blas ? blas : tlas) + 8 * (size_t)cur;
-            const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-            const float4 cw = nd[6];
+            PT_NODE_LOAD(nd)
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
             uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
                      w3 = __float_as_uint(cw.w);
-#define PT_SLAB(T, LX, LY, LZ, HX, HY, HZ)                                                         \
-    {                                                                                             \
-        float tn;                                                                                 \
-        const bool h = ptm::box_test({ LX, LY, LZ }, { HX, HY, HZ }, org, inv, tmin, best_t, tn); \
-        T = h ? tn : INF;                                                                         \
-    }
-            PT_SLAB(t0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x)
-            PT_SLAB(t1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y)
-            PT_SLAB(t2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z)
-            PT_SLAB(t3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w)
-#undef PT_SLAB
+            PT_SLAB4(t0, x)
+            PT_SLAB4(t1, y)
+            PT_SLAB4(t2, z)
+            PT_SLAB4(t3, w)
 #define PT_CSWAP(TA, WA, TB_, WB)                            \
     {                                                        \
         const bool sw = TB_ < TA;                            \
@@ -526,6 +552,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                                          (r2.x * dir_w.x + r2.y * dir_w.y) + r2.z * dir_w.z };
                     org = oo;
                     inv = { ptm::safe_inv(od.x), ptm::safe_inv(od.y), ptm::safe_inv(od.z) };
+                    ixn = inv.x < 0.f ? 3 : 0;
+                    iyn = inv.y < 0.f ? 4 : 1;
+                    izn = inv.z < 0.f ? 5 : 2;
                     pre = ptm::ray_setup(oo, od);
                     push(EXIT_MARK, 0.f);
                     in_blas = true;
@@ -595,8 +624,7 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
 }
 
 // ---- shade: closesthit / miss + the bounce logic of raygen.rgen:76-83, regeneration, compaction
-constexpr int SH_ITEMS = 4;
-
+template <int SH_ITEMS>
 __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ tri4, const float4 *__restrict__ shade4,
                                               const float4 *__restrict__ hit, Radiance rad, QueueView in,
@@ -831,7 +859,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         pl.grid = ctx->num_cus * std::max(1, std::min(per_cu, 8));
         return PT_OK;
     }
-    const size_t scene_bytes = 128 * (size_t)s->n_wide + sizeof(float4) * 3 * (size_t)s->n_tris;
+    const size_t scene_bytes = 128 * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;  // 3 permuted triangle copies
     if (want == PT_EXTEND_LDS && scene_bytes > 96 * 1024) { ctx->err = "scene does not fit LDS"; return PT_ERR_UNSUPPORTED; }
     pl.lds_scene = want == PT_EXTEND_LDS || (want == PT_EXTEND_AUTO && scene_bytes <= 24 * 1024);
     pl.variant = pl.lds_scene ? PT_EXTEND_LDS : PT_EXTEND_HBM;
@@ -1086,7 +1114,10 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
         return e;
     };
 
-    const int shade_grid = ctx->num_cus * 8;
+    int shade_items = 4, shade_bpc = 8;
+    if (const char *e = getenv("PT_TUNE_SHADE_ITEMS")) shade_items = atoi(e);
+    if (const char *e = getenv("PT_TUNE_SHADE_BPC")) shade_bpc = std::max(1, atoi(e));
+    const int shade_grid = ctx->num_cus * shade_bpc;
     QueueView qv[2];
     for (int i = 0; i < 2; i++) qv[i] = { w.d_qslot[i], w.d_qctr[i], w.d_qstate[i], w.d_qrayA[i], w.d_qrayB[i] };
 
@@ -1109,9 +1140,14 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, w.d_hit_inst, &w.d_count[cur], &w.d_count[cur ^ 1],
                               ctx->d_stats, p->tmin, p->tmax, count_visits, st);
                 hipEvent_t e1 = profile ? new_event() : nullptr;
-                k_shade<<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, rad, qv[cur], qv[cur ^ 1],
-                                                   &w.d_count[cur], &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,
-                                                   w.d_hit_inst);
+#define PT_LAUNCH_SHADE(N)                                                                                          \
+    k_shade<N><<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, rad, qv[cur], qv[cur ^ 1], \
+                                          &w.d_count[cur], &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,    \
+                                          w.d_hit_inst)
+                if (shade_items == 1) PT_LAUNCH_SHADE(1);
+                else if (shade_items == 2) PT_LAUNCH_SHADE(2);
+                else PT_LAUNCH_SHADE(4);
+#undef PT_LAUNCH_SHADE
                 hipEvent_t e2 = profile ? new_event() : nullptr;
                 if (profile) {
                     ev_triples.push_back(e_prev);
