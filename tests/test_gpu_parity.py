@@ -443,6 +443,70 @@ def test_c4_grid_of_10000_instances(pt, orc, gpu_ctx, cornell_arrays):
     film.close(); gs.close()
 
 
+def test_pt_main_host_driver_writes_the_same_image(pt, gpu_ctx, cornell_gpu, tmp_path):
+    """The C++20 host driver (reference main() without Vulkan/GLFW) against the Python path."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(pt.__file__), "pt_main")
+    if not os.path.exists(exe):
+        pt.build()
+    pfm, ppm = str(tmp_path / "o.pfm"), str(tmp_path / "o.ppm")
+    out = subprocess.run([exe, "--obj", pt.ASSET_CORNELL, "--width", "96", "--height", "64", "--frames", "3", "--spp", "4",
+                          "--depth", "8", "--pfm", pfm, "--ppm", ppm], check=True, capture_output=True, text=True, cwd=pt.REPO)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    film = pt.Film(gpu_ctx, 96, 64)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(width=96, height=64, spp_per_frame=4, max_depth=8, frame_count=3))
+    assert info["rays"] == gpu_ctx.stats().rays and info["triangles"] == 36 and info["paths"] == 96 * 64 * 4 * 3
+    raw = open(pfm, "rb").read()
+    head = b"PF\n96 64\n-1.0\n"
+    assert raw.startswith(head)
+    img = np.frombuffer(raw[len(head):], np.float32).reshape(64, 96, 3)[::-1]
+    assert img.tobytes() == film.read_f32().tobytes()
+    praw = open(ppm, "rb").read()
+    rgb = np.frombuffer(praw[len(b"P6\n96 64\n255\n"):], np.uint8).reshape(64, 96, 3)
+    assert (rgb == film.read_bgra8()[..., [2, 1, 0]]).all()
+    film.close()
+
+
+def test_prepare_then_render_and_degenerate_shapes(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    film = pt.Film(gpu_ctx, 40, 24)
+    p = pt.default_params(width=40, height=24, spp_per_frame=7, max_depth=1, frame_count=5)
+    pt.render_prepare(cornell_gpu, film, p)
+    st = gpu_ctx.stats()
+    assert st.frames_in_flight >= 1 and st.sample_groups >= 1
+    for spp, depth in ((1, 1), (1, 8), (7, 1), (33, 2)):
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(width=40, height=24, spp_per_frame=spp, max_depth=depth, frame_count=2))
+        ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 2, width=40, height=24, spp_per_frame=spp, max_depth=depth)
+        assert gpu_ctx.stats().rays == orays
+        assert film.read_f32().tobytes() == ofilm.tobytes()
+    # a later frame index and a moved camera
+    film.clear()
+    kw = dict(width=40, height=24, spp_per_frame=3, max_depth=4, cam_origin=(0.3, -1.2, 4.0), cam_target=(0.1, -0.9, 1.5),
+              env=(0.2, 0.3, 0.9), tmin=0.01, tmax=50.0)
+    pt.render(cornell_gpu, film, pt.default_params(frame=7, frame_count=1, **kw))
+    img, _, _, _ = cornell_oracle.render_frame(orc.default_params(frame=7, **kw))
+    o = np.zeros_like(img)
+    orc.accumulate_f32(o, img, 7)
+    assert film.read_f32().tobytes() == o.tobytes()
+    film.close()
+
+
+def test_4k_film_bit_exact(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    """3840x2160 (8.3 M pixels, partial last tile row): 1 spp, depth 4 -- ~20 M rays on the oracle."""
+    kw = dict(width=3840, height=2160, spp_per_frame=1, max_depth=4)
+    film = pt.Film(gpu_ctx, 3840, 2160)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(**kw))
+    img, rays, _, _ = cornell_oracle.render_frame(orc.default_params(**kw))
+    st = gpu_ctx.stats()
+    assert st.paths == 3840 * 2160 and st.rays == rays
+    assert film.read_f32().tobytes() == img.tobytes()
+    film.close()
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):
