@@ -231,12 +231,15 @@ def main():
             gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
             pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
             traffic = None
-            prof = os.path.join(REPO, "profiles", "r01_pmc_extend.json" if args.config == "c2" else "r01_pmc_extend_c5.json")
+            prof = os.path.join(REPO, "profiles", {"c2": "r01_pmc_extend.json", "c4": "r01_pmc_extend_c4.json",
+                                                   "c5": "r01_pmc_extend_c5.json"}[args.config])
+            pmc = None
             if os.path.exists(prof):
                 try:   # PMC HBM bytes per ray of the same kernel (committed rocprofv3 run) x this run's rays per launch
-                    traffic = round(json.load(open(prof))["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
+                    pmc = json.load(open(prof))
+                    traffic = round(pmc["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
                 except Exception:
-                    traffic = None
+                    traffic = pmc = None
             out["roofline"] = {
                 "bound": "hbm", "kernel": {1: "k_extend_flat", 2: "k_extend<lds>", 3: "k_extend<hbm>"}.get(st.extend_variant, "?"),
                 "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
@@ -249,6 +252,12 @@ def main():
                            "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
                            "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
                 "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
+                "pmc_profile": None if not pmc else {   # from the committed rocprofv3 PMC passes of this kernel
+                    "valu_busy_fraction": round(pmc["valu_busy_fraction"], 3),
+                    "valu_wave_instr_per_64_rays": round(pmc["valu_wave_instr_per_64_rays"], 1),
+                    "wait_any_fraction_of_wave_cycles": round(pmc["wait_any_fraction_of_wave_cycles"], 3),
+                    "l2_hit_rate": round(pmc["l2_hit_rate"], 3), "hbm_bytes_per_ray": round(pmc["hbm_bytes_per_ray"], 1),
+                    "source": os.path.relpath(prof, REPO)},
                 "pipeline_algorithmic_GBps": round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2),
                 "note": ("Cornell (<8 KB scene+BVH) never leaves SGPRs/LDS: extend is VALU-issue bound, HBM sees only "
                          "queue I/O; the HBM fraction is physically meaningful on config C5 (1M triangles) only")
