@@ -624,15 +624,30 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
 }
 
 // ---- shade: closesthit / miss + the bounce logic of raygen.rgen:76-83, regeneration, compaction
-template <int SH_ITEMS>
+template <int SH_ITEMS, bool LDS_TABLES>
 __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
-                                              const float4 *__restrict__ tri4, const float4 *__restrict__ shade4,
+                                              const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
+                                              uint32_t n_tris,
                                               const float4 *__restrict__ hit, Radiance rad, QueueView in,
                                               QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out,
                                               const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst)
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float4 *tri4 = g_tri4;
+    const float4 *shade4 = g_shade4;
+    if (LDS_TABLES) {  // small scenes: the per-triangle tables live in LDS, no dependent global gathers
+        float4 *s_tri = reinterpret_cast<float4 *>(smem);
+        float4 *s_shade = s_tri + 3 * (size_t)n_tris;
+        for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
+            s_tri[i] = g_tri4[i];
+            s_shade[i] = g_shade4[i];
+        }
+        __syncthreads();
+        tri4 = s_tri;
+        shade4 = s_shade;
+    }
     const uint32_t n = *count_in;
     constexpr uint32_t CHUNK = TB * SH_ITEMS;
     for (uint32_t base = blockIdx.x * CHUNK; base < n; base += gridDim.x * CHUNK) {
@@ -1118,6 +1133,9 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     if (const char *e = getenv("PT_TUNE_SHADE_ITEMS")) shade_items = atoi(e);
     if (const char *e = getenv("PT_TUNE_SHADE_BPC")) shade_bpc = std::max(1, atoi(e));
     const int shade_grid = ctx->num_cus * shade_bpc;
+    const size_t shade_smem = sizeof(float4) * 6 * (size_t)s->n_tris;
+    bool shade_lds = shade_smem <= 16 * 1024;  // per-triangle tables of small scenes are staged in LDS
+    if (const char *e = getenv("PT_TUNE_SHADE_LDS")) shade_lds = shade_lds && atoi(e) != 0;
     QueueView qv[2];
     for (int i = 0; i < 2; i++) qv[i] = { w.d_qslot[i], w.d_qctr[i], w.d_qstate[i], w.d_qrayA[i], w.d_qrayB[i] };
 
@@ -1140,13 +1158,15 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, w.d_hit_inst, &w.d_count[cur], &w.d_count[cur ^ 1],
                               ctx->d_stats, p->tmin, p->tmax, count_visits, st);
                 hipEvent_t e1 = profile ? new_event() : nullptr;
-#define PT_LAUNCH_SHADE(N)                                                                                          \
-    k_shade<N><<<shade_grid, TB, 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, w.d_hit, rad, qv[cur], qv[cur ^ 1], \
-                                          &w.d_count[cur], &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,    \
-                                          w.d_hit_inst)
-                if (shade_items == 1) PT_LAUNCH_SHADE(1);
-                else if (shade_items == 2) PT_LAUNCH_SHADE(2);
-                else PT_LAUNCH_SHADE(4);
+#define PT_LAUNCH_SHADE(N, L)                                                                                       \
+    k_shade<N, L><<<shade_grid, TB, (L) ? shade_smem : 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, w.d_hit, \
+                                                                rad, qv[cur], qv[cur ^ 1], &w.d_count[cur],              \
+                                                                &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,   \
+                                                                w.d_hit_inst)
+                if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
+                else if (shade_items == 1) { PT_LAUNCH_SHADE(1, false); }
+                else if (shade_items == 2) { PT_LAUNCH_SHADE(2, false); }
+                else { PT_LAUNCH_SHADE(4, false); }
 #undef PT_LAUNCH_SHADE
                 hipEvent_t e2 = profile ? new_event() : nullptr;
                 if (profile) {
