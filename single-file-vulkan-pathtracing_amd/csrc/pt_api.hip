@@ -35,7 +35,6 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    ctx->lds_bytes = (int)prop.sharedMemPerBlock;
     if (stream) {
         ctx->stream = reinterpret_cast<hipStream_t>(stream);
     } else {

@@ -21,9 +21,8 @@ struct pt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
-    int lds_bytes = 65536;
     std::string err;
-    // statistics block in device memory: [0] rays (u64), [1] paths (u64)
+    // statistics block in device memory (u64 x 4): [0] rays, [1] unused, [2] BVH4 nodes visited, [3] triangles tested
     unsigned long long *d_stats = nullptr;
     pt_stats stats{};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;

@@ -3,17 +3,21 @@
 // Replaces what runs behind vkCmdTraceRaysKHR (main.cpp:659): raygen.rgen:41-91 with its
 // traceRayEXT (raygen.rgen:63-75), closesthit.rchit:50-65 and miss.rmiss:8-12.
 //
-// Structure.  A *slot* is one (frame, pixel) pair; it runs that pixel's
-// spp_per_frame samples one after the other, so the reference's single `color` accumulator
-// (raygen.rgen:42,76) is reproduced add-for-add.  Live paths sit in dense, double-buffered
-// queues (index = queue position, all accesses coalesced):
+// Structure.  A *slot* is one (frame, sample group, pixel) triple; it runs its
+// samples one after the other ("regeneration"), and its radiance is either accumulated in path
+// order (one group) or logged term by term and replayed in order by k_resolve (several groups):
+// either way the reference's single `color` accumulator (raygen.rgen:42,76) is reproduced
+// add-for-add.  Live paths sit in dense, double-buffered queues (index = queue position, all
+// accesses coalesced):
 //     qslot, qctr (sample | depth<<16), qstate {seed, weight}, qray {origin, direction}
 // One round = two kernels over the live queue:
-//     k_extend  : closest hit of ray[q] -> hit[q]      (persistent grid, LDS short stack,
-//                                                        BVH + triangles staged in LDS when small)
-//     k_shade   : hit[q] -> emission/environment into color[slot], bounce, or start the next
-//                 sample of the same pixel ("regeneration"); survivors are compacted into the
-//                 other queue with wave ballots + one atomic per 1024-path chunk
+//     k_extend  : closest hit of ray[q] -> hit[q]   persistent threads over the BVH4, LDS short
+//                                                   stack + HBM spill, lane refill; nodes and
+//                                                   triangles staged in LDS when the scene is small
+//                 (k_extend_inst: the same over TLAS + BLAS; k_extend_flat: one wide leaf)
+//     k_shade   : hit[q] -> emission/environment radiance, bounce, or the next sample of the
+//                 slot; survivors are compacted into the other queue with wave ballots + one
+//                 atomic per 1024-path chunk
 // k_generate fills the queue for a batch of frames, k_resolve applies raygen.rgen:86-90.
 #include "pt_internal.h"
 #include "pt_math.h"
@@ -889,7 +893,6 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     int per_cu = 0;
     PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TB, pl.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
-    if (const char *e = getenv("PT_TUNE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(atoi(e), per_cu));
     if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
     pl.grid = ctx->num_cus * per_cu;
     // stack bound: a BVH4 node pushes <= 3 entries per level; wide height <= binary height/2 + 1
@@ -1129,13 +1132,11 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
         return e;
     };
 
-    int shade_items = 4, shade_bpc = 8;
-    if (const char *e = getenv("PT_TUNE_SHADE_ITEMS")) shade_items = atoi(e);
-    if (const char *e = getenv("PT_TUNE_SHADE_BPC")) shade_bpc = std::max(1, atoi(e));
-    const int shade_grid = ctx->num_cus * shade_bpc;
+    // measured on MI355X: 4 paths per thread (one queue-tail atomic per 1024 paths) and 8 blocks per CU;
+    // 1 path/thread is 40 % slower, 2 equal, grid size flat between 4 and 16 blocks per CU
+    const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 6 * (size_t)s->n_tris;
-    bool shade_lds = shade_smem <= 16 * 1024;  // per-triangle tables of small scenes are staged in LDS
-    if (const char *e = getenv("PT_TUNE_SHADE_LDS")) shade_lds = shade_lds && atoi(e) != 0;
+    const bool shade_lds = shade_smem <= 16 * 1024;  // per-triangle tables of small scenes are staged in LDS
     QueueView qv[2];
     for (int i = 0; i < 2; i++) qv[i] = { w.d_qslot[i], w.d_qctr[i], w.d_qstate[i], w.d_qrayA[i], w.d_qrayB[i] };
 
@@ -1164,8 +1165,6 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                                                                 &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,   \
                                                                 w.d_hit_inst)
                 if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
-                else if (shade_items == 1) { PT_LAUNCH_SHADE(1, false); }
-                else if (shade_items == 2) { PT_LAUNCH_SHADE(2, false); }
                 else { PT_LAUNCH_SHADE(4, false); }
 #undef PT_LAUNCH_SHADE
                 hipEvent_t e2 = profile ? new_event() : nullptr;
