@@ -507,6 +507,53 @@ def test_4k_film_bit_exact(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
     film.close()
 
 
+def test_c5_full_size_soup_structure_and_hits(pt, orc, gpu_ctx, tmp_path):
+    """BASELINE.json config 5 at full size: the 1 000 000-triangle soup through the OBJ loader, the
+    on-device LBVH/BVH4 build and the HBM traversal variant; hit records bit-exact vs the oracle."""
+    path = str(tmp_path / "soup1m.obj")
+    pt.write_soup_obj(path, 1000000, 1)
+    v, i, f = pt.load_obj(path)
+    os.remove(path)
+    assert i.size == 3000000
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    info = gs.info()
+    assert info.n_tris == 1000000 and info.bvh_height == osc.bvh_info().height
+    keys, prim, _ = gs.read_bvh()
+    okeys, oprim = osc.bvh_keys()
+    assert (np.diff(keys.astype(np.int64)) >= 0).all()                 # sorted
+    assert (keys == okeys).all() and (prim == oprim).all()             # same order as the CPU builder
+    assert (np.sort(prim) == np.arange(1000000)).all()                 # a permutation
+    wide = gs.read_bvh4()
+    words = wide[:, 24:28].ravel()
+    leaves = words[(words != 0xFFFFFFFF) & (words & 0x80000000 != 0)]
+    first, cnt = (leaves & 0x0FFFFFFF).astype(np.int64), ((leaves >> 28) & 7).astype(np.int64) + 1
+    cover = np.zeros(1000001, np.int64)
+    np.add.at(cover, first, 1)
+    np.add.at(cover, first + cnt, -1)
+    assert (np.cumsum(cover)[:-1] == 1).all()                          # every triangle in exactly one leaf
+    p = orc.default_params(width=1920, height=1080)
+    rng = np.random.default_rng(9)
+    rays = [np.concatenate(orc.primary_ray(p, int(x), int(y), orc.seed(int(x), int(y), 0, 0))[:2])
+            for x, y in zip(rng.integers(300, 1620, 4000), rng.integers(150, 930, 4000))]
+    org = rng.uniform(-1, 1, (16000, 3)).astype(np.float32) + np.float32([0, -1, 0])
+    d = rng.normal(size=(16000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([np.array(rays, np.float32), np.concatenate([org, d.astype(np.float32)], 1)])
+    hits = gs.trace(rays, tmax=10000.0)
+    ohits, _ = osc.trace(rays, mode=1)
+    assert hits.tobytes() == ohits.tobytes()
+    assert (hits["prim"] != pt.MISS).mean() > 0.7
+    # one small frame through the whole pipeline at full scene size
+    film = pt.Film(gpu_ctx, 128, 72)
+    gpu_ctx.reset_stats()
+    kw = dict(width=128, height=72, spp_per_frame=2, max_depth=16)
+    pt.render(gs, film, pt.default_params(**kw))
+    ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
+    assert gpu_ctx.stats().rays == orays and gpu_ctx.stats().extend_variant == pt.EXTEND_HBM
+    assert film.read_f32().tobytes() == ofilm.tobytes()
+    film.close(); gs.close()
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):
