@@ -57,6 +57,11 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int k = 0; k < PT_MAX_PIPES; k++) {
+        if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+        if (ctx->pipe_stream[k]) (void)hipStreamDestroy(ctx->pipe_stream[k]);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -16,6 +16,8 @@
 //            {rmin.z,rmax.xyz} {bits(left), bits(right), 0, 0}; child bit31 = leaf position       64 B
 //   wide   : BVH4 collapsed from it, 8 x float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
 //            hi.z[4] child[4] spare; leaf child = LEAF | (count-1)<<28 | first sorted position     128 B
+constexpr int PT_MAX_PIPES = 4;  // concurrent wavefront pipelines (streams) per pt_render
+
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -26,6 +28,8 @@ struct pt_ctx {
     unsigned long long *d_stats = nullptr;
     pt_stats stats{};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipStream_t pipe_stream[PT_MAX_PIPES] = {};  // extra pipelines of pt_render ([0] unused: that is `stream`)
+    hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_PIPES] = {};
     void *d_spill = nullptr;   // HBM overflow of the traversal short stack: [level][thread] uint2
     size_t spill_bytes = 0;
 };

@@ -129,17 +129,17 @@ __device__ __forceinline__ void chunk_offsets(const bool (&alive)[ITEMS], uint32
 }
 
 // ---- generate: sample 0 of every (frame, pixel) slot of the batch ----------------------------
-__global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t *__restrict__ tiles, uint32_t n_slots,
-                                                 Radiance rad, QueueView out, uint32_t *count_out)
+__global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t *__restrict__ tiles, uint32_t slot_base,
+                                                 uint32_t n_slots, Radiance rad, QueueView out, uint32_t *count_out)
 {
     __shared__ uint32_t s_wcnt[1][4];
     __shared__ uint32_t s_base;
     for (uint32_t base = blockIdx.x * TB; base < n_slots; base += gridDim.x * TB) {
-        const uint32_t slot = base + threadIdx.x;
+        const uint32_t slot = slot_base + base + threadIdx.x;
         bool alive[1] = { false };
         uint32_t seed = 0, sample0 = 0;
         ptm::f3 org{}, dir{};
-        if (slot < n_slots) {
+        if (base + threadIdx.x < n_slots) {
             uint32_t f, g, px, py;
             slot_pixel(rc, tiles, slot, f, g, px, py);
             if (rc.groups == 1u) rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
@@ -859,7 +859,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk
         const uint32_t bound_i = 3u * (s->tlas_height / 2u + 1u) + 4u + 3u * (s->height / 2u + 1u) + 2u;
         pl.spill_levels = bound_i > (uint32_t)LDS_STACK ? bound_i - (uint32_t)LDS_STACK : 0u;
-        const size_t need_i = (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
+        const size_t need_i = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
         if (need_i > ctx->spill_bytes) {
             (void)hipFree(ctx->d_spill);
             ctx->d_spill = nullptr;
@@ -898,7 +898,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     // stack bound: a BVH4 node pushes <= 3 entries per level; wide height <= binary height/2 + 1
     const uint32_t bound = 3u * (s->height / 2u + 1u) + 1u;
     pl.spill_levels = bound > (uint32_t)LDS_STACK ? bound - (uint32_t)LDS_STACK : 0u;
-    const size_t need = (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
+    const size_t need = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
     if (need > ctx->spill_bytes) {
         (void)hipFree(ctx->d_spill);
         ctx->d_spill = nullptr;
@@ -911,10 +911,12 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 
 void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
                    uint32_t *hit_inst, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
-                   float tmin, float tmax, bool count, hipStream_t st)
+                   float tmin, float tmax, bool count, hipStream_t st, int pipe = 0)
 {
+    // each concurrently running extend kernel owns its own [spill_levels][grid*TB] region
+    const size_t spill_off = (size_t)pipe * std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB;
     if (s->n_inst) {
-        uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill);
+        uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
         const uint32_t str = (uint32_t)pl.grid * TB;
         if (count)
             k_extend_inst<true><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->d_inst6, s->d_tlas_prim_of,
@@ -930,7 +932,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         k_extend_flat<<<pl.grid, TB, 0, st>>>(s->d_tri4, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, tmin, tmax);
         return;
     }
-    uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill);
+    uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
 #define PT_LAUNCH_EXTEND(L, C)                                                                                          \
     k_extend<L, C><<<pl.grid, TB, pl.smem, st>>>(s->d_wide, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, \
@@ -1005,7 +1007,7 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         PT_HIP(ctx, hipMalloc((void **)&w.d_terms, sizeof(float) * 3 * nterms));
         w.cap_terms = nterms;
     }
-    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 4));  // [0],[1] queue sizes
+    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
     return PT_OK;
 }
 
@@ -1124,11 +1126,11 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
     std::vector<hipEvent_t> evs, ev_triples;
-    auto new_event = [&]() -> hipEvent_t {
+    auto new_event = [&](hipStream_t on) -> hipEvent_t {
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
         evs.push_back(e);
-        (void)hipEventRecord(e, st);
+        (void)hipEventRecord(e, on);
         return e;
     };
 
@@ -1137,8 +1139,29 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 6 * (size_t)s->n_tris;
     const bool shade_lds = shade_smem <= 16 * 1024;  // per-triangle tables of small scenes are staged in LDS
-    QueueView qv[2];
-    for (int i = 0; i < 2; i++) qv[i] = { w.d_qslot[i], w.d_qctr[i], w.d_qstate[i], w.d_qrayA[i], w.d_qrayB[i] };
+    // Several pipelines on separate streams: the slot lanes of a batch are split into parts that run their
+    // rounds independently, so the VALU-bound extend of one overlaps the HBM-bound shade of another
+    // (measured on MI355X, Cornell box: 1 pipeline 13.4, 2: 15.2, 3: 15.0, 4: 14.1 Grays/s; restricting the
+    // kernels' blocks per CU to leave room for each other never helped).  Small batches keep one pipeline.
+    struct Pipe {
+        hipStream_t st;
+        uint32_t slot_begin, n_slots;
+        QueueView qv[2];
+        float4 *hit;
+        uint32_t *hit_inst;
+        uint32_t *count;  // [2] queue sizes of this pipeline
+        int cur;
+        bool done;
+    };
+    int n_pipes = (uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1;
+    if (const char *e = getenv("PT_TUNE_PIPES")) n_pipes = atoi(e);
+    n_pipes = std::max(1, std::min(n_pipes, std::min<int>(PT_MAX_PIPES, (int)(lanes * groups))));
+    for (int k = 1; k < n_pipes; k++)
+        if (!ctx->pipe_stream[k]) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[k], hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+        }
+    if (n_pipes > 1 && !ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
 
     ctx->stats.extend_variant = pl.variant;
     PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
@@ -1146,44 +1169,87 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
         for (uint32_t done = 0; done < p->frame_count; done += lanes) {
             rc.frame_base = p->frame + (int32_t)done;
             rc.lanes_active = std::min(lanes, p->frame_count - done);
-            PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 4, st));
-            const uint32_t gen_slots = rc.lanes_active * groups * rc.slots_per_lane;
-            const int gen_grid = (int)std::min<uint32_t>((gen_slots + TB - 1) / TB, (uint32_t)ctx->num_cus * 16u);
-            k_generate<<<gen_grid, TB, 0, st>>>(rc, w.d_tiles, gen_slots, rad, qv[0], &w.d_count[0]);
-            ctx->stats.launches_other++;
-            int cur = 0;
+            PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 2 * PT_MAX_PIPES, st));
+            const uint32_t slot_lanes = rc.lanes_active * groups;
+            const int pipes_now = std::min<int>(n_pipes, (int)slot_lanes);
+            Pipe pipe[PT_MAX_PIPES];
+            for (int k = 0; k < pipes_now; k++) {
+                const uint32_t l0 = (uint32_t)((uint64_t)slot_lanes * k / pipes_now);
+                const uint32_t l1 = (uint32_t)((uint64_t)slot_lanes * (k + 1) / pipes_now);
+                Pipe &pp = pipe[k];
+                pp.st = k == 0 ? st : ctx->pipe_stream[k];
+                pp.slot_begin = l0 * rc.slots_per_lane;
+                pp.n_slots = (l1 - l0) * rc.slots_per_lane;
+                for (int i = 0; i < 2; i++)
+                    pp.qv[i] = { w.d_qslot[i] + pp.slot_begin, w.d_qctr[i] + pp.slot_begin, w.d_qstate[i] + pp.slot_begin,
+                                 w.d_qrayA[i] + pp.slot_begin, w.d_qrayB[i] + pp.slot_begin };
+                pp.hit = w.d_hit + pp.slot_begin;
+                pp.hit_inst = w.d_hit_inst + pp.slot_begin;
+                pp.count = w.d_count + 2 * k;
+                pp.cur = 0;
+                pp.done = false;
+            }
+            if (pipes_now > 1) {  // the other streams start after the counters are cleared
+                PT_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+                for (int k = 1; k < pipes_now; k++) PT_HIP(ctx, hipStreamWaitEvent(ctx->pipe_stream[k], ctx->ev_fork, 0));
+            }
+            for (int k = 0; k < pipes_now; k++) {
+                Pipe &pp = pipe[k];
+                const int gen_grid = (int)std::min<uint32_t>((pp.n_slots + TB - 1) / TB, (uint32_t)ctx->num_cus * 16u);
+                k_generate<<<gen_grid, TB, 0, pp.st>>>(rc, w.d_tiles, pp.slot_begin, pp.n_slots, rad, pp.qv[0], &pp.count[0]);
+                ctx->stats.launches_other++;
+            }
             const uint32_t max_rounds = group_size * p->max_depth;  // every sample of a slot at full depth
-            uint32_t h_count = 1;
-            hipEvent_t e_prev = profile ? new_event() : nullptr;  // one event between consecutive kernels
+            hipEvent_t e_prev[PT_MAX_PIPES] = {};
+            if (profile)
+                for (int k = 0; k < pipes_now; k++) e_prev[k] = new_event(pipe[k].st);  // one event between consecutive kernels
             for (uint32_t round = 0; round < max_rounds; round++) {
-                launch_extend(pl, s, qv[cur].rayA, qv[cur].rayB, w.d_hit, w.d_hit_inst, &w.d_count[cur], &w.d_count[cur ^ 1],
-                              ctx->d_stats, p->tmin, p->tmax, count_visits, st);
-                hipEvent_t e1 = profile ? new_event() : nullptr;
-#define PT_LAUNCH_SHADE(N, L)                                                                                       \
-    k_shade<N, L><<<shade_grid, TB, (L) ? shade_smem : 0, st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, w.d_hit, \
-                                                                rad, qv[cur], qv[cur ^ 1], &w.d_count[cur],              \
-                                                                &w.d_count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,   \
-                                                                w.d_hit_inst)
-                if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
-                else { PT_LAUNCH_SHADE(4, false); }
+                for (int k = 0; k < pipes_now; k++) {
+                    Pipe &pp = pipe[k];
+                    if (pp.done) continue;
+                    const int cur = pp.cur;
+                    launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
+                                  ctx->d_stats, p->tmin, p->tmax, count_visits, pp.st, k);
+                    hipEvent_t e1 = profile ? new_event(pp.st) : nullptr;
+#define PT_LAUNCH_SHADE(N, L)                                                                                              \
+    k_shade<N, L><<<shade_grid, TB, (L) ? shade_smem : 0, pp.st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, \
+                                                                   rad, pp.qv[cur], pp.qv[cur ^ 1], &pp.count[cur],        \
+                                                                   &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,   \
+                                                                   pp.hit_inst)
+                    if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
+                    else { PT_LAUNCH_SHADE(4, false); }
 #undef PT_LAUNCH_SHADE
-                hipEvent_t e2 = profile ? new_event() : nullptr;
-                if (profile) {
-                    ev_triples.push_back(e_prev);
-                    ev_triples.push_back(e1);
-                    ev_triples.push_back(e2);
-                    e_prev = e2;
+                    hipEvent_t e2 = profile ? new_event(pp.st) : nullptr;
+                    if (profile) {
+                        ev_triples.push_back(e_prev[k]);
+                        ev_triples.push_back(e1);
+                        ev_triples.push_back(e2);
+                        e_prev[k] = e2;
+                    }
+                    ctx->stats.launches_extend++;
+                    ctx->stats.launches_shade++;
+                    pp.cur ^= 1;
                 }
-                ctx->stats.launches_extend++;
-                ctx->stats.launches_shade++;
                 ctx->stats.rounds++;
-                cur ^= 1;
-                // every pixel needs >= spp rounds; after that poll the live count now and then
+                // every slot needs >= group_size rounds; after that poll the live counts now and then
                 if (round + 1 >= group_size && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
-                    PT_HIP(ctx, hipMemcpyAsync(&h_count, &w.d_count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                    PT_HIP(ctx, hipStreamSynchronize(st));
-                    if (h_count == 0) break;
+                    uint32_t h_count[PT_MAX_PIPES] = {};
+                    for (int k = 0; k < pipes_now; k++)
+                        if (!pipe[k].done)
+                            PT_HIP(ctx, hipMemcpyAsync(&h_count[k], &pipe[k].count[pipe[k].cur], sizeof(uint32_t), hipMemcpyDeviceToHost, pipe[k].st));
+                    bool all_done = true;
+                    for (int k = 0; k < pipes_now; k++) {
+                        if (pipe[k].done) continue;
+                        PT_HIP(ctx, hipStreamSynchronize(pipe[k].st));
+                        if (h_count[k] == 0) pipe[k].done = true;
+                        else all_done = false;
+                    }
+                    if (all_done) break;
                 }
+            }
+            for (int k = 1; k < pipes_now; k++) {  // join before the resolve reads every pipeline's slots
+                PT_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->pipe_stream[k]));
+                PT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0));
             }
             k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra);
             ctx->stats.launches_other++;
