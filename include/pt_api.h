@@ -76,6 +76,7 @@ typedef struct pt_scene_info {
     uint32_t n_wide_nodes;    /* BVH4 nodes (128 B each) the traversal kernels walk               */
     uint32_t n_instances;     /* 0 = single-level scene                                           */
     uint32_t n_tlas_nodes;    /* BVH4 nodes of the TLAS                                           */
+    uint32_t leaf_max;        /* triangles per BVH4 leaf of the collapse rule (bvh4 read-back)    */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
     uint64_t device_bytes;    /* resident scene + BVH bytes                                     */

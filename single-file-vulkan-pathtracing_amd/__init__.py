@@ -53,6 +53,7 @@ class Params(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_height", C.c_uint32),
                 ("n_wide_nodes", C.c_uint32), ("n_instances", C.c_uint32), ("n_tlas_nodes", C.c_uint32),
+                ("leaf_max", C.c_uint32),
                 ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
                 ("device_bytes", C.c_uint64)]
 

@@ -319,34 +319,36 @@ __global__ void k_single(const float4 *__restrict__ tlo, const float4 *__restric
 }
 
 
-// 7. BVH4 collapse.  Binary nodes at even depth whose subtree holds more than PT_LEAF_MAX triangles
+// 7. BVH4 collapse.  Binary nodes at even depth whose subtree holds more than leaf_max primitives
 // become wide nodes; their internal children (odd depth) are absorbed, so a wide node holds the
-// up-to-4 grandchildren.  Any binary subtree with <= PT_LEAF_MAX triangles becomes ONE leaf child
+// up-to-4 grandchildren.  Any binary subtree with <= leaf_max primitives becomes ONE leaf child
 // (its triangles are contiguous in sorted order): child word = LEAF | (count-1)<<28 | first.
 // Wide node = 128 B = one gfx950 L2 line: 6 float4 {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]}
 // {hi.z[4]}, 1 uint4 children (0xFFFFFFFF = empty slot, box lo = hi = +inf: never hit), 1 spare.
-__device__ __forceinline__ bool leaf_like(uint32_t ref, const uint2 *__restrict__ range)
+__device__ __forceinline__ bool leaf_like(uint32_t ref, const uint2 *__restrict__ range, uint32_t leaf_max)
 {
     if (ref & PT_LEAF) return true;
     const uint2 r = range[ref];
-    return r.y - r.x + 1u <= PT_LEAF_MAX;
+    return r.y - r.x + 1u <= leaf_max;
 }
 
 __global__ __launch_bounds__(TB) void k_wide_flag(int n_int, const uint32_t *__restrict__ parent_int,
-                                                  const uint2 *__restrict__ range, uint32_t *__restrict__ flag)
+                                                  const uint2 *__restrict__ range, uint32_t *__restrict__ flag,
+                                                  uint32_t leaf_max)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
     if (i >= n_int) return;
     uint32_t depth = 0;
     for (uint32_t a = (uint32_t)i; a != 0u; a = parent_int[a]) depth++;
     const uint2 r = range[i];
-    const bool big = r.y - r.x + 1u > PT_LEAF_MAX;
+    const bool big = r.y - r.x + 1u > leaf_max;
     flag[i] = (i == 0 || (big && (depth & 1u) == 0u)) ? 1u : 0u;
 }
 
 __device__ __forceinline__ void wide_child(uint32_t ref, int n, const uint2 *__restrict__ range,
                                            const uint32_t *__restrict__ widx, const float4 *__restrict__ box_lo,
-                                           const float4 *__restrict__ box_hi, uint32_t &word, float4 &lo, float4 &hi)
+                                           const float4 *__restrict__ box_hi, uint32_t leaf_max, uint32_t &word,
+                                           float4 &lo, float4 &hi)
 {
     if (ref & PT_LEAF) {
         const uint32_t pos = ref & ~PT_LEAF;
@@ -357,7 +359,7 @@ __device__ __forceinline__ void wide_child(uint32_t ref, int n, const uint2 *__r
     }
     const uint2 r = range[ref];
     const uint32_t cnt = r.y - r.x + 1u;
-    word = cnt <= PT_LEAF_MAX ? (PT_LEAF | ((cnt - 1u) << 28) | r.x) : widx[ref];
+    word = cnt <= leaf_max ? (PT_LEAF | ((cnt - 1u) << 28) | r.x) : widx[ref];
     lo = box_lo[(size_t)n + ref];
     hi = box_hi[(size_t)n + ref];
 }
@@ -365,7 +367,8 @@ __device__ __forceinline__ void wide_child(uint32_t ref, int n, const uint2 *__r
 __global__ __launch_bounds__(TB) void k_wide_emit(int n, int n_int, const uint2 *__restrict__ topo,
                                                   const uint2 *__restrict__ range, const uint32_t *__restrict__ flag,
                                                   const uint32_t *__restrict__ widx, const float4 *__restrict__ box_lo,
-                                                  const float4 *__restrict__ box_hi, float4 *__restrict__ wide)
+                                                  const float4 *__restrict__ box_hi, float4 *__restrict__ wide,
+                                                  uint32_t leaf_max)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
     if (i >= n_int || !flag[i]) return;
@@ -376,21 +379,21 @@ __global__ __launch_bounds__(TB) void k_wide_emit(int n, int n_int, const uint2 
         hi[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);  // test sees an empty interval
     }
     int m = 0;
-    if (leaf_like((uint32_t)i, range)) {  // tiny scene: the root itself is one leaf
-        wide_child((uint32_t)i, n, range, widx, box_lo, box_hi, word[0], lo[0], hi[0]);
+    if (leaf_like((uint32_t)i, range, leaf_max)) {  // tiny scene: the root itself is one leaf
+        wide_child((uint32_t)i, n, range, widx, box_lo, box_hi, leaf_max, word[0], lo[0], hi[0]);
         m = 1;
     } else {
         const uint2 ch = topo[i];
         const uint32_t c2[2] = { ch.x, ch.y };
         for (int a = 0; a < 2; a++) {
-            if (leaf_like(c2[a], range)) {
-                wide_child(c2[a], n, range, widx, box_lo, box_hi, word[m], lo[m], hi[m]);
+            if (leaf_like(c2[a], range, leaf_max)) {
+                wide_child(c2[a], n, range, widx, box_lo, box_hi, leaf_max, word[m], lo[m], hi[m]);
                 m++;
             } else {  // absorbed odd-depth node: its two children move up
                 const uint2 g = topo[c2[a]];
-                wide_child(g.x, n, range, widx, box_lo, box_hi, word[m], lo[m], hi[m]);
+                wide_child(g.x, n, range, widx, box_lo, box_hi, leaf_max, word[m], lo[m], hi[m]);
                 m++;
-                wide_child(g.y, n, range, widx, box_lo, box_hi, word[m], lo[m], hi[m]);
+                wide_child(g.y, n, range, widx, box_lo, box_hi, leaf_max, word[m], lo[m], hi[m]);
                 m++;
             }
         }
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, c
     }
 }
 
-static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, BvhOut &out)
+static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, uint32_t leaf_max, BvhOut &out)
 {
     hipStream_t st = ctx->stream;
     const uint32_t gt = (n + TB - 1) / TB;
@@ -545,7 +548,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
     if (n > 1) {
         const int n_int = (int)n - 1;
         const uint32_t gi = (uint32_t)(n_int + TB - 1) / TB;
-        k_wide_flag<<<gi, TB, 0, st>>>(n_int, d_pint.p, d_range.p, d_wflag.p);
+        k_wide_flag<<<gi, TB, 0, st>>>(n_int, d_pint.p, d_range.p, d_wflag.p, leaf_max);
         PT_HIP(ctx, hipMemcpyAsync(d_widx.p, d_wflag.p, sizeof(uint32_t) * (size_t)n_int, hipMemcpyDeviceToDevice, st));
         k_rs_scan<<<1, 1024, 0, st>>>(d_widx.p, (uint32_t)n_int);
         uint32_t last_idx = 0, last_flag = 0;
@@ -554,7 +557,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         PT_HIP(ctx, hipStreamSynchronize(st));
         n_wide = last_idx + last_flag;
         PT_HIP(ctx, hipMalloc((void **)&out.d_wide, 128 * (size_t)n_wide));
-        k_wide_emit<<<gi, TB, 0, st>>>((int)n, n_int, d_topo.p, d_range.p, d_wflag.p, d_widx.p, d_blo.p, d_bhi.p, out.d_wide);
+        k_wide_emit<<<gi, TB, 0, st>>>((int)n, n_int, d_topo.p, d_range.p, d_wflag.p, d_widx.p, d_blo.p, d_bhi.p, out.d_wide, leaf_max);
     } else {
         PT_HIP(ctx, hipMalloc((void **)&out.d_wide, 128));
         k_wide_single<<<1, 1, 0, st>>>(out.d_nodes, out.d_wide);
@@ -599,7 +602,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p);
     BvhOut o;
-    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, o);
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o);
     s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
     if (rc != PT_OK) return rc;
     s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height;
@@ -704,7 +707,7 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     const uint32_t g = (n + TB - 1) / TB;
     k_inst_boxes<<<g, TB, 0, st>>>(s->d_wide, d_in.p, n, d_tlo.p, d_thi.p);
     BvhOut o;
-    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, o);
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_TLAS_LEAF_MAX, o);
     (void)hipFree(o.d_keys);
     (void)hipFree(o.d_nodes);
     s->d_tlas_wide = o.d_wide;

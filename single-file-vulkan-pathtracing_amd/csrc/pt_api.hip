@@ -1,5 +1,6 @@
 // pt_api.hip -- the C-ABI (include/pt_api.h) over the HIP kernels.  No exception leaves this file.
 #include "pt_internal.h"
+#include "pt_math.h"
 
 #include <cstring>
 #include <new>
@@ -120,6 +121,7 @@ pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
     info->n_wide_nodes = s->n_wide;
     info->n_instances = s->n_inst;
     info->n_tlas_nodes = s->n_tlas_wide;
+    info->leaf_max = PT_BLAS_LEAF_MAX;
     for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
     info->build_ms = s->build_ms;
     info->device_bytes = s->device_bytes;

@@ -149,7 +149,7 @@ def test_bvh4_collapse_matches_reference_rule(pt, orc, gpu_ctx, n, seed):
     if n == 1:
         assert wide.shape[0] == 1 and wide[0, 24] == 0x80000000 and (wide[0, 25:28] == 0xFFFFFFFF).all()
     else:
-        ref = _collapse_reference(osc.bvh_nodes(), n)
+        ref = _collapse_reference(osc.bvh_nodes(), n, leaf_max=gs.info().leaf_max)
         assert wide.shape == ref.shape
         assert wide.tobytes() == ref.tobytes()
     # every sorted position sits in exactly one leaf
@@ -165,8 +165,8 @@ def test_bvh4_collapse_matches_reference_rule(pt, orc, gpu_ctx, n, seed):
 
 def test_bvh4_cornell(pt, orc, cornell_gpu, cornell_oracle):
     wide = cornell_gpu.read_bvh4()
-    assert wide.tobytes() == _collapse_reference(cornell_oracle.bvh_nodes(), 36).tobytes()
-    assert cornell_gpu.info().n_wide_nodes == wide.shape[0] <= 12
+    assert wide.tobytes() == _collapse_reference(cornell_oracle.bvh_nodes(), 36, leaf_max=cornell_gpu.info().leaf_max).tobytes()
+    assert cornell_gpu.info().n_wide_nodes == wide.shape[0] <= 18
 
 
 def test_trace_primary_rays_bit_exact(pt, orc, cornell_gpu, cornell_oracle):

@@ -113,7 +113,7 @@ def test_struct_layouts_match_header(pt):
     import ctypes as C
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
     assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2
-    assert C.sizeof(pt.SceneInfo) == 4 * 6 + 4 * 6 + 4 + 4 + 8  # 4 pad before the u64
+    assert C.sizeof(pt.SceneInfo) == 4 * 7 + 4 * 6 + 4 + 8
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
     assert list(p.cam_origin) == [0.0, -1.0, 5.0] and list(p.cam_target) == [0.0, -1.0, 2.0]
