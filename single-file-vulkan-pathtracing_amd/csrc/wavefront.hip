@@ -389,9 +389,10 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
 // (one identity instance, main.cpp:515-538); semantics in DESIGN.md section 3.
 constexpr uint32_t EXIT_MARK = 0x7FFFFFFFu;
 
-template <bool COUNT>
-__global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ tlas, const float4 *__restrict__ blas,
-                                                    const float4 *__restrict__ tri4, const float4 *__restrict__ inst6,
+template <bool COUNT, bool LDS_BLAS>
+__global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ tlas, const float4 *__restrict__ g_blas,
+                                                    const float4 *__restrict__ g_tri4, uint32_t n_blas_wide,
+                                                    uint32_t n_tris, const float4 *__restrict__ inst6,
                                                     const uint32_t *__restrict__ inst_id, const float4 *__restrict__ rayA,
                                                     const float2 *__restrict__ rayB, float4 *__restrict__ hit,
                                                     uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
@@ -401,6 +402,22 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
+    const float4 *blas = g_blas;
+    const float4 *tri4 = g_tri4;
+    if (LDS_BLAS) {  // the BLAS is shared by every instance: keep it (and 3 permuted triangle copies) in LDS
+        float4 *s_blas = reinterpret_cast<float4 *>(smem + (size_t)LDS_STACK * TB * sizeof(uint2));
+        float4 *s_tri = s_blas + 8 * (size_t)n_blas_wide;
+        for (uint32_t i = threadIdx.x; i < 8 * n_blas_wide; i += TB) s_blas[i] = g_blas[i];
+        for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
+            const float4 v = g_tri4[i];
+            s_tri[i] = make_float4(v.y, v.z, v.x, v.w);
+            s_tri[3 * n_tris + i] = make_float4(v.z, v.x, v.y, v.w);
+            s_tri[6 * n_tris + i] = v;
+        }
+        __syncthreads();
+        blas = s_blas;
+        tri4 = s_tri;
+    }
     const uint32_t n = *count_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (count_zero) *count_zero = 0u;
@@ -415,7 +432,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
     bool have = false, exhausted = false, in_blas = false;
     uint32_t q = 0;
     ptm::f3 org_w{}, dir_w{}, inv_w{};   // world-space ray
-    ptm::f3 org{}, inv{};                 // ray of the level being walked
+    ptm::f3 org{}, inv{}, orgp{};         // ray of the level being walked (orgp: origin permuted to kx,ky,kz)
+    uint32_t tri_base = 0;
     int ixn = 0, iyn = 1, izn = 2;        // near-plane float4 indices for the level being walked
     ptm::RayPre pre{};
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
@@ -490,8 +508,14 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
 
         // ---- node phase (either level)
         while (have && !(cur & PT_LEAF)) {
-            const float4 *nd = (in_blas ? blas : tlas) + 8 * (size_t)cur;
-            PT_NODE_LOAD(nd)
+            float4 nx, fx, ny, fy, nz, fz, cw;
+            if (LDS_BLAS && in_blas) {
+                const float4 *nd = blas + 8 * (size_t)cur;
+                nx = nd[ixn]; fx = nd[3 - ixn]; ny = nd[iyn]; fy = nd[5 - iyn]; nz = nd[izn]; fz = nd[7 - izn]; cw = nd[6];
+            } else {
+                const float4 *nd = (LDS_BLAS ? tlas : (in_blas ? g_blas : tlas)) + 8 * (size_t)cur;
+                nx = nd[ixn]; fx = nd[3 - ixn]; ny = nd[iyn]; fy = nd[5 - iyn]; nz = nd[izn]; fz = nd[7 - izn]; cw = nd[6];
+            }
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
             uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
@@ -527,10 +551,13 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                     if (COUNT) c_tris += cnt;
                     for (uint32_t k = 0; k < cnt; k++) {
                         const uint32_t pos = first + k;
-                        const float4 a = tri4[3 * (size_t)pos + 0], b = tri4[3 * (size_t)pos + 1],
-                                     c = tri4[3 * (size_t)pos + 2];
+                        const size_t ti = LDS_BLAS ? (size_t)tri_base + 3 * (size_t)pos : 3 * (size_t)pos;
+                        const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
                         float t, V, W, det;
-                        if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
+                        const bool th = LDS_BLAS
+                            ? ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)
+                            : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det);
+                        if (th) {
                             const uint32_t prim = __float_as_uint(a.w);
                             // closest t; equal t -> lowest (gl_InstanceID, gl_PrimitiveID)
                             if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
@@ -560,6 +587,11 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                     iyn = inv.y < 0.f ? 4 : 1;
                     izn = inv.z < 0.f ? 5 : 2;
                     pre = ptm::ray_setup(oo, od);
+                    if (LDS_BLAS) {
+                        tri_base = (uint32_t)pre.kz * 3u * n_tris;
+                        orgp = { ptm::sel3(pre.kz, oo.y, oo.z, oo.x), ptm::sel3(pre.kz, oo.z, oo.x, oo.y),
+                                 ptm::sel3(pre.kz, oo.x, oo.y, oo.z) };
+                    }
                     push(EXIT_MARK, 0.f);
                     in_blas = true;
                     cur = 0u;  // BLAS root
@@ -849,10 +881,13 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     if (s->n_inst) {  // two-level scenes: one kernel variant (BVH4s read through L1/L2)
         if (want == PT_EXTEND_FLAT || want == PT_EXTEND_LDS) { ctx->err = "instanced scenes only have the HBM extend variant"; return PT_ERR_UNSUPPORTED; }
         pl.variant = PT_EXTEND_HBM;
-        pl.lds_scene = false;
-        pl.smem = (size_t)LDS_STACK * TB * sizeof(uint2);
+        const size_t blas_bytes = 128 * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;
+        pl.lds_scene = blas_bytes <= 24 * 1024;  // here: the BLAS (shared by all instances) is staged in LDS
+        pl.smem = (size_t)LDS_STACK * TB * sizeof(uint2) + (pl.lds_scene ? blas_bytes : 0);
         int per_cu_i = 0;
-        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_i, reinterpret_cast<const void *>(k_extend_inst<false>), TB, pl.smem));
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                        &per_cu_i, pl.lds_scene ? reinterpret_cast<const void *>(k_extend_inst<false, true>)
+                                                : reinterpret_cast<const void *>(k_extend_inst<false, false>), TB, pl.smem));
         per_cu_i = std::max(1, std::min(per_cu_i, 8));
         if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
         pl.grid = ctx->num_cus * per_cu_i;
@@ -918,14 +953,16 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     if (s->n_inst) {
         uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
         const uint32_t str = (uint32_t)pl.grid * TB;
-        if (count)
-            k_extend_inst<true><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->d_inst6, s->d_tlas_prim_of,
-                                                               rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp, str,
-                                                               pl.refill, tmin, tmax);
-        else
-            k_extend_inst<false><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->d_inst6, s->d_tlas_prim_of,
-                                                                rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp, str,
-                                                                pl.refill, tmin, tmax);
+#define PT_LAUNCH_INST(C, L)                                                                                            \
+    k_extend_inst<C, L><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6, \
+                                                      s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero,     \
+                                                      stats, sp, str, pl.refill, tmin, tmax)
+        if (pl.lds_scene) {
+            if (count) PT_LAUNCH_INST(true, true); else PT_LAUNCH_INST(false, true);
+        } else {
+            if (count) PT_LAUNCH_INST(true, false); else PT_LAUNCH_INST(false, false);
+        }
+#undef PT_LAUNCH_INST
         return;
     }
     if (pl.variant == PT_EXTEND_FLAT) {
