@@ -22,6 +22,8 @@
 #include "pt_internal.h"
 #include "pt_math.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -946,17 +948,20 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 
 void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
                    uint32_t *hit_inst, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
-                   float tmin, float tmax, bool count, hipStream_t st, int pipe = 0)
+                   float tmin, float tmax, bool count, hipStream_t st, int pipe = 0, hipEvent_t ev0 = nullptr,
+                   hipEvent_t ev1 = nullptr)
 {
+    // hipExtLaunchKernelGGL stamps THIS kernel's start/stop into ev0/ev1 (null = plain launch): under
+    // two overlapping pipelines an event recorded between kernels would also count queueing time
     // each concurrently running extend kernel owns its own [spill_levels][grid*TB] region
     const size_t spill_off = (size_t)pipe * std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB;
     if (s->n_inst) {
         uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
         const uint32_t str = (uint32_t)pl.grid * TB;
-#define PT_LAUNCH_INST(C, L)                                                                                            \
-    k_extend_inst<C, L><<<pl.grid, TB, pl.smem, st>>>(s->d_tlas_wide, s->d_wide, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6, \
-                                                      s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero,     \
-                                                      stats, sp, str, pl.refill, tmin, tmax)
+#define PT_LAUNCH_INST(C, L)                                                                                             \
+    hipExtLaunchKernelGGL((k_extend_inst<C, L>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas_wide, \
+                          s->d_wide, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6, s->d_tlas_prim_of, rayA, rayB, hit,           \
+                          hit_inst, count_in, count_zero, stats, sp, str, pl.refill, tmin, tmax)
         if (pl.lds_scene) {
             if (count) PT_LAUNCH_INST(true, true); else PT_LAUNCH_INST(false, true);
         } else {
@@ -966,14 +971,16 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         return;
     }
     if (pl.variant == PT_EXTEND_FLAT) {
-        k_extend_flat<<<pl.grid, TB, 0, st>>>(s->d_tri4, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, tmin, tmax);
+        hipExtLaunchKernelGGL(k_extend_flat, dim3(pl.grid), dim3(TB), 0u, st, ev0, ev1, 0u, s->d_tri4, s->n_tris, rayA, rayB, hit,
+                              count_in, count_zero, stats, tmin, tmax);
         return;
     }
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
-#define PT_LAUNCH_EXTEND(L, C)                                                                                          \
-    k_extend<L, C><<<pl.grid, TB, pl.smem, st>>>(s->d_wide, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, \
-                                                 count_zero, stats, spill, stride, pl.refill, tmin, tmax)
+#define PT_LAUNCH_EXTEND(L, C)                                                                                        \
+    hipExtLaunchKernelGGL((k_extend<L, C>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide,    \
+                          s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
+                          pl.refill, tmin, tmax)
     if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(true, false);
     } else {
@@ -1162,12 +1169,11 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
-    std::vector<hipEvent_t> evs, ev_triples;
-    auto new_event = [&](hipStream_t on) -> hipEvent_t {
+    std::vector<hipEvent_t> evs, ev_extend, ev_shade;  // (start, stop) pairs filled in by the launches
+    auto new_event = [&]() -> hipEvent_t {
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
         evs.push_back(e);
-        (void)hipEventRecord(e, on);
         return e;
     };
 
@@ -1237,31 +1243,25 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 ctx->stats.launches_other++;
             }
             const uint32_t max_rounds = group_size * p->max_depth;  // every sample of a slot at full depth
-            hipEvent_t e_prev[PT_MAX_PIPES] = {};
-            if (profile)
-                for (int k = 0; k < pipes_now; k++) e_prev[k] = new_event(pipe[k].st);  // one event between consecutive kernels
             for (uint32_t round = 0; round < max_rounds; round++) {
                 for (int k = 0; k < pipes_now; k++) {
                     Pipe &pp = pipe[k];
                     if (pp.done) continue;
                     const int cur = pp.cur;
+                    hipEvent_t x0 = nullptr, x1 = nullptr, h0 = nullptr, h1 = nullptr;
+                    if (profile) { x0 = new_event(); x1 = new_event(); h0 = new_event(); h1 = new_event(); }
                     launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
-                                  ctx->d_stats, p->tmin, p->tmax, count_visits, pp.st, k);
-                    hipEvent_t e1 = profile ? new_event(pp.st) : nullptr;
-#define PT_LAUNCH_SHADE(N, L)                                                                                              \
-    k_shade<N, L><<<shade_grid, TB, (L) ? shade_smem : 0, pp.st>>>(rc, w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, \
-                                                                   rad, pp.qv[cur], pp.qv[cur ^ 1], &pp.count[cur],        \
-                                                                   &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr,   \
-                                                                   pp.hit_inst)
+                                  ctx->d_stats, p->tmin, p->tmax, count_visits, pp.st, k, x0, x1);
+#define PT_LAUNCH_SHADE(N, L)                                                                                                  \
+    hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
+                          w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
+                          &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst)
                     if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
                     else { PT_LAUNCH_SHADE(4, false); }
 #undef PT_LAUNCH_SHADE
-                    hipEvent_t e2 = profile ? new_event(pp.st) : nullptr;
                     if (profile) {
-                        ev_triples.push_back(e_prev[k]);
-                        ev_triples.push_back(e1);
-                        ev_triples.push_back(e2);
-                        e_prev[k] = e2;
+                        ev_extend.push_back(x0); ev_extend.push_back(x1);
+                        ev_shade.push_back(h0); ev_shade.push_back(h1);
                     }
                     ctx->stats.launches_extend++;
                     ctx->stats.launches_shade++;
@@ -1309,12 +1309,10 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
         ctx->stats.paths += valid * p->spp_per_frame * p->frame_count;
     }
     if (profile) {
-        for (size_t i = 0; i + 2 < ev_triples.size(); i += 3) {
+        for (size_t i = 0; i + 1 < ev_extend.size(); i += 2) {
             float a = 0.f, b = 0.f;
-            (void)hipEventElapsedTime(&a, ev_triples[i], ev_triples[i + 1]);
-            (void)hipEventElapsedTime(&b, ev_triples[i + 1], ev_triples[i + 2]);
-            ctx->stats.ms_extend += a;
-            ctx->stats.ms_shade += b;
+            if (hipEventElapsedTime(&a, ev_extend[i], ev_extend[i + 1]) == hipSuccess) ctx->stats.ms_extend += a;
+            if (hipEventElapsedTime(&b, ev_shade[i], ev_shade[i + 1]) == hipSuccess) ctx->stats.ms_shade += b;
         }
     }
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
