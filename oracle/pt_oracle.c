@@ -677,6 +677,7 @@ void orc_sample_direction(float r1, float r2, const float n[3], int libm, float 
 typedef struct job {
     const orc_scene *s; const orc_params *p; int mode, tid, nthreads;
     float *frame_color; orc_hit *first_hits; orc_counters cnt;
+    uint32_t x0, y0, rw, rh; /* rectangle to render; output is rw x rh, row-major */
 } job;
 
 static void render_pixel(job *jb, uint32_t px, uint32_t py)
@@ -692,7 +693,7 @@ static void render_pixel(job *jb, uint32_t px, uint32_t py)
             orc_hit h;
             orc_trace(s, jb->mode, org, dir, p->tmin, p->tmax, &h, &jb->cnt);
             if (jb->first_hits && sample == 0 && depth == 0)
-                jb->first_hits[(size_t)py * p->width + px] = h;
+                jb->first_hits[(size_t)(py - jb->y0) * jb->rw + (px - jb->x0)] = h;
             if (h.prim == ORC_MISS) { /* miss.rmiss:10-11 then raygen.rgen:76, 81-83 */
                 for (int k = 0; k < 3; k++) color[k] = color[k] + weight[k] * p->env[k];
                 break;
@@ -709,21 +710,28 @@ static void render_pixel(job *jb, uint32_t px, uint32_t py)
                 weight[k] = weight[k] * ((brdf[k] * dt) / 0.15915493667125702f);
         }
     }
-    float *out = jb->frame_color + 3 * ((size_t)py * p->width + px);
+    float *out = jb->frame_color + 3 * ((size_t)(py - jb->y0) * jb->rw + (px - jb->x0));
     for (int k = 0; k < 3; k++) out[k] = color[k] / (float)p->spp_per_frame; /* :86 */
 }
 
 static void *worker(void *arg)
 {
     job *jb = arg;
-    for (uint32_t y = (uint32_t)jb->tid; y < jb->p->height; y += (uint32_t)jb->nthreads)
-        for (uint32_t x = 0; x < jb->p->width; x++) render_pixel(jb, x, y);
+    for (uint32_t y = jb->y0 + (uint32_t)jb->tid; y < jb->y0 + jb->rh; y += (uint32_t)jb->nthreads)
+        for (uint32_t x = jb->x0; x < jb->x0 + jb->rw; x++) render_pixel(jb, x, y);
     return NULL;
 }
 
 uint64_t orc_render_frame(const orc_scene *s, const orc_params *p, int mode, int nthreads,
                           float *frame_color, orc_hit *first_hits, orc_counters *cnt)
 {
+    return orc_render_rect(s, p, mode, nthreads, 0, 0, p->width, p->height, frame_color, first_hits, cnt);
+}
+
+uint64_t orc_render_rect(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0, uint32_t y0,
+                         uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits, orc_counters *cnt)
+{
+    if (x0 + rw > p->width || y0 + rh > p->height) return 0;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     job jobs[256];
@@ -731,6 +739,7 @@ uint64_t orc_render_frame(const orc_scene *s, const orc_params *p, int mode, int
     for (int t = 0; t < nthreads; t++) {
         jobs[t].s = s; jobs[t].p = p; jobs[t].mode = mode; jobs[t].tid = t; jobs[t].nthreads = nthreads;
         jobs[t].frame_color = frame_color; jobs[t].first_hits = first_hits;
+        jobs[t].x0 = x0; jobs[t].y0 = y0; jobs[t].rw = rw; jobs[t].rh = rh;
         memset(&jobs[t].cnt, 0, sizeof(orc_counters));
     }
     if (nthreads == 1) worker(&jobs[0]);

@@ -113,6 +113,12 @@ void orc_sample_direction(float r1, float r2, const float n[3], int libm, float 
 uint64_t orc_render_frame(const orc_scene *s, const orc_params *p, int mode, int nthreads,
                           float *frame_color, orc_hit *first_hits, orc_counters *cnt);
 
+/* The same for the pixel rectangle [x0, x0+rw) x [y0, y0+rh) of the width x height launch only
+ * (output rw x rh, row-major): full-size configs are checked through crops.                  */
+uint64_t orc_render_rect(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0,
+                         uint32_t y0, uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits,
+                         orc_counters *cnt);
+
 /* raygen.rgen:88-90 in float32 (canonical film): film = (color + film*frame)/(frame+1) */
 void orc_accumulate_f32(float *film_rgb, const float *frame_color, int32_t frame, uint64_t n_pixels);
 /* raygen.rgen:88-90 as the reference displays it: rgba8 image in B,G,R,A byte order

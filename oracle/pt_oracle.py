@@ -75,6 +75,9 @@ def lib():
         L.orc_render_frame.restype = C.c_uint64
         L.orc_render_frame.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.POINTER(Counters)]
+        L.orc_render_rect.restype = C.c_uint64
+        L.orc_render_rect.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
         L.orc_accumulate_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]
         L.orc_accumulate_bgra8.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]
         _LIB = L
@@ -188,6 +191,17 @@ class Scene:
         rays = lib().orc_render_frame(self.h, C.byref(params), mode, nthreads, img.ctypes.data,
                                       fh.ctypes.data if want_first_hits else None, C.byref(cnt))
         return img, int(rays), cnt, fh
+
+
+def render_rect(scene, params, x0, y0, rw, rh, mode=1, nthreads=None):
+    """-> (frame_color[rh,rw,3] f32, rays) for the pixel rectangle of the params.width x height launch."""
+    if nthreads is None:
+        nthreads = os.cpu_count() or 1
+    img = np.zeros((rh, rw, 3), dtype=np.float32)
+    cnt = Counters()
+    rays = lib().orc_render_rect(scene.h, C.byref(params), mode, nthreads, x0, y0, rw, rh, img.ctypes.data, None,
+                                 C.byref(cnt))
+    return img, int(rays)
 
 
 def primary_ray(params, px, py, seed_value):

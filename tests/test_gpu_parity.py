@@ -554,6 +554,29 @@ def test_c5_full_size_soup_structure_and_hits(pt, orc, gpu_ctx, tmp_path):
     film.close(); gs.close()
 
 
+def test_c2_full_size_32spp_crop_matches_golden(pt, orc, gpu_ctx, cornell_gpu):
+    """BASELINE config 2 exactly (1920x1080, 64 spp = 2 frames x 32, depth 8) on the GPU; the committed
+    oracle crop of that launch must come out bit for bit, frame by frame and after the blend."""
+    g = np.load(os.path.join(HERE, "golden", "c2_crop_1080p_32spp_d8.npz"))
+    x0, y0, rw, rh = [int(v) for v in g["rect"]]
+    kw = dict(width=1920, height=1080, spp_per_frame=32, max_depth=8)
+    film = pt.Film(gpu_ctx, 1920, 1080)
+    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=1, **kw))
+    assert np.ascontiguousarray(film.read_f32()[y0:y0 + rh, x0:x0 + rw]).tobytes() == g["frame0"].tobytes()
+    pt.render(cornell_gpu, film, pt.default_params(frame=1, frame_count=1, **kw))
+    want = g["frame0"].copy()
+    orc.accumulate_f32(want, np.ascontiguousarray(g["frame1"]), 1)
+    assert np.ascontiguousarray(film.read_f32()[y0:y0 + rh, x0:x0 + rw]).tobytes() == want.tobytes()
+    # both frames in one call (batched, sample groups chosen automatically)
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, **kw))
+    assert np.ascontiguousarray(film.read_f32()[y0:y0 + rh, x0:x0 + rw]).tobytes() == want.tobytes()
+    st = gpu_ctx.stats()
+    assert st.paths == 1920 * 1080 * 64 and 3.36 < st.rays / st.paths < 3.40
+    film.close()
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):

@@ -266,3 +266,20 @@ def test_instances_brute_equals_tlas_and_hits_are_consistent(orc, cornell_arrays
     a, ra, _, _ = sc.render_frame(p, mode=0)
     b, rb, _, _ = sc.render_frame(p, mode=1)
     assert ra == rb and a.tobytes() == b.tobytes()
+
+
+def test_c2_crop_golden_and_rect_consistency(orc, cornell_oracle):
+    """BASELINE config 2 at full size is checked through a crop: the committed golden (frames 0, 1 of the
+    1920x1080 / 32 spp / depth 8 launch, rectangle rect) must be reproduced by the oracle."""
+    g = np.load(os.path.join(HERE, "golden", "c2_crop_1080p_32spp_d8.npz"))
+    x0, y0, rw, rh = [int(v) for v in g["rect"]]
+    for frame, key in ((0, "frame0"), (1, "frame1")):
+        p = orc.default_params(width=1920, height=1080, spp_per_frame=32, max_depth=8, frame=frame)
+        img, rays = orc.render_rect(cornell_oracle, p, x0, y0, rw, rh)
+        assert rays == int(g["rays"][frame])
+        assert img.tobytes() == g[key].tobytes()
+    # a rectangle of a launch equals the same pixels of the full launch
+    p = orc.default_params(width=80, height=48, spp_per_frame=3, max_depth=5)
+    full, _, _, _ = cornell_oracle.render_frame(p)
+    part, _ = orc.render_rect(cornell_oracle, p, 17, 9, 40, 30, nthreads=3)
+    assert part.tobytes() == np.ascontiguousarray(full[9:39, 17:57]).tobytes()
