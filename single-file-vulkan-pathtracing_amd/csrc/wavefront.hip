@@ -1355,11 +1355,15 @@ pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, flo
         (void)hipMemcpyAsync(d_b, b.data(), sizeof(float2) * n, hipMemcpyHostToDevice, st);
         const uint32_t cnt_head[2] = { n, 0u };
         (void)hipMemcpyAsync(d_cnt, cnt_head, sizeof(cnt_head), hipMemcpyHostToDevice, st);
+        (void)hipEventRecord(ctx->ev_a, st);
         launch_extend(pl, s, d_a, d_b, d_hit, d_hi, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, st);
+        (void)hipEventRecord(ctx->ev_b, st);
         k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, s->d_tri4, s->n_inst ? d_hi : nullptr, s->d_tlas_prim_of, n, d_out);
         (void)hipMemcpyAsync(hits, d_out, sizeof(pt_hit) * n, hipMemcpyDeviceToHost, st);
         if ((e = hipStreamSynchronize(st)) != hipSuccess) fail(e, "pt_trace");
         else if ((e = hipGetLastError()) != hipSuccess) fail(e, "pt_trace");
+        float ms = 0.f;
+        if (ret == PT_OK && hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b) == hipSuccess) ctx->stats.ms_extend += ms;
         ctx->stats.launches_extend++;
     }
     (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_hit); (void)hipFree(d_out); (void)hipFree(d_cnt); (void)hipFree(d_hi);
