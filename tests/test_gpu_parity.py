@@ -577,6 +577,36 @@ def test_c2_full_size_32spp_crop_matches_golden(pt, orc, gpu_ctx, cornell_gpu):
     film.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_tiny_scenes_end_to_end(pt, orc, gpu_ctx, n):
+    """Degenerate trees (a root that is one leaf, a root with 2 leaves, ...) through trace and render,
+    every extend variant."""
+    rng = np.random.default_rng(n)
+    v = np.zeros((n, 3, 3), np.float32)
+    for k in range(n):
+        c = np.float32([rng.uniform(-0.6, 0.6), rng.uniform(-1.6, -0.4), rng.uniform(-0.5, 0.5)])
+        v[k] = c + rng.uniform(-0.5, 0.5, (3, 3)).astype(np.float32)
+    f = np.tile(np.float32([0.7, 0.6, 0.5, 0.0, 0.0, 0.0]), (n, 1))
+    f[0, 3:] = (5.0, 4.0, 3.0)
+    i = np.arange(3 * n, dtype=np.uint32)
+    gs, osc = pt.Scene(gpu_ctx, v.reshape(-1), i, f.reshape(-1)), orc.Scene(v.reshape(-1), i, f.reshape(-1))
+    p = orc.default_params(width=64, height=64)
+    rays = np.array([np.concatenate(orc.primary_ray(p, x, y, orc.seed(x, y, 0, 0))[:2])
+                     for y in range(0, 64, 2) for x in range(0, 64, 2)], np.float32)
+    oh, _ = osc.trace(rays, mode=0)
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_FLAT, pt.EXTEND_LDS, pt.EXTEND_HBM):
+        assert gs.trace(rays, extend=variant).tobytes() == oh.tobytes()
+    assert (oh["prim"] != orc.MISS).any()
+    kw = dict(width=48, height=48, spp_per_frame=5, max_depth=6)
+    film = pt.Film(gpu_ctx, 48, 48)
+    gpu_ctx.reset_stats()
+    pt.render(gs, film, pt.default_params(frame_count=2, **kw))
+    ofilm, obgra, orays = _render_oracle(orc, osc, 2, **kw)
+    assert gpu_ctx.stats().rays == orays
+    assert film.read_f32().tobytes() == ofilm.tobytes()
+    film.close(); gs.close()
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):
