@@ -132,27 +132,75 @@ __global__ __launch_bounds__(TB) void k_rs_hist(const unsigned long long *__rest
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of `total` counters in place, one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *__restrict__ hist, uint32_t total)
+// In-place exclusive scan of `total` counters over many blocks: per-tile sums -> scan of the sums
+// (one block) -> per-tile scan + offset.  A tile is 2048 counters (256 threads x 8).
+constexpr int SC_PER = 8;
+constexpr int SC_TILE = TB * SC_PER;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &block_total)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = min(b + per, total);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; i++) s += hist[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t v = threadIdx.x >= (uint32_t)o ? part[threadIdx.x - o] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = b; i < e; i++) {
-        const uint32_t v = hist[i];
-        hist[i] = run;
-        run += v;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int w = 0; w < 4; w++) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    block_total = tot;
+    __syncthreads();
+    return off + inc - v;
+}
+
+__global__ __launch_bounds__(TB) void k_scan_sums(const uint32_t *__restrict__ data, uint32_t total,
+                                                  uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_PER;
+    uint32_t v = 0;
+    for (int k = 0; k < SC_PER; k++)
+        if (base + k < total) v += data[base + k];
+    uint32_t tot;
+    (void)block_exclusive_scan(v, s_wave, tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// exclusive scan of the tile sums in place (one block; a few thousand entries at most)
+__global__ __launch_bounds__(TB) void k_scan_top(uint32_t *__restrict__ sums, uint32_t n)
+{
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += TB) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, s_wave, tot);
+        if (i < n) sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_scan_apply(uint32_t *__restrict__ data, uint32_t total,
+                                                   const uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_PER;
+    uint32_t x[SC_PER], v = 0;
+    for (int k = 0; k < SC_PER; k++) {
+        x[k] = base + k < total ? data[base + k] : 0u;
+        v += x[k];
+    }
+    uint32_t tot;
+    uint32_t run = sums[blockIdx.x] + block_exclusive_scan(v, s_wave, tot);
+    for (int k = 0; k < SC_PER; k++) {
+        if (base + k < total) data[base + k] = run;
+        run += x[k];
     }
 }
 
@@ -281,11 +329,11 @@ __global__ __launch_bounds__(TB) void k_refit(const float4 *__restrict__ tlo, co
     for (;;) {
         // publish my subtree's box, then arrive (agent-scope release; the explicit vmcnt wait
         // keeps the arrival from overtaking the write-back)
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t old = atomicAdd(&flags[node], 1u);
         if (old == 0u) return;  // sibling subtree not finished: its last thread continues
-        __threadfence();        // acquire the sibling's box
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // acquire the sibling's box
         const uint2 ch = topo[node];
         const size_t li = (ch.x & PT_LEAF) ? (size_t)(ch.x & ~PT_LEAF) : (size_t)n + ch.x;
         const size_t ri = (ch.y & PT_LEAF) ? (size_t)(ch.y & ~PT_LEAF) : (size_t)n + ch.y;
@@ -478,20 +526,35 @@ __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, c
         mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
         mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
     }
+    __shared__ float s_mn[4][3], s_mx[4][3];
     for (int k = 0; k < 3; k++) {
         const float a = wave_min(mn[k]), b = wave_max(mx[k]);
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&scene_ord[k], f2ord(a));
-            atomicMax(&scene_ord[3 + k], f2ord(b));
+            s_mn[threadIdx.x >> 6][k] = a;
+            s_mx[threadIdx.x >> 6][k] = b;
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one atomic pair per block and axis (6 words shared by the whole grid)
+        const int k = threadIdx.x;
+        atomicMin(&scene_ord[k], f2ord(fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]))));
+        atomicMax(&scene_ord[3 + k], f2ord(fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]))));
+    }
+}
+
+static void exclusive_scan(uint32_t *d_data, uint32_t total, uint32_t *d_sums, hipStream_t st)
+{
+    const uint32_t tiles = (total + SC_TILE - 1) / SC_TILE;
+    k_scan_sums<<<tiles, TB, 0, st>>>(d_data, total, d_sums);
+    k_scan_top<<<1, TB, 0, st>>>(d_sums, tiles);
+    k_scan_apply<<<tiles, TB, 0, st>>>(d_data, total, d_sums);
 }
 
 static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, uint32_t leaf_max, BvhOut &out)
 {
     hipStream_t st = ctx->stream;
     const uint32_t gt = (n + TB - 1) / TB;
-    DevBuf<uint32_t> d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height, d_wflag, d_widx;
+    DevBuf<uint32_t> d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height, d_wflag, d_widx, d_sums;
     DevBuf<float4> d_blo, d_bhi;
     DevBuf<unsigned long long> d_keys[2];
     DevBuf<uint2> d_topo, d_range;
@@ -502,6 +565,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         PT_HIP(ctx, d_vals[i].alloc(n));
     }
     PT_HIP(ctx, d_hist.alloc(256 * (size_t)nblocks));
+    PT_HIP(ctx, d_sums.alloc(std::max<size_t>(256 * (size_t)nblocks, n) / SC_TILE + 2));
     PT_HIP(ctx, d_topo.alloc(n));
     PT_HIP(ctx, d_range.alloc(n));
     PT_HIP(ctx, d_wflag.alloc(n));
@@ -528,7 +592,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 8 * pass;
         k_rs_hist<<<nblocks, TB, 0, st>>>(d_keys[cur].p, n, shift, d_hist.p, nblocks);
-        k_rs_scan<<<1, 1024, 0, st>>>(d_hist.p, 256u * nblocks);
+        exclusive_scan(d_hist.p, 256u * nblocks, d_sums.p, st);
         k_rs_scatter<<<nblocks, TB, 0, st>>>(d_keys[cur].p, d_vals[cur].p, d_keys[cur ^ 1].p, d_vals[cur ^ 1].p, n, shift,
                                              d_hist.p, nblocks);
         cur ^= 1;
@@ -550,7 +614,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         const uint32_t gi = (uint32_t)(n_int + TB - 1) / TB;
         k_wide_flag<<<gi, TB, 0, st>>>(n_int, d_pint.p, d_range.p, d_wflag.p, leaf_max);
         PT_HIP(ctx, hipMemcpyAsync(d_widx.p, d_wflag.p, sizeof(uint32_t) * (size_t)n_int, hipMemcpyDeviceToDevice, st));
-        k_rs_scan<<<1, 1024, 0, st>>>(d_widx.p, (uint32_t)n_int);
+        exclusive_scan(d_widx.p, (uint32_t)n_int, d_sums.p, st);
         uint32_t last_idx = 0, last_flag = 0;
         PT_HIP(ctx, hipMemcpyAsync(&last_idx, d_widx.p + (n_int - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipMemcpyAsync(&last_flag, d_wflag.p + (n_int - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
