@@ -71,8 +71,7 @@ struct pt_film {
         float *d_terms = nullptr;                 // per slot: ordered radiance terms [term_cap][3]  (groups > 1)
         uint32_t *d_nterm = nullptr;              // per slot: number of logged terms               (groups > 1)
         // double-buffered dense queues (index = queue position)
-        uint32_t *d_qslot[2] = { nullptr, nullptr };
-        uint32_t *d_qctr[2] = { nullptr, nullptr };   // sample | depth<<16
+        uint2 *d_qid[2] = { nullptr, nullptr };       // {slot, sample | depth<<16}
         float4 *d_qstate[2] = { nullptr, nullptr };   // {bits(seed), weight.rgb}
         float4 *d_qrayA[2] = { nullptr, nullptr };    // {org.xyz, dir.x}
         float2 *d_qrayB[2] = { nullptr, nullptr };    // {dir.y, dir.z}

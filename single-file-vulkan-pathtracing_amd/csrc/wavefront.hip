@@ -9,7 +9,7 @@
 // either way the reference's single `color` accumulator (raygen.rgen:42,76) is reproduced
 // add-for-add.  Live paths sit in dense, double-buffered queues (index = queue position, all
 // accesses coalesced):
-//     qslot, qctr (sample | depth<<16), qstate {seed, weight}, qray {origin, direction}
+//     qid {slot, sample | depth<<16}, qstate {seed, weight}, qray {origin, direction}
 // One round = two kernels over the live queue:
 //     k_extend  : closest hit of ray[q] -> hit[q]   persistent threads over the BVH4, LDS short
 //                                                   stack + HBM spill, lane refill; nodes and
@@ -75,8 +75,7 @@ __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radian
 }
 
 struct QueueView {
-    uint32_t *slot;
-    uint32_t *ctr;
+    uint2 *id;  // {slot, sample | depth<<16}
     float4 *state;
     float4 *rayA;
     float2 *rayB;
@@ -156,8 +155,7 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
         uint32_t dst[1];
         chunk_offsets<1>(alive, dst, count_out, s_wcnt, &s_base);
         if (alive[0]) {
-            out.slot[dst[0]] = slot;
-            out.ctr[dst[0]] = sample0;
+            out.id[dst[0]] = make_uint2(slot, sample0);
             out.state[dst[0]] = make_float4(__uint_as_float(seed), 1.f, 1.f, 1.f);  // raygen.rgen:59
             out.rayA[dst[0]] = make_float4(org.x, org.y, org.z, dir.x);
             out.rayB[dst[0]] = make_float2(dir.y, dir.z);
@@ -698,8 +696,8 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
             const uint32_t q = base + it * TB + threadIdx.x;
             alive[it] = false;
             if (q >= n) continue;
-            const uint32_t slot = in.slot[q];
-            const uint32_t ctr = in.ctr[q];
+            const uint2 id = in.id[q];
+            const uint32_t slot = id.x, ctr = id.y;
             const float4 st = in.state[q];
             const float4 h = hit[q];
             uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
@@ -779,8 +777,7 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
 #pragma unroll
         for (int it = 0; it < SH_ITEMS; it++) {
             if (alive[it]) {
-                out.slot[dst[it]] = o_slot[it];
-                out.ctr[dst[it]] = o_ctr[it];
+                out.id[dst[it]] = make_uint2(o_slot[it], o_ctr[it]);
                 out.state[dst[it]] = o_state[it];
                 out.rayA[dst[it]] = o_rayA[it];
                 out.rayB[dst[it]] = o_rayB[it];
@@ -1019,16 +1016,15 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
     const size_t ns = std::max<size_t>(w.n_slots, 1);
     if (ns > w.cap_slots) {
         for (int i = 0; i < 2; i++) {
-            (void)hipFree(w.d_qslot[i]); (void)hipFree(w.d_qctr[i]); (void)hipFree(w.d_qstate[i]);
+            (void)hipFree(w.d_qid[i]); (void)hipFree(w.d_qstate[i]);
             (void)hipFree(w.d_qrayA[i]); (void)hipFree(w.d_qrayB[i]);
-            w.d_qslot[i] = w.d_qctr[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
+            w.d_qid[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
         }
         (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst); (void)hipFree(w.d_nterm);
         w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr;
         w.cap_slots = 0;
         for (int i = 0; i < 2; i++) {
-            PT_HIP(ctx, hipMalloc((void **)&w.d_qslot[i], sizeof(uint32_t) * ns));
-            PT_HIP(ctx, hipMalloc((void **)&w.d_qctr[i], sizeof(uint32_t) * ns));
+            PT_HIP(ctx, hipMalloc((void **)&w.d_qid[i], sizeof(uint2) * ns));
             PT_HIP(ctx, hipMalloc((void **)&w.d_qstate[i], sizeof(float4) * ns));
             PT_HIP(ctx, hipMalloc((void **)&w.d_qrayA[i], sizeof(float4) * ns));
             PT_HIP(ctx, hipMalloc((void **)&w.d_qrayB[i], sizeof(float2) * ns));
@@ -1113,8 +1109,7 @@ void ptw_free_work(pt_film *f)
     (void)hipFree(w.d_terms);
     (void)hipFree(w.d_nterm);
     for (int i = 0; i < 2; i++) {
-        (void)hipFree(w.d_qslot[i]);
-        (void)hipFree(w.d_qctr[i]);
+        (void)hipFree(w.d_qid[i]);
         (void)hipFree(w.d_qstate[i]);
         (void)hipFree(w.d_qrayA[i]);
         (void)hipFree(w.d_qrayB[i]);
@@ -1224,7 +1219,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 pp.slot_begin = l0 * rc.slots_per_lane;
                 pp.n_slots = (l1 - l0) * rc.slots_per_lane;
                 for (int i = 0; i < 2; i++)
-                    pp.qv[i] = { w.d_qslot[i] + pp.slot_begin, w.d_qctr[i] + pp.slot_begin, w.d_qstate[i] + pp.slot_begin,
+                    pp.qv[i] = { w.d_qid[i] + pp.slot_begin, w.d_qstate[i] + pp.slot_begin,
                                  w.d_qrayA[i] + pp.slot_begin, w.d_qrayB[i] + pp.slot_begin };
                 pp.hit = w.d_hit + pp.slot_begin;
                 pp.hit_inst = w.d_hit_inst + pp.slot_begin;
