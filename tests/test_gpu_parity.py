@@ -607,6 +607,33 @@ def test_tiny_scenes_end_to_end(pt, orc, gpu_ctx, n):
     film.close(); gs.close()
 
 
+def test_no_device_memory_leak_over_object_lifecycles(pt, cornell_arrays):
+    """Contexts, scenes (incl. instances), films and their workspaces give all device memory back."""
+    import torch
+    torch.cuda.synchronize()
+    inst = pt.cornell_grid_instances(n=10)
+
+    def cycle():
+        ctx = pt.Context(0)
+        sc = pt.Scene(ctx, *cornell_arrays)
+        film = pt.Film(ctx, 320, 200)
+        pt.render(sc, film, pt.default_params(width=320, height=200, spp_per_frame=4, max_depth=4, frame_count=3))
+        sc.set_instances(inst)
+        pt.render(sc, film, pt.default_params(width=320, height=200, spp_per_frame=4, max_depth=4, frame_count=1,
+                                              sample_groups=2, flags=pt.FLAG_PROFILE | pt.FLAG_COUNT_VISITS))
+        sc.trace(np.zeros((10, 6), np.float32) + np.float32([0, -1, 5, 0, 0, -1]))
+        film.close(); sc.close(); ctx.close()
+
+    cycle()                                   # first cycle pays one-time runtime allocations
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"leaked {(free0 - free1) / 2**20:.1f} MiB over 10 cycles"
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):
