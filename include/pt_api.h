@@ -112,7 +112,9 @@ void pt_film_destroy(pt_film *film);
 enum { PT_PIPELINE_WAVEFRONT = 0 /* generate / extend / shade queues */ };
 enum {
     PT_FLAG_PROFILE = 1u,      /* hipEvent-time every extend/shade launch (adds events to the stream)       */
-    PT_FLAG_COUNT_VISITS = 2u  /* instrumented traversal: count BVH4 nodes / triangles visited (slower)      */
+    PT_FLAG_COUNT_VISITS = 2u, /* instrumented traversal: count BVH4 nodes / triangles visited (slower)      */
+    PT_FLAG_ASYNC = 4u         /* pt_render only queues the work (no waitIdle, main.cpp:683); pt_sync and the */
+                               /* film read-backs wait for it.  No timing statistics; not with PT_FLAG_PROFILE */
 };
 /* Which closest-hit kernel runs.  All variants implement the same closest-hit definition and
  * return identical bits; AUTO picks by scene size. */
@@ -145,7 +147,8 @@ void pt_params_default(pt_params *p); /* the reference's compile-time constants,
 
 /* Renders frames [frame, frame+frame_count) into the film: each frame is one reference launch
  * (spp_per_frame samples/pixel, <= max_depth rays each) blended by raygen.rgen:88-90.
- * Blocking (returns after the device is done), like submit + waitIdle (main.cpp:672-683).   */
+ * Blocking (returns after the device is done), like submit + waitIdle (main.cpp:672-683),
+ * unless PT_FLAG_ASYNC is set.                                                               */
 pt_status pt_render(pt_scene *scene, pt_film *film, const pt_params *params);
 /* Allocates (or grows) the film's wavefront workspace for exactly the shape pt_render would pick
  * for these params, without rendering -- so the first timed pt_render does not pay for hipMalloc

@@ -28,6 +28,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "
 PIPELINE_WAVEFRONT = 0
 FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
+FLAG_ASYNC = 4
 EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM = 0, 1, 2, 3
 EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4 (collapsed LBVH), scene staged in LDS", 3: "BVH4 (collapsed LBVH), scene in HBM/L2"}
 MISS = 0xFFFFFFFF

@@ -1164,6 +1164,8 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
+    const bool async = (p->flags & PT_FLAG_ASYNC) != 0;
+    if (async && profile) { ctx->err = "PT_FLAG_ASYNC and PT_FLAG_PROFILE exclude each other"; return PT_ERR_INVALID_ARG; }
     std::vector<hipEvent_t> evs, ev_extend, ev_shade;  // (start, stop) pairs filled in by the launches
     auto new_event = [&]() -> hipEvent_t {
         hipEvent_t e = nullptr;
@@ -1264,7 +1266,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 }
                 ctx->stats.rounds++;
                 // every slot needs >= group_size rounds; after that poll the live counts now and then
-                if (round + 1 >= group_size && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
+                if (!async && round + 1 >= group_size && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
                     uint32_t h_count[PT_MAX_PIPES] = {};
                     for (int k = 0; k < pipes_now; k++)
                         if (!pipe[k].done)
@@ -1288,11 +1290,13 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
         }
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
-    PT_HIP(ctx, hipStreamSynchronize(st));
-    PT_HIP(ctx, hipGetLastError());
-    float ms = 0.f;
-    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
-    ctx->stats.ms_total += ms;
+    if (!async) {
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        PT_HIP(ctx, hipGetLastError());
+        float ms = 0.f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+        ctx->stats.ms_total += ms;
+    }
     {
         // samples started = valid local pixels x spp x frames
         uint64_t valid = 0;

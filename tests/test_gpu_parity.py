@@ -634,6 +634,21 @@ def test_no_device_memory_leak_over_object_lifecycles(pt, cornell_arrays):
     assert free0 - free1 < (8 << 20), f"leaked {(free0 - free1) / 2**20:.1f} MiB over 10 cycles"
 
 
+def test_async_render_equals_blocking(pt, gpu_ctx, cornell_gpu):
+    """PT_FLAG_ASYNC: frames are queued without the reference's per-frame waitIdle (main.cpp:683)."""
+    kw = dict(width=160, height=96, spp_per_frame=8, max_depth=8)
+    a, b = pt.Film(gpu_ctx, 160, 96), pt.Film(gpu_ctx, 160, 96)
+    for k in range(4):
+        pt.render(cornell_gpu, a, pt.default_params(frame=k, frame_count=1, flags=pt.FLAG_ASYNC, **kw))
+    gpu_ctx.sync()
+    pt.render(cornell_gpu, b, pt.default_params(frame=0, frame_count=4, **kw))
+    assert a.read_f32().tobytes() == b.read_f32().tobytes()
+    assert a.read_bgra8().tobytes() == b.read_bgra8().tobytes()
+    with pytest.raises(pt.PtError):
+        pt.render(cornell_gpu, a, pt.default_params(flags=pt.FLAG_ASYNC | pt.FLAG_PROFILE, **kw))
+    a.close(); b.close()
+
+
 def test_error_paths(pt, gpu_ctx, cornell_gpu):
     film = pt.Film(gpu_ctx, 32, 32)
     with pytest.raises(pt.PtError):
