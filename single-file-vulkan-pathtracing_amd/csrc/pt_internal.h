@@ -68,7 +68,7 @@ struct pt_film {
         uint32_t n_slots = 0;                     // lanes * n_tiles * 64
         uint32_t *d_tiles = nullptr;              // local tile -> global tile id
         float4 *d_color = nullptr;                // per slot: frame colour accumulator rgb + pad (groups == 1)
-        float *d_terms = nullptr;                 // per slot: ordered radiance terms [term_cap][3]  (groups > 1)
+        float4 *d_terms = nullptr;                // per slot: ordered radiance terms [term_cap] rgb+pad (groups > 1)
         uint32_t *d_nterm = nullptr;              // per slot: number of logged terms               (groups > 1)
         // double-buffered dense queues (index = queue position)
         uint2 *d_qid[2] = { nullptr, nullptr };       // {slot, sample | depth<<16}
