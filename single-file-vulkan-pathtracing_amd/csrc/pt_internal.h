@@ -68,7 +68,8 @@ struct pt_film {
         uint32_t n_slots = 0;                     // lanes * n_tiles * 64
         uint32_t *d_tiles = nullptr;              // local tile -> global tile id
         float4 *d_color = nullptr;                // per slot: frame colour accumulator rgb + pad (groups == 1)
-        float4 *d_terms = nullptr;                // per slot: ordered radiance terms [term_cap] rgb+pad (groups > 1)
+        float4 *d_terms = nullptr;                // per slot: ordered radiance terms, dense primary log   (groups > 1)
+        float4 *d_terms_over = nullptr;           // per slot: overflow of the primary log (worst-case sized)
         uint32_t *d_nterm = nullptr;              // per slot: number of logged terms               (groups > 1)
         // double-buffered dense queues (index = queue position)
         uint2 *d_qid[2] = { nullptr, nullptr };       // {slot, sample | depth<<16}
@@ -78,7 +79,7 @@ struct pt_film {
         float4 *d_hit = nullptr;                      // {bits(pos), t, u, v}
         uint32_t *d_hit_inst = nullptr;               // instance (TLAS sorted position); only for two-level scenes
         uint32_t *d_count = nullptr;                  // [2] queue sizes
-        size_t cap_slots = 0, cap_color = 0, cap_terms = 0;  // allocated capacities (buffers only grow)
+        size_t cap_slots = 0, cap_color = 0, cap_terms = 0, cap_terms_over = 0;  // allocated capacities (buffers only grow)
     } work;
 };
 

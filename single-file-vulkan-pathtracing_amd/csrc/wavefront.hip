@@ -45,6 +45,7 @@ struct RenderConst {
     uint32_t groups;           // sample groups per (frame, pixel): slot lane = frame_lane * groups + group
     uint32_t group_size;       // samples per group: group g runs samples [g*group_size, min(spp, (g+1)*group_size))
     uint32_t term_cap;         // radiance-term log capacity per slot = group_size * max_depth (groups > 1)
+    uint32_t term_pcap;        // entries of it kept in the dense primary log (the rest is the overflow log)
 };
 
 // Where a slot's radiance goes.  groups == 1: one accumulator per slot, added to in path order
@@ -53,7 +54,8 @@ struct RenderConst {
 // the same float adds in the same order as the reference's single `color`, still bit-exact.
 struct Radiance {
     float4 *color;     // [n_slots]              (groups == 1)
-    float4 *terms;     // [n_slots][term_cap], rgb + pad: 16-B aligned scattered writes (groups > 1)
+    float4 *terms;     // primary log [n_slots][term_pcap], rgb + pad (groups > 1): dense, typical use
+    float4 *terms_over;  // overflow log [n_slots][term_cap - term_pcap]: worst case, rarely touched
     uint32_t *nterm;   // [n_slots]              (groups > 1)
 };
 
@@ -68,7 +70,8 @@ __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radian
         rad.color[slot] = c;
     } else {
         const uint32_t k = rad.nterm[slot];
-        rad.terms[(size_t)slot * rc.term_cap + k] = make_float4(r, g, b, 0.f);
+        if (k < rc.term_pcap) rad.terms[(size_t)slot * rc.term_pcap + k] = make_float4(r, g, b, 0.f);
+        else rad.terms_over[(size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)] = make_float4(r, g, b, 0.f);
         rad.nterm[slot] = k + 1u;
     }
 }
@@ -813,9 +816,10 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
             for (uint32_t g = 0; g < rc.groups; g++) {
                 const size_t slot = ((size_t)f * rc.groups + g) * rc.slots_per_lane + local;
                 const uint32_t nt = rad.nterm[slot];
-                const float4 *t = rad.terms + slot * rc.term_cap;
+                const float4 *t = rad.terms + slot * rc.term_pcap;
+                const float4 *to = rad.terms_over + slot * (rc.term_cap - rc.term_pcap);
                 for (uint32_t k = 0; k < nt; k++) {
-                    const float4 e = t[k];
+                    const float4 e = k < rc.term_pcap ? t[k] : to[k - rc.term_pcap];
                     c.x = c.x + e.x;
                     c.y = c.y + e.y;
                     c.z = c.z + e.z;
@@ -988,7 +992,8 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 
 // Workspace for (rank, world) tiles, `lanes` frames in flight and `groups` sample groups.  Buffers only
 // ever grow: a later call with a smaller shape reuses them (hipMalloc of tens of GB costs 100s of ms).
-pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap)
+pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap,
+                      uint32_t term_pcap)
 {
     pt_ctx *ctx = f->ctx;
     pt_film::Work &w = f->work;
@@ -1040,19 +1045,28 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         PT_HIP(ctx, hipMalloc((void **)&w.d_color, sizeof(float4) * ns));
         w.cap_color = ns;
     }
-    const size_t nterms = groups > 1 ? ns * (size_t)term_cap : 0;
-    if (nterms > w.cap_terms) {
+    // primary log: term_pcap entries per slot (dense, what is normally touched); overflow: the rest of the
+    // worst case (one entry per ray), allocated but rarely touched
+    const size_t n_prim = groups > 1 ? ns * (size_t)term_pcap : 0;
+    const size_t n_over = groups > 1 ? ns * (size_t)(term_cap - term_pcap) : 0;
+    if (n_prim > w.cap_terms) {
         (void)hipFree(w.d_terms);
         w.d_terms = nullptr; w.cap_terms = 0;
-        PT_HIP(ctx, hipMalloc((void **)&w.d_terms, sizeof(float4) * nterms));
-        w.cap_terms = nterms;
+        PT_HIP(ctx, hipMalloc((void **)&w.d_terms, sizeof(float4) * n_prim));
+        w.cap_terms = n_prim;
+    }
+    if (n_over > w.cap_terms_over) {
+        (void)hipFree(w.d_terms_over);
+        w.d_terms_over = nullptr; w.cap_terms_over = 0;
+        PT_HIP(ctx, hipMalloc((void **)&w.d_terms_over, sizeof(float4) * n_over));
+        w.cap_terms_over = n_over;
     }
     if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
     return PT_OK;
 }
 
 struct RenderShape {
-    uint32_t lanes = 1, groups = 1, group_size = 1, term_cap = 0;
+    uint32_t lanes = 1, groups = 1, group_size = 1, term_cap = 0, term_pcap = 0;
 };
 
 // frames in flight x sample groups: enough live paths (~32M) to fill the chip several times over
@@ -1089,6 +1103,7 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
     sh.group_size = (p->spp_per_frame + groups - 1) / groups;
     sh.groups = (p->spp_per_frame + sh.group_size - 1) / sh.group_size;  // no empty groups
     sh.term_cap = sh.groups > 1 ? sh.group_size * p->max_depth : 0u;
+    sh.term_pcap = std::min(sh.term_cap, sh.group_size + 2u);  // ~1 term per sample is typical (the miss that ends it)
     sh.lanes = lanes;
     return sh;
 }
@@ -1115,6 +1130,7 @@ void ptw_free_work(pt_film *f)
     (void)hipFree(w.d_tiles);
     (void)hipFree(w.d_color);
     (void)hipFree(w.d_terms);
+    (void)hipFree(w.d_terms_over);
     (void)hipFree(w.d_nterm);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(w.d_qid[i]);
@@ -1136,7 +1152,7 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
     const RenderShape sh = choose_shape(f, p);
-    rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap);
+    rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
     s->ctx->stats.frames_in_flight = sh.lanes;
     s->ctx->stats.sample_groups = sh.groups;
     return rc_;
@@ -1153,12 +1169,12 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     if (rc_ != PT_OK) return rc_;
     const RenderShape sh = choose_shape(f, p);
     const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
-    rc_ = ensure_work(f, p->rank, p->world, lanes, groups, term_cap);
+    rc_ = ensure_work(f, p->rank, p->world, lanes, groups, term_cap, sh.term_pcap);
     if (rc_ != PT_OK) return rc_;
     ctx->stats.frames_in_flight = lanes;
     ctx->stats.sample_groups = groups;
     pt_film::Work &w = f->work;
-    const Radiance rad = { w.d_color, w.d_terms, w.d_nterm };
+    const Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm };
 
     RenderConst rc{};
     rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
@@ -1169,6 +1185,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     rc.spp = p->spp_per_frame; rc.max_depth = p->max_depth;
     rc.slots_per_lane = w.n_tiles * 64u;
     rc.groups = groups; rc.group_size = group_size; rc.term_cap = term_cap;
+    rc.term_pcap = sh.term_pcap;
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
