@@ -33,14 +33,17 @@ BYTES_SHADE = 104.0
 BYTES_PER_PATH = 96.0
 
 
-def cpu_baseline(arrays, name, width, height, spp, depth):
+def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0):
     """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
-    bounded sample of the same workload: the same image at a few spp, all cores.  Also returns
-    the instrumented traversal counts (child boxes tested, triangles tested per ray) of the
-    same LBVH the GPU builds -- the input of the scene-gather term of the algorithmic bytes."""
+    bounded sample of the same workload: the same image, all cores, as many samples per pixel as fit
+    into ~budget_s seconds (calibrated with a 1-spp pass, at most spp_max)."""
     from oracle import pt_oracle as orc
     osc = orc.Scene(*arrays)
     cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    osc.render_frame(orc.default_params(width=width, height=height, spp_per_frame=1, max_depth=depth), mode=1, nthreads=cores)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(spp_max, budget_s / max(t1, 1e-3))))
     p = orc.default_params(width=width, height=height, spp_per_frame=spp, max_depth=depth)
     t0 = time.perf_counter()
     _, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
@@ -206,9 +209,9 @@ def main():
             if args.config == "c4":
                 base = None        # the oracle binding used here has no instance set-up in cpu_baseline: skipped for C4
             elif args.config == "c2":
-                base, _, _ = cpu_baseline(arrays, scene_name, W, H, 4, args.depth)
-            else:   # 1/16 of the image area, 1 spp: ~0.5 M rays through the 1M-triangle LBVH
-                base, _, _ = cpu_baseline(arrays, scene_name, W // 4, H // 4, 1, args.depth)
+                base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth)
+            else:
+                base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth)
         # traversal work per ray, counted by an instrumented build of the same kernel on the same
         # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
         nodes_per_ray = tris_per_ray = 0.0
