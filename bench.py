@@ -48,7 +48,7 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0):
     t0 = time.perf_counter()
     _, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
     dt = time.perf_counter() - t0
-    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp,
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
                       f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads"}
     return base, cnt.nodes_visited / max(rays, 1), cnt.tris_tested / max(rays, 1)
@@ -215,6 +215,7 @@ def main():
         # traversal work per ray, counted by an instrumented build of the same kernel on the same
         # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
         nodes_per_ray = tris_per_ray = 0.0
+        frame0_rays_gpu = None
         if st.extend_variant != pt.EXTEND_FLAT:
             ctx.reset_stats()
             scratch = pt.Film(ctx, W, H)
@@ -222,6 +223,7 @@ def main():
             cst = ctx.stats()
             nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
             tris_per_ray = cst.tris_tested / max(cst.rays, 1)
+            frame0_rays_gpu = cst.rays
             scratch.close()
         if flags and st.launches_extend and st.ms_extend > 0:
             # dominant kernel = k_extend (closest-hit traversal).  Algorithmic bytes: 40 B/ray; the
@@ -270,7 +272,11 @@ def main():
                          "scene + BVH4 = 118 MB > L2: every node/triangle fetch is a 128/48-B gather through L2/MALL/HBM"),
             }
         if base and not args.no_cpu_baseline and world == 1:
+            cpu_rays, cpu_spp = base.pop("_rays"), base.pop("_spp")
             out["cpu_baseline"] = base
+            if cpu_spp == args.spp and frame0_rays_gpu is not None:
+                # the oracle rendered exactly frame 0 of this workload: the exact ray counts must agree
+                out["frame0_ray_count"] = {"gpu": frame0_rays_gpu, "cpu_oracle": cpu_rays, "equal": frame0_rays_gpu == cpu_rays}
         print(json.dumps(out), flush=True)
 
     film.close()
