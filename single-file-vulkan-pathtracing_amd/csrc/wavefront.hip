@@ -209,14 +209,15 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
                                                unsigned long long *stats, uint2 *__restrict__ spill,
-                                               uint32_t spill_stride, int refill_min_idle, float tmin, float tmax)
+                                               uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
+                                               int lds_stack)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
     const float4 *wide = g_wide;
     const float4 *tri4 = g_tri4;
     if (LDS_SCENE) {
-        float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)LDS_STACK * TB * sizeof(uint2));
+        float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * TB * sizeof(uint2));
         float4 *s_tri = s_wide + 8 * (size_t)n_wide;
         for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) s_wide[i] = g_wide[i];
         // three copies of the triangles with components permuted to (kx,ky,kz) for kz = 0,1,2:
@@ -260,14 +261,14 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
 
     auto push = [&](uint32_t w, float t) {
         const uint2 e = make_uint2(w, __float_as_uint(t));
-        if (sp < LDS_STACK) my_stack[sp * TB] = e;
-        else my_spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
+        if (sp < lds_stack) my_stack[sp * TB] = e;
+        else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
         sp++;
     };
     auto pop = [&]() -> uint32_t {  // next subtree that can still contain the closest hit
         while (sp > 0) {
             sp--;
-            const uint2 e = sp < LDS_STACK ? my_stack[sp * TB] : my_spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            const uint2 e = sp < lds_stack ? my_stack[sp * TB] : my_spill[(size_t)(sp - lds_stack) * spill_stride];
             if (__uint_as_float(e.y) <= best_t) return e.x;
         }
         return SENTINEL;
@@ -875,6 +876,7 @@ struct ExtendPlan {
     int grid = 0;
     uint32_t spill_levels = 0;
     int refill = REFILL_MIN_IDLE;
+    int lds_stack = LDS_STACK;  // stack entries per lane kept in LDS (single-level kernel)
 };
 
 pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
@@ -920,7 +922,10 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     if (want == PT_EXTEND_LDS && scene_bytes > 96 * 1024) { ctx->err = "scene does not fit LDS"; return PT_ERR_UNSUPPORTED; }
     pl.lds_scene = want == PT_EXTEND_LDS || (want == PT_EXTEND_AUTO && scene_bytes <= 24 * 1024);
     pl.variant = pl.lds_scene ? PT_EXTEND_LDS : PT_EXTEND_HBM;
-    pl.smem = (size_t)LDS_STACK * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
+    // deep trees of big scenes: 12 LDS entries measured best on the 1M-triangle soup (4: -15 %, 8: -3 %,
+    // 16: -5 %, 24: -16 %: beyond 12 the extra LDS costs occupancy)
+    pl.lds_stack = pl.lds_scene ? LDS_STACK : 12;
+    pl.smem = (size_t)pl.lds_stack * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
     const void *fn = pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false>)
                                   : reinterpret_cast<const void *>(k_extend<false, false>);
     const void *fn_count = pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, true>)
@@ -935,7 +940,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     pl.grid = ctx->num_cus * per_cu;
     // stack bound: a BVH4 node pushes <= 3 entries per level; wide height <= binary height/2 + 1
     const uint32_t bound = 3u * (s->height / 2u + 1u) + 1u;
-    pl.spill_levels = bound > (uint32_t)LDS_STACK ? bound - (uint32_t)LDS_STACK : 0u;
+    pl.spill_levels = bound > (uint32_t)pl.lds_stack ? bound - (uint32_t)pl.lds_stack : 0u;
     const size_t need = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
     if (need > ctx->spill_bytes) {
         (void)hipFree(ctx->d_spill);
@@ -981,7 +986,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 #define PT_LAUNCH_EXTEND(L, C)                                                                                        \
     hipExtLaunchKernelGGL((k_extend<L, C>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide,    \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
-                          pl.refill, tmin, tmax)
+                          pl.refill, tmin, tmax, pl.lds_stack)
     if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(true, false);
     } else {
