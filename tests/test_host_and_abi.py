@@ -131,6 +131,41 @@ def test_no_cpu_fallback(pt):
     assert e.value.status == 2  # PT_ERR_NO_DEVICE
 
 
+def test_abi_is_null_safe_without_a_gpu(pt):
+    """Every entry point must reject null handles with PT_ERR_INVALID_ARG (or be a no-op for the
+    destroy functions) -- callable without a GPU, nothing may crash."""
+    import ctypes as C
+    L = pt.lib_amd()
+    L.pt_ctx_destroy(None)
+    L.pt_scene_destroy(None)
+    L.pt_film_destroy(None)
+    L.pt_params_default(None)
+    assert L.pt_last_error(None) is not None
+    null = C.c_void_p()
+    out = C.c_void_p()
+    assert L.pt_sync(None) == 1
+    assert L.pt_scene_create(None, None, 0, None, 0, None, C.byref(out)) == 1
+    assert L.pt_scene_set_instances(None, None, 0) == 1
+    assert L.pt_scene_get_info(None, None) == 1
+    assert L.pt_scene_read_bvh(None, None, None, None) == 1
+    assert L.pt_scene_read_bvh4(None, None) == 1
+    assert L.pt_film_create(None, 4, 4, C.byref(out)) == 1
+    assert L.pt_film_create_external(None, 4, 4, None, C.byref(out)) == 1
+    assert L.pt_film_clear(None) == 1 and L.pt_film_read_f32(None, None) == 1 and L.pt_film_read_bgra8(None, None) == 1
+    p = pt.default_params()
+    assert L.pt_render(None, None, C.byref(p)) == 1 and L.pt_render_prepare(None, None, C.byref(p)) == 1
+    assert L.pt_trace(None, None, 0, C.c_float(0), C.c_float(1), 0, None) == 1
+    assert L.pt_get_stats(None, None) == 1 and L.pt_reset_stats(None) == 1
+    assert L.pt_ctx_create(0, None, None) == 1
+    assert out.value is None and null.value is None
+    H = pt.lib_host()
+    err = C.create_string_buffer(64)
+    assert H.pth_load_obj(None, None, None, err, 64) != 0
+    H.pth_free_scene(None)
+    assert H.pth_write_ppm_bgra8(None, None, 0, 0) != 0 and H.pth_write_pfm(None, None, 0, 0) != 0
+    assert H.pth_write_soup_obj(None, 0, 0) != 0
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(REPO, "single-file-vulkan-pathtracing_amd")
     for root, _, files in os.walk(pkg):
