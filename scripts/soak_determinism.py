@@ -1,0 +1,19 @@
+"""dev tool: repeated renders of the same work must give bit-identical films (race detector for the
+two-pipeline scheduling, lane refill, compaction atomics and term logs)."""
+import hashlib, importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
+ctx = pt.Context(0); sc = pt.Scene.from_obj(ctx); film = pt.Film(ctx, 1920, 1080)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+cases = [dict(frame_count=8), dict(frame_count=8, sample_groups=4, frames_in_flight=2), dict(frame_count=3, rank=1, world=3),
+         dict(frame_count=5, frames_in_flight=1, sample_groups=1)]
+t0 = time.time()
+for c in cases:
+    hashes = set(); rays = set()
+    for i in range(N):
+        film.clear(); ctx.reset_stats()
+        pt.render(sc, film, pt.default_params(width=1920, height=1080, spp_per_frame=32, max_depth=8, **c))
+        hashes.add(hashlib.sha256(film.read_f32().tobytes()).hexdigest()); rays.add(ctx.stats().rays)
+    print(c, "distinct films:", len(hashes), "distinct ray counts:", len(rays), "OK" if len(hashes) == 1 and len(rays) == 1 else "MISMATCH")
+    assert len(hashes) == 1 and len(rays) == 1
+print("soak ok in %.1f s" % (time.time() - t0))

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
                                                unsigned long long *stats, uint2 *__restrict__ spill,
                                                uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
-                                               int lds_stack)
+                                               int lds_stack, int raw_hit)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
@@ -365,8 +365,11 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
             }
             if (cur == SENTINEL) {  // traversal finished: emit the hit record, the lane becomes idle
                 const bool miss = best_pos == PT_MISS;
-                hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                     miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                // raw_hit (render path): (V, W, det) go out undivided and k_shade takes the two quotients at
+                // full lane occupancy; here they would run once per finishing lane group
+                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                                 : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
+                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
                 have = false;
             }
         }
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                                                     uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
                                                     uint32_t *count_zero, unsigned long long *stats,
                                                     uint2 *__restrict__ spill, uint32_t spill_stride, int refill_min_idle,
-                                                    float tmin, float tmax)
+                                                    float tmin, float tmax, int raw_hit)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
@@ -603,8 +606,11 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
             }
             if (cur == SENTINEL) {
                 const bool miss = best_pos == PT_MISS;
-                hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                     miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                // raw_hit (render path): (V, W, det) go out undivided and k_shade takes the two quotients at
+                // full lane occupancy; here they would run once per finishing lane group
+                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                                 : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
+                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
                 hit_inst[q] = best_ipos;
                 have = false;
             }
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
                                                     const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                                     float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                                     uint32_t *count_zero, unsigned long long *stats, float tmin,
-                                                    float tmax)
+                                                    float tmax, int raw_hit)
 {
     const uint32_t n = *count_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -657,8 +663,9 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
             }
         }
         const bool miss = best_pos == PT_MISS;
-        hit[q] = make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t, miss ? 0.f : ptm::fdiv(best_V, best_det),
-                             miss ? 0.f : ptm::fdiv(best_W, best_det));
+        hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                         : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t, miss ? 0.f : ptm::fdiv(best_V, best_det),
+                                       miss ? 0.f : ptm::fdiv(best_W, best_det));
     }
 }
 
@@ -725,9 +732,11 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
                 if (!terminated) {
                     const float4 a = tri4[3 * pos + 0], b = tri4[3 * pos + 1], c = tri4[3 * pos + 2];
                     // closesthit.rchit:56-57: position from barycentrics, (v0*b0 + v1*b1) + v2*b2
-                    const float b0 = (1.0f - h.z) - h.w;
-                    org = { (a.x * b0 + b.x * h.z) + c.x * h.w, (a.y * b0 + b.y * h.z) + c.y * h.w,
-                            (a.z * b0 + b.z * h.z) + c.z * h.w };
+                    // the hit record carries (V, W, det) of the watertight test; attribs = (V/det, W/det)
+                    const float hu = ptm::fdiv(h.y, h.w), hv = ptm::fdiv(h.z, h.w);
+                    const float b0 = (1.0f - hu) - hv;
+                    org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv,
+                            (a.z * b0 + b.z * hu) + c.z * hv };
                     ptm::f3 nrm = { s0.x, s0.y, s0.z };
                     if (inst6) {
                         // instanced scene: position by the object->world matrix, normal by the inverse
@@ -954,9 +963,10 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 
 void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
                    uint32_t *hit_inst, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
-                   float tmin, float tmax, bool count, hipStream_t st, int pipe = 0, hipEvent_t ev0 = nullptr,
-                   hipEvent_t ev1 = nullptr)
+                   float tmin, float tmax, bool count, bool raw_hit, hipStream_t st, int pipe = 0,
+                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
+    const int raw = raw_hit ? 1 : 0;  // hit records as (pos, V, W, det) for k_shade instead of (pos, t, u, v)
     // hipExtLaunchKernelGGL stamps THIS kernel's start/stop into ev0/ev1 (null = plain launch): under
     // two overlapping pipelines an event recorded between kernels would also count queueing time
     // each concurrently running extend kernel owns its own [spill_levels][grid*TB] region
@@ -967,7 +977,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 #define PT_LAUNCH_INST(C, L)                                                                                             \
     hipExtLaunchKernelGGL((k_extend_inst<C, L>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas_wide, \
                           s->d_wide, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6, s->d_tlas_prim_of, rayA, rayB, hit,           \
-                          hit_inst, count_in, count_zero, stats, sp, str, pl.refill, tmin, tmax)
+                          hit_inst, count_in, count_zero, stats, sp, str, pl.refill, tmin, tmax, raw)
         if (pl.lds_scene) {
             if (count) PT_LAUNCH_INST(true, true); else PT_LAUNCH_INST(false, true);
         } else {
@@ -978,7 +988,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     }
     if (pl.variant == PT_EXTEND_FLAT) {
         hipExtLaunchKernelGGL(k_extend_flat, dim3(pl.grid), dim3(TB), 0u, st, ev0, ev1, 0u, s->d_tri4, s->n_tris, rayA, rayB, hit,
-                              count_in, count_zero, stats, tmin, tmax);
+                              count_in, count_zero, stats, tmin, tmax, raw);
         return;
     }
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
@@ -986,7 +996,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 #define PT_LAUNCH_EXTEND(L, C)                                                                                        \
     hipExtLaunchKernelGGL((k_extend<L, C>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide,    \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
-                          pl.refill, tmin, tmax, pl.lds_stack)
+                          pl.refill, tmin, tmax, pl.lds_stack, raw)
     if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(true, false);
     } else {
@@ -1278,7 +1288,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                     hipEvent_t x0 = nullptr, x1 = nullptr, h0 = nullptr, h1 = nullptr;
                     if (profile) { x0 = new_event(); x1 = new_event(); h0 = new_event(); h1 = new_event(); }
                     launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
-                                  ctx->d_stats, p->tmin, p->tmax, count_visits, pp.st, k, x0, x1);
+                                  ctx->d_stats, p->tmin, p->tmax, count_visits, true, pp.st, k, x0, x1);
 #define PT_LAUNCH_SHADE(N, L)                                                                                                  \
     hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
@@ -1385,7 +1395,7 @@ pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, flo
         const uint32_t cnt_head[2] = { n, 0u };
         (void)hipMemcpyAsync(d_cnt, cnt_head, sizeof(cnt_head), hipMemcpyHostToDevice, st);
         (void)hipEventRecord(ctx->ev_a, st);
-        launch_extend(pl, s, d_a, d_b, d_hit, d_hi, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, st);
+        launch_extend(pl, s, d_a, d_b, d_hit, d_hi, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, false, st);
         (void)hipEventRecord(ctx->ev_b, st);
         k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, s->d_tri4, s->n_inst ? d_hi : nullptr, s->d_tlas_prim_of, n, d_out);
         (void)hipMemcpyAsync(hits, d_out, sizeof(pt_hit) * n, hipMemcpyDeviceToHost, st);

@@ -634,6 +634,25 @@ def test_no_device_memory_leak_over_object_lifecycles(pt, cornell_arrays):
     assert free0 - free1 < (8 << 20), f"leaked {(free0 - free1) / 2**20:.1f} MiB over 10 cycles"
 
 
+def test_repeated_renders_are_bit_identical(pt, gpu_ctx, cornell_gpu):
+    """Race detector for the scheduling machinery (two pipelines on two streams, lane refill, compaction
+    atomics, ordered term logs): the same work must give the same bits and the same ray count every time,
+    whatever order the hardware happened to run the waves in."""
+    import hashlib
+    film = pt.Film(gpu_ctx, 640, 360)
+    for extend in (pt.EXTEND_LDS, pt.EXTEND_HBM):
+        for kw in (dict(frame_count=6), dict(frame_count=6, sample_groups=4, frames_in_flight=2),
+                   dict(frame_count=3, rank=1, world=3)):
+            seen = set()
+            for _ in range(6):
+                film.clear(); gpu_ctx.reset_stats()
+                pt.render(cornell_gpu, film, pt.default_params(width=640, height=360, spp_per_frame=16, max_depth=8,
+                                                               extend=extend, **kw))
+                seen.add((hashlib.sha256(film.read_f32().tobytes()).hexdigest(), gpu_ctx.stats().rays))
+            assert len(seen) == 1, (extend, kw, seen)
+    film.close()
+
+
 def test_async_render_equals_blocking(pt, gpu_ctx, cornell_gpu):
     """PT_FLAG_ASYNC: frames are queued without the reference's per-frame waitIdle (main.cpp:683)."""
     kw = dict(width=160, height=96, spp_per_frame=8, max_depth=8)
