@@ -513,8 +513,25 @@ struct BvhOut {
     float4 *d_nodes = nullptr;             // binary nodes, 64 B
     float4 *d_wide = nullptr;              // BVH4 nodes, 128 B
     uint32_t n_nodes = 0, n_wide = 0, height = 0;
+    uint32_t stack_need = 0;               // most entries a depth-first walk of the BVH4 can have pending
     float bmin[3]{}, bmax[3]{};
 };
+
+// Exact traversal-stack bound of a small BVH4: a node with k children pushes at most k-1 of them
+// before descending, so need(node) = k-1 + max over internal children.  Lets the extend kernel of
+// LDS-resident scenes run without the spill path (and its branches) at all.
+static uint32_t wide_stack_need(const std::vector<uint32_t> &w, uint32_t node, uint32_t depth)
+{
+    if (depth > 64) return 1u << 20;  // malformed: forces the spilling variant
+    uint32_t k = 0, deepest = 0;
+    for (int c = 0; c < 4; c++) {
+        const uint32_t word = w[32 * (size_t)node + 24 + c];
+        if (word == 0xFFFFFFFFu) continue;
+        k++;
+        if (!(word & PT_LEAF)) deepest = std::max(deepest, wide_stack_need(w, word, depth + 1));
+    }
+    return (k ? k - 1 : 0) + deepest;
+}
 
 __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n,
                                                uint32_t *__restrict__ scene_ord)
@@ -627,6 +644,13 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         k_wide_single<<<1, 1, 0, st>>>(out.d_nodes, out.d_wide);
     }
     out.n_wide = n_wide;
+    out.stack_need = 0xFFFFFFFFu;  // unknown: callers fall back to the height bound
+    if (n_wide <= 1024) {
+        std::vector<uint32_t> h_wide(32 * (size_t)n_wide);
+        PT_HIP(ctx, hipMemcpyAsync(h_wide.data(), out.d_wide, 128 * (size_t)n_wide, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        out.stack_need = wide_stack_need(h_wide, 0, 0);
+    }
     uint32_t ord[6];
     PT_HIP(ctx, hipMemcpyAsync(ord, d_scene.p, sizeof(ord), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipMemcpyAsync(&out.height, d_height.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -669,7 +693,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o);
     s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
     if (rc != PT_OK) return rc;
-    s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height;
+    s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height; s->stack_need = o.stack_need;
     for (int k = 0; k < 3; k++) { s->bmin[k] = o.bmin[k]; s->bmax[k] = o.bmax[k]; }
     k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4);
     PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));

@@ -44,6 +44,7 @@ struct pt_scene {
     float4 *d_nodes = nullptr;            // binary LBVH (parity read-back; the collapse reads it)
     float4 *d_wide = nullptr;             // BVH4, 8 x float4 = 128 B per node: what traversal walks
     uint32_t n_wide = 0;
+    uint32_t stack_need = 0xFFFFFFFFu;    // exact bound of pending traversal-stack entries (small scenes), else unknown
     unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
     uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
     uint64_t device_bytes = 0;

@@ -178,6 +178,14 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
 //  * LDS_SCENE: nodes + triangles are staged into LDS once per persistent block and traversal
 //    touches no HBM at all (scenes up to ~24 KB).
 constexpr int LDS_STACK = 8;
+// Stack entries are one 64-bit word (child word | entry distance << 32) and the LDS part is addressed
+// through an LDS-typed pointer: with generic pointers the compiler merges the LDS and the spill
+// access into FLAT loads/stores of the two halves (seen in the ISA), which cost VMEM issue and latency.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+__device__ __forceinline__ unsigned long long stack_entry(uint32_t w, float t)
+{
+    return (unsigned long long)w | ((unsigned long long)__float_as_uint(t) << 32);
+}
 
 // Slab test of the 4 children of a BVH4 node with the near/far planes picked by the ray's direction
 // signs THROUGH THE LOAD ADDRESS (ixn/iyn/izn = float4 index of the near planes: 0|3, 1|4, 2|5), so no
@@ -216,7 +224,7 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // at ~88 atomics/us on this chip, which short Cornell traversals (3.6 nodes/ray) exceed 3x over.
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
-template <bool LDS_SCENE, bool COUNT>
+template <bool LDS_SCENE, bool COUNT, bool SPILL>
 __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
@@ -250,8 +258,8 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         if (count_zero) *count_zero = 0u;  // the queue the coming shade pass appends to
         if (stats) atomicAdd(stats, (unsigned long long)n);  // exact ray count
     }
-    uint2 *my_stack = stack + threadIdx.x;
-    uint2 *my_spill = spill + (size_t)blockIdx.x * TB + threadIdx.x;
+    lds_u64 *my_stack = (lds_u64 *)reinterpret_cast<unsigned long long *>(stack) + threadIdx.x;
+    unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -273,16 +281,18 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     unsigned long long c_nodes = 0, c_tris = 0;
 
     auto push = [&](uint32_t w, float t) {
-        const uint2 e = make_uint2(w, __float_as_uint(t));
-        if (sp < lds_stack) my_stack[sp * TB] = e;
+        const unsigned long long e = stack_entry(w, t);
+        if (!SPILL || sp < lds_stack) my_stack[sp * TB] = e;  // !SPILL: the host proved lds_stack entries suffice
         else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
         sp++;
     };
     auto pop = [&]() -> uint32_t {  // next subtree that can still contain the closest hit
         while (sp > 0) {
             sp--;
-            const uint2 e = sp < lds_stack ? my_stack[sp * TB] : my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if (__uint_as_float(e.y) <= best_t) return e.x;
+            unsigned long long e;
+            if (!SPILL || sp < lds_stack) e = my_stack[sp * TB];
+            else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
+            if (__uint_as_float((uint32_t)(e >> 32)) <= best_t) return (uint32_t)e;
         }
         return SENTINEL;
     };
@@ -443,8 +453,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
         if (count_zero) *count_zero = 0u;
         if (stats) atomicAdd(stats, (unsigned long long)n);
     }
-    uint2 *my_stack = stack + threadIdx.x;
-    uint2 *my_spill = spill + (size_t)blockIdx.x * TB + threadIdx.x;
+    lds_u64 *my_stack = (lds_u64 *)reinterpret_cast<unsigned long long *>(stack) + threadIdx.x;
+    unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
     uint32_t cursor = 0;
 
     auto push = [&](uint32_t w, float t) {
-        const uint2 e = make_uint2(w, __float_as_uint(t));
+        const unsigned long long e = stack_entry(w, t);
         if (sp < LDS_STACK) my_stack[sp * TB] = e;
         else my_spill[(size_t)(sp - LDS_STACK) * spill_stride] = e;
         sp++;
@@ -475,7 +485,10 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             sp--;
-            const uint2 e = sp < LDS_STACK ? my_stack[sp * TB] : my_spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            unsigned long long e64;
+            if (sp < LDS_STACK) e64 = my_stack[sp * TB];
+            else e64 = my_spill[(size_t)(sp - LDS_STACK) * spill_stride];
+            const uint2 e = make_uint2((uint32_t)e64, (uint32_t)(e64 >> 32));
             if (e.x == EXIT_MARK) {  // the instance is done: back to the world-space ray and the TLAS
                 inv = inv_w;
                 slab_origin(org_w, inv_w, on, of);
@@ -900,6 +913,7 @@ struct ExtendPlan {
     uint32_t spill_levels = 0;
     int refill = REFILL_MIN_IDLE;
     int lds_stack = LDS_STACK;  // stack entries per lane kept in LDS (single-level kernel)
+    bool spill = true;          // false: the scene's exact stack bound fits lds_stack, kernel without spill path
 };
 
 pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
@@ -948,11 +962,17 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     // deep trees of big scenes: 12 LDS entries measured best on the 1M-triangle soup (4: -15 %, 8: -3 %,
     // 16: -5 %, 24: -16 %: beyond 12 the extra LDS costs occupancy)
     pl.lds_stack = pl.lds_scene ? LDS_STACK : 12;
+    // LDS-resident scenes are small enough for an exact stack bound (lbvh_build.hip: wide_stack_need):
+    // if it fits 16 LDS entries the kernel is instantiated without the spill path (Cornell: 9)
+    pl.spill = !(pl.lds_scene && s->stack_need <= 16u);
+    if (!pl.spill) pl.lds_stack = (int)std::max(s->stack_need, 1u);
     pl.smem = (size_t)pl.lds_stack * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
-    const void *fn = pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false>)
-                                  : reinterpret_cast<const void *>(k_extend<false, false>);
-    const void *fn_count = pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, true>)
-                                        : reinterpret_cast<const void *>(k_extend<false, true>);
+    const void *fn = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, false, false>)
+                     : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false, true>)
+                                    : reinterpret_cast<const void *>(k_extend<false, false, true>);
+    const void *fn_count = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, true, false>)
+                           : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, true, true>)
+                                          : reinterpret_cast<const void *>(k_extend<false, true, true>);
     if (pl.smem > 48 * 1024)
         PT_HIP(ctx, hipFuncSetAttribute(fn_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
     if (pl.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
@@ -962,7 +982,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
     pl.grid = ctx->num_cus * per_cu;
     // stack bound: a BVH4 node pushes <= 3 entries per level; wide height <= binary height/2 + 1
-    const uint32_t bound = 3u * (s->height / 2u + 1u) + 1u;
+    const uint32_t bound = std::min(3u * (s->height / 2u + 1u) + 1u, s->stack_need);
     pl.spill_levels = bound > (uint32_t)pl.lds_stack ? bound - (uint32_t)pl.lds_stack : 0u;
     const size_t need = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
     if (need > ctx->spill_bytes) {
@@ -1007,14 +1027,16 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     }
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
-#define PT_LAUNCH_EXTEND(L, C)                                                                                        \
-    hipExtLaunchKernelGGL((k_extend<L, C>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide,    \
+#define PT_LAUNCH_EXTEND(L, C, S)                                                                                     \
+    hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide, \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
                           pl.refill, tmin, tmax, pl.lds_stack, raw)
-    if (pl.lds_scene) {
-        if (count) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(true, false);
+    if (!pl.spill) {
+        if (count) PT_LAUNCH_EXTEND(true, true, false); else PT_LAUNCH_EXTEND(true, false, false);
+    } else if (pl.lds_scene) {
+        if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
-        if (count) PT_LAUNCH_EXTEND(false, true); else PT_LAUNCH_EXTEND(false, false);
+        if (count) PT_LAUNCH_EXTEND(false, true, true); else PT_LAUNCH_EXTEND(false, false, true);
     }
 #undef PT_LAUNCH_EXTEND
 }

@@ -684,3 +684,51 @@ def test_error_paths(pt, gpu_ctx, cornell_gpu):
         cornell_gpu.set_instances(np.zeros((1, 3, 4), np.float32))       # singular matrix
     assert cornell_gpu.info().n_instances == 0
     film.close()
+
+
+def _stack_need(wide, node=0):
+    ch = [int(x) for x in wide[node, 24:28] if x != 0xFFFFFFFF]
+    return max(len(ch) - 1, 0) + max([_stack_need(wide, c) for c in ch if not c & 0x80000000], default=0)
+
+
+def _octave_chain(levels, per_level, seed):
+    """Triangles clustered at 2^-k along the diagonal: the LBVH degenerates into a deep chain."""
+    rng = np.random.default_rng(seed)
+    v = []
+    for k in range(levels):
+        s = np.float32(2.0 ** -k)
+        c = np.float32(0.9) * s * np.ones(3, np.float32)
+        v.append(c + rng.uniform(-0.2, 0.2, (per_level, 3, 3)).astype(np.float32) * s)
+    v = np.concatenate(v).astype(np.float32)
+    n = v.shape[0]
+    faces = rng.uniform(0.2, 1, (n, 6)).astype(np.float32)
+    faces[:, 3:] *= (rng.uniform(0, 1, (n, 1)) < 0.2)
+    return v.reshape(-1), np.arange(3 * n, dtype=np.uint32), faces.reshape(-1).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["soup40", "soup150", "soup450", "chain"])
+def test_small_scenes_every_stack_regime_bit_exact(pt, orc, gpu_ctx, kind):
+    """LDS-resident scenes pick their traversal-stack regime from the exact stack bound of their BVH4
+    (no-spill kernel when it fits 16 LDS entries, LDS + HBM spill otherwise); the HBM variant always
+    spills past 12.  All of them must return the oracle's hits and film."""
+    v, i, f = _octave_chain(19, 6, 5) if kind == "chain" else _soup(int(kind[4:]), len(kind), spread=0.3)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    need = _stack_need(_collapse_reference(osc.bvh_nodes(), osc.n_tris, leaf_max=2))
+    assert (need > 16) == (kind == "chain"), need      # the chain is what exercises LDS + spill
+    rng = np.random.default_rng(7)
+    rays = np.concatenate([rng.uniform(-1.5, 1.5, (20000, 3)), rng.normal(size=(20000, 3))], axis=1).astype(np.float32)
+    rays[:5000, :3] = rng.uniform(0, 1, (5000, 1)).astype(np.float32) ** 4 + rng.normal(size=(5000, 3)).astype(np.float32) * 0.01
+    want, _ = osc.trace(rays)
+    assert (want["prim"] != 0xFFFFFFFF).mean() > 0.02
+    kw = dict(width=96, height=64, spp_per_frame=4, max_depth=12, cam_origin=(0.5, 0.5, 4.0), cam_target=(0.0, 0.0, 1.0))
+    ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
+    for extend in (pt.EXTEND_LDS, pt.EXTEND_HBM):
+        got = gs.trace(rays, extend=extend)
+        assert got.tobytes() == want.tobytes(), (kind, extend)
+        film = pt.Film(gpu_ctx, 96, 64)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(extend=extend, **kw))
+        assert film.read_f32().tobytes() == ofilm.tobytes(), (kind, extend)
+        assert gpu_ctx.stats().rays == orays
+        film.close()
+    gs.close()
