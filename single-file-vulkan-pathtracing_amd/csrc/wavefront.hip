@@ -188,31 +188,53 @@ __device__ __forceinline__ unsigned long long stack_entry(uint32_t w, float t)
 }
 
 // Slab test of the 4 children of a BVH4 node with the near/far planes picked by the ray's direction
-// signs THROUGH THE LOAD ADDRESS (ixn/iyn/izn = float4 index of the near planes: 0|3, 1|4, 2|5), so no
+// signs THROUGH THE LOAD ADDRESS (ax/ay/az = 48 bytes when the direction component is negative: the near
+// plane of x is then float4 3 instead of 0, its far plane 0 instead of 3 -- one add or sub per load), so no
 // per-child min/max of the two plane distances is needed.  Conservative like ptm::box_test.
+#define PT_F4(P) (*reinterpret_cast<const float4 *>(P))
 #define PT_NODE_LOAD(ND)                                                                                 \
-    const float4 nx = (ND)[ixn], fx = (ND)[3 - ixn], ny = (ND)[iyn], fy = (ND)[5 - iyn], nz = (ND)[izn], \
-                 fz = (ND)[7 - izn], cw = (ND)[6];
+    const char *nb_ = reinterpret_cast<const char *>(ND);                                                \
+    const float4 nx = PT_F4(nb_ + ax), fx = PT_F4(nb_ - ax + 48), ny = PT_F4(nb_ + ay + 16),             \
+                 fy = PT_F4(nb_ - ay + 64), nz = PT_F4(nb_ + az + 32), fz = PT_F4(nb_ - az + 80),        \
+                 cw = PT_F4(nb_ + 96);
 // Plane distances are ONE fma each, n * inv + (-org * inv), instead of (n - org) * inv: 6 VALU
-// instructions less per child.  The rounding of the folded origin term (absolute error <= 2^-23 |org*inv|
-// after the pad subtraction itself) is covered by moving it 2^-22 |org*inv| DOWN for the near planes and
-// UP for the far planes (slab_origin below), so tn stays a lower and tf an upper bound; the relative
-// errors (v_rcp_f32's 1 ulp, the fma's rounding) are covered by the 4e-7 factor on tf as before.  Box
-// tests are not part of the numerical contract -- they only have to never reject a box that holds a hit.
+// instructions less per child.  The rounding of the folded origin term and of the scaled far-plane
+// reciprocal (absolute error <= 2^-22 |org*inv| in total) is covered by moving the origin term
+// 2^-21 |org*inv| DOWN for the near planes and UP for the far planes (slab_setup below), so tn stays a lower
+// and tf an upper bound.  The relative errors (v_rcp_f32's 1 ulp, the fma's rounding) are covered by a
+// factor 1 + 4e-7 on the far distances, folded into the far planes' reciprocal and origin term (invf, of)
+// so it costs nothing per node; a negative far distance only gets more negative, and such a box is behind
+// the ray anyway.  Box tests are not part of the numerical contract -- they only have to never reject a
+// box that holds a hit.
+// (max_raw/min_raw: fmaxf/fminf on a kernel argument or a loop-carried value make the compiler re-quiet
+// that operand with a v_max x,x in every iteration; the instruction itself already has maxNum semantics)
 #define PT_SLAB4(T, C)                                                                                           \
     {                                                                                                            \
         const float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, inv.x, on.x), __builtin_fmaf(ny.C, inv.y, on.y)),      \
-                               fmaxf(__builtin_fmaf(nz.C, inv.z, on.z), tmin));                                  \
-        const float tf = fminf(fminf(__builtin_fmaf(fx.C, inv.x, of.x), __builtin_fmaf(fy.C, inv.y, of.y)),      \
-                               fminf(__builtin_fmaf(fz.C, inv.z, of.z), best_t));                                \
-        T = tn <= tf * 1.0000004f ? tn : INF;                                                                    \
+                               max_raw_s(__builtin_fmaf(nz.C, inv.z, on.z), tmin));                              \
+        const float tf = fminf(fminf(__builtin_fmaf(fx.C, invf.x, of.x), __builtin_fmaf(fy.C, invf.y, of.y)),    \
+                               min_raw(__builtin_fmaf(fz.C, invf.z, of.z), best_t));                             \
+        T = tn <= tf ? tn : INF;                                                                                 \
     }
-__device__ __forceinline__ void slab_origin(const ptm::f3 org, const ptm::f3 inv, ptm::f3 &on, ptm::f3 &of)
+__device__ __forceinline__ float max_raw_s(float a, float uniform_b)
+{
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "s"(uniform_b), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void slab_setup(const ptm::f3 org, const ptm::f3 inv, ptm::f3 &invf, ptm::f3 &on, ptm::f3 &of)
 {
     const float ox = -(org.x * inv.x), oy = -(org.y * inv.y), oz = -(org.z * inv.z);
-    const float px = fabsf(ox) * 0x1p-22f, py = fabsf(oy) * 0x1p-22f, pz = fabsf(oz) * 0x1p-22f;
+    const float px = fabsf(ox) * 0x1p-21f, py = fabsf(oy) * 0x1p-21f, pz = fabsf(oz) * 0x1p-21f;
     on = { ox - px, oy - py, oz - pz };
-    of = { ox + px, oy + py, oz + pz };
+    of = { (ox + px) * 1.0000004f, (oy + py) * 1.0000004f, (oz + pz) * 1.0000004f };
+    invf = { inv.x * 1.0000004f, inv.y * 1.0000004f, inv.z * 1.0000004f };
 }
 constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the wave pulls new rays
 
@@ -270,9 +292,9 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
     const uint32_t wave_stride = gridDim.x * TB;
     uint32_t cursor = 0;
-    ptm::f3 inv{}, on{}, of{}, orgp{};  // on/of: folded origin terms of the near/far plane distances
+    ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};  // slab_setup: near/far reciprocals and folded origin terms
     ptm::RayPre pre{};
-    int ixn = 0, iyn = 1, izn = 2;  // float4 index of the near planes inside a node
+    uint32_t ax = 0, ay = 0, az = 0;  // 48 where the direction component is negative (PT_NODE_LOAD)
     uint32_t tri_base = 0;           // LDS_SCENE: start of the triangle copy for this ray's kz
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
@@ -313,10 +335,10 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup(org, dir);
                     inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
-                    slab_origin(org, inv, on, of);
-                    ixn = inv.x < 0.f ? 3 : 0;
-                    iyn = inv.y < 0.f ? 4 : 1;
-                    izn = inv.z < 0.f ? 5 : 2;
+                    slab_setup(org, inv, invf, on, of);
+                    ax = inv.x < 0.f ? 48u : 0u;
+                    ay = inv.y < 0.f ? 48u : 0u;
+                    az = inv.z < 0.f ? 48u : 0u;
                     if (LDS_SCENE) {
                         tri_base = (uint32_t)pre.kz * 3u * n_tris;
                         orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y),
@@ -462,9 +484,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
     bool have = false, exhausted = false, in_blas = false;
     uint32_t q = 0;
     ptm::f3 org_w{}, dir_w{}, inv_w{};   // world-space ray
-    ptm::f3 inv{}, on{}, of{}, orgp{};    // ray of the level being walked (on/of: folded slab origins; orgp: origin permuted to kx,ky,kz)
+    ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};  // ray of the level being walked (on/of: folded slab origins; orgp: origin permuted to kx,ky,kz)
     uint32_t tri_base = 0;
-    int ixn = 0, iyn = 1, izn = 2;        // near-plane float4 indices for the level being walked
+    uint32_t ax = 0, ay = 0, az = 0;      // 48 where the walked level's direction component is negative
     ptm::RayPre pre{};
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS, best_ipos = PT_MISS, best_iid = PT_MISS;
@@ -491,10 +513,10 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
             const uint2 e = make_uint2((uint32_t)e64, (uint32_t)(e64 >> 32));
             if (e.x == EXIT_MARK) {  // the instance is done: back to the world-space ray and the TLAS
                 inv = inv_w;
-                slab_origin(org_w, inv_w, on, of);
-                ixn = inv.x < 0.f ? 3 : 0;
-                iyn = inv.y < 0.f ? 4 : 1;
-                izn = inv.z < 0.f ? 5 : 2;
+                slab_setup(org_w, inv_w, invf, on, of);
+                ax = inv.x < 0.f ? 48u : 0u;
+                ay = inv.y < 0.f ? 48u : 0u;
+                az = inv.z < 0.f ? 48u : 0u;
                 in_blas = false;
                 continue;
             }
@@ -521,10 +543,10 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                     dir_w = { ra.w, rb.x, rb.y };
                     inv_w = { ptm::safe_inv(dir_w.x), ptm::safe_inv(dir_w.y), ptm::safe_inv(dir_w.z) };
                     inv = inv_w;
-                    slab_origin(org_w, inv_w, on, of);
-                    ixn = inv.x < 0.f ? 3 : 0;
-                    iyn = inv.y < 0.f ? 4 : 1;
-                    izn = inv.z < 0.f ? 5 : 2;
+                    slab_setup(org_w, inv_w, invf, on, of);
+                    ax = inv.x < 0.f ? 48u : 0u;
+                    ay = inv.y < 0.f ? 48u : 0u;
+                    az = inv.z < 0.f ? 48u : 0u;
                     in_blas = false;
                     best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
@@ -543,11 +565,13 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
         while (have && !(cur & PT_LEAF)) {
             float4 nx, fx, ny, fy, nz, fz, cw;
             if (LDS_BLAS && in_blas) {
-                const float4 *nd = blas + 8 * (size_t)cur;
-                nx = nd[ixn]; fx = nd[3 - ixn]; ny = nd[iyn]; fy = nd[5 - iyn]; nz = nd[izn]; fz = nd[7 - izn]; cw = nd[6];
+                const char *nd = reinterpret_cast<const char *>(blas + 8 * (size_t)cur);
+                nx = PT_F4(nd + ax); fx = PT_F4(nd - ax + 48); ny = PT_F4(nd + ay + 16); fy = PT_F4(nd - ay + 64);
+                nz = PT_F4(nd + az + 32); fz = PT_F4(nd - az + 80); cw = PT_F4(nd + 96);
             } else {
-                const float4 *nd = (LDS_BLAS ? tlas : (in_blas ? g_blas : tlas)) + 8 * (size_t)cur;
-                nx = nd[ixn]; fx = nd[3 - ixn]; ny = nd[iyn]; fy = nd[5 - iyn]; nz = nd[izn]; fz = nd[7 - izn]; cw = nd[6];
+                const char *nd = reinterpret_cast<const char *>((LDS_BLAS ? tlas : (in_blas ? g_blas : tlas)) + 8 * (size_t)cur);
+                nx = PT_F4(nd + ax); fx = PT_F4(nd - ax + 48); ny = PT_F4(nd + ay + 16); fy = PT_F4(nd - ay + 64);
+                nz = PT_F4(nd + az + 32); fz = PT_F4(nd - az + 80); cw = PT_F4(nd + 96);
             }
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
@@ -615,10 +639,10 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                                          (r1.x * dir_w.x + r1.y * dir_w.y) + r1.z * dir_w.z,
                                          (r2.x * dir_w.x + r2.y * dir_w.y) + r2.z * dir_w.z };
                     inv = { ptm::safe_inv(od.x), ptm::safe_inv(od.y), ptm::safe_inv(od.z) };
-                    slab_origin(oo, inv, on, of);
-                    ixn = inv.x < 0.f ? 3 : 0;
-                    iyn = inv.y < 0.f ? 4 : 1;
-                    izn = inv.z < 0.f ? 5 : 2;
+                    slab_setup(oo, inv, invf, on, of);
+                    ax = inv.x < 0.f ? 48u : 0u;
+                    ay = inv.y < 0.f ? 48u : 0u;
+                    az = inv.z < 0.f ? 48u : 0u;
                     pre = ptm::ray_setup(oo, od);
                     if (LDS_BLAS) {
                         tri_base = (uint32_t)pre.kz * 3u * n_tris;
