@@ -151,7 +151,7 @@ pt_status pt_scene_read_bvh4(const pt_scene *s, uint32_t *nodes32)
 static pt_status film_create(pt_ctx *ctx, uint32_t w, uint32_t h, void *ext, pt_film **out)
 {
     if (!ctx) return PT_ERR_INVALID_ARG;
-    if (!out || w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 28)) { ctx->err = "bad film size"; return PT_ERR_INVALID_ARG; }
+    if (!out || w == 0 || h == 0 || w > 524280u || h > 524280u || (uint64_t)w * h >= (1ull << 28)) { ctx->err = "bad film size"; return PT_ERR_INVALID_ARG; }
     *out = nullptr;
     PT_HIP(ctx, hipSetDevice(ctx->device));
     pt_film *f = new (std::nothrow) pt_film();

@@ -33,6 +33,25 @@ namespace {
 constexpr int TB = 256;
 constexpr uint32_t SENTINEL = 0xFFFFFFFFu;
 
+// Exact unsigned division by a run-time constant without the ~28-instruction v_rcp sequence
+// (Granlund & Montgomery 1994, N = 32): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n).
+struct FastDiv {
+    uint32_t m = 1, s1 = 0, s2 = 0;
+    void init(uint32_t d)
+    {
+        uint32_t l = 0;
+        while ((1ull << l) < d) l++;
+        m = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+        s1 = l < 1u ? l : 1u;
+        s2 = l > 0u ? l - 1u : 0u;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const
+    {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+};
+
 struct RenderConst {
     ptm::Camera cam;
     float env[3];
@@ -46,6 +65,7 @@ struct RenderConst {
     uint32_t group_size;       // samples per group: group g runs samples [g*group_size, min(spp, (g+1)*group_size))
     uint32_t term_cap;         // radiance-term log capacity per slot = group_size * max_depth (groups > 1)
     uint32_t term_pcap;        // entries of it kept in the dense primary log (the rest is the overflow log)
+    FastDiv div_spl, div_groups;  // slot -> frame lane / sample group without integer divides
 };
 
 // Where a slot's radiance goes.  groups == 1: one accumulator per slot, added to in path order
@@ -86,14 +106,13 @@ struct QueueView {
 __device__ __forceinline__ void slot_pixel(const RenderConst &rc, const uint32_t *__restrict__ tiles, uint32_t slot,
                                            uint32_t &lane_f, uint32_t &group, uint32_t &px, uint32_t &py)
 {
-    const uint32_t lane = slot / rc.slots_per_lane;
-    lane_f = lane / rc.groups;
+    const uint32_t lane = rc.div_spl.div(slot);
+    lane_f = rc.div_groups.div(lane);
     group = lane - lane_f * rc.groups;
     const uint32_t local = slot - lane * rc.slots_per_lane;
-    const uint32_t g = tiles[local >> 6];
-    const uint32_t ty = g / rc.tiles_x, tx = g - ty * rc.tiles_x;
-    px = tx * 8u + (local & 7u);
-    py = ty * 8u + ((local >> 3) & 7u);
+    const uint32_t g = tiles[local >> 6];  // tile x | tile y << 16
+    px = (g & 0xFFFFu) * 8u + (local & 7u);
+    py = (g >> 16) * 8u + ((local >> 3) & 7u);
 }
 
 // Block-wide ordered compaction of up to ITEMS x 256 survivors: wave ballots for the in-wave
@@ -1079,7 +1098,7 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         std::vector<uint32_t> tiles;
         for (uint32_t ty = 0; ty < tiles_y; ty++)
             for (uint32_t tx = 0; tx < tiles_x; tx++)
-                if ((tx + ty) % world == rank) tiles.push_back(ty * tiles_x + tx);
+                if ((tx + ty) % world == rank) tiles.push_back(tx | (ty << 16));
         w.rank = rank; w.world = world;
         w.n_tiles = (uint32_t)tiles.size();
         PT_HIP(ctx, hipMalloc((void **)&w.d_tiles, sizeof(uint32_t) * std::max<size_t>(tiles.size(), 1)));
@@ -1260,6 +1279,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     rc.spp = p->spp_per_frame; rc.max_depth = p->max_depth;
     rc.slots_per_lane = w.n_tiles * 64u;
     rc.groups = groups; rc.group_size = group_size; rc.term_cap = term_cap;
+    rc.div_spl.init(std::max(rc.slots_per_lane, 1u)); rc.div_groups.init(std::max(groups, 1u));
     rc.term_pcap = sh.term_pcap;
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
