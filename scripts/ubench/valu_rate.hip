@@ -21,6 +21,36 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
         if (OP == 9) { REP8(asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %2, %2, %1\n v_mul_lo_u32 %3, %3, %1\n v_mul_lo_u32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
         if (OP == 10) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %2, %1\n v_cmp_lt_f32 vcc, %3, %1\n v_cmp_gt_f32 vcc, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
         if (OP == 11) { REP8(asm volatile("v_add_u32 %0, %0, %1\n v_xor_b32 %2, %2, %1\n v_lshrrev_b32 %3, 3, %3\n v_and_b32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 12) { REP8(asm volatile("v_fmac_f32 %0, %1, %1\n v_fmac_f32 %2, %1, %1\n v_fmac_f32 %3, %1, %1\n v_fmac_f32 %4, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 13) { REP8(asm volatile("v_min_u32 %0, %0, %1\n v_max_u32 %2, %2, %1\n v_min_u32 %3, %3, %1\n v_max_u32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 14) { REP8(asm volatile("v_and_or_b32 %0, %0, %1, %1\n v_and_or_b32 %2, %2, %1, %1\n v_and_or_b32 %3, %3, %1, %1\n v_and_or_b32 %4, %4, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 15) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 2, %1\n v_lshl_add_u32 %2, %2, 2, %1\n v_lshl_add_u32 %3, %3, 2, %1\n v_lshl_add_u32 %4, %4, 2, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 16) { REP8(asm volatile("v_med3_f32 %0, %0, %1, %2\n v_med3_f32 %2, %2, %1, %3\n v_med3_f32 %3, %3, %1, %4\n v_med3_f32 %4, %4, %1, %0" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 17) { REP8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %1, vcc\n v_cndmask_b32 %3, %3, %1, vcc\n v_cndmask_b32 %4, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 18) { REP8(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %2, %1\n v_mov_b32 %3, %1\n v_mov_b32 %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 19) { REP8(asm volatile("v_bfi_b32 %0, %0, %1, %1\n v_bfi_b32 %2, %2, %1, %1\n v_bfi_b32 %3, %3, %1, %1\n v_bfi_b32 %4, %4, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 20) { REP8(asm volatile("v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %2, %2, %1\n v_mul_hi_u32 %3, %3, %1\n v_mul_hi_u32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 21) { REP8(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n v_sqrt_f32 %4, %4" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 22) { REP8(asm volatile("v_div_fixup_f32 %0, %0, %1, %1\n v_div_fixup_f32 %2, %2, %1, %1\n v_div_fixup_f32 %3, %3, %1, %1\n v_div_fixup_f32 %4, %4, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 23) { REP8(asm volatile("v_sub_f32 %0, %0, %1\n v_sub_f32 %2, %2, %1\n v_sub_f32 %3, %3, %1\n v_sub_f32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 24) { REP8(asm volatile("v_add3_u32 %0, %0, %1, %1\n v_add3_u32 %2, %2, %1, %1\n v_add3_u32 %3, %3, %1, %1\n v_add3_u32 %4, %4, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 25) { REP8(asm volatile("v_cmp_lt_f32 s[10:11], %0, %1\n v_cmp_gt_f32 s[12:13], %2, %1\n v_cmp_lt_f32 s[14:15], %3, %1\n v_cmp_gt_f32 s[16:17], %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "s10","s11","s12","s13","s14","s15","s16","s17");) }
+        if (OP == 26) { REP8(asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_fma_f32 %4, %4, %4, %4" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 27) { REP8(asm volatile("v_mul_f32_e64 %0, %0, %1\n v_mul_f32_e64 %2, %2, %1\n v_mul_f32_e64 %3, %3, %1\n v_mul_f32_e64 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 28) { REP8(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %1\n v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 29) { REP8(asm volatile("v_perm_b32 %0, %0, %1, %1\n v_perm_b32 %2, %2, %1, %1\n v_perm_b32 %3, %3, %1, %1\n v_perm_b32 %4, %4, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 30) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %1, vcc\n v_cmp_gt_f32 vcc, %3, %1\n v_cndmask_b32 %4, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 31) { REP8(asm volatile("v_cmp_lt_f32 s[10:11], %0, %1\n v_cndmask_b32 %2, %2, %1, s[10:11]\n v_cmp_gt_f32 s[12:13], %3, %1\n v_cndmask_b32 %4, %4, %1, s[12:13]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "s10","s11","s12","s13");) }
+        if (OP == 32) { REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %2, %2, %1, vcc\n v_cndmask_b32_e64 %3, %3, %1, vcc\n v_cndmask_b32_e64 %4, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 33) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %1, vcc\n v_cndmask_b32 %3, %3, %1, vcc\n v_cndmask_b32 %4, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 34) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %2, %2, %1, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %4, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 35) { REP8(asm volatile("v_cmp_lt_f32 s[10:11], %0, %2\n v_cndmask_b32 %0, %0, %2, s[10:11]\n v_cndmask_b32 %2, %2, %1, s[10:11]\n v_cndmask_b32 %3, %3, %4, s[10:11]\n v_cndmask_b32 %4, %4, %1, s[10:11]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "s10","s11");) }
+        if (OP == 36) { REP8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_add_f32 %2, %2, %1\n v_cndmask_b32 %3, %3, %1, vcc\n v_add_f32 %4, %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 37) { REP8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %1, s[10:11]\n v_cndmask_b32 %3, %3, %1, vcc\n v_cndmask_b32 %4, %4, %1, s[10:11]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc","s10","s11");) }
+        if (OP == 38) { REP8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n s_nop 0\n v_cndmask_b32 %3, %3, %1, vcc\n s_nop 0" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 39) { REP8(asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %1, vcc\n v_addc_co_u32 %4, vcc, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 40) { REP8(asm volatile("v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %4, %0, vcc\n v_cndmask_b32 %4, %0, %2, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
+        if (OP == 41) { REP8(asm volatile("v_cndmask_b32 %0, %2, %3, s[10:11]\n v_cndmask_b32 %2, %3, %4, s[10:11]\n v_cndmask_b32 %3, %4, %0, s[10:11]\n v_cndmask_b32 %4, %0, %2, s[10:11]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "s10","s11");) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + a;
 }
@@ -44,5 +74,10 @@ int main()
     run<0>("v_add_f32", d); run<1>("v_fma_f32", d); run<6>("v_mul_f32", d); run<2>("v_pk_add_f32", d); run<3>("v_pk_fma_f32", d);
     run<4>("v_cndmask", d); run<5>("v_min/max", d); run<8>("v_min3/max3", d); run<10>("v_cmp_f32", d); run<7>("v_rcp_f32", d);
     run<9>("v_mul_lo_u32", d); run<11>("int add/xor/shift", d);
+    run<12>("v_fmac_f32 (VOP2)", d); run<13>("v_min/max_u32", d); run<14>("v_and_or_b32", d); run<15>("v_lshl_add_u32", d); run<16>("v_med3_f32", d); run<17>("v_cndmask e32 vcc", d); run<18>("v_mov_b32", d); run<19>("v_bfi_b32", d); run<20>("v_mul_hi_u32", d); run<21>("v_sqrt_f32", d); run<22>("v_div_fixup_f32", d); run<23>("v_sub_f32", d); run<24>("v_add3_u32", d); run<25>("v_cmp e64 sgpr", d); run<26>("v_fma_f32 2 srcs", d); run<27>("v_mul_f32 e64", d); run<28>("v_add_u32", d); run<29>("v_perm_b32", d);
+    run<30>("cmp vcc + cndmask vcc", d); run<31>("cmp sgpr + cndmask sgpr", d); run<32>("cndmask e64 vcc", d); run<33>("cmp vcc, 3x cndmask vcc", d);
+    run<34>("cswap: cmp vcc + 4 cndmask e32 (x5/iter)", d); run<35>("cswap: cmp sgpr + 4 cndmask e64 (x5/iter)", d);
+  run<36>("P1 cnd32vcc,add,cnd32vcc,add", d); run<37>("P2 cnd32vcc,cnd64sgpr alternating", d); run<38>("P3 cnd32vcc,s_nop alternating (2 valu/grp)", d); run<39>("P4 4x v_addc_co (vcc carry in/out)", d); run<40>("P5 4x cnd e32 vcc, distinct srcs", d); run<41>("P6 4x cnd e64 sgpr, distinct srcs", d);
+    printf("(the two cswap lines issue 5 instructions per group, not 4: multiply their figure by 4/5... i.e. cycles per GROUP = figure x 4)\n");
     return 0;
 }

@@ -29,6 +29,25 @@ namespace ptm {
 struct f3 { float x, y, z; };
 
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+
+// x / (1/(2 pi)) for three values at once (raygen.rgen:79-80 divides by the pdf as a true division).
+// For THIS divisor, q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c) equals the
+// correctly rounded quotient for every float with 2^-100 <= |x| <= 2^120: proven by enumerating all of
+// them (tests/exhaustive_div_by_pdf.c, run by the CPU test-suite); anything else takes the real divide.
+constexpr float PT_PDF = 0.15915493667125702f;   // 0x1.45f306p-3
+constexpr float PT_PDF_RCP = 6.2831854820251465f;  // RN(1 / PT_PDF) = 0x1.921fb6p+2
+__device__ __forceinline__ void div3_by_pdf(float &x, float &y, float &z)
+{
+    const float lo = fminf(fminf(fabsf(x), fabsf(y)), fabsf(z)), hi = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+    if (lo >= 0x1p-100f && hi <= 0x1p+120f) {
+        const float qx = x * PT_PDF_RCP, qy = y * PT_PDF_RCP, qz = z * PT_PDF_RCP;
+        x = __builtin_fmaf(__builtin_fmaf(-qx, PT_PDF, x), PT_PDF_RCP, qx);
+        y = __builtin_fmaf(__builtin_fmaf(-qy, PT_PDF, y), PT_PDF_RCP, qy);
+        z = __builtin_fmaf(__builtin_fmaf(-qz, PT_PDF, z), PT_PDF_RCP, qz);
+    } else {
+        x = fdiv(x, PT_PDF); y = fdiv(y, PT_PDF); z = fdiv(z, PT_PDF);
+    }
+}
 // NOTE: __fsqrt_rn() lowers to the bare 1-ulp v_sqrt_f32 on gfx950 (ROCm 7.2); __builtin_sqrtf
 // gets the correctly rounded expansion (v_sqrt_f32 + two fma corrections), which is what the
 // canonical arithmetic requires.
@@ -128,14 +147,16 @@ __device__ __forceinline__ void primary_ray(const Camera &cam, uint32_t px, uint
 // ---- bounce: raygen.rgen:14-39 ---------------------------------------------------------
 __device__ __forceinline__ f3 sample_direction(float r1, float r2, const f3 n)
 {
-    f3 T;
-    if (fabsf(n.x) > fabsf(n.y)) {  // createCoordinateSystem, strict >
-        const float l = fsqrt(n.x * n.x + n.z * n.z);
-        T = { fdiv(n.z, l), fdiv(0.0f, l), fdiv(-n.x, l) };
-    } else {
-        const float l = fsqrt(n.y * n.y + n.z * n.z);
-        T = { fdiv(0.0f, l), fdiv(-n.z, l), fdiv(n.y, l) };
-    }
+    // createCoordinateSystem (strict >): Nt = normalize(n.z, 0, -n.x) or normalize(0, -n.z, n.y).  Both
+    // branches are sqrt(p*p + q*q) and the quotients q/l, p/l with (p, q) = (n.x, n.z) or (n.y, n.z), so
+    // they are taken once and placed by selects -- same operands, same bits, no divergent second pass.
+    // (-p)/l == -(p/l) exactly; 0/l is +0 for l > 0 and NaN otherwise (l is a square root: never < 0).
+    const bool bx = fabsf(n.x) > fabsf(n.y);
+    const float p = bx ? n.x : n.y, q = n.z;
+    const float l = fsqrt(p * p + q * q);
+    const float ql = fdiv(q, l), pl = fdiv(p, l);
+    const float zl = l > 0.0f ? 0.0f : __builtin_nanf("");
+    const f3 T = { bx ? ql : zl, bx ? zl : -ql, bx ? -pl : pl };
     const f3 B = { n.y * T.z - n.z * T.y, n.z * T.x - n.x * T.z, n.x * T.y - n.y * T.x };
     const float sq = fsqrt(1.0f - r1 * r1);  // uniform hemisphere, pdf 1/(2*pi)
     const float phi = 6.2831854820251465f * r2;

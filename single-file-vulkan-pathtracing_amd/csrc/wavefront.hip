@@ -834,9 +834,11 @@ __global__ __launch_bounds__(TB) void k_shade(RenderConst rc, const uint32_t *__
                     dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
                     const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
                     // raygen.rgen:79-80: weight *= brdf * dot / pdf, pdf = 1/(2*pi) as a true divide
-                    wr = wr * ptm::fdiv(s0.w * dt, 0.15915493667125702f);
-                    wg = wg * ptm::fdiv(s1.x * dt, 0.15915493667125702f);
-                    wb = wb * ptm::fdiv(s1.y * dt, 0.15915493667125702f);
+                    float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
+                    ptm::div3_by_pdf(fr, fg, fb);
+                    wr = wr * fr;
+                    wg = wg * fg;
+                    wb = wb * fb;
                 }
             }
             if (terminated) {
