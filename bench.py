@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--sample-groups", type=int, default=0)
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm"], default="auto", help="closest-hit kernel variant")
+    ap.add_argument("--bvh-quality", choices=["fast_trace", "fast_build"], default="fast_trace",
+                    help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,6 +119,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = pt.Context(local_rank, stream=stream.cuda_stream)
     scene = pt.Scene(ctx, *arrays)          # upload + on-device LBVH build (untimed, reported apart)
+    if args.bvh_quality == "fast_build":
+        scene.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)
     if args.config == "c4":
         t0 = time.perf_counter()
         scene.set_instances(pt.cornell_grid_instances())      # TLAS build on device
@@ -196,7 +200,9 @@ def main():
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
-                    "build_ms": round(info.build_ms, 3), "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant, str(st.extend_variant))},
+                    "build_ms": round(info.build_ms, 3), "bvh4_nodes": info.n_wide_nodes,
+                    "bvh4_builder": ["collapsed LBVH", "surface-area sweep (<= 2048 triangles, ePreferFastTrace)"][info.bvh4_builder],
+                    "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant, str(st.extend_variant))},
         }
         if rays_minmax:
             out["rays_per_rank_min_max"] = rays_minmax

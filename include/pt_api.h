@@ -77,18 +77,28 @@ typedef struct pt_scene_info {
     uint32_t n_instances;     /* 0 = single-level scene                                           */
     uint32_t n_tlas_nodes;    /* BVH4 nodes of the TLAS                                           */
     uint32_t leaf_max;        /* triangles per BVH4 leaf of the collapse rule (bvh4 read-back)    */
+    uint32_t bvh4_builder;    /* which BVH4 is traversed: 0 collapsed LBVH, 1 surface-area sweep   */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
     uint64_t device_bytes;    /* resident scene + BVH bytes                                     */
 } pt_scene_info;
 pt_status pt_scene_get_info(const pt_scene *scene, pt_scene_info *info);
 
+/* Build quality, the counterpart of vk::BuildAccelerationStructureFlagBitsKHR (main.cpp:419 passes
+ * ePreferFastTrace, which is the default here too).  FAST_TRACE: scenes of <= 2048 triangles get their
+ * BVH4 from a surface-area sweep (host, microseconds) instead of the collapsed device LBVH -- about
+ * 1/6 less traversal work on the Cornell box; larger scenes keep the LBVH either way.  FAST_BUILD: always
+ * the collapsed LBVH.  Hit records and images do not depend on the choice (closest t, lowest
+ * primitive id).  Call before pt_scene_set_instances.                                          */
+typedef enum pt_bvh_quality { PT_BVH_PREFER_FAST_TRACE = 0, PT_BVH_PREFER_FAST_BUILD = 1 } pt_bvh_quality;
+pt_status pt_scene_set_bvh_quality(pt_scene *scene, uint32_t quality);
+
 /* Debug/parity read-back of the device-built LBVH.  keys/prim_of_pos: n_tris entries each;
  * nodes16: n_nodes x 16 dwords {lmin[3] lmax[3] rmin[3] rmax[3] left right 0 0}, child bit31 =
  * leaf (sorted position).  Any pointer may be NULL.                                         */
 pt_status pt_scene_read_bvh(const pt_scene *scene, uint64_t *keys, uint32_t *prim_of_pos,
                             uint32_t *nodes16);
-/* The BVH4 collapsed from it: n_wide_nodes x 32 dwords {lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
+/* The BVH4 that is traversed (collapsed from that LBVH, or the surface-area one): n_wide_nodes x 32 dwords {lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
  * hi.z[4] child[4] 0[4]}; child = 0xFFFFFFFF empty | node index | bit31: leaf,
  * (count-1)<<28 | first sorted position.                                                     */
 pt_status pt_scene_read_bvh4(const pt_scene *scene, uint32_t *nodes32);

@@ -30,6 +30,7 @@ FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4
 EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM = 0, 1, 2, 3
+BVH_PREFER_FAST_TRACE, BVH_PREFER_FAST_BUILD = 0, 1
 EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4 (collapsed LBVH), scene staged in LDS", 3: "BVH4 (collapsed LBVH), scene in HBM/L2"}
 MISS = 0xFFFFFFFF
 
@@ -54,7 +55,7 @@ class Params(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_height", C.c_uint32),
                 ("n_wide_nodes", C.c_uint32), ("n_instances", C.c_uint32), ("n_tlas_nodes", C.c_uint32),
-                ("leaf_max", C.c_uint32),
+                ("leaf_max", C.c_uint32), ("bvh4_builder", C.c_uint32),
                 ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
                 ("device_bytes", C.c_uint64)]
 
@@ -76,7 +77,7 @@ HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"),
 
 # every symbol include/pt_api.h and include/pt_host.h declare
 API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "pt_scene_create", "pt_scene_destroy",
-               "pt_scene_set_instances",
+               "pt_scene_set_instances", "pt_scene_set_bvh_quality",
                "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_film_create", "pt_film_create_external", "pt_film_clear",
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render",
                "pt_render_prepare", "pt_trace",
@@ -113,6 +114,7 @@ def lib_amd():
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None
         L.pt_scene_set_instances.argtypes = [vp, vp, C.c_uint32]
+        L.pt_scene_set_bvh_quality.argtypes = [vp, C.c_uint32]
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.pt_scene_read_bvh.argtypes = [vp, vp, vp, vp]
         L.pt_scene_read_bvh4.argtypes = [vp, vp]
@@ -275,6 +277,10 @@ class Scene:
         single identity instance (main.cpp:515-538)."""
         x = np.ascontiguousarray(xforms3x4, dtype=np.float32).reshape(-1, 12)
         self.ctx._check(lib_amd().pt_scene_set_instances(self.h, x.ctypes.data if len(x) else None, len(x)))
+
+    def set_bvh_quality(self, quality):
+        """BVH_PREFER_FAST_TRACE (default; main.cpp:419) or BVH_PREFER_FAST_BUILD (always the collapsed LBVH)."""
+        self.ctx._check(lib_amd().pt_scene_set_bvh_quality(self.h, quality))
 
     def info(self):
         i = SceneInfo()

@@ -502,6 +502,7 @@ struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)); }
+    T *release() { T *q = p; p = nullptr; return q; }
 };
 
 }  // namespace
@@ -516,22 +517,6 @@ struct BvhOut {
     uint32_t stack_need = 0;               // most entries a depth-first walk of the BVH4 can have pending
     float bmin[3]{}, bmax[3]{};
 };
-
-// Exact traversal-stack bound of a small BVH4: a node with k children pushes at most k-1 of them
-// before descending, so need(node) = k-1 + max over internal children.  Lets the extend kernel of
-// LDS-resident scenes run without the spill path (and its branches) at all.
-static uint32_t wide_stack_need(const std::vector<uint32_t> &w, uint32_t node, uint32_t depth)
-{
-    if (depth > 64) return 1u << 20;  // malformed: forces the spilling variant
-    uint32_t k = 0, deepest = 0;
-    for (int c = 0; c < 4; c++) {
-        const uint32_t word = w[32 * (size_t)node + 24 + c];
-        if (word == 0xFFFFFFFFu) continue;
-        k++;
-        if (!(word & PT_LEAF)) deepest = std::max(deepest, wide_stack_need(w, word, depth + 1));
-    }
-    return (k ? k - 1 : 0) + deepest;
-}
 
 __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n,
                                                uint32_t *__restrict__ scene_ord)
@@ -649,7 +634,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         std::vector<uint32_t> h_wide(32 * (size_t)n_wide);
         PT_HIP(ctx, hipMemcpyAsync(h_wide.data(), out.d_wide, 128 * (size_t)n_wide, hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
-        out.stack_need = wide_stack_need(h_wide, 0, 0);
+        out.stack_need = pt_wide_stack_need(h_wide);
     }
     uint32_t ord[6];
     PT_HIP(ctx, hipMemcpyAsync(ord, d_scene.p, sizeof(ord), hipMemcpyDeviceToHost, st));
@@ -700,8 +685,75 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
+    s->d_wide_lbvh = s->d_wide; s->n_wide_lbvh = s->n_wide; s->stack_need_lbvh = s->stack_need;
+    s->bvh4_builder = 0;
+    s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
+    if (n <= PT_SAH_MAX_TRIS) {
+        // small scene: keep what a rebuild of the BVH4 in another leaf order needs, then apply the default
+        // quality (ePreferFastTrace, main.cpp:419)
+        std::vector<float4> lo(n), hi(n);
+        PT_HIP(ctx, hipMemcpy(lo.data(), d_tlo.p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+        PT_HIP(ctx, hipMemcpy(hi.data(), d_thi.p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+        s->h_tlo.resize(3 * (size_t)n);
+        s->h_thi.resize(3 * (size_t)n);
+        for (uint32_t i = 0; i < n; i++) {
+            s->h_tlo[3 * i + 0] = lo[i].x; s->h_tlo[3 * i + 1] = lo[i].y; s->h_tlo[3 * i + 2] = lo[i].z;
+            s->h_thi[3 * i + 0] = hi[i].x; s->h_thi[3 * i + 1] = hi[i].y; s->h_thi[3 * i + 2] = hi[i].z;
+        }
+        s->d_tri_orig = d_tri_orig.release();
+        s->d_faces = d_faces.release();
+        return ptb_set_bvh_quality(s, PT_BVH_PREFER_FAST_TRACE);
+    }
+    return PT_OK;
+}
+
+// Chooses the BVH4 that is traversed (pt_internal.h).  Re-packs the per-triangle tables in its leaf order.
+pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
+{
+    pt_ctx *ctx = s->ctx;
+    if (quality > PT_BVH_PREFER_FAST_BUILD) { ctx->err = "unknown BVH quality"; return PT_ERR_INVALID_ARG; }
+    if (s->n_inst) { ctx->err = "set the BVH quality before the instances"; return PT_ERR_UNSUPPORTED; }
+    const bool want_sah = quality == PT_BVH_PREFER_FAST_TRACE && s->n_tris <= PT_SAH_MAX_TRIS && s->d_tri_orig;
+    if (want_sah == (s->bvh4_builder == 1u)) return PT_OK;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = s->n_tris;
+    if (want_sah && !s->d_wide_sah) {
+        float scale = 0.f;  // leaf_pad() of the device build, same float operations
+        for (int k = 0; k < 3; k++) scale = fmaxf(scale, fmaxf(fabsf(s->bmin[k]), fabsf(s->bmax[k])));
+        const float pad = scale * 3.814697265625e-06f;
+        std::vector<uint32_t> rows, order;
+        pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pad, PT_BLAS_LEAF_MAX, rows, order);
+        if (order.size() != n || rows.empty()) { ctx->err = "internal: SAH build lost triangles"; return PT_ERR_HIP; }
+        s->n_wide_sah = (uint32_t)(rows.size() / 32);
+        s->stack_need_sah = pt_wide_stack_need(rows);
+        PT_HIP(ctx, hipMalloc((void **)&s->d_wide_sah, rows.size() * sizeof(uint32_t)));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of_sah, sizeof(uint32_t) * n));
+        PT_HIP(ctx, hipMemcpy(s->d_wide_sah, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        PT_HIP(ctx, hipMemcpy(s->d_prim_of_sah, order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    }
+    PT_HIP(ctx, hipStreamSynchronize(st));  // nothing may still be traversing the old tables
+    if (want_sah) {
+        s->d_wide = s->d_wide_sah; s->n_wide = s->n_wide_sah; s->stack_need = s->stack_need_sah; s->bvh4_builder = 1;
+    } else {
+        s->d_wide = s->d_wide_lbvh; s->n_wide = s->n_wide_lbvh; s->stack_need = s->stack_need_lbvh; s->bvh4_builder = 0;
+    }
+    k_pack<<<(n + TB - 1) / TB, TB, 0, st>>>(s->d_tri_orig, s->d_faces, want_sah ? s->d_prim_of_sah : s->d_prim_of, n, s->d_tri4,
+                                           s->d_shade4);
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
     s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
     return PT_OK;
+}
+
+void ptb_free_scene_buffers(pt_scene *s)
+{
+    (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_wide_lbvh ? s->d_wide_lbvh : s->d_wide);  // d_wide aliases d_wide_lbvh or d_wide_sah
+    (void)hipFree(s->d_wide_sah); (void)hipFree(s->d_prim_of_sah);
+    (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
+    (void)hipFree(s->d_tri_orig); (void)hipFree(s->d_faces);
+    s->d_tri4 = s->d_shade4 = s->d_nodes = s->d_wide = s->d_wide_lbvh = s->d_wide_sah = s->d_tri_orig = nullptr;
+    s->d_prim_of_sah = s->d_prim_of = nullptr; s->d_keys = nullptr; s->d_faces = nullptr;
 }
 
 // ---- instances: TLAS over world boxes of the transformed BLAS root box --------------------------

@@ -109,9 +109,15 @@ void pt_scene_destroy(pt_scene *s)
 {
     if (!s) return;
     ptb_free_instances(s);
-    (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes); (void)hipFree(s->d_wide);
-    (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
+    ptb_free_scene_buffers(s);
     delete s;
+}
+
+pt_status pt_scene_set_bvh_quality(pt_scene *s, uint32_t quality)
+{
+    if (!s) return PT_ERR_INVALID_ARG;
+    PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return ptb_set_bvh_quality(s, quality);
 }
 
 pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
@@ -122,6 +128,7 @@ pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
     info->n_instances = s->n_inst;
     info->n_tlas_nodes = s->n_tlas_wide;
     info->leaf_max = PT_BLAS_LEAF_MAX;
+    info->bvh4_builder = s->bvh4_builder;
     for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
     info->build_ms = s->build_ms;
     info->device_bytes = s->device_bytes;

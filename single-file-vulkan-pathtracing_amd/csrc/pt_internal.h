@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/pt_api.h"
 
@@ -45,6 +46,17 @@ struct pt_scene {
     float4 *d_wide = nullptr;             // BVH4, 8 x float4 = 128 B per node: what traversal walks
     uint32_t n_wide = 0;
     uint32_t stack_need = 0xFFFFFFFFu;    // exact bound of pending traversal-stack entries (small scenes), else unknown
+    // BVH quality (main.cpp:419 asks the driver for ePreferFastTrace).  d_wide / n_wide / stack_need above and
+    // the order of tri4/shade4 describe the BVH4 that is TRAVERSED: the collapsed LBVH (builder 0) or, for
+    // scenes of <= PT_SAH_MAX_TRIS triangles, a surface-area sweep built on the host (builder 1, bvh4_sah.hip).
+    // d_wide aliases one of the two owned arrays below.
+    uint32_t bvh4_builder = 0;
+    float4 *d_wide_lbvh = nullptr; uint32_t n_wide_lbvh = 0, stack_need_lbvh = 0xFFFFFFFFu;
+    float4 *d_wide_sah = nullptr;  uint32_t n_wide_sah = 0, stack_need_sah = 0xFFFFFFFFu;
+    uint32_t *d_prim_of_sah = nullptr;      // leaf order of the SAH BVH4 (position -> prim id)
+    float4 *d_tri_orig = nullptr;           // small scenes keep the unsorted triangles + materials so the
+    float *d_faces = nullptr;               // per-triangle tables can be re-packed in another leaf order
+    std::vector<float> h_tlo, h_thi;        // small scenes: unpadded triangle boxes (3 floats each)
     unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
     uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
     uint64_t device_bytes = 0;
@@ -97,6 +109,13 @@ struct pt_film {
 pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
                           uint32_t n_tris, const float *h_faces);
 pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
+pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality);
+void ptb_free_scene_buffers(pt_scene *s);
+constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
+// bvh4_sah.hip: host surface-area sweep -> BVH4 rows (32 dwords each) + leaf order
+void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, float pad, uint32_t leaf_max,
+                       std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
+uint32_t pt_wide_stack_need(const std::vector<uint32_t> &rows32);
 void ptb_free_instances(pt_scene *s);
 // wavefront.hip
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);

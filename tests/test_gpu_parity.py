@@ -145,6 +145,8 @@ def _collapse_reference(nodes, n_tris, leaf_max=4):
 def test_bvh4_collapse_matches_reference_rule(pt, orc, gpu_ctx, n, seed):
     v, i, f = _soup(n, seed)
     gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    gs.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)   # the collapsed LBVH (small scenes default to the SAH BVH4)
+    assert gs.info().bvh4_builder == 0
     wide = gs.read_bvh4()
     if n == 1:
         assert wide.shape[0] == 1 and wide[0, 24] == 0x80000000 and (wide[0, 25:28] == 0xFFFFFFFF).all()
@@ -163,10 +165,73 @@ def test_bvh4_collapse_matches_reference_rule(pt, orc, gpu_ctx, n, seed):
     gs.close()
 
 
-def test_bvh4_cornell(pt, orc, cornell_gpu, cornell_oracle):
-    wide = cornell_gpu.read_bvh4()
-    assert wide.tobytes() == _collapse_reference(cornell_oracle.bvh_nodes(), 36, leaf_max=cornell_gpu.info().leaf_max).tobytes()
-    assert cornell_gpu.info().n_wide_nodes == wide.shape[0] <= 18
+def test_bvh4_cornell(pt, orc, gpu_ctx, cornell_arrays, cornell_oracle):
+    sc = pt.Scene(gpu_ctx, *cornell_arrays)
+    assert sc.info().bvh4_builder == 1             # default = ePreferFastTrace (main.cpp:419): surface-area BVH4
+    sc.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)
+    wide = sc.read_bvh4()
+    assert wide.tobytes() == _collapse_reference(cornell_oracle.bvh_nodes(), 36, leaf_max=sc.info().leaf_max).tobytes()
+    assert sc.info().n_wide_nodes == wide.shape[0] <= 18 and sc.info().bvh4_builder == 0
+    sc.close()
+
+
+def _leaf_cover(wide, n):
+    words = wide[:, 24:28].ravel()
+    leaves = words[(words != 0xFFFFFFFF) & (words & 0x80000000 != 0)]
+    seen = np.zeros(n, np.int64)
+    for w in leaves:
+        first, cnt = int(w & 0x0FFFFFFF), int((w >> 28) & 7) + 1
+        seen[first:first + cnt] += 1
+    return seen
+
+
+@pytest.mark.parametrize("n,seed", [(0, 0), (1, 1), (2, 2), (3, 3), (7, 4), (100, 5), (2048, 6), (2049, 7)])
+def test_fast_trace_bvh4_is_a_valid_tree_and_changes_no_hit(pt, orc, gpu_ctx, cornell_arrays, n, seed):
+    """pt_scene_set_bvh_quality: the surface-area BVH4 of small scenes (n = 0 here is the Cornell box) covers
+    every triangle exactly once, is reachable from node 0, and returns the oracle's hits -- as does the
+    collapsed LBVH after switching back.  Above 2048 triangles both qualities are the LBVH."""
+    v, i, f = cornell_arrays if n == 0 else _soup(n, seed, spread=0.3)
+    nt = len(i) // 3
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    assert gs.info().bvh4_builder == (1 if nt <= 2048 else 0)
+    rng = np.random.default_rng(seed)
+    rays = np.concatenate([rng.uniform(-1.2, 1.2, (30000, 3)), rng.normal(size=(30000, 3))], axis=1).astype(np.float32)
+    want, _ = osc.trace(rays)
+    for quality in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD, pt.BVH_PREFER_FAST_TRACE):
+        gs.set_bvh_quality(quality)
+        info = gs.info()
+        assert info.bvh4_builder == (1 if quality == pt.BVH_PREFER_FAST_TRACE and nt <= 2048 else 0)
+        wide = gs.read_bvh4()
+        assert wide.shape[0] == info.n_wide_nodes
+        assert (_leaf_cover(wide, nt) == 1).all()
+        words = wide[:, 24:28]
+        kids = words[(words != 0xFFFFFFFF) & (words & 0x80000000 == 0)]
+        assert sorted(kids.tolist()) == list(range(1, wide.shape[0]))      # every node but the root has one parent
+        fl = wide.view(np.float32)
+        used = words != 0xFFFFFFFF
+        for ax in range(3):
+            assert (fl[:, 4 * ax:4 * ax + 4][used] <= fl[:, 12 + 4 * ax:16 + 4 * ax][used]).all()
+            assert np.isinf(fl[:, 4 * ax:4 * ax + 4][~used]).all()
+        for extend in (pt.EXTEND_AUTO, pt.EXTEND_HBM):
+            assert gs.trace(rays, extend=extend).tobytes() == want.tobytes(), (n, quality, extend)
+    with pytest.raises(pt.PtError):
+        gs.set_bvh_quality(7)
+    gs.close()
+
+
+def test_fast_trace_bvh4_saves_traversal_work_on_the_cornell_box(pt, gpu_ctx, cornell_arrays):
+    sc, film = pt.Scene(gpu_ctx, *cornell_arrays), pt.Film(gpu_ctx, 320, 180)
+    work, films = [], []
+    for quality in (pt.BVH_PREFER_FAST_BUILD, pt.BVH_PREFER_FAST_TRACE):
+        sc.set_bvh_quality(quality)
+        film.clear(); gpu_ctx.reset_stats()
+        pt.render(sc, film, pt.default_params(width=320, height=180, spp_per_frame=8, max_depth=8, flags=pt.FLAG_COUNT_VISITS))
+        st = gpu_ctx.stats()
+        work.append((100 * st.nodes_visited + 60 * st.tris_tested) / st.rays)
+        films.append(film.read_f32().tobytes())
+    assert films[0] == films[1]
+    assert work[1] < 0.9 * work[0], work
+    sc.close(); film.close()
 
 
 def test_trace_primary_rays_bit_exact(pt, orc, cornell_gpu, cornell_oracle):
@@ -713,6 +778,7 @@ def test_small_scenes_every_stack_regime_bit_exact(pt, orc, gpu_ctx, kind):
     spills past 12.  All of them must return the oracle's hits and film."""
     v, i, f = _octave_chain(19, 6, 5) if kind == "chain" else _soup(int(kind[4:]), len(kind), spread=0.3)
     gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    gs.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)         # the LBVH of the chain is the deep one
     need = _stack_need(_collapse_reference(osc.bvh_nodes(), osc.n_tris, leaf_max=2))
     assert (need > 16) == (kind == "chain"), need      # the chain is what exercises LDS + spill
     rng = np.random.default_rng(7)

@@ -113,7 +113,7 @@ def test_struct_layouts_match_header(pt):
     import ctypes as C
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
     assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2
-    assert C.sizeof(pt.SceneInfo) == 4 * 7 + 4 * 6 + 4 + 8
+    assert C.sizeof(pt.SceneInfo) == 4 * 8 + 4 * 6 + 4 + 4 + 8  # one pad dword before the u64
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
     assert list(p.cam_origin) == [0.0, -1.0, 5.0] and list(p.cam_target) == [0.0, -1.0, 2.0]
@@ -146,6 +146,7 @@ def test_abi_is_null_safe_without_a_gpu(pt):
     assert L.pt_sync(None) == 1
     assert L.pt_scene_create(None, None, 0, None, 0, None, C.byref(out)) == 1
     assert L.pt_scene_set_instances(None, None, 0) == 1
+    assert L.pt_scene_set_bvh_quality(None, 0) == 1
     assert L.pt_scene_get_info(None, None) == 1
     assert L.pt_scene_read_bvh(None, None, None, None) == 1
     assert L.pt_scene_read_bvh4(None, None) == 1
