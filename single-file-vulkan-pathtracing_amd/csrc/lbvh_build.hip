@@ -722,7 +722,7 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
         for (int k = 0; k < 3; k++) scale = fmaxf(scale, fmaxf(fabsf(s->bmin[k]), fabsf(s->bmax[k])));
         const float pad = scale * 3.814697265625e-06f;
         std::vector<uint32_t> rows, order;
-        pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pad, PT_BLAS_LEAF_MAX, rows, order);
+        pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pad, PT_SAH_LEAF_MAX, rows, order);
         if (order.size() != n || rows.empty()) { ctx->err = "internal: SAH build lost triangles"; return PT_ERR_HIP; }
         s->n_wide_sah = (uint32_t)(rows.size() / 32);
         s->stack_need_sah = pt_wide_stack_need(rows);
