@@ -221,6 +221,7 @@ def main():
         # traversal work per ray, counted by an instrumented build of the same kernel on the same
         # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
         nodes_per_ray = tris_per_ray = 0.0
+        node_occ = tri_occ = None
         frame0_rays_gpu = None
         if st.extend_variant != pt.EXTEND_FLAT:
             ctx.reset_stats()
@@ -229,6 +230,8 @@ def main():
             cst = ctx.stats()
             nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
             tris_per_ray = cst.tris_tested / max(cst.rays, 1)
+            node_occ = cst.nodes_visited / (64.0 * cst.node_steps) if cst.node_steps else None
+            tri_occ = cst.tris_tested / (64.0 * cst.tri_steps) if cst.tri_steps else None
             frame0_rays_gpu = cst.rays
             scratch.close()
         if flags and st.launches_extend and st.ms_extend > 0:
@@ -260,6 +263,8 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
                 "algorithmic_bytes_per_ray": round(bytes_extend, 1),
                 "gather": {"bvh4_nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                           "lane_occupancy_node_steps": round(node_occ, 3) if node_occ else None,
+                           "lane_occupancy_triangle_steps": round(tri_occ, 3) if tri_occ else None,
                            "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
                            "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
                 "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),

@@ -191,6 +191,10 @@ typedef struct pt_stats {
     uint64_t tris_tested;      /* triangles tested                -- only with PT_FLAG_COUNT_VISITS  */
     uint32_t frames_in_flight; /* shape of the last pt_render / pt_render_prepare                    */
     uint32_t sample_groups;
+    /* wave64 steps of the single-level extend kernel (PT_FLAG_COUNT_VISITS): how often a WAVE ran the node
+     * code / the triangle code.  nodes_visited / (64 * node_steps) is the lane occupancy of the node phase,
+     * tris_tested / (64 * tri_steps) that of the triangle tests.                                        */
+    uint64_t node_steps, tri_steps;
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

@@ -65,7 +65,8 @@ class Stats(C.Structure):
                 ("launches_extend", C.c_uint32), ("launches_shade", C.c_uint32), ("launches_other", C.c_uint32),
                 ("ms_total", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float),
                 ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("frames_in_flight", C.c_uint32), ("sample_groups", C.c_uint32)]
+                ("frames_in_flight", C.c_uint32), ("sample_groups", C.c_uint32),
+                ("node_steps", C.c_uint64), ("tri_steps", C.c_uint64)]
 
 
 class HostScene(C.Structure):

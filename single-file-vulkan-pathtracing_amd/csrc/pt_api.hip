@@ -44,8 +44,8 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     }
     if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return fail("hipEventCreate", e);
-    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * 4)) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 4)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * 8)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8)) != hipSuccess) return fail("hipMemset", e);
     *out = ctx;
     return PT_OK;
 }
@@ -266,12 +266,14 @@ pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, floa
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
 {
     if (!ctx || !out) return PT_ERR_INVALID_ARG;
-    unsigned long long h[4];
+    unsigned long long h[8];
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     ctx->stats.rays = h[0];
     ctx->stats.nodes_visited = h[2];
     ctx->stats.tris_tested = h[3];
+    ctx->stats.node_steps = h[4];
+    ctx->stats.tri_steps = h[5];
     *out = ctx->stats;
     return PT_OK;
 }
@@ -280,7 +282,7 @@ pt_status pt_reset_stats(pt_ctx *ctx)
 {
     if (!ctx) return PT_ERR_INVALID_ARG;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 4));
+    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8));
     ctx->stats = pt_stats{};
     return PT_OK;
 }

@@ -25,7 +25,7 @@ struct pt_ctx {
     bool own_stream = false;
     int num_cus = 256;
     std::string err;
-    // statistics block in device memory (u64 x 4): [0] rays, [1] unused, [2] BVH4 nodes visited, [3] triangles tested
+    // statistics block in device memory (u64 x 8): [0] rays, [1] unused, [2] BVH4 nodes visited, [3] triangles tested, [4] wave steps of the node code, [5] of the triangle code
     unsigned long long *d_stats = nullptr;
     pt_stats stats{};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
     uint32_t cur = SENTINEL;
     int sp = 0;
-    unsigned long long c_nodes = 0, c_tris = 0;
+    unsigned long long c_nodes = 0, c_tris = 0, c_node_steps = 0, c_tri_steps = 0;
 
     auto push = [&](uint32_t w, float t) {
         const unsigned long long e = stack_entry(w, t);
@@ -384,7 +384,10 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         while (have && !(cur & PT_LEAF)) {
             const float4 *nd = wide + (LDS_SCENE ? LDS_NODE_F4 : 8u) * (size_t)cur;
             PT_NODE_LOAD(nd)
-            if (COUNT) c_nodes++;
+            if (COUNT) {
+                c_nodes++;
+                if (lane == __ffsll((long long)__ballot(1)) - 1) c_node_steps++;  // one lane per wave step
+            }
             float t0, t1, t2, t3;
             uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
                      w3 = __float_as_uint(cw.w);
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                 const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
                 if (COUNT) c_tris += cnt;
                 for (uint32_t k = 0; k < cnt; k++) {
+                    if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) c_tri_steps++;
                     const uint32_t pos = first + k;
                     const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : 3 * (size_t)pos;
                     const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
@@ -448,10 +452,14 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         for (int o = 32; o > 0; o >>= 1) {
             c_nodes += __shfl_xor(c_nodes, o, 64);
             c_tris += __shfl_xor(c_tris, o, 64);
+            c_node_steps += __shfl_xor(c_node_steps, o, 64);
+            c_tri_steps += __shfl_xor(c_tri_steps, o, 64);
         }
         if (lane == 0 && stats) {
             atomicAdd(stats + 2, c_nodes);
             atomicAdd(stats + 3, c_tris);
+            atomicAdd(stats + 4, c_node_steps);
+            atomicAdd(stats + 5, c_tri_steps);
         }
     }
 }
