@@ -23,5 +23,7 @@ run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 python scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep the merge small: drop the big per-dispatch CSVs except stats
-find $OUT -name "*.csv" -size +8M -delete
+# keep the merge small (gpurun merges <= 64 MiB back): only the kernel-stats CSV and the summaries stay
+find $OUT -name "*.csv" ! -name "*kernel_stats.csv" -delete
+find $OUT -name "*.db" -delete
 du -sh $OUT

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""dev tool: condense a scripts/gpu_profile.sh directory into the small per-config PMC record that bench.py
+reads (profiles/r01_pmc_extend*.json).  usage: make_pmc_json.py <prof dir> <out json> [config args string]
+Formulas: HBM bytes = 2 x FETCH_SIZE KiB (gfx950 read correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB;
+VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz, rocprofv3 --stats average);
+wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; L2 hit = TCC_HIT / TCC_REQ."""
+import json
+import os
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else ""
+s = json.load(open(os.path.join(root, "summary.json")))
+bench = None
+for line in open(os.path.join(root, "stats.log")):
+    if line.startswith("{") and '"metric"' in line:
+        bench = json.loads(line)
+# dominant extend kernel of the timed region = the non-counting instantiation with most total time
+cands = {k: v for k, v in s["kernels"].items() if k.startswith("k_extend") and ", true" not in k.split("<")[1][5:10]}
+name = max((k for k in s["kernels"] if k.startswith("k_extend")), key=lambda k: s["kernels"][k]["total_ns"])
+e, kt = s["pmc"][name], s["kernels"][name]
+pl = lambda c: e[c + "_per_launch"]
+rays_per_launch = bench["rays"] / bench["roofline"]["launches"]
+avg_us = kt["avg_ns"] / 1e3
+rec = {
+    "kernel": name, "config": cfg,
+    "source": f"{os.path.basename(root.rstrip('/'))}: rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set "
+              f"(scripts/gpu_profile.sh) on `python bench.py {cfg} --warmup 0 --no-cpu-baseline`",
+    "launches": kt["calls"], "rays_per_launch_in_profile_run": rays_per_launch,
+    "rocprof_avg_launch_us": avg_us, "bench_hipext_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"],
+    "fetch_size_kib_per_launch": pl("FETCH_SIZE"), "write_size_kib_per_launch": pl("WRITE_SIZE"),
+    "hbm_read_bytes_per_launch_x2_gfx950": e["hbm_read_bytes_per_launch_gfx950_x2"],
+    "hbm_write_bytes_per_launch": e["hbm_write_bytes_per_launch"], "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+    "hbm_bytes_per_ray": e["hbm_bytes_per_launch"] / rays_per_launch,
+    "valu_busy_fraction": pl("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * avg_us * 2400.0),
+    "valu_wave_instr_per_64_rays": pl("SQ_INSTS_VALU") / (rays_per_launch / 64.0),
+    "valu_active_lanes_per_instr": pl("SQ_THREAD_CYCLES_VALU") / pl("SQ_INSTS_VALU"),
+    "wait_any_fraction_of_wave_cycles": pl("SQ_WAIT_ANY") / pl("SQ_WAVE_CYCLES"),
+    "lds_bank_conflict_fraction_of_lds_cycles": (pl("SQ_LDS_BANK_CONFLICT") / pl("SQ_LDS_IDX_ACTIVE")) if pl("SQ_LDS_IDX_ACTIVE") else None,
+    "l2_hit_rate": pl("TCC_HIT_sum") / pl("TCC_REQ_sum"),
+}
+json.dump(rec, open(out, "w"), indent=1)
+print(json.dumps(rec, indent=1))

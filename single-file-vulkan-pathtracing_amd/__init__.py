@@ -31,7 +31,7 @@ FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4
 EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM = 0, 1, 2, 3
 BVH_PREFER_FAST_TRACE, BVH_PREFER_FAST_BUILD = 0, 1
-EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4 (collapsed LBVH), scene staged in LDS", 3: "BVH4 (collapsed LBVH), scene in HBM/L2"}
+EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4, scene staged in LDS", 3: "BVH4, scene in HBM/L2"}
 MISS = 0xFFFFFFFF
 
 
