@@ -88,11 +88,29 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    # PT_BENCH_EMULATE=1 (dev check of the N > 1 code path on a 1-GPU box): every rank uses GPU 0 and the
+    # collectives run over gloo on host copies.  Never used for reported numbers.
+    emulate = os.environ.get("PT_BENCH_EMULATE") == "1" and world > 1
+    if emulate:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if emulate else dev     # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def reduce_film(t):
+        if emulate:
+            h = t.cpu()
+            ptd.reduce_film(h, dst=0)
+            if rank == 0:
+                t.copy_(h)
+        else:
+            ptd.reduce_film(t, dst=0)
 
     pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
     ptd = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
@@ -151,26 +169,26 @@ def main():
         pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, **common))
         if world > 1:
             tmp = film_t.clone()
-            ptd.reduce_film(tmp, dst=0)
+            reduce_film(tmp)
     film.clear()
     ctx.reset_stats()
 
     barrier()
     t0 = time.perf_counter()
     pt.render(scene, film, timed)
-    ptd.reduce_film(film_t, dst=0)      # the one collective per presented image (no-op for N=1)
+    reduce_film(film_t)                 # the one collective per presented image (no-op for N=1)
     barrier()
     dt = time.perf_counter() - t0
 
     st = ctx.stats()
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    rays_total, paths_total = ptd.sum_counters([st.rays, st.paths], dev)
+    rays_total, paths_total = ptd.sum_counters([st.rays, st.paths], cdev)
     rays_minmax = None
     if world > 1:
-        lo = torch.tensor([st.rays], dtype=torch.int64, device=dev)
+        lo = torch.tensor([st.rays], dtype=torch.int64, device=cdev)
         hi = lo.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)

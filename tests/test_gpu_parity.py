@@ -798,3 +798,28 @@ def test_small_scenes_every_stack_regime_bit_exact(pt, orc, gpu_ctx, kind):
         assert gpu_ctx.stats().rays == orays
         film.close()
     gs.close()
+
+
+def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (per-rank tile shards, counters, one film reduce) with every rank on GPU 0 and gloo
+    on host copies (PT_BENCH_EMULATE=1): same exact ray count as N = 1 and a well-formed JSON line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(HERE)
+    args = ["--steps", "2", "--warmup", "1", "--width", "320", "--height", "184", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, PT_BENCH_EMULATE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(repo, "bench.py"),
+                          "--gpus", "2"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["steps"] == 2
+    assert j2["rays"] == j1["rays"] and j2["paths"] == j1["paths"]
+    lo, hi = j2["rays_per_rank_min_max"]
+    assert lo + hi == j2["rays"] and hi - lo < 0.02 * hi          # interleaved tiles balance the ranks
+    for k in ("metric", "value", "unit", "ms_per_step", "roofline", "config"):
+        assert k in j2
