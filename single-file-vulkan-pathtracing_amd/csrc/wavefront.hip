@@ -393,6 +393,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         // VOTE: one step per outer iteration, of the kind (node / leaf) that more lanes are waiting for
         bool do_leaf = true;
         bool do_node = have && !(cur & PT_LEAF);
+        const int n_have = __popcll(__ballot(have));
         if (VOTE) {
             const bool want_leaf = have && (cur & PT_LEAF) && cur != SENTINEL;
             const int nn = __popcll(__ballot(do_node)), nl = __popcll(__ballot(want_leaf));
@@ -432,10 +433,17 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
             if (t1 < INF) push(w1, t1);
             cur = t0 < INF ? w0 : pop();
             do_node = !VOTE && !(cur & PT_LEAF);
+            if (!VOTE) {
+                // fewer than 1/6 of the wave's rays still descending while the rest waits with a leaf: let the
+                // leaves go first, the stragglers resume in the next round of the outer loop (node-step lane
+                // occupancy 40 % -> 55 %, triangle steps 34 % -> 31 %, C2 +3 %; 1/4: +2.5 %, 1/12: +2.5 %)
+                const int n_cont = __popcll(__ballot(do_node));
+                if (n_cont * 6 < n_have) break;
+            }
         }
         // ---- leaf phase
         if (have) {
-            if (cur != SENTINEL && (!VOTE || (do_leaf && (cur & PT_LEAF)))) {
+            if (cur != SENTINEL && (cur & PT_LEAF) && (!VOTE || do_leaf)) {
                 const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
                 if (COUNT) c_tris += cnt;
                 for (uint32_t k = 0; k < cnt; k++) {
@@ -613,7 +621,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
         }
         if (__ballot(have) == 0ull) break;
 
-        // ---- node phase (either level).  (Vote-scheduled single steps as in k_extend measured -4 % here.)
+        // ---- node phase (either level).  (Vote-scheduled single steps as in k_extend measured -4 % here, leaving
+        // the node loop early when few lanes still descend +-0.)
         while (have && !(cur & PT_LEAF)) {
             float4 nx, fx, ny, fy, nz, fz, cw;
             if (LDS_BLAS && in_blas) {
