@@ -65,6 +65,7 @@ struct RenderConst {
     uint32_t group_size;       // samples per group: group g runs samples [g*group_size, min(spp, (g+1)*group_size))
     uint32_t term_cap;         // radiance-term log capacity per slot = group_size * max_depth (groups > 1)
     uint32_t term_pcap;        // entries of it kept in the dense primary log (the rest is the overflow log)
+    uint32_t n_slots;          // all slots of this render (the primary log is term-major: [term_pcap][n_slots])
     FastDiv div_spl, div_groups;  // slot -> frame lane / sample group without integer divides
 };
 
@@ -74,7 +75,8 @@ struct RenderConst {
 // the same float adds in the same order as the reference's single `color`, still bit-exact.
 struct Radiance {
     float4 *color;     // [n_slots]              (groups == 1)
-    float4 *terms;     // primary log [n_slots][term_pcap], rgb + pad (groups > 1): dense, typical use
+    float4 *terms;     // primary log [term_pcap][n_slots], rgb + pad (groups > 1): neighbouring slots write their
+                       // k-th term side by side (slot-major rows measured 20 % slower in k_shade)
     float4 *terms_over;  // overflow log [n_slots][term_cap - term_pcap]: worst case, rarely touched
     uint32_t *nterm;   // [n_slots]              (groups > 1)
 };
@@ -90,7 +92,7 @@ __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radian
         rad.color[slot] = c;
     } else {
         const uint32_t k = rad.nterm[slot];
-        if (k < rc.term_pcap) rad.terms[(size_t)slot * rc.term_pcap + k] = make_float4(r, g, b, 0.f);
+        if (k < rc.term_pcap) rad.terms[(size_t)k * rc.n_slots + slot] = make_float4(r, g, b, 0.f);
         else rad.terms_over[(size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)] = make_float4(r, g, b, 0.f);
         rad.nterm[slot] = k + 1u;
     }
@@ -940,10 +942,9 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
             for (uint32_t g = 0; g < rc.groups; g++) {
                 const size_t slot = ((size_t)f * rc.groups + g) * rc.slots_per_lane + local;
                 const uint32_t nt = rad.nterm[slot];
-                const float4 *t = rad.terms + slot * rc.term_pcap;
                 const float4 *to = rad.terms_over + slot * (rc.term_cap - rc.term_pcap);
                 for (uint32_t k = 0; k < nt; k++) {
-                    const float4 e = k < rc.term_pcap ? t[k] : to[k - rc.term_pcap];
+                    const float4 e = k < rc.term_pcap ? rad.terms[(size_t)k * rc.n_slots + slot] : to[k - rc.term_pcap];
                     c.x = c.x + e.x;
                     c.y = c.y + e.y;
                     c.z = c.z + e.z;
@@ -1327,6 +1328,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     rc.groups = groups; rc.group_size = group_size; rc.term_cap = term_cap;
     rc.div_spl.init(std::max(rc.slots_per_lane, 1u)); rc.div_groups.init(std::max(groups, 1u));
     rc.term_pcap = sh.term_pcap;
+    rc.n_slots = w.n_slots;
 
     const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
