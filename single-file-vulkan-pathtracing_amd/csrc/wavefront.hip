@@ -1235,9 +1235,13 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
                 const double r = d > want ? d / want : want / d;
                 if (r < best) { best = r; g = d; }
             }
-            // worst-case log: one 16-B term per ray
+            // worst-case log: one 16-B term per ray.  It is allocated in full (only the dense primary part is
+            // normally touched), so it has to fit: at most 80 GB of the 288 and half of what is free right now
             const uint64_t log_bytes = (uint64_t)lanes * pixels_local * p->spp_per_frame * p->max_depth * 16ull;
-            if (g > 1 && log_bytes <= (32ull << 30)) groups = g;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+            const uint64_t have_log = f->work.cap_terms_over * sizeof(float4);  // already ours: counts as free
+            if (g > 1 && log_bytes <= (80ull << 30) && log_bytes <= have_log + free_b / 2) groups = g;
         }
     }
     groups = std::max(1u, std::min(groups, p->spp_per_frame));

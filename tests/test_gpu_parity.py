@@ -823,3 +823,23 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     assert lo + hi == j2["rays"] and hi - lo < 0.02 * hi          # interleaved tiles balance the ranks
     for k in ("metric", "value", "unit", "ms_per_step", "roofline", "config"):
         assert k in j2
+
+
+def test_term_log_overflow_path_bit_exact(pt, orc, gpu_ctx, cornell_arrays):
+    """Every surface emits, so every ray adds a radiance term: with sample groups the slots' logs run far past
+    the dense primary part (group_size + 2 entries) into the overflow log.  Still the oracle's bits."""
+    v, i, f = cornell_arrays
+    f = f.reshape(-1, 6).copy()
+    f[:, 3:] = np.float32(0.25) + f[:, :3] * np.float32(0.5)      # Ke > 0 everywhere
+    gs, osc = pt.Scene(gpu_ctx, v, i, f.reshape(-1)), orc.Scene(v, i, f.reshape(-1))
+    kw = dict(width=64, height=40, spp_per_frame=16, max_depth=12)
+    ofilm, obgra, orays = _render_oracle(orc, osc, 2, **kw)
+    for groups in (1, 2, 8, 16):
+        film = pt.Film(gpu_ctx, 64, 40)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(frame=0, frame_count=2, sample_groups=groups, **kw))
+        assert gpu_ctx.stats().rays == orays
+        assert film.read_f32().tobytes() == ofilm.tobytes(), groups
+        assert film.read_bgra8().tobytes() == obgra.tobytes(), groups
+        film.close()
+    gs.close()
