@@ -55,6 +55,7 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
