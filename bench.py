@@ -257,8 +257,10 @@ def main():
             # 36-triangle scene + LBVH are LDS-resident so there is no scene-gather term.
             # scene gather: counted only when the scene exceeds the 32 MiB of L2
             scene_bytes = info.device_bytes
-            # one BVH4 node visit = 4 child boxes x 32 B = 128 B; one triangle = 36 B of positions
-            gather = (nodes_per_ray * 128.0 + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
+            # one BVH4 node visit of the HBM variant = 64 B (4 fp16 child boxes 48 B + 4 child words 16 B; the
+            # two-level kernel reads fp32 nodes, 128 B); one triangle = 36 B of positions
+            node_bytes = 128.0 if args.config == "c4" else 64.0
+            gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
             bytes_extend = BYTES_EXTEND + gather
             gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
             pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays

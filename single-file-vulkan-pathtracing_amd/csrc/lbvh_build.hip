@@ -15,6 +15,8 @@
 #include "pt_internal.h"
 #include "pt_math.h"
 
+#include <hip/hip_fp16.h>
+
 #include <vector>
 
 namespace {
@@ -648,6 +650,59 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
     return PT_OK;
 }
 
+// fp16 copy of a BVH4 for traversal out of HBM/L2: coordinates normalised to the scene box,
+// x' = (x - c) * rs, lower bounds rounded down and upper bounds up (after a 2^-18 allowance for the float
+// rounding of the normalisation itself), so every fp16 box contains its fp32 box.  Empty slots stay +inf.
+__global__ __launch_bounds__(TB) void k_wide_half(const float4 *__restrict__ wide, uint32_t n_wide, float cx, float cy,
+                                                  float cz, float rsx, float rsy, float rsz, uint4 *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n_wide) return;
+    const float4 *nd = wide + 8 * (size_t)i;
+    const float c[3] = { cx, cy, cz }, rs[3] = { rsx, rsy, rsz };
+    uint32_t d[12];
+    for (int ax = 0; ax < 3; ax++) {
+        const float4 lo = nd[ax], hi = nd[3 + ax];
+        const float l[4] = { lo.x, lo.y, lo.z, lo.w }, h[4] = { hi.x, hi.y, hi.z, hi.w };
+        uint32_t hl[4], hh[4];
+        for (int k = 0; k < 4; k++) {
+            hl[k] = __half_as_ushort(__float2half_rd((l[k] - c[ax]) * rs[ax] - 3.814697265625e-06f));
+            hh[k] = __half_as_ushort(__float2half_ru((h[k] - c[ax]) * rs[ax] + 3.814697265625e-06f));
+        }
+        d[2 * ax + 0] = hl[0] | (hl[1] << 16); d[2 * ax + 1] = hl[2] | (hl[3] << 16);
+        d[6 + 2 * ax + 0] = hh[0] | (hh[1] << 16); d[6 + 2 * ax + 1] = hh[2] | (hh[3] << 16);
+    }
+    const float4 cw = nd[6];
+    uint4 *o = out + 4 * (size_t)i;
+    o[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+    o[2] = make_uint4(d[8], d[9], d[10], d[11]);
+    o[3] = make_uint4(__float_as_uint(cw.x), __float_as_uint(cw.y), __float_as_uint(cw.z), __float_as_uint(cw.w));
+}
+
+// (re)builds s->d_wide16 from the BVH4 that is currently traversed
+static pt_status make_wide16(pt_scene *s)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) ext = fmaxf(ext, s->bmax[k] - s->bmin[k]);
+    for (int k = 0; k < 3; k++) {
+        s->norm_c[k] = 0.5f * (s->bmin[k] + s->bmax[k]);
+        // half extent, never degenerate (flat scenes) and never so small that the padded boxes leave fp16's range
+        s->norm_s[k] = fmaxf(0.5f * (s->bmax[k] - s->bmin[k]), fmaxf(ext * 0x1p-10f, 1e-30f));
+        s->norm_rs[k] = 1.0f / s->norm_s[k];
+    }
+    (void)hipFree(s->d_wide16);
+    s->d_wide16 = nullptr;
+    PT_HIP(ctx, hipMalloc((void **)&s->d_wide16, 64 * (size_t)s->n_wide));
+    k_wide_half<<<(s->n_wide + TB - 1) / TB, TB, 0, st>>>(s->d_wide, s->n_wide, s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_rs[0],
+                                                         s->norm_rs[1], s->norm_rs[2], reinterpret_cast<uint4 *>(s->d_wide16));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
                           uint32_t n_tris, const float *h_faces)
 {
@@ -702,9 +757,10 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
         }
         s->d_tri_orig = d_tri_orig.release();
         s->d_faces = d_faces.release();
-        return ptb_set_bvh_quality(s, PT_BVH_PREFER_FAST_TRACE);
+        const pt_status q = ptb_set_bvh_quality(s, PT_BVH_PREFER_FAST_TRACE);
+        if (q != PT_OK) return q;
     }
-    return PT_OK;
+    return s->d_wide16 ? PT_OK : make_wide16(s);
 }
 
 // Chooses the BVH4 that is traversed (pt_internal.h).  Re-packs the per-triangle tables in its leaf order.
@@ -742,7 +798,7 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
-    return PT_OK;
+    return make_wide16(s);
 }
 
 void ptb_free_scene_buffers(pt_scene *s)
@@ -751,7 +807,8 @@ void ptb_free_scene_buffers(pt_scene *s)
     (void)hipFree(s->d_wide_lbvh ? s->d_wide_lbvh : s->d_wide);  // d_wide aliases d_wide_lbvh or d_wide_sah
     (void)hipFree(s->d_wide_sah); (void)hipFree(s->d_prim_of_sah);
     (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
-    (void)hipFree(s->d_tri_orig); (void)hipFree(s->d_faces);
+    (void)hipFree(s->d_tri_orig); (void)hipFree(s->d_faces); (void)hipFree(s->d_wide16);
+    s->d_wide16 = nullptr;
     s->d_tri4 = s->d_shade4 = s->d_nodes = s->d_wide = s->d_wide_lbvh = s->d_wide_sah = s->d_tri_orig = nullptr;
     s->d_prim_of_sah = s->d_prim_of = nullptr; s->d_keys = nullptr; s->d_faces = nullptr;
 }

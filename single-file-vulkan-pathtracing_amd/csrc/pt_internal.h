@@ -15,6 +15,8 @@
 //   shade4 : 3 x float4 per triangle  {n.xyz, brdf.r} {brdf.gb, emission.rg} {emission.b,0,0,0} 48 B
 //   nodes  : binary LBVH, 4 x float4 per internal node {lmin.xyz,lmax.x} {lmax.yz,rmin.xy}
 //            {rmin.z,rmax.xyz} {bits(left), bits(right), 0, 0}; child bit31 = leaf position       64 B
+//   wide16 : the same BVH4 with fp16 boxes, 16 dwords per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4]
+//            as halves (2 dwords each), child[4]                                                      64 B
 //   wide   : BVH4 collapsed from it, 8 x float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
 //            hi.z[4] child[4] spare; leaf child = LEAF | (count-1)<<28 | first sorted position     128 B
 constexpr int PT_MAX_PIPES = 4;  // concurrent wavefront pipelines (streams) per pt_render
@@ -52,6 +54,10 @@ struct pt_scene {
     // scenes of <= PT_SAH_MAX_TRIS triangles, a surface-area sweep built on the host (builder 1, bvh4_sah.hip).
     // d_wide aliases one of the two owned arrays below.
     uint32_t bvh4_builder = 0;
+    // 64-B copy of the traversed BVH4 for scenes that are walked in HBM/L2 (lbvh_build.hip make_wide16):
+    // boxes as fp16 of coordinates normalised to the scene box, rounded outwards; halves the bytes per node
+    uint2 *d_wide16 = nullptr;
+    float norm_c[3]{}, norm_s[3]{1.f, 1.f, 1.f}, norm_rs[3]{1.f, 1.f, 1.f};  // x' = (x - c) * rs,  s = 1/rs
     float4 *d_wide_lbvh = nullptr; uint32_t n_wide_lbvh = 0, stack_need_lbvh = 0xFFFFFFFFu;
     float4 *d_wide_sah = nullptr;  uint32_t n_wide_sah = 0, stack_need_sah = 0xFFFFFFFFu;
     uint32_t *d_prim_of_sah = nullptr;      // leaf order of the SAH BVH4 (position -> prim id)

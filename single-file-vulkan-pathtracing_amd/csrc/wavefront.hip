@@ -262,6 +262,23 @@ __device__ __forceinline__ void slab_setup(const ptm::f3 org, const ptm::f3 inv,
     of = { (ox + px) * 1.0000004f, (oy + py) * 1.0000004f, (oz + pz) * 1.0000004f };
     invf = { inv.x * 1.0000004f, inv.y * 1.0000004f, inv.z * 1.0000004f };
 }
+// ---- 64-B nodes (scene walked in HBM/L2): the planes are fp16 of box coordinates normalised to the scene box
+// (lbvh_build.hip k_wide_half, rounded outwards).  v_fma_mix_f32 reads the half straight out of the loaded
+// dword, so the slab arithmetic costs exactly what it costs with fp32 planes; the ray is normalised the same
+// way at refill (org' = (org - c) * rs, inv' = inv * s), which leaves every distance t unchanged.
+struct NormBox { float cx, cy, cz, sx, sy, sz, rsx, rsy, rsz; };
+#define PT_MIXH(DST, REG, HI, INVC, ONC) \
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[" #HI ",0,0] op_sel_hi:[1,0,0]" : "=v"(DST) : "v"(REG), "v"(INVC), "v"(ONC))
+#define PT_SLAB4H(T, REGC, HI)                                                                      \
+    {                                                                                               \
+        float nxv, nyv, nzv, fxv, fyv, fzv;                                                         \
+        PT_MIXH(nxv, hnx.REGC, HI, inv.x, on.x); PT_MIXH(nyv, hny.REGC, HI, inv.y, on.y);           \
+        PT_MIXH(nzv, hnz.REGC, HI, inv.z, on.z); PT_MIXH(fxv, hfx.REGC, HI, invf.x, of.x);          \
+        PT_MIXH(fyv, hfy.REGC, HI, invf.y, of.y); PT_MIXH(fzv, hfz.REGC, HI, invf.z, of.z);         \
+        const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                              \
+        const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                              \
+        T = tn <= tf ? tn : INF;                                                                    \
+    }
 constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the wave pulls new rays
 
 // Persistent threads with dynamic ray fetch (Aila & Laine 2009, re-tiled for wave64): a lane whose
@@ -273,7 +290,8 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
 template <bool LDS_SCENE, bool COUNT, bool SPILL>
-__global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
+__global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
+                                               NormBox nb, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
@@ -370,10 +388,17 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup(org, dir);
                     inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
-                    slab_setup(org, inv, invf, on, of);
-                    ax = inv.x < 0.f ? 48u : 0u;
-                    ay = inv.y < 0.f ? 48u : 0u;
-                    az = inv.z < 0.f ? 48u : 0u;
+                    if (LDS_SCENE) {
+                        slab_setup(org, inv, invf, on, of);
+                    } else {  // fp16 nodes live in the normalised scene box
+                        const ptm::f3 orgn = { (org.x - nb.cx) * nb.rsx, (org.y - nb.cy) * nb.rsy, (org.z - nb.cz) * nb.rsz };
+                        inv = { inv.x * nb.sx, inv.y * nb.sy, inv.z * nb.sz };
+                        slab_setup(orgn, inv, invf, on, of);
+                    }
+                    // byte offset of the near planes inside a node: 3 planes of 16 B (fp32 node) or 8 B (fp16 node)
+                    ax = inv.x < 0.f ? (LDS_SCENE ? 48u : 24u) : 0u;
+                    ay = inv.y < 0.f ? (LDS_SCENE ? 48u : 24u) : 0u;
+                    az = inv.z < 0.f ? (LDS_SCENE ? 48u : 24u) : 0u;
                     if (LDS_SCENE) {
                         tri_base = (uint32_t)pre.kz * 3u * n_tris;
                         orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y),
@@ -404,19 +429,32 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
             do_leaf = !node_turn;
         }
         while (do_node) {
-            const float4 *nd = wide + (LDS_SCENE ? LDS_NODE_F4 : 8u) * (size_t)cur;
-            PT_NODE_LOAD(nd)
             if (COUNT) {
                 c_nodes++;
                 if (lane == __ffsll((long long)__ballot(1)) - 1) c_node_steps++;  // one lane per wave step
             }
             float t0, t1, t2, t3;
-            uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z),
-                     w3 = __float_as_uint(cw.w);
-            PT_SLAB4(t0, x)
-            PT_SLAB4(t1, y)
-            PT_SLAB4(t2, z)
-            PT_SLAB4(t3, w)
+            uint32_t w0, w1, w2, w3;
+            if (LDS_SCENE) {
+                const float4 *nd = wide + LDS_NODE_F4 * (size_t)cur;
+                PT_NODE_LOAD(nd)
+                w0 = __float_as_uint(cw.x); w1 = __float_as_uint(cw.y); w2 = __float_as_uint(cw.z); w3 = __float_as_uint(cw.w);
+                PT_SLAB4(t0, x)
+                PT_SLAB4(t1, y)
+                PT_SLAB4(t2, z)
+                PT_SLAB4(t3, w)
+            } else {
+                const char *nb_ = reinterpret_cast<const char *>(g_wide16) + 64 * (size_t)cur;
+                const uint2 hnx = *reinterpret_cast<const uint2 *>(nb_ + ax), hfx = *reinterpret_cast<const uint2 *>(nb_ - ax + 24),
+                            hny = *reinterpret_cast<const uint2 *>(nb_ + ay + 8), hfy = *reinterpret_cast<const uint2 *>(nb_ - ay + 32),
+                            hnz = *reinterpret_cast<const uint2 *>(nb_ + az + 16), hfz = *reinterpret_cast<const uint2 *>(nb_ - az + 40);
+                const uint4 cw = *reinterpret_cast<const uint4 *>(nb_ + 48);
+                w0 = cw.x; w1 = cw.y; w2 = cw.z; w3 = cw.w;
+                PT_SLAB4H(t0, x, 0)
+                PT_SLAB4H(t1, x, 1)
+                PT_SLAB4H(t2, y, 0)
+                PT_SLAB4H(t3, y, 1)
+            }
 #define PT_CSWAP(TA, WA, TB_, WB)                            \
     {                                                        \
         const bool sw = TB_ < TA;                            \
@@ -1117,8 +1155,11 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     }
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
+    const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],
+                           s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
 #define PT_LAUNCH_EXTEND(L, C, S)                                                                                     \
     hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide, \
+                          s->d_wide16, nbox,                                                                          \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
                           pl.refill, tmin, tmax, pl.lds_stack, raw)
     if (!pl.spill) {

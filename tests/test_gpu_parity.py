@@ -843,3 +843,33 @@ def test_term_log_overflow_path_bit_exact(pt, orc, gpu_ctx, cornell_arrays):
         assert film.read_bgra8().tobytes() == obgra.tobytes(), groups
         film.close()
     gs.close()
+
+
+@pytest.mark.parametrize("shape", ["planar", "line", "far_from_origin", "huge"])
+def test_fp16_node_boxes_stay_conservative_on_awkward_extents(pt, orc, gpu_ctx, shape):
+    """The HBM traversal walks 64-B nodes whose boxes are fp16 of coordinates normalised to the scene box.
+    Scenes with a degenerate axis, far from the origin or very large must still give the oracle's hits."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    v, i, f = _soup(n, 17, spread=0.05)
+    v = v.reshape(n, 3, 3).copy()
+    if shape == "planar":
+        v[:, :, 2] = np.float32(0.25)                      # every triangle in the plane z = 0.25
+    elif shape == "line":
+        v[:, :, 1] = np.float32(-0.5); v[:, :, 2] *= np.float32(1e-3)
+    elif shape == "far_from_origin":
+        v += np.array([1000.0, -2000.0, 500.0], np.float32)
+    elif shape == "huge":
+        v *= np.float32(3.0e4)
+    v = np.ascontiguousarray(v, np.float32).reshape(-1)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    ext = float((hi - lo).max())
+    org = (rng.uniform(-0.2, 1.2, (40000, 3)) * (hi - lo) + lo + rng.normal(size=(40000, 3)) * 0.05 * ext).astype(np.float32)
+    tgt = (rng.uniform(0, 1, (40000, 3)) * (hi - lo) + lo).astype(np.float32)
+    rays = np.concatenate([org, (tgt - org) / np.linalg.norm(tgt - org, axis=1, keepdims=True)], axis=1).astype(np.float32)
+    want, _ = osc.trace(rays, tmax=1e9)
+    assert (want["prim"] != 0xFFFFFFFF).mean() > 0.05
+    got = gs.trace(rays, tmax=1e9, extend=pt.EXTEND_HBM)
+    assert got.tobytes() == want.tobytes(), shape
+    gs.close()
