@@ -1,0 +1,84 @@
+"""dev tool: randomized closest-hit parity, GPU (every extend variant that fits) vs the oracle.
+Stresses what the box tests must survive: axis-aligned and near-axis-aligned directions, origins on vertices and
+edges, scenes at scales 1e-3 .. 1e4 and far from the origin, slivers, duplicated triangles, tiny/huge t ranges.
+
+Contract checked ("degenerate triangles"): where the oracle's brute force and its LBVH
+traversal agree -- always, except for false hits of the zero-edge rule on (nearly) zero-area triangles that the
+ray's box walk never reaches -- every GPU variant must return exactly that record; on the rare rays where the
+two oracle modes differ, a GPU BVH variant must return one of the two and the flat variant the brute-force one."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
+from oracle import pt_oracle as orc
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+ctx = pt.Context(0)
+bad = 0
+n_degenerate = 0
+t0 = time.time()
+for seed in range(N):
+    rng = np.random.default_rng(SEED0 + seed)
+    n = int(rng.choice([1, 2, 3, 7, 36, 150, 700, 3000, 12000]))
+    scale = float(rng.choice([1e-3, 1.0, 1.0, 30.0, 1e4]))
+    offset = rng.choice([0.0, 0.0, 1.0, 100.0]) * scale * rng.normal(size=3)
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    if rng.random() < 0.3:
+        c[:, :, int(rng.integers(3))] = 0.25           # planar scene
+    spread = float(rng.choice([0.02, 0.1, 0.5]))
+    tri = c + rng.uniform(-spread, spread, (n, 3, 3))
+    if rng.random() < 0.3:                              # slivers
+        k = rng.integers(0, n, max(1, n // 5)); tri[k, 2] = tri[k, 0] + (tri[k, 1] - tri[k, 0]) * rng.uniform(0, 1, (len(k), 1)) + 1e-6 * rng.normal(size=(len(k), 3))
+    if rng.random() < 0.3 and n > 4:                    # duplicates (ties -> lowest prim id)
+        k = rng.integers(0, n, n // 4); tri[k] = tri[rng.integers(0, n, len(k))]
+    tri = (tri * scale + offset).astype(np.float32)
+    v = tri.reshape(-1); i = np.arange(3 * n, dtype=np.uint32); f = rng.uniform(0, 1, 6 * n).astype(np.float32)
+    m = 20000
+    lo, hi = tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0)
+    ext = np.maximum(hi - lo, 1e-6 * scale)
+    org = (rng.uniform(-0.3, 1.3, (m, 3)) * ext + lo).astype(np.float32)
+    tgt = tri[rng.integers(0, n, m), rng.integers(0, 3, m)] * rng.uniform(0, 1, (m, 1)).astype(np.float32) + tri[rng.integers(0, n, m), rng.integers(0, 3, m)] * 0  # towards vertices/edges-ish
+    tgt = (tgt + (tri[rng.integers(0, n, m)].mean(1) - tgt) * rng.uniform(0, 1, (m, 1))).astype(np.float32)
+    d = tgt - org
+    # a quarter axis-aligned, a quarter nearly so, some starting exactly on a vertex
+    k = rng.random(m)
+    ax = rng.integers(0, 3, m)
+    d[k < 0.25] = 0; d[k < 0.25, ax[k < 0.25]] = rng.choice([-1.0, 1.0], (k < 0.25).sum())
+    near = (k >= 0.25) & (k < 0.5)
+    d[near] *= rng.choice([1e-7, 1e-4, 1.0], (near.sum(), 3))
+    onv = k > 0.9
+    org[onv] = tri[rng.integers(0, n, onv.sum()), rng.integers(0, 3, onv.sum())]
+    nz = np.linalg.norm(d, axis=1) > 0
+    d[~nz] = [0, 0, 1]
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    tmin = float(rng.choice([1e-3, 1e-6, 0.0])) * scale
+    tmax = float(rng.choice([1e4, 1e9, 3.0])) * scale
+    osc = orc.Scene(v, i, f)
+    want, _ = osc.trace(rays, tmin=tmin, tmax=tmax, mode=1)
+    brute = osc.trace(rays, tmin=tmin, tmax=tmax, mode=0)[0] if n <= 3000 else want
+    same = brute.view(np.uint8).reshape(m, -1) == want.view(np.uint8).reshape(m, -1)
+    agree = same.all(axis=1)
+    n_degenerate += int((~agree).sum())
+    gs = pt.Scene(ctx, v, i, f)
+    for q in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD):
+        gs.set_bvh_quality(q)
+        for ext_v in (pt.EXTEND_AUTO, pt.EXTEND_HBM, pt.EXTEND_LDS, pt.EXTEND_FLAT):
+            try:
+                got = gs.trace(rays, tmin=tmin, tmax=tmax, extend=ext_v)
+            except pt.PtError:
+                continue
+            gb = got.view(np.uint8).reshape(m, -1)
+            eq_w = (gb == want.view(np.uint8).reshape(m, -1)).all(axis=1)
+            eq_b = (gb == brute.view(np.uint8).reshape(m, -1)).all(axis=1)
+            ok = eq_b if ext_v == pt.EXTEND_FLAT else np.where(agree, eq_w, eq_w | eq_b)
+            if not ok.all():
+                diff = np.nonzero(~ok)[0]
+                bad += 1
+                print(f"MISMATCH seed {seed} n {n} scale {scale} quality {q} extend {ext_v}: {len(diff)} rays, first {diff[:3]}",
+                      got[diff[:2]], want[diff[:2]], rays[diff[:2]])
+    gs.close()
+print(f"fuzz: {N} scenes, mismatching (scene, variant) pairs: {bad}; rays where the oracle's brute force and LBVH differ "
+      f"(zero-area false hits): {n_degenerate}; {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
