@@ -886,3 +886,15 @@ def test_randomized_closest_hit_fuzz():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "mismatching (scene, variant) pairs: 0" in out.stdout
+
+
+def test_randomized_render_fuzz():
+    """scripts/fuzz_render.py: random ragged film sizes, spp, depth, frame ranges, frames in flight, sample groups,
+    rank/world splits, extend variants and cameras; film bits vs the oracle (1500 configurations run by hand)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fuzz_render.py"), "40", "31000"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "mismatches: 0" in out.stdout
