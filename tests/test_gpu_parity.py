@@ -898,3 +898,16 @@ def test_randomized_render_fuzz():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "mismatches: 0" in out.stdout
+
+
+def test_randomized_instance_fuzz():
+    """scripts/fuzz_instances.py: random base scenes x random instance sets (rotations, non-uniform and mirrored
+    scales 0.005..15, translations up to 300, coincident instances) through the two-level extend kernel against the
+    oracle's TLAS walk (and its brute force over every (instance, triangle)); 60 scenes ran clean by hand, 6 here."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fuzz_instances.py"), "6", "5100"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "mismatching scenes: 0" in out.stdout
