@@ -911,3 +911,61 @@ def test_randomized_instance_fuzz():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "mismatching scenes: 0" in out.stdout
+
+
+# ---- the reference's own compiled shaders (tests/golden/spirv_pixels.npz, see tests/test_spirv_pin.py) -------------
+
+def _spirv_fixture():
+    return np.load(os.path.join(HERE, "golden", "spirv_pixels.npz"))
+
+
+def test_spirv_reference_shaders_1080p_progressive(pt, gpu_ctx, cornell_gpu):
+    """HIP path vs the outputs of shaders/*.spv executed by oracle/spirv_vm.py, with no oracle in between:
+    1920x1080 launch, frames 0..2 one `pt_render` per frame as main.cpp:647-685 dispatches them, then the three
+    frames batched in one call; float film at 275 pixels and the rgba8 display image at 46 pixels, every frame."""
+    g = _spirv_fixture()
+    w, h = [int(v) for v in g["a_launch"]]
+    ax, ay = g["a_pixels"][:, 0], g["a_pixels"][:, 1]
+    bx, by = g["b_pixels"][:, 0], g["b_pixels"][:, 1]
+    kw = dict(width=w, height=h, spp_per_frame=32, max_depth=8)
+    film = pt.Film(gpu_ctx, w, h)
+    for frame in range(4):
+        pt.render(cornell_gpu, film, pt.default_params(frame=frame, frame_count=1, **kw))
+        if frame < g["a_texels"].shape[0]:
+            got = np.ascontiguousarray(film.read_f32()[ay, ax])
+            assert got.tobytes() == np.ascontiguousarray(g["a_texels"][frame, :, :3]).tobytes(), frame
+        got8 = film.read_bgra8()[by, bx][:, [2, 1, 0, 3]]
+        assert (got8 == g["b_rgba8"][frame]).all(), frame
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=3, **kw))
+    assert np.ascontiguousarray(film.read_f32()[ay, ax]).tobytes() == np.ascontiguousarray(g["a_texels"][2, :, :3]).tobytes()
+    film.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_spirv_reference_shaders_full_small_launch(pt, gpu_ctx, cornell_gpu, variant):
+    """every invocation of a complete 120x68 launch, frames 0 and 1, every extend variant: texels and the exact
+    number of traceRayEXT calls the reference's raygen made."""
+    g = _spirv_fixture()
+    w, h = [int(v) for v in g["c_launch"]]
+    film = pt.Film(gpu_ctx, w, h)
+    for frame in (0, 1):
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(width=w, height=h, spp_per_frame=32, max_depth=8, frame=frame,
+                                                       frame_count=1, extend=variant))
+        assert film.read_f32().tobytes() == np.ascontiguousarray(g["c_texels"][frame, :, :, :3]).tobytes()
+        assert gpu_ctx.stats().rays == int(g["c_traces"][frame].sum())
+    film.close()
+
+
+def test_spirv_reference_shaders_c2_crop(pt, gpu_ctx, cornell_gpu):
+    """BASELINE config 2 (1080p, 64 spp = 2 frames x 32, depth 8): the 96x64 rectangle at (912, 508) as the
+    reference's shaders compute it."""
+    g = _spirv_fixture()
+    x0, y0, rw, rh = [int(v) for v in g["d_rect"]]
+    film = pt.Film(gpu_ctx, 1920, 1080)
+    pt.render(cornell_gpu, film, pt.default_params(width=1920, height=1080, spp_per_frame=32, max_depth=8, frame=0, frame_count=2))
+    got = np.ascontiguousarray(film.read_f32()[y0:y0 + rh, x0:x0 + rw])
+    assert got.tobytes() == np.ascontiguousarray(g["d_texels"][1, :, :, :3]).tobytes()
+    film.close()
