@@ -1,5 +1,5 @@
 /*
- * pt_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; parity unpinned, see pt_oracle.h).
+ * pt_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; pinned against the reference's compiled shaders, see pt_oracle.h).
  *
  * Restates, in plain C with fully specified float32 arithmetic:
  *   shaders/common.glsl:13-37        pcg, pcg2d, rand

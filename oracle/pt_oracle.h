@@ -7,12 +7,23 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it.
  * The product (single-file-vulkan-pathtracing_amd/) never links, imports or executes it.
  *
- * PARITY STATUS: **parity unpinned**.  The reference has no tests, golden vectors or
- * fixtures and cannot be built or run here (needs Vulkan SDK + an
- * RT driver + GLFW + tinyobjloader, none present).  The oracle is pinned only by
- *   (1) the hand-checkable known-answer vectors of SURVEY.md section 8c (an independent
- *       numpy emulation of the same shaders), see tests/golden/kats.json, and
- *   (2) its own self-consistency (brute force == LBVH, libm vs polynomial sincos).
+ * PARITY STATUS: pinned against outputs of the reference itself, run here.  The reference has
+ * no tests or golden vectors and its host program cannot be built
+ * (Vulkan SDK + RT driver + GLFW + tinyobjloader, none present), but its compiled shaders --
+ * shaders/{raygen.rgen,closesthit.rchit,miss.rmiss}.spv, the whole radiance loop -- are
+ * committed, and oracle/spirv_vm.py executes them instruction by instruction.  Pins:
+ *   (1) tests/golden/spirv_pixels.npz (generator tests/golden/make_spirv_goldens.py): texels and
+ *       traceRayEXT counts those binaries produce for 275 pixels x 3 progressive frames of the
+ *       1920x1080 launch, 46 pixels x 4 frames through the rgba8 storage image, every
+ *       invocation of a 120x68 launch x 2 frames and a 96x64 crop of BASELINE config 2:
+ *       this oracle reproduces all of it bit for bit (tests/test_spirv_pin.py);
+ *   (2) the known-answer vectors of SURVEY.md section 8c (tests/golden/kats.json);
+ *   (3) self-consistency (brute force == LBVH, libm vs polynomial sincos).
+ * NOT pinned, because Vulkan leaves it to the driver and no driver exists here: the
+ * ray/triangle intersection behind traceRayEXT, the ulp-level results of sin/cos/sqrt/
+ * normalize, and the unorm8 rounding of the storage image.  For these the VM is given this
+ * project's canonical definitions (below), so (1) checks the shader-level restatement
+ * (seeds, order of rand() calls, camera, loops, shading, throughput, blend), not those.
  *
  * Canonical arithmetic (what "bit-exact" means for this project):
  * every float operation is IEEE-754 binary32, round-to-nearest-even, never contracted
