@@ -46,9 +46,9 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0):
     spp = int(max(1, min(spp_max, budget_s / max(t1, 1e-3))))
     p = orc.default_params(width=width, height=height, spp_per_frame=spp, max_depth=depth)
     t0 = time.perf_counter()
-    _, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
+    img, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
     dt = time.perf_counter() - t0
-    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp,
+    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
                       f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads"}
     return base, cnt.nodes_visited / max(rays, 1), cnt.tris_tested / max(rays, 1)
@@ -240,7 +240,7 @@ def main():
         # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
         nodes_per_ray = tris_per_ray = 0.0
         node_occ = tri_occ = None
-        frame0_rays_gpu = None
+        frame0_rays_gpu = frame0_film_gpu = None
         if st.extend_variant != pt.EXTEND_FLAT:
             ctx.reset_stats()
             scratch = pt.Film(ctx, W, H)
@@ -251,6 +251,7 @@ def main():
             node_occ = cst.nodes_visited / (64.0 * cst.node_steps) if cst.node_steps else None
             tri_occ = cst.tris_tested / (64.0 * cst.tri_steps) if cst.tri_steps else None
             frame0_rays_gpu = cst.rays
+            frame0_film_gpu = scratch.read_f32()
             scratch.close()
         if flags and st.launches_extend and st.ms_extend > 0:
             # dominant kernel = k_extend (closest-hit traversal).  Algorithmic bytes: 40 B/ray; the
@@ -303,11 +304,13 @@ def main():
                          "scene + BVH4 = 118 MB > L2: every node/triangle fetch is a 128/48-B gather through L2/MALL/HBM"),
             }
         if base and not args.no_cpu_baseline and world == 1:
-            cpu_rays, cpu_spp = base.pop("_rays"), base.pop("_spp")
+            cpu_rays, cpu_spp, cpu_img = base.pop("_rays"), base.pop("_spp"), base.pop("_img")
             out["cpu_baseline"] = base
             if cpu_spp == args.spp and frame0_rays_gpu is not None:
-                # the oracle rendered exactly frame 0 of this workload: the exact ray counts must agree
+                # the oracle rendered exactly frame 0 of this workload (the whole image): exact ray counts and every
+                # float of the film must agree (checker only: none of this is in the timed region)
                 out["frame0_ray_count"] = {"gpu": frame0_rays_gpu, "cpu_oracle": cpu_rays, "equal": frame0_rays_gpu == cpu_rays}
+                out["frame0_film_bit_exact"] = bool(frame0_film_gpu.tobytes() == cpu_img.tobytes())
         print(json.dumps(out), flush=True)
 
     film.close()
