@@ -208,6 +208,7 @@ constexpr uint32_t LDS_NODE_F4 = 9;  // float4 per LDS node (8 used)
 // through an LDS-typed pointer: with generic pointers the compiler merges the LDS and the spill
 // access into FLAT loads/stores of the two halves (seen in the ISA), which cost VMEM issue and latency.
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ unsigned long long stack_entry(uint32_t w, float t)
 {
     return (unsigned long long)w | ((unsigned long long)__float_as_uint(t) << 32);
@@ -279,6 +280,9 @@ struct NormBox { float cx, cy, cz, sx, sy, sz, rsx, rsy, rsz; };
         const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                              \
         T = tn <= tf ? tn : INF;                                                                    \
     }
+#ifndef PT_EXTEND_WAVES
+#define PT_EXTEND_WAVES 7  // min waves per SIMD asked of the compiler for the no-spill LDS variant: 72 VGPRs instead of 76, no spills (8: 13 spilled, -13 %)
+#endif
 constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the wave pulls new rays
 
 // Persistent threads with dynamic ray fetch (Aila & Laine 2009, re-tiled for wave64): a lane whose
@@ -290,7 +294,7 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
 template <bool LDS_SCENE, bool COUNT, bool SPILL>
-__global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
+__global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAVES : 1) void k_extend(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
                                                NormBox nb, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
@@ -307,15 +311,35 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     // keeps the inner loop.
     constexpr bool VOTE = !LDS_SCENE;
     constexpr int VOTE_NODE_NUM = 2, VOTE_NODE_DEN = 1;
+    // COMPACT (scene in LDS and its exact stack bound fits: the Cornell box): child words are re-coded to 14 bits
+    // when the nodes are staged (leaf: bit 13 | (count-1) << 11 | first; inner: node index; done: 0x3FFF) and a
+    // stack entry is ONE dword, the entry distance truncated to its top 18 bits above the child word
+    // (sign, exponent, 9 mantissa bits: rounds a non-negative distance DOWN, so the pop test stays conservative).
+    // Half the stack bytes in LDS: 15 KB instead of 25 KB per block for the Cornell box, which lifts the LDS cap
+    // on resident blocks from 6 to 10 per CU.  The host only picks it for tmin >= 0.
+    constexpr bool COMPACT = LDS_SCENE && !SPILL;
+    constexpr uint32_t LEAF_BIT = COMPACT ? 0x2000u : PT_LEAF;
+    constexpr uint32_t DONE = COMPACT ? 0x3FFFu : SENTINEL;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
     const float4 *wide = g_wide;
     const float4 *tri4 = g_tri4;
     if (LDS_SCENE) {
-        float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * TB * sizeof(uint2));
+        float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * TB * (COMPACT ? sizeof(uint32_t) : sizeof(uint2)));
         float4 *s_tri = s_wide + LDS_NODE_F4 * (size_t)n_wide;
-        for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) s_wide[(i >> 3) * LDS_NODE_F4 + (i & 7u)] = g_wide[i];
+        for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) {
+            float4 v = g_wide[i];
+            if (COMPACT && (i & 7u) == 6u) {  // the four child words
+                auto cw = [](float f) {
+                    const uint32_t w = __float_as_uint(f);
+                    const uint32_t c = (w & PT_LEAF) ? (0x2000u | (((w >> 28) & 3u) << 11) | (w & 0x7FFu)) : (w & 0x1FFFu);
+                    return __uint_as_float(w == SENTINEL ? 0x3FFFu : c);
+                };
+                v = make_float4(cw(v.x), cw(v.y), cw(v.z), cw(v.w));
+            }
+            s_wide[(i >> 3) * LDS_NODE_F4 + (i & 7u)] = v;
+        }
         // three copies of the triangles with components permuted to (kx,ky,kz) for kz = 0,1,2:
         // the triangle test then needs no per-lane component selects (ptm::tri_test_perm)
         for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
@@ -334,6 +358,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         if (stats) atomicAdd(stats, (unsigned long long)n);  // exact ray count
     }
     lds_u64 *my_stack = (lds_u64 *)reinterpret_cast<unsigned long long *>(stack) + threadIdx.x;
+    lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(stack) + threadIdx.x;
     unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
@@ -351,17 +376,30 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
     uint32_t tri_base = 0;           // LDS_SCENE: start of the triangle copy for this ray's kz
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
-    uint32_t cur = SENTINEL;
+    uint32_t cur = DONE;
     int sp = 0;
     unsigned long long c_nodes = 0, c_tris = 0, c_node_steps = 0, c_tri_steps = 0;
 
     auto push = [&](uint32_t w, float t) {
+        if (COMPACT) {
+            my_stack32[sp * TB] = (__float_as_uint(t) & 0xFFFFC000u) | w;
+            sp++;
+            return;
+        }
         const unsigned long long e = stack_entry(w, t);
         if (!SPILL || sp < lds_stack) my_stack[sp * TB] = e;  // !SPILL: the host proved lds_stack entries suffice
         else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
         sp++;
     };
     auto pop = [&]() -> uint32_t {  // next subtree that can still contain the closest hit
+        if (COMPACT) {
+            while (sp > 0) {
+                sp--;
+                const uint32_t e = my_stack32[sp * TB];
+                if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
+            }
+            return DONE;
+        }
         while (sp > 0) {
             sp--;
             unsigned long long e;
@@ -369,7 +407,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
             else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
             if (__uint_as_float((uint32_t)(e >> 32)) <= best_t) return (uint32_t)e;
         }
-        return SENTINEL;
+        return DONE;
     };
 
     for (;;) {
@@ -419,10 +457,10 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         // ---- node phase: every lane descends until it holds a leaf (or runs out of nodes)
         // VOTE: one step per outer iteration, of the kind (node / leaf) that more lanes are waiting for
         bool do_leaf = true;
-        bool do_node = have && !(cur & PT_LEAF);
+        bool do_node = have && !(cur & LEAF_BIT);
         const int n_have = __popcll(__ballot(have));
         if (VOTE) {
-            const bool want_leaf = have && (cur & PT_LEAF) && cur != SENTINEL;
+            const bool want_leaf = have && (cur & LEAF_BIT) && cur != DONE;
             const int nn = __popcll(__ballot(do_node)), nl = __popcll(__ballot(want_leaf));
             const bool node_turn = nn * VOTE_NODE_NUM >= nl * VOTE_NODE_DEN;
             do_node = do_node && node_turn;
@@ -472,7 +510,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
             if (t2 < INF) push(w2, t2);
             if (t1 < INF) push(w1, t1);
             cur = t0 < INF ? w0 : pop();
-            do_node = !VOTE && !(cur & PT_LEAF);
+            do_node = !VOTE && !(cur & LEAF_BIT);
             if (!VOTE) {
                 // fewer than 1/6 of the wave's rays still descending while the rest waits with a leaf: let the
                 // leaves go first, the stragglers resume in the next round of the outer loop (node-step lane
@@ -483,8 +521,9 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
         }
         // ---- leaf phase
         if (have) {
-            if (cur != SENTINEL && (cur & PT_LEAF) && (!VOTE || do_leaf)) {
-                const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+            if (cur != DONE && (cur & LEAF_BIT) && (!VOTE || do_leaf)) {
+                const uint32_t first = COMPACT ? (cur & 0x7FFu) : (cur & 0x0FFFFFFFu);
+                const uint32_t cnt = (COMPACT ? ((cur >> 11) & 3u) : ((cur >> 28) & 7u)) + 1u;
                 if (COUNT) c_tris += cnt;
                 for (uint32_t k = 0; k < cnt; k++) {
                     if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) c_tri_steps++;
@@ -505,7 +544,7 @@ __global__ __launch_bounds__(TB) void k_extend(const float4 *__restrict__ g_wide
                 }
                 cur = pop();
             }
-            if (cur == SENTINEL) {  // traversal finished: emit the hit record, the lane becomes idle
+            if (cur == DONE) {  // traversal finished: emit the hit record, the lane becomes idle
                 const bool miss = best_pos == PT_MISS;
                 // raw_hit (render path): (V, W, det) go out undivided and k_shade takes the two quotients at
                 // full lane occupancy; here they would run once per finishing lane group
@@ -1040,6 +1079,8 @@ struct ExtendPlan {
     int refill = REFILL_MIN_IDLE;
     int lds_stack = LDS_STACK;  // stack entries per lane kept in LDS (single-level kernel)
     bool spill = true;          // false: the scene's exact stack bound fits lds_stack, kernel without spill path
+                                // (and with one-dword stack entries: COMPACT in k_extend)
+    size_t smem_wide_entries = 0;  // LDS bytes of the same plan run by the 8-byte-entry kernel (negative tmin)
 };
 
 pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
@@ -1091,9 +1132,15 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     pl.lds_stack = pl.lds_scene ? LDS_STACK : 12;
     // LDS-resident scenes are small enough for an exact stack bound (lbvh_build.hip: wide_stack_need):
     // if it fits 16 LDS entries the kernel is instantiated without the spill path (Cornell: 9)
-    pl.spill = !(pl.lds_scene && s->stack_need <= 16u);
+    // (the no-spill kernel packs child words into 14 bits: <= 2047 triangles, <= 8191 nodes, leaves of <= 4)
+    pl.spill = !(pl.lds_scene && s->stack_need <= 16u && s->n_tris <= 2047u && s->n_wide <= 8191u);
     if (!pl.spill) pl.lds_stack = (int)std::max(s->stack_need, 1u);
-    pl.smem = (size_t)pl.lds_stack * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
+    pl.smem_wide_entries = (size_t)pl.lds_stack * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
+    pl.smem = pl.spill ? pl.smem_wide_entries : (size_t)pl.lds_stack * TB * sizeof(uint32_t) + scene_bytes;
+    if (!pl.spill && pl.smem_wide_entries > 48 * 1024) {
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem_wide_entries));
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem_wide_entries));
+    }
     const void *fn = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, false, false>)
                      : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false, true>)
                                     : reinterpret_cast<const void *>(k_extend<false, false, true>);
@@ -1157,12 +1204,16 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     const uint32_t stride = (uint32_t)pl.grid * TB;
     const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],
                            s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
+    // one-dword stack entries truncate the entry distance toward zero, which is only conservative for t >= 0:
+    // a negative tmin (not valid in Vulkan, accepted here) runs the same plan through the 8-byte-entry kernel
+    const bool no_spill = !pl.spill && tmin >= 0.f;
+    const size_t smem = (!pl.spill && !no_spill) ? pl.smem_wide_entries : pl.smem;
 #define PT_LAUNCH_EXTEND(L, C, S)                                                                                     \
-    hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_wide, \
+    hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, \
                           s->d_wide16, nbox,                                                                          \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
                           pl.refill, tmin, tmax, pl.lds_stack, raw)
-    if (!pl.spill) {
+    if (no_spill) {
         if (count) PT_LAUNCH_EXTEND(true, true, false); else PT_LAUNCH_EXTEND(true, false, false);
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);

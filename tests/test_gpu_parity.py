@@ -969,3 +969,21 @@ def test_spirv_reference_shaders_c2_crop(pt, gpu_ctx, cornell_gpu):
     got = np.ascontiguousarray(film.read_f32()[y0:y0 + rh, x0:x0 + rw])
     assert got.tobytes() == np.ascontiguousarray(g["d_texels"][1, :, :, :3]).tobytes()
     film.close()
+
+
+def test_negative_tmin_takes_the_wide_stack_entries(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    """The no-spill LDS kernel packs a stack entry into one dword with the entry distance truncated toward zero,
+    conservative only for t >= 0; a negative tmin (hits behind the origin count) must run the 8-byte-entry kernel
+    and still give the oracle's records.  Rays start inside the box, so most have geometry on both sides."""
+    rng = np.random.default_rng(11)
+    n = 40000
+    org = np.stack([rng.uniform(-0.9, 0.9, n), rng.uniform(-1.9, -0.1, n), rng.uniform(-0.9, 0.9, n)], 1)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    for tmin in (-0.75, -1e-3, 0.0):
+        want, _ = cornell_oracle.trace(rays, tmin=tmin, tmax=10.0, mode=0)
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_FLAT):
+            got = cornell_gpu.trace(rays, tmin=tmin, tmax=10.0, extend=variant)
+            assert got.tobytes() == want.tobytes(), (tmin, variant)
+    assert (want["t"] < 0.9).any()
