@@ -362,7 +362,6 @@ __global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAV
     unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
 
     bool have = false, exhausted = false;
     uint32_t q = 0;
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAV
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= refill_min_idle) {
             if (!have) {
-                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
+                const uint32_t v = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
                     q = qq;
@@ -1128,7 +1127,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     pl.lds_scene = want == PT_EXTEND_LDS || (want == PT_EXTEND_AUTO && scene_bytes <= 24 * 1024);
     pl.variant = pl.lds_scene ? PT_EXTEND_LDS : PT_EXTEND_HBM;
     // deep trees of big scenes: 12 LDS entries measured best on the 1M-triangle soup (4: -15 %, 8: -3 %,
-    // 16: -5 %, 24: -16 %: beyond 12 the extra LDS costs occupancy)
+    // 16: -5 %, 24: -16 %: beyond 12 the extra LDS costs occupancy; 9/10/11, which would admit a 7th block per CU: -2.4 %)
     pl.lds_stack = pl.lds_scene ? LDS_STACK : 12;
     // LDS-resident scenes are small enough for an exact stack bound (lbvh_build.hip: wide_stack_need):
     // if it fits 16 LDS entries the kernel is instantiated without the spill path (Cornell: 9)
