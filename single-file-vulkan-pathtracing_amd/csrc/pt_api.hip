@@ -7,6 +7,24 @@
 
 static thread_local std::string g_create_err;
 
+// The layers below use std::vector / std::string: a failed host allocation must come back as a status, never as
+// an exception through the C boundary.
+template <class F>
+static pt_status guarded(pt_ctx *ctx, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try { if (ctx) ctx->err = "out of host memory"; } catch (...) {}
+        return PT_ERR_OOM;
+    } catch (const std::exception &e) {
+        try { if (ctx) ctx->err = std::string("internal error: ") + e.what(); } catch (...) {}
+        return PT_ERR_HIP;
+    } catch (...) {
+        return PT_ERR_HIP;
+    }
+}
+
 extern "C" {
 
 pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
@@ -91,7 +109,7 @@ pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts, 
     pt_scene *s = new (std::nothrow) pt_scene();
     if (!s) return PT_ERR_OOM;
     s->ctx = ctx;
-    pt_status rc = ptb_build_scene(s, vertices, n_verts, indices, n_tris, faces);
+    pt_status rc = guarded(ctx, [&] { return ptb_build_scene(s, vertices, n_verts, indices, n_tris, faces); });
     if (rc != PT_OK) { pt_scene_destroy(s); return rc; }
     *out = s;
     return PT_OK;
@@ -103,7 +121,7 @@ pt_status pt_scene_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n
     if (n && !xforms3x4) { s->ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
     if (n >= (1u << 28)) { s->ctx->err = "too many instances"; return PT_ERR_INVALID_ARG; }
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    return ptb_set_instances(s, xforms3x4, n);
+    return guarded(s->ctx, [&] { return ptb_set_instances(s, xforms3x4, n); });
 }
 
 void pt_scene_destroy(pt_scene *s)
@@ -118,7 +136,7 @@ pt_status pt_scene_set_bvh_quality(pt_scene *s, uint32_t quality)
 {
     if (!s) return PT_ERR_INVALID_ARG;
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    return ptb_set_bvh_quality(s, quality);
+    return guarded(s->ctx, [&] { return ptb_set_bvh_quality(s, quality); });
 }
 
 pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
@@ -245,7 +263,7 @@ pt_status pt_render(pt_scene *s, pt_film *f, const pt_params *p)
     if (!s || !f || !p) return PT_ERR_INVALID_ARG;
     if (s->ctx != f->ctx) { s->ctx->err = "scene and film belong to different contexts"; return PT_ERR_INVALID_ARG; }
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    return ptw_render(s, f, p);
+    return guarded(s->ctx, [&] { return ptw_render(s, f, p); });
 }
 
 pt_status pt_render_prepare(pt_scene *s, pt_film *f, const pt_params *p)
@@ -253,7 +271,7 @@ pt_status pt_render_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     if (!s || !f || !p) return PT_ERR_INVALID_ARG;
     if (s->ctx != f->ctx) { s->ctx->err = "scene and film belong to different contexts"; return PT_ERR_INVALID_ARG; }
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    return ptw_prepare(s, f, p);
+    return guarded(s->ctx, [&] { return ptw_prepare(s, f, p); });
 }
 
 pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits)
@@ -261,7 +279,7 @@ pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, floa
     if (!s) return PT_ERR_INVALID_ARG;
     if (n && (!rays6 || !hits)) { s->ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
     PT_HIP(s->ctx, hipSetDevice(s->ctx->device));
-    return ptw_trace(s, rays6, n, tmin, tmax, extend, hits);
+    return guarded(s->ctx, [&] { return ptw_trace(s, rays6, n, tmin, tmax, extend, hits); });
 }
 
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)

@@ -294,7 +294,7 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
 template <bool LDS_SCENE, bool COUNT, bool SPILL>
-__global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAVES : 1) void k_extend(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
+__device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
                                                NormBox nb, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAV
     unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;  // (v_mbcnt instead of this mask: C5 -5 %, measured twice)
 
     bool have = false, exhausted = false;
     uint32_t q = 0;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAV
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= refill_min_idle) {
             if (!have) {
-                const uint32_t v = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
                     q = qq;
@@ -569,6 +570,30 @@ __global__ __launch_bounds__(TB, (LDS_SCENE && !SPILL && !COUNT) ? PT_EXTEND_WAV
         }
     }
 }
+
+#define PT_EXTEND_PARAMS                                                                                    \
+    const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16, NormBox nb,                \
+        const float4 *__restrict__ g_tri4, uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,       \
+        const float2 *__restrict__ rayB, float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,           \
+        uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill, uint32_t spill_stride,          \
+        int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit
+#define PT_EXTEND_ARGS                                                                                               \
+    g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
+        refill_min_idle, tmin, tmax, lds_stack, raw_hit
+template <bool LDS_SCENE, bool COUNT, bool SPILL>
+__global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
+{
+    extend_body<LDS_SCENE, COUNT, SPILL>(PT_EXTEND_ARGS);
+}
+// The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
+// asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations
+// keep the plain launch bounds they were tuned with.
+__global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7(PT_EXTEND_PARAMS)
+{
+    extend_body<true, false, false>(PT_EXTEND_ARGS);
+}
+#undef PT_EXTEND_PARAMS
+#undef PT_EXTEND_ARGS
 
 // ---- extend, two-level variant (BASELINE config C4: instanced scenes) ----------------------------
 // TLAS = BVH4 over the instances' world boxes, BLAS = the scene's BVH4 in object space.  Same
@@ -1140,7 +1165,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem_wide_entries));
         PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem_wide_entries));
     }
-    const void *fn = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, false, false>)
+    const void *fn = !pl.spill ? reinterpret_cast<const void *>(k_extend_lds7)
                      : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false, true>)
                                     : reinterpret_cast<const void *>(k_extend<false, false, true>);
     const void *fn_count = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, true, false>)
@@ -1213,7 +1238,11 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
                           pl.refill, tmin, tmax, pl.lds_stack, raw)
     if (no_spill) {
-        if (count) PT_LAUNCH_EXTEND(true, true, false); else PT_LAUNCH_EXTEND(true, false, false);
+        if (count) PT_LAUNCH_EXTEND(true, true, false);
+        else
+            hipExtLaunchKernelGGL(k_extend_lds7, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
+                                  s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw);
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
