@@ -3,7 +3,7 @@
 ARGS=$1; shift
 L=single-file-vulkan-pathtracing_amd/libpt_amd.so
 cp $L /tmp/keep.so
-for r in 1 2 3; do
+for r in $(seq 1 ${AB_ROUNDS:-3}); do
   for B in "$@"; do
     cp $B $L; echo -n "$(basename $B): "
     python bench.py --no-cpu-baseline $ARGS 2>/dev/null | python -c "

@@ -28,10 +28,18 @@
 #include <cstdlib>
 #include <vector>
 
-namespace {
+#include "extend_kernel.h"  // TB, SENTINEL, NormBox, k_extend<>, k_extend_lds7, the slab / stack helpers
 
-constexpr int TB = 256;
-constexpr uint32_t SENTINEL = 0xFFFFFFFFu;
+// extend_hbm.hip: k_extend<false, *, true>, compiled with the max-ILP scheduler
+const void *ptw_extend_hbm_fn(bool count);
+void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                           const float4 *wide, const uint2 *wide16, const float *norm_c, const float *norm_s,
+                           const float *norm_rs, const float4 *tri4, uint32_t n_wide, uint32_t n_tris, const float4 *rayA,
+                           const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
+                           unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
+                           float tmax, int lds_stack, int raw_hit);
+
+namespace {
 
 // Exact unsigned division by a run-time constant without the ~28-instruction v_rcp sequence
 // (Granlund & Montgomery 1994, N = 32): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n).
@@ -185,415 +193,6 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
         }
     }
 }
-
-// ---- extend: closest hit for every queued ray (traceRayEXT, raygen.rgen:63-75) ---------------
-// Persistent grid (gridDim = CUs x resident blocks); each block walks 256-ray chunks of the
-// dense queue, one ray per lane, over the BVH4 (128-B nodes = one L2 line per visit).
-//  * children are visited nearest-first (4-element sorting network on the entry distances);
-//  * stack entries are (child word, entry distance): a popped subtree that now starts behind the
-//    best hit is dropped without touching memory (culling uses <= so equal-t candidates survive
-//    for the deterministic lowest-primitive-id tie-break);
-//  * short stack: the first LDS_STACK entries of every lane live in LDS as stack[level][thread]
-//    (conflict-free), deeper entries spill to a per-thread column in HBM -- LDS use is constant
-//    whatever the tree height, so occupancy is not capped by the scene;
-//  * LDS_SCENE: nodes + triangles are staged into LDS once per persistent block and traversal
-//    touches no HBM at all (scenes up to ~24 KB).
-constexpr int LDS_STACK = 8;
-// Nodes staged in LDS are spaced 144 B instead of 128 B: lanes of a wave sit on DIFFERENT nodes but read
-// the SAME field of them, and with a 128-B stride (a multiple of the bank cycle) those 16-B reads all fall
-// on the same 4 banks -- an n-way conflict for n distinct nodes.  144 B = 36 banks shifts consecutive
-// nodes by 4 banks, so 8 nodes tile the 32 banks exactly (measured: +0.6 % on C2, within noise on C4).
-constexpr uint32_t LDS_NODE_F4 = 9;  // float4 per LDS node (8 used)
-// Stack entries are one 64-bit word (child word | entry distance << 32) and the LDS part is addressed
-// through an LDS-typed pointer: with generic pointers the compiler merges the LDS and the spill
-// access into FLAT loads/stores of the two halves (seen in the ISA), which cost VMEM issue and latency.
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-__device__ __forceinline__ unsigned long long stack_entry(uint32_t w, float t)
-{
-    return (unsigned long long)w | ((unsigned long long)__float_as_uint(t) << 32);
-}
-
-// Slab test of the 4 children of a BVH4 node with the near/far planes picked by the ray's direction
-// signs THROUGH THE LOAD ADDRESS (ax/ay/az = 48 bytes when the direction component is negative: the near
-// plane of x is then float4 3 instead of 0, its far plane 0 instead of 3 -- one add or sub per load), so no
-// per-child min/max of the two plane distances is needed.  Conservative like ptm::box_test.
-#define PT_F4(P) (*reinterpret_cast<const float4 *>(P))
-#define PT_NODE_LOAD(ND)                                                                                 \
-    const char *nb_ = reinterpret_cast<const char *>(ND);                                                \
-    const float4 nx = PT_F4(nb_ + ax), fx = PT_F4(nb_ - ax + 48), ny = PT_F4(nb_ + ay + 16),             \
-                 fy = PT_F4(nb_ - ay + 64), nz = PT_F4(nb_ + az + 32), fz = PT_F4(nb_ - az + 80),        \
-                 cw = PT_F4(nb_ + 96);
-// Plane distances are ONE fma each, n * inv + (-org * inv), instead of (n - org) * inv: 6 VALU
-// instructions less per child.  The rounding of the folded origin term and of the scaled far-plane
-// reciprocal (absolute error <= 2^-22 |org*inv| in total) is covered by moving the origin term
-// 2^-21 |org*inv| DOWN for the near planes and UP for the far planes (slab_setup below), so tn stays a lower
-// and tf an upper bound.  The relative errors (v_rcp_f32's 1 ulp, the fma's rounding) are covered by a
-// factor 1 + 4e-7 on the far distances, folded into the far planes' reciprocal and origin term (invf, of)
-// so it costs nothing per node; a negative far distance only gets more negative, and such a box is behind
-// the ray anyway.  Box tests are not part of the numerical contract -- they only have to never reject a
-// box that holds a hit.
-// (max_raw/min_raw: fmaxf/fminf on a kernel argument or a loop-carried value make the compiler re-quiet
-// that operand with a v_max x,x in every iteration; the instruction itself already has maxNum semantics)
-#define PT_SLAB4(T, C)                                                                                           \
-    {                                                                                                            \
-        const float tn = fmaxf(fmaxf(__builtin_fmaf(nx.C, inv.x, on.x), __builtin_fmaf(ny.C, inv.y, on.y)),      \
-                               max_raw_s(__builtin_fmaf(nz.C, inv.z, on.z), tmin));                              \
-        const float tf = fminf(fminf(__builtin_fmaf(fx.C, invf.x, of.x), __builtin_fmaf(fy.C, invf.y, of.y)),    \
-                               min_raw(__builtin_fmaf(fz.C, invf.z, of.z), best_t));                             \
-        T = tn <= tf ? tn : INF;                                                                                 \
-    }
-__device__ __forceinline__ float max_raw_s(float a, float uniform_b)
-{
-    float r;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "s"(uniform_b), "v"(a));
-    return r;
-}
-__device__ __forceinline__ float min_raw(float a, float b)
-{
-    float r;
-    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void slab_setup(const ptm::f3 org, const ptm::f3 inv, ptm::f3 &invf, ptm::f3 &on, ptm::f3 &of)
-{
-    const float ox = -(org.x * inv.x), oy = -(org.y * inv.y), oz = -(org.z * inv.z);
-    const float px = fabsf(ox) * 0x1p-21f, py = fabsf(oy) * 0x1p-21f, pz = fabsf(oz) * 0x1p-21f;
-    on = { ox - px, oy - py, oz - pz };
-    of = { (ox + px) * 1.0000004f, (oy + py) * 1.0000004f, (oz + pz) * 1.0000004f };
-    invf = { inv.x * 1.0000004f, inv.y * 1.0000004f, inv.z * 1.0000004f };
-}
-// ---- 64-B nodes (scene walked in HBM/L2): the planes are fp16 of box coordinates normalised to the scene box
-// (lbvh_build.hip k_wide_half, rounded outwards).  v_fma_mix_f32 reads the half straight out of the loaded
-// dword, so the slab arithmetic costs exactly what it costs with fp32 planes; the ray is normalised the same
-// way at refill (org' = (org - c) * rs, inv' = inv * s), which leaves every distance t unchanged.
-struct NormBox { float cx, cy, cz, sx, sy, sz, rsx, rsy, rsz; };
-#define PT_MIXH(DST, REG, HI, INVC, ONC) \
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[" #HI ",0,0] op_sel_hi:[1,0,0]" : "=v"(DST) : "v"(REG), "v"(INVC), "v"(ONC))
-#define PT_SLAB4H(T, REGC, HI)                                                                      \
-    {                                                                                               \
-        float nxv, nyv, nzv, fxv, fyv, fzv;                                                         \
-        PT_MIXH(nxv, hnx.REGC, HI, inv.x, on.x); PT_MIXH(nyv, hny.REGC, HI, inv.y, on.y);           \
-        PT_MIXH(nzv, hnz.REGC, HI, inv.z, on.z); PT_MIXH(fxv, hfx.REGC, HI, invf.x, of.x);          \
-        PT_MIXH(fyv, hfy.REGC, HI, invf.y, of.y); PT_MIXH(fzv, hfz.REGC, HI, invf.z, of.z);         \
-        const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                              \
-        const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                              \
-        T = tn <= tf ? tn : INF;                                                                    \
-    }
-#ifndef PT_EXTEND_WAVES
-#define PT_EXTEND_WAVES 7  // min waves per SIMD asked of the compiler for the no-spill LDS variant: 72 VGPRs instead of 76, no spills (8: 13 spilled, -13 %)
-#endif
-constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the wave pulls new rays
-
-// Persistent threads with dynamic ray fetch (Aila & Laine 2009, re-tiled for wave64): a lane whose
-// ray is finished does not wait for the slowest ray of its wave; once >= REFILL_MIN_IDLE lanes are
-// idle they take the next rays of the wave's OWN sequence of 64-ray chunks (chunk w, w + #waves,
-// w + 2*#waves, ... of the dense queue; ballot + popcount give the per-lane offsets).  The cursor
-// is wave-private, so there is no shared dequeue word at all: a single device-scope head saturates
-// at ~88 atomics/us on this chip, which short Cornell traversals (3.6 nodes/ray) exceed 3x over.
-// Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
-// instructions per wave than per average lane).
-template <bool LDS_SCENE, bool COUNT, bool SPILL>
-__device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
-                                               NormBox nb, const float4 *__restrict__ g_tri4,
-                                               uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
-                                               const float2 *__restrict__ rayB, float4 *__restrict__ hit,
-                                               const uint32_t *__restrict__ count_in, uint32_t *count_zero,
-                                               unsigned long long *stats, uint2 *__restrict__ spill,
-                                               uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
-                                               int lds_stack, int raw_hit)
-{
-    // Scenes in HBM (deep trees, incoherent rays): inside the classic while-while loop the node phase ran
-    // at 18 % lane occupancy on the 1M-triangle soup (device counters) -- lanes that already hold a leaf wait
-    // for the last lane to finish descending.  There the wave instead takes ONE step per iteration, of the
-    // kind (node or leaf) that more of its lanes are waiting for, node steps counting double: node occupancy
-    // 36 %, triangle steps 36 %, C5 +11 %.  The LDS-resident Cornell box loses 5 % to the extra votes, so it
-    // keeps the inner loop.
-    constexpr bool VOTE = !LDS_SCENE;
-    constexpr int VOTE_NODE_NUM = 2, VOTE_NODE_DEN = 1;
-    // COMPACT (scene in LDS and its exact stack bound fits: the Cornell box): child words are re-coded to 14 bits
-    // when the nodes are staged (leaf: bit 13 | (count-1) << 11 | first; inner: node index; done: 0x3FFF) and a
-    // stack entry is ONE dword, the entry distance truncated to its top 18 bits above the child word
-    // (sign, exponent, 9 mantissa bits: rounds a non-negative distance DOWN, so the pop test stays conservative).
-    // Half the stack bytes in LDS: 15 KB instead of 25 KB per block for the Cornell box, which lifts the LDS cap
-    // on resident blocks from 6 to 10 per CU.  The host only picks it for tmin >= 0.
-    constexpr bool COMPACT = LDS_SCENE && !SPILL;
-    constexpr uint32_t LEAF_BIT = COMPACT ? 0x2000u : PT_LEAF;
-    constexpr uint32_t DONE = COMPACT ? 0x3FFFu : SENTINEL;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
-    const float4 *wide = g_wide;
-    const float4 *tri4 = g_tri4;
-    if (LDS_SCENE) {
-        float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * TB * (COMPACT ? sizeof(uint32_t) : sizeof(uint2)));
-        float4 *s_tri = s_wide + LDS_NODE_F4 * (size_t)n_wide;
-        for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) {
-            float4 v = g_wide[i];
-            if (COMPACT && (i & 7u) == 6u) {  // the four child words
-                auto cw = [](float f) {
-                    const uint32_t w = __float_as_uint(f);
-                    const uint32_t c = (w & PT_LEAF) ? (0x2000u | (((w >> 28) & 3u) << 11) | (w & 0x7FFu)) : (w & 0x1FFFu);
-                    return __uint_as_float(w == SENTINEL ? 0x3FFFu : c);
-                };
-                v = make_float4(cw(v.x), cw(v.y), cw(v.z), cw(v.w));
-            }
-            s_wide[(i >> 3) * LDS_NODE_F4 + (i & 7u)] = v;
-        }
-        // three copies of the triangles with components permuted to (kx,ky,kz) for kz = 0,1,2:
-        // the triangle test then needs no per-lane component selects (ptm::tri_test_perm)
-        for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
-            const float4 v = g_tri4[i];
-            s_tri[i] = make_float4(v.y, v.z, v.x, v.w);                    // kz = 0: (kx,ky,kz) = (1,2,0)
-            s_tri[3 * n_tris + i] = make_float4(v.z, v.x, v.y, v.w);       // kz = 1: (2,0,1)
-            s_tri[6 * n_tris + i] = v;                                     // kz = 2: (0,1,2)
-        }
-        __syncthreads();
-        wide = s_wide;
-        tri4 = s_tri;
-    }
-    const uint32_t n = *count_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (count_zero) *count_zero = 0u;  // the queue the coming shade pass appends to
-        if (stats) atomicAdd(stats, (unsigned long long)n);  // exact ray count
-    }
-    lds_u64 *my_stack = (lds_u64 *)reinterpret_cast<unsigned long long *>(stack) + threadIdx.x;
-    lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(stack) + threadIdx.x;
-    unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
-    const float INF = __builtin_inff();
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;  // (v_mbcnt instead of this mask: C5 -5 %, measured twice)
-
-    bool have = false, exhausted = false;
-    uint32_t q = 0;
-    // wave-private ray sequence: virtual index v -> queue position (v/64)*wave_stride + wave_base + v%64
-    const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
-    const uint32_t wave_stride = gridDim.x * TB;
-    uint32_t cursor = 0;
-    ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};  // slab_setup: near/far reciprocals and folded origin terms
-    ptm::RayPre pre{};
-    uint32_t ax = 0, ay = 0, az = 0;  // 48 where the direction component is negative (PT_NODE_LOAD)
-    uint32_t tri_base = 0;           // LDS_SCENE: start of the triangle copy for this ray's kz
-    float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
-    uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
-    uint32_t cur = DONE;
-    int sp = 0;
-    unsigned long long c_nodes = 0, c_tris = 0, c_node_steps = 0, c_tri_steps = 0;
-
-    auto push = [&](uint32_t w, float t) {
-        if (COMPACT) {
-            my_stack32[sp * TB] = (__float_as_uint(t) & 0xFFFFC000u) | w;
-            sp++;
-            return;
-        }
-        const unsigned long long e = stack_entry(w, t);
-        if (!SPILL || sp < lds_stack) my_stack[sp * TB] = e;  // !SPILL: the host proved lds_stack entries suffice
-        else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
-        sp++;
-    };
-    auto pop = [&]() -> uint32_t {  // next subtree that can still contain the closest hit
-        if (COMPACT) {
-            while (sp > 0) {
-                sp--;
-                const uint32_t e = my_stack32[sp * TB];
-                if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
-            }
-            return DONE;
-        }
-        while (sp > 0) {
-            sp--;
-            unsigned long long e;
-            if (!SPILL || sp < lds_stack) e = my_stack[sp * TB];
-            else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if (__uint_as_float((uint32_t)(e >> 32)) <= best_t) return (uint32_t)e;
-        }
-        return DONE;
-    };
-
-    for (;;) {
-        // ---- refill idle lanes from the queue head
-        const unsigned long long idle = __ballot(!have);
-        const int n_idle = __popcll(idle);
-        if (!exhausted && n_idle >= refill_min_idle) {
-            if (!have) {
-                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
-                const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
-                if (qq < n) {
-                    q = qq;
-                    const float4 ra = rayA[q];
-                    const float2 rb = rayB[q];
-                    const ptm::f3 org = { ra.x, ra.y, ra.z };
-                    const ptm::f3 dir = { ra.w, rb.x, rb.y };
-                    pre = ptm::ray_setup(org, dir);
-                    inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
-                    if (LDS_SCENE) {
-                        slab_setup(org, inv, invf, on, of);
-                    } else {  // fp16 nodes live in the normalised scene box
-                        const ptm::f3 orgn = { (org.x - nb.cx) * nb.rsx, (org.y - nb.cy) * nb.rsy, (org.z - nb.cz) * nb.rsz };
-                        inv = { inv.x * nb.sx, inv.y * nb.sy, inv.z * nb.sz };
-                        slab_setup(orgn, inv, invf, on, of);
-                    }
-                    // byte offset of the near planes inside a node: 3 planes of 16 B (fp32 node) or 8 B (fp16 node)
-                    ax = inv.x < 0.f ? (LDS_SCENE ? 48u : 24u) : 0u;
-                    ay = inv.y < 0.f ? (LDS_SCENE ? 48u : 24u) : 0u;
-                    az = inv.z < 0.f ? (LDS_SCENE ? 48u : 24u) : 0u;
-                    if (LDS_SCENE) {
-                        tri_base = (uint32_t)pre.kz * 3u * n_tris;
-                        orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y),
-                                 ptm::sel3(pre.kz, org.x, org.y, org.z) };
-                    }
-                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
-                    best_pos = PT_MISS; best_prim = PT_MISS;
-                    cur = 0u;  // wide root
-                    sp = 0;
-                    have = true;
-                }
-            }
-            cursor += (uint32_t)n_idle;
-            exhausted = (cursor >> 6) * wave_stride + wave_base >= n;  // chunk of the next refill starts past the end
-        }
-        if (__ballot(have) == 0ull) break;
-
-        // ---- node phase: every lane descends until it holds a leaf (or runs out of nodes)
-        // VOTE: one step per outer iteration, of the kind (node / leaf) that more lanes are waiting for
-        bool do_leaf = true;
-        bool do_node = have && !(cur & LEAF_BIT);
-        const int n_have = __popcll(__ballot(have));
-        if (VOTE) {
-            const bool want_leaf = have && (cur & LEAF_BIT) && cur != DONE;
-            const int nn = __popcll(__ballot(do_node)), nl = __popcll(__ballot(want_leaf));
-            const bool node_turn = nn * VOTE_NODE_NUM >= nl * VOTE_NODE_DEN;
-            do_node = do_node && node_turn;
-            do_leaf = !node_turn;
-        }
-        while (do_node) {
-            if (COUNT) {
-                c_nodes++;
-                if (lane == __ffsll((long long)__ballot(1)) - 1) c_node_steps++;  // one lane per wave step
-            }
-            float t0, t1, t2, t3;
-            uint32_t w0, w1, w2, w3;
-            if (LDS_SCENE) {
-                const float4 *nd = wide + LDS_NODE_F4 * (size_t)cur;
-                PT_NODE_LOAD(nd)
-                w0 = __float_as_uint(cw.x); w1 = __float_as_uint(cw.y); w2 = __float_as_uint(cw.z); w3 = __float_as_uint(cw.w);
-                PT_SLAB4(t0, x)
-                PT_SLAB4(t1, y)
-                PT_SLAB4(t2, z)
-                PT_SLAB4(t3, w)
-            } else {
-                const char *nb_ = reinterpret_cast<const char *>(g_wide16) + 64 * (size_t)cur;
-                const uint2 hnx = *reinterpret_cast<const uint2 *>(nb_ + ax), hfx = *reinterpret_cast<const uint2 *>(nb_ - ax + 24),
-                            hny = *reinterpret_cast<const uint2 *>(nb_ + ay + 8), hfy = *reinterpret_cast<const uint2 *>(nb_ - ay + 32),
-                            hnz = *reinterpret_cast<const uint2 *>(nb_ + az + 16), hfz = *reinterpret_cast<const uint2 *>(nb_ - az + 40);
-                const uint4 cw = *reinterpret_cast<const uint4 *>(nb_ + 48);
-                w0 = cw.x; w1 = cw.y; w2 = cw.z; w3 = cw.w;
-                PT_SLAB4H(t0, x, 0)
-                PT_SLAB4H(t1, x, 1)
-                PT_SLAB4H(t2, y, 0)
-                PT_SLAB4H(t3, y, 1)
-            }
-#define PT_CSWAP(TA, WA, TB_, WB)                            \
-    {                                                        \
-        const bool sw = TB_ < TA;                            \
-        const float ta = sw ? TB_ : TA, tb = sw ? TA : TB_;  \
-        const uint32_t wa = sw ? WB : WA, wb = sw ? WA : WB; \
-        TA = ta; TB_ = tb; WA = wa; WB = wb;                 \
-    }
-            PT_CSWAP(t0, w0, t1, w1)
-            PT_CSWAP(t2, w2, t3, w3)
-            PT_CSWAP(t0, w0, t2, w2)
-            PT_CSWAP(t1, w1, t3, w3)
-            PT_CSWAP(t1, w1, t2, w2)
-#undef PT_CSWAP
-            if (t3 < INF) push(w3, t3);  // farthest first, so the nearest pending pops first
-            if (t2 < INF) push(w2, t2);
-            if (t1 < INF) push(w1, t1);
-            cur = t0 < INF ? w0 : pop();
-            do_node = !VOTE && !(cur & LEAF_BIT);
-            if (!VOTE) {
-                // fewer than 1/6 of the wave's rays still descending while the rest waits with a leaf: let the
-                // leaves go first, the stragglers resume in the next round of the outer loop (node-step lane
-                // occupancy 40 % -> 55 %, triangle steps 34 % -> 31 %, C2 +3 %; 1/4: +2.5 %, 1/12: +2.5 %)
-                const int n_cont = __popcll(__ballot(do_node));
-                if (n_cont * 6 < n_have) break;
-            }
-        }
-        // ---- leaf phase
-        if (have) {
-            if (cur != DONE && (cur & LEAF_BIT) && (!VOTE || do_leaf)) {
-                const uint32_t first = COMPACT ? (cur & 0x7FFu) : (cur & 0x0FFFFFFFu);
-                const uint32_t cnt = (COMPACT ? ((cur >> 11) & 3u) : ((cur >> 28) & 7u)) + 1u;
-                if (COUNT) c_tris += cnt;
-                for (uint32_t k = 0; k < cnt; k++) {
-                    if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) c_tri_steps++;
-                    const uint32_t pos = first + k;
-                    const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : 3 * (size_t)pos;
-                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
-                    float t, V, W, det;
-                    const bool th = LDS_SCENE
-                        ? ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)
-                        : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det);
-                    if (th) {
-                        const uint32_t prim = __float_as_uint(a.w);
-                        // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
-                        if (t < best_t || (t == best_t && prim < best_prim)) {
-                            best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
-                        }
-                    }
-                }
-                cur = pop();
-            }
-            if (cur == DONE) {  // traversal finished: emit the hit record, the lane becomes idle
-                const bool miss = best_pos == PT_MISS;
-                // raw_hit (render path): (V, W, det) go out undivided and k_shade takes the two quotients at
-                // full lane occupancy; here they would run once per finishing lane group
-                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
-                                 : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
-                have = false;
-            }
-        }
-    }
-    if (COUNT) {
-        for (int o = 32; o > 0; o >>= 1) {
-            c_nodes += __shfl_xor(c_nodes, o, 64);
-            c_tris += __shfl_xor(c_tris, o, 64);
-            c_node_steps += __shfl_xor(c_node_steps, o, 64);
-            c_tri_steps += __shfl_xor(c_tri_steps, o, 64);
-        }
-        if (lane == 0 && stats) {
-            atomicAdd(stats + 2, c_nodes);
-            atomicAdd(stats + 3, c_tris);
-            atomicAdd(stats + 4, c_node_steps);
-            atomicAdd(stats + 5, c_tri_steps);
-        }
-    }
-}
-
-#define PT_EXTEND_PARAMS                                                                                    \
-    const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16, NormBox nb,                \
-        const float4 *__restrict__ g_tri4, uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,       \
-        const float2 *__restrict__ rayB, float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,           \
-        uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill, uint32_t spill_stride,          \
-        int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit
-#define PT_EXTEND_ARGS                                                                                               \
-    g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
-        refill_min_idle, tmin, tmax, lds_stack, raw_hit
-template <bool LDS_SCENE, bool COUNT, bool SPILL>
-__global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
-{
-    extend_body<LDS_SCENE, COUNT, SPILL>(PT_EXTEND_ARGS);
-}
-// The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
-// asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations
-// keep the plain launch bounds they were tuned with.
-__global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7(PT_EXTEND_PARAMS)
-{
-    extend_body<true, false, false>(PT_EXTEND_ARGS);
-}
-#undef PT_EXTEND_PARAMS
-#undef PT_EXTEND_ARGS
 
 // ---- extend, two-level variant (BASELINE config C4: instanced scenes) ----------------------------
 // TLAS = BVH4 over the instances' world boxes, BLAS = the scene's BVH4 in object space.  Same
@@ -1167,10 +766,10 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     }
     const void *fn = !pl.spill ? reinterpret_cast<const void *>(k_extend_lds7)
                      : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false, true>)
-                                    : reinterpret_cast<const void *>(k_extend<false, false, true>);
+                                    : ptw_extend_hbm_fn(false);
     const void *fn_count = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, true, false>)
                            : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, true, true>)
-                                          : reinterpret_cast<const void *>(k_extend<false, true, true>);
+                                          : ptw_extend_hbm_fn(true);
     if (pl.smem > 48 * 1024)
         PT_HIP(ctx, hipFuncSetAttribute(fn_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
     if (pl.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
@@ -1246,7 +845,9 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
-        if (count) PT_LAUNCH_EXTEND(false, true, true); else PT_LAUNCH_EXTEND(false, false, true);
+        ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
+                              s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
+                              tmax, pl.lds_stack, raw);
     }
 #undef PT_LAUNCH_EXTEND
 }
