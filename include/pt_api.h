@@ -195,6 +195,8 @@ typedef struct pt_stats {
      * code / the triangle code.  nodes_visited / (64 * node_steps) is the lane occupancy of the node phase,
      * tris_tested / (64 * tri_steps) that of the triangle tests.                                        */
     uint64_t node_steps, tri_steps;
+    /* batches whose sample-group term log filled up and that were rendered again with one group (exact either way) */
+    uint32_t redone_batches, reserved_;
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

@@ -66,7 +66,8 @@ class Stats(C.Structure):
                 ("ms_total", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float),
                 ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("frames_in_flight", C.c_uint32), ("sample_groups", C.c_uint32),
-                ("node_steps", C.c_uint64), ("tri_steps", C.c_uint64)]
+                ("node_steps", C.c_uint64), ("tri_steps", C.c_uint64),
+                ("redone_batches", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class HostScene(C.Structure):

@@ -91,6 +91,8 @@ struct pt_film {
         float4 *d_terms = nullptr;                // per slot: ordered radiance terms, dense primary log   (groups > 1)
         float4 *d_terms_over = nullptr;           // per slot: overflow of the primary log (worst-case sized)
         uint32_t *d_nterm = nullptr;              // per slot: number of logged terms               (groups > 1)
+        uint32_t *d_spill_head = nullptr;         // per slot: last entry of the slot in the spill pool (groups > 1)
+        float4 *d_spill = nullptr;                // shared pool {r, g, b, previous entry of the slot}: terms beyond term_cap
         // double-buffered dense queues (index = queue position)
         uint2 *d_qid[2] = { nullptr, nullptr };       // {slot, sample | depth<<16}
         float4 *d_qstate[2] = { nullptr, nullptr };   // {bits(seed), weight.rgb}

@@ -85,9 +85,18 @@ struct Radiance {
     float4 *color;     // [n_slots]              (groups == 1)
     float4 *terms;     // primary log [term_pcap][n_slots], rgb + pad (groups > 1): neighbouring slots write their
                        // k-th term side by side (slot-major rows measured 20 % slower in k_shade)
-    float4 *terms_over;  // overflow log [n_slots][term_cap - term_pcap]: worst case, rarely touched
+    float4 *terms_over;  // overflow log [n_slots][term_cap - term_pcap]: rarely touched; sized to a memory budget
     uint32_t *nterm;   // [n_slots]              (groups > 1)
+    // terms beyond a slot's term_cap go to a pool shared by all slots, chained backwards per slot (a slot has one
+    // live path, so its chain has one writer): {r, g, b, index of the slot's previous pool entry}
+    float4 *spill;
+    uint32_t *spill_head;          // [n_slots] last pool entry of the slot, SPILL_NONE if none
+    unsigned long long *spill_count;
+    uint32_t spill_cap;
+    unsigned long long *overflow;  // set when the pool is full too: the host re-renders the batch with groups == 1
 };
+constexpr uint32_t SPILL_NONE = 0xFFFFFFFFu;
+constexpr uint32_t SPILL_POOL_ENTRIES = 4u << 20;  // 64 MB
 
 __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radiance &rad, uint32_t slot, float r, float g,
                                              float b)
@@ -101,7 +110,16 @@ __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radian
     } else {
         const uint32_t k = rad.nterm[slot];
         if (k < rc.term_pcap) rad.terms[(size_t)k * rc.n_slots + slot] = make_float4(r, g, b, 0.f);
-        else rad.terms_over[(size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)] = make_float4(r, g, b, 0.f);
+        else if (k < rc.term_cap) rad.terms_over[(size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)] = make_float4(r, g, b, 0.f);
+        else {
+            const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
+            if (idx < rad.spill_cap) {
+                rad.spill[idx] = make_float4(r, g, b, __uint_as_float(rad.spill_head[slot]));
+                rad.spill_head[slot] = (uint32_t)idx;
+            } else {
+                *rad.overflow = 1ull;  // this batch's film update is discarded and redone with groups == 1
+            }
+        }
         rad.nterm[slot] = k + 1u;
     }
 }
@@ -175,7 +193,10 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
             uint32_t f, g, px, py;
             slot_pixel(rc, tiles, slot, f, g, px, py);
             if (rc.groups == 1u) rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
-            else rad.nterm[slot] = 0u;
+            else {
+                rad.nterm[slot] = 0u;
+                rad.spill_head[slot] = SPILL_NONE;
+            }
             sample0 = g * rc.group_size;
             if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
                 alive[0] = true;
@@ -644,10 +665,23 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
         } else {  // replay the groups' term logs in sample order: the reference's sequence of adds
             for (uint32_t g = 0; g < rc.groups; g++) {
                 const size_t slot = ((size_t)f * rc.groups + g) * rc.slots_per_lane + local;
-                const uint32_t nt = rad.nterm[slot];
+                const uint32_t nt_all = rad.nterm[slot], nt = min(nt_all, rc.term_cap);
                 const float4 *to = rad.terms_over + slot * (rc.term_cap - rc.term_pcap);
                 for (uint32_t k = 0; k < nt; k++) {
                     const float4 e = k < rc.term_pcap ? rad.terms[(size_t)k * rc.n_slots + slot] : to[k - rc.term_pcap];
+                    c.x = c.x + e.x;
+                    c.y = c.y + e.y;
+                    c.z = c.z + e.z;
+                }
+                // the few slots with more terms: their pool entries are chained newest-first, so the j-th one in
+                // path order is reached by walking m-1-j links (m is small; quadratic in m, rare).  (When the pool
+                // itself overflowed the chain is incomplete: the host discards this batch.)
+                const uint32_t m = nt_all - nt;
+                for (uint32_t j = 0; j < m; j++) {
+                    uint32_t idx = rad.spill_head[slot];
+                    for (uint32_t w = j + 1; w < m && idx != SPILL_NONE; w++) idx = __float_as_uint(rad.spill[idx].w);
+                    if (idx == SPILL_NONE) break;
+                    const float4 e = rad.spill[idx];
                     c.x = c.x + e.x;
                     c.y = c.y + e.y;
                     c.z = c.z + e.z;
@@ -890,8 +924,8 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
             (void)hipFree(w.d_qrayA[i]); (void)hipFree(w.d_qrayB[i]);
             w.d_qid[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
         }
-        (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst); (void)hipFree(w.d_nterm);
-        w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr;
+        (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst); (void)hipFree(w.d_nterm); (void)hipFree(w.d_spill_head);
+        w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr; w.d_spill_head = nullptr;
         w.cap_slots = 0;
         for (int i = 0; i < 2; i++) {
             PT_HIP(ctx, hipMalloc((void **)&w.d_qid[i], sizeof(uint2) * ns));
@@ -902,6 +936,7 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         PT_HIP(ctx, hipMalloc((void **)&w.d_hit, sizeof(float4) * ns));
         PT_HIP(ctx, hipMalloc((void **)&w.d_hit_inst, sizeof(uint32_t) * ns));
         PT_HIP(ctx, hipMalloc((void **)&w.d_nterm, sizeof(uint32_t) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_spill_head, sizeof(uint32_t) * ns));
         w.cap_slots = ns;
     }
     if (groups == 1 && ns > w.cap_color) {
@@ -927,14 +962,17 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         w.cap_terms_over = n_over;
     }
     if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
+    if (groups > 1 && !w.d_spill) PT_HIP(ctx, hipMalloc((void **)&w.d_spill, sizeof(float4) * SPILL_POOL_ENTRIES));
     return PT_OK;
 }
 
 struct RenderShape {
     uint32_t lanes = 1, groups = 1, group_size = 1, term_cap = 0, term_pcap = 0;
+    bool bounded = false;  // term_cap < group_size * max_depth: a full log is detected and the batch redone ungrouped
 };
 
-// frames in flight x sample groups: enough live paths (~32M) to fill the chip several times over
+// frames in flight x sample groups: enough live paths (~32M) to fill the chip several times over, and slots that
+// do not live longer than they have to
 RenderShape choose_shape(const pt_film *f, const pt_params *p)
 {
     RenderShape sh;
@@ -950,15 +988,26 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
         lanes = (uint32_t)(((uint64_t)p->frame_count + batches - 1) / batches);
     }
     lanes = std::max(1u, std::min(lanes, p->frame_count));
-    // sample groups: when the frames in flight alone cannot fill the chip (few frames asked for),
-    // split each pixel's samples over several slots; the term logs keep the sum order exact.
+    // A blocking render can check a batch and redo it; PT_FLAG_ASYNC can not, and keeps the worst-case log.
+    const bool can_redo = (p->flags & PT_FLAG_ASYNC) == 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const uint64_t have_log = f->work.cap_terms_over * sizeof(float4);  // already ours: counts as free
+    // sample groups: split each pixel's samples over several slots; the term logs keep the sum order exact.
+    //  (a) few frames asked for: the frames in flight alone cannot fill the chip;
+    //  (b) a slot lives group_size x depth rounds and every round costs ~27 us of launch-bound time per pipeline
+    //      whatever its queue holds: 16 frames x 4 groups need 64 rounds instead of 256 (Cornell box, 1080p: +4 %),
+    //      as long as the slots (<= 160 M: 21 GB of queues + 25 GB of primary log) allow it.
     uint32_t groups = p->sample_groups;
     if (groups == 0) {
         groups = 1;
         const uint64_t have = std::max<uint64_t>((uint64_t)lanes * pixels_local, 1);
-        if (have * 2 <= target) {
-            // even groups only (uneven tails measured 8 % slower): the divisor of spp closest to target/have
-            const double want = (double)target / (double)have;
+        double want = (double)target / (double)have;
+        const uint64_t slot_budget = 160ull << 20;
+        if (can_redo && have * 4 <= slot_budget) want = std::max(want, 4.0);
+        else if (can_redo && have * 2 <= slot_budget) want = std::max(want, 2.0);
+        if (want >= 2.0) {
+            // even groups only (uneven tails measured 8 % slower): the divisor of spp closest to `want`
             uint32_t g = 1;
             double best = 1e30;
             for (uint32_t d = 1; d <= p->spp_per_frame; d++) {
@@ -966,20 +1015,28 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
                 const double r = d > want ? d / want : want / d;
                 if (r < best) { best = r; g = d; }
             }
-            // worst-case log: one 16-B term per ray.  It is allocated in full (only the dense primary part is
-            // normally touched), so it has to fit: at most 80 GB of the 288 and half of what is free right now
+            // without the redo the worst-case log (one 16-B term per ray) is allocated in full, so it has to fit:
+            // at most 80 GB of the 288 and half of what is free right now
             const uint64_t log_bytes = (uint64_t)lanes * pixels_local * p->spp_per_frame * p->max_depth * 16ull;
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-            const uint64_t have_log = f->work.cap_terms_over * sizeof(float4);  // already ours: counts as free
-            if (g > 1 && log_bytes <= (80ull << 30) && log_bytes <= have_log + free_b / 2) groups = g;
+            if (g > 1 && (can_redo || (log_bytes <= (80ull << 30) && log_bytes <= have_log + free_b / 2))) groups = g;
         }
     }
     groups = std::max(1u, std::min(groups, p->spp_per_frame));
     sh.group_size = (p->spp_per_frame + groups - 1) / groups;
     sh.groups = (p->spp_per_frame + sh.group_size - 1) / sh.group_size;  // no empty groups
-    sh.term_cap = sh.groups > 1 ? sh.group_size * p->max_depth : 0u;
-    sh.term_pcap = std::min(sh.term_cap, sh.group_size + 2u);  // ~1 term per sample is typical (the miss that ends it)
+    const uint32_t worst = sh.groups > 1 ? sh.group_size * p->max_depth : 0u;  // every ray of a slot adds a term
+    sh.term_cap = worst;
+    sh.term_pcap = std::min(worst, sh.group_size + 2u);  // ~1 term per sample is typical (the miss that ends it)
+    if (sh.groups > 1 && can_redo) {
+        // overflow log within a budget (16 GB, a quarter of the free memory) instead of the worst case (136 GB for
+        // 16 frames x 4 groups at 1080p); a slot that fills it raises a flag and the batch is redone with groups == 1
+        const uint64_t n_slots = (uint64_t)lanes * sh.groups * pixels_local;
+        const uint64_t budget = std::min<uint64_t>(16ull << 30, (have_log + free_b) / 4);
+        uint64_t ocap = std::min<uint64_t>(worst - sh.term_pcap, budget / std::max<uint64_t>(n_slots * sizeof(float4), 1));
+        if (const char *e = getenv("PT_TUNE_TERM_OCAP")) ocap = std::min<uint64_t>(ocap, (uint64_t)std::max(0, atoi(e)));  // tests
+        sh.term_cap = sh.term_pcap + (uint32_t)ocap;
+        sh.bounded = sh.term_cap < worst;
+    }
     sh.lanes = lanes;
     return sh;
 }
@@ -1008,6 +1065,8 @@ void ptw_free_work(pt_film *f)
     (void)hipFree(w.d_terms);
     (void)hipFree(w.d_terms_over);
     (void)hipFree(w.d_nterm);
+    (void)hipFree(w.d_spill_head);
+    (void)hipFree(w.d_spill);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(w.d_qid[i]);
         (void)hipFree(w.d_qstate[i]);
@@ -1034,7 +1093,7 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     return rc_;
 }
 
-pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
+static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool nested)
 {
     pt_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
@@ -1047,10 +1106,15 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
     rc_ = ensure_work(f, p->rank, p->world, lanes, groups, term_cap, sh.term_pcap);
     if (rc_ != PT_OK) return rc_;
-    ctx->stats.frames_in_flight = lanes;
-    ctx->stats.sample_groups = groups;
+    if (!nested) {
+        ctx->stats.frames_in_flight = lanes;
+        ctx->stats.sample_groups = groups;
+    }
     pt_film::Work &w = f->work;
-    const Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm };
+    unsigned long long *const d_overflow = ctx->d_stats + 6, *const d_spill_count = ctx->d_stats + 7;
+    uint32_t spill_cap = sh.bounded ? SPILL_POOL_ENTRIES : 0u;  // worst-case logs never reach the pool
+    if (const char *e = getenv("PT_TUNE_TERM_SPILL")) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)std::max(0, atoi(e)));  // tests
+    Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
 
     RenderConst rc{};
     rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
@@ -1065,7 +1129,7 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     rc.term_pcap = sh.term_pcap;
     rc.n_slots = w.n_slots;
 
-    const bool profile = (p->flags & PT_FLAG_PROFILE) != 0;
+    const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;  // (a redo would re-record the pooled events of its caller)
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
     const bool async = (p->flags & PT_FLAG_ASYNC) != 0;
     if (async && profile) { ctx->err = "PT_FLAG_ASYNC and PT_FLAG_PROFILE exclude each other"; return PT_ERR_INVALID_ARG; }
@@ -1110,12 +1174,18 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     if (n_pipes > 1 && !ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
 
     ctx->stats.extend_variant = pl.variant;
-    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     if (w.n_slots > 0) {
         for (uint32_t done = 0; done < p->frame_count; done += lanes) {
             rc.frame_base = p->frame + (int32_t)done;
             rc.lanes_active = std::min(lanes, p->frame_count - done);
+            unsigned long long rays_before = 0;
+            if (sh.bounded) {  // the exact ray counter as it is before this batch, should the batch have to be redone
+                PT_HIP(ctx, hipStreamSynchronize(st));
+                PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
+            }
             PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 2 * PT_MAX_PIPES, st));
+            if (sh.bounded) PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
             const uint32_t slot_lanes = rc.lanes_active * groups;
             const int pipes_now = std::min<int>(n_pipes, (int)slot_lanes);
             Pipe pipe[PT_MAX_PIPES];
@@ -1191,19 +1261,47 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
                 PT_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->pipe_stream[k]));
                 PT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0));
             }
-            k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra);
-            ctx->stats.launches_other++;
+            bool redo = false;
+            if (sh.bounded) {  // did a slot fill its term log?
+                unsigned long long flag = 0;
+                PT_HIP(ctx, hipStreamSynchronize(st));
+                PT_HIP(ctx, hipMemcpy(&flag, d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+                redo = flag != 0ull;
+            }
+            if (!redo) {
+                k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra);
+                ctx->stats.launches_other++;
+            } else {
+                // Rare (scenes where most surfaces emit): nothing of this batch has touched the film yet.  Put the ray
+                // counter back, clear the flag and render the same frames with one slot per (frame, pixel) -- the plain
+                // accumulator needs no log -- then return to this call's workspace shape.
+                PT_HIP(ctx, hipMemcpy(ctx->d_stats, &rays_before, sizeof(rays_before), hipMemcpyHostToDevice));
+                PT_HIP(ctx, hipMemset(d_overflow, 0, sizeof(unsigned long long)));
+                ctx->stats.redone_batches++;
+                pt_params q = *p;
+                q.frame = rc.frame_base;
+                q.frame_count = rc.lanes_active;
+                q.frames_in_flight = rc.lanes_active;
+                q.sample_groups = 1;
+                rc_ = render_impl(s, f, &q, true);
+                if (rc_ != PT_OK) return rc_;
+                rc_ = ensure_work(f, p->rank, p->world, lanes, groups, term_cap, sh.term_pcap);
+                if (rc_ != PT_OK) return rc_;
+                rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+            }
         }
     }
-    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     if (!async) {
         PT_HIP(ctx, hipStreamSynchronize(st));
         PT_HIP(ctx, hipGetLastError());
-        float ms = 0.f;
-        PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
-        ctx->stats.ms_total += ms;
+        if (!nested) {
+            float ms = 0.f;
+            PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+            ctx->stats.ms_total += ms;
+        }
     }
-    {
+    if (!nested) {
         // samples started = valid local pixels x spp x frames
         uint64_t valid = 0;
         const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
@@ -1222,6 +1320,8 @@ pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
     }
     return PT_OK;
 }
+
+pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p) { return render_impl(s, f, p, false); }
 
 pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits)
 {

@@ -987,3 +987,57 @@ def test_negative_tmin_takes_the_wide_stack_entries(pt, orc, gpu_ctx, cornell_gp
             got = cornell_gpu.trace(rays, tmin=tmin, tmax=10.0, extend=variant)
             assert got.tobytes() == want.tobytes(), (tmin, variant)
     assert (want["t"] < 0.9).any()
+
+
+@pytest.mark.parametrize("ocap,pool", [(0, 0), (3, 64), (0, None), (2, None)])
+def test_full_term_log_spills_to_the_pool_or_the_batch_is_redone_exactly(pt, orc, gpu_ctx, cornell_arrays, cornell_gpu,
+                                                                         cornell_oracle, ocap, pool):
+    """The overflow part of the sample-group term log is sized to a memory budget, not to the worst case.  Terms beyond
+    it go to a pool shared by all slots (per-slot chains, replayed in path order by k_resolve); when the pool is full
+    too a flag is raised and the whole batch is rendered again with one group.  PT_TUNE_TERM_OCAP / PT_TUNE_TERM_SPILL
+    shrink both so that this happens at test sizes: (a) a scene where every surface emits (every ray logs a term),
+    several batches and frames blended onto an existing film; (b) the Cornell box itself with the AUTO shape."""
+    v, i, f = cornell_arrays
+    f = f.reshape(-1, 6).copy()
+    f[:, 3:] = np.float32(0.25) + f[:, :3] * np.float32(0.5)      # Ke > 0 everywhere
+    gs, osc = pt.Scene(gpu_ctx, v, i, f.reshape(-1)), orc.Scene(v, i, f.reshape(-1))
+    kw = dict(width=72, height=40, spp_per_frame=16, max_depth=12)
+    ofilm, obgra, orays = _render_oracle(orc, osc, 5, **kw)
+    os.environ["PT_TUNE_TERM_OCAP"] = str(ocap)
+    if pool is not None:
+        os.environ["PT_TUNE_TERM_SPILL"] = str(pool)
+    try:
+        film = pt.Film(gpu_ctx, 72, 40)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(frame=0, frame_count=1, sample_groups=4, **kw))            # 1 batch
+        pt.render(gs, film, pt.default_params(frame=1, frame_count=4, sample_groups=8, frames_in_flight=2,
+                                              flags=pt.FLAG_PROFILE, **kw))                               # 2 batches
+        st = gpu_ctx.stats()
+        assert st.redone_batches == (3 if pool is not None else 0)       # the default pool (4 M entries) absorbs it all
+        assert st.rays == orays and st.paths == 72 * 40 * 16 * 5
+        assert film.read_f32().tobytes() == ofilm.tobytes()
+        assert film.read_bgra8().tobytes() == obgra.tobytes()
+        film.close()
+        # (b) the reference's scene, AUTO shape: exact whether terms spill, a batch is redone, or neither
+        kw = dict(width=96, height=64, spp_per_frame=32, max_depth=8)
+        ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 2, **kw)
+        film = pt.Film(gpu_ctx, 96, 64)
+        for groups in (0, 4):
+            film.clear()
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, sample_groups=groups, **kw))
+            st = gpu_ctx.stats()
+            assert st.sample_groups > 1 and st.redone_batches <= 1
+            assert st.rays == orays and film.read_f32().tobytes() == ofilm.tobytes()
+        os.environ.pop("PT_TUNE_TERM_OCAP", None)
+        os.environ.pop("PT_TUNE_TERM_SPILL", None)
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, **kw))
+        assert gpu_ctx.stats().redone_batches == 0 and gpu_ctx.stats().rays == orays
+        assert film.read_f32().tobytes() == ofilm.tobytes()
+        film.close()
+    finally:
+        os.environ.pop("PT_TUNE_TERM_OCAP", None)
+        os.environ.pop("PT_TUNE_TERM_SPILL", None)
+        gs.close()
