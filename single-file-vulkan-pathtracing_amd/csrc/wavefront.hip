@@ -182,35 +182,49 @@ __device__ __forceinline__ void chunk_offsets(const bool (&alive)[ITEMS], uint32
 __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t *__restrict__ tiles, uint32_t slot_base,
                                                  uint32_t n_slots, Radiance rad, QueueView out, uint32_t *count_out)
 {
-    __shared__ uint32_t s_wcnt[1][4];
+    // four slots per thread and ONE queue-tail atomic per 1024 slots, as in k_shade: with one atomic per 256 slots
+    // the 133 M slots of 16 frames x 4 sample groups spent 2.9 ms per launch on the ~88 atomics/us a single word takes
+    constexpr int GEN_ITEMS = 4;
+    constexpr uint32_t CHUNK = TB * GEN_ITEMS;
+    __shared__ uint32_t s_wcnt[GEN_ITEMS][4];
     __shared__ uint32_t s_base;
-    for (uint32_t base = blockIdx.x * TB; base < n_slots; base += gridDim.x * TB) {
-        const uint32_t slot = slot_base + base + threadIdx.x;
-        bool alive[1] = { false };
-        uint32_t seed = 0, sample0 = 0;
-        ptm::f3 org{}, dir{};
-        if (base + threadIdx.x < n_slots) {
-            uint32_t f, g, px, py;
-            slot_pixel(rc, tiles, slot, f, g, px, py);
-            if (rc.groups == 1u) rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
-            else {
-                rad.nterm[slot] = 0u;
-                rad.spill_head[slot] = SPILL_NONE;
-            }
-            sample0 = g * rc.group_size;
-            if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
-                alive[0] = true;
-                seed = ptm::make_seed(px, py, sample0, rc.frame_base + (int32_t)f, rc.spp);
-                ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+    for (uint32_t base = blockIdx.x * CHUNK; base < n_slots; base += gridDim.x * CHUNK) {
+        bool alive[GEN_ITEMS];
+        uint32_t o_slot[GEN_ITEMS], o_seed[GEN_ITEMS], o_sample[GEN_ITEMS];
+        ptm::f3 o_org[GEN_ITEMS], o_dir[GEN_ITEMS];
+#pragma unroll
+        for (int it = 0; it < GEN_ITEMS; it++) {
+            const uint32_t local = base + it * TB + threadIdx.x;
+            const uint32_t slot = slot_base + local;
+            alive[it] = false;
+            o_slot[it] = slot; o_seed[it] = 0u; o_sample[it] = 0u; o_org[it] = {}; o_dir[it] = {};
+            if (local < n_slots) {
+                uint32_t f, g, px, py;
+                slot_pixel(rc, tiles, slot, f, g, px, py);
+                if (rc.groups == 1u) rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // raygen.rgen:42
+                else {
+                    rad.nterm[slot] = 0u;
+                    rad.spill_head[slot] = SPILL_NONE;
+                }
+                const uint32_t sample0 = g * rc.group_size;
+                o_sample[it] = sample0;
+                if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
+                    alive[it] = true;
+                    o_seed[it] = ptm::make_seed(px, py, sample0, rc.frame_base + (int32_t)f, rc.spp);
+                    ptm::primary_ray(rc.cam, px, py, o_seed[it], o_org[it], o_dir[it]);
+                }
             }
         }
-        uint32_t dst[1];
-        chunk_offsets<1>(alive, dst, count_out, s_wcnt, &s_base);
-        if (alive[0]) {
-            out.id[dst[0]] = make_uint2(slot, sample0);
-            out.state[dst[0]] = make_float4(__uint_as_float(seed), 1.f, 1.f, 1.f);  // raygen.rgen:59
-            out.rayA[dst[0]] = make_float4(org.x, org.y, org.z, dir.x);
-            out.rayB[dst[0]] = make_float2(dir.y, dir.z);
+        uint32_t dst[GEN_ITEMS];
+        chunk_offsets<GEN_ITEMS>(alive, dst, count_out, s_wcnt, &s_base);
+#pragma unroll
+        for (int it = 0; it < GEN_ITEMS; it++) {
+            if (alive[it]) {
+                out.id[dst[it]] = make_uint2(o_slot[it], o_sample[it]);
+                out.state[dst[it]] = make_float4(__uint_as_float(o_seed[it]), 1.f, 1.f, 1.f);  // raygen.rgen:59
+                out.rayA[dst[it]] = make_float4(o_org[it].x, o_org[it].y, o_org[it].z, o_dir[it].x);
+                out.rayB[dst[it]] = make_float2(o_dir[it].y, o_dir[it].z);
+            }
         }
     }
 }
@@ -1211,7 +1225,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
             }
             for (int k = 0; k < pipes_now; k++) {
                 Pipe &pp = pipe[k];
-                const int gen_grid = (int)std::min<uint32_t>((pp.n_slots + TB - 1) / TB, (uint32_t)ctx->num_cus * 16u);
+                const int gen_grid = (int)std::min<uint32_t>((pp.n_slots + 4 * TB - 1) / (4 * TB), (uint32_t)ctx->num_cus * 16u);
                 k_generate<<<gen_grid, TB, 0, pp.st>>>(rc, w.d_tiles, pp.slot_begin, pp.n_slots, rad, pp.qv[0], &pp.count[0]);
                 ctx->stats.launches_other++;
             }
