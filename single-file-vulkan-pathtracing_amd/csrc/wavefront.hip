@@ -528,7 +528,8 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
                                               uint32_t n_tris,
                                               const float4 *__restrict__ hit, Radiance rad, QueueView in,
                                               QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out,
-                                              const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst)
+                                              const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst,
+                                              const float4 *__restrict__ shade64, const float4 *__restrict__ ke4)
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
@@ -573,7 +574,18 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
                 add_radiance(rc, rad, slot, wr * rc.env[0], wg * rc.env[1], wb * rc.env[2]);
                 terminated = true;
             } else {
-                const float4 s0 = shade4[3 * pos + 0], s1 = shade4[3 * pos + 1], s2 = shade4[3 * pos + 2];
+                // per-triangle record.  Tables in LDS: {n, brdf.r} {brdf.gb, Ke.rg} {Ke.b} + the three vertices.
+                // Tables in HBM: every 16-B load of a wave whose lanes hit different triangles is one L1 look-up
+                // per lane, so the record is regrouped (k_pack) into {v0, n.x} {v1, n.y} {v2, n.z} {brdf, emits}
+                // + Ke apart: 4 look-ups per hit instead of 6, 1 instead of 3 when the path ends here.
+                float4 s0, s1, s2, a{}, b{}, c{};
+                if (LDS_TABLES) {
+                    s0 = shade4[3 * pos + 0]; s1 = shade4[3 * pos + 1]; s2 = shade4[3 * pos + 2];
+                } else {
+                    const float4 r3 = shade64[4 * (size_t)pos + 3];
+                    const float4 ke = r3.w != 0.f ? ke4[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    s0 = make_float4(0.f, 0.f, 0.f, r3.x); s1 = make_float4(r3.y, r3.z, ke.x, ke.y); s2 = make_float4(ke.z, 0.f, 0.f, 0.f);
+                }
                 // raygen.rgen:76: color += weight * emission.  Adding +0 changes no bit of a
                 // non-negative accumulator, so the read-modify-write is skipped for non-emitters
                 // (NaN compares false and still takes the add).
@@ -582,7 +594,12 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
                 depth++;
                 terminated = depth >= rc.max_depth;  // raygen.rgen:62 loop bound
                 if (!terminated) {
-                    const float4 a = tri4[3 * pos + 0], b = tri4[3 * pos + 1], c = tri4[3 * pos + 2];
+                    if (LDS_TABLES) {
+                        a = tri4[3 * pos + 0]; b = tri4[3 * pos + 1]; c = tri4[3 * pos + 2];
+                    } else {
+                        a = shade64[4 * (size_t)pos + 0]; b = shade64[4 * (size_t)pos + 1]; c = shade64[4 * (size_t)pos + 2];
+                        s0.x = a.w; s0.y = b.w; s0.z = c.w;
+                    }
                     // closesthit.rchit:56-57: position from barycentrics, (v0*b0 + v1*b1) + v2*b2
                     // the hit record carries (V, W, det) of the watertight test; attribs = (V/det, W/det)
                     const float hu = ptm::fdiv(h.y, h.w), hv = ptm::fdiv(h.z, h.w);
@@ -1242,7 +1259,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
 #define PT_LAUNCH_SHADE(N, L)                                                                                                  \
     hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
-                          &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst)
+                          &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst, s->d_shade64, s->d_ke4)
                     if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
                     else { PT_LAUNCH_SHADE(4, false); }
 #undef PT_LAUNCH_SHADE
