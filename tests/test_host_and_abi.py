@@ -112,7 +112,7 @@ def test_abi_exports_every_declared_symbol(pt):
 def test_struct_layouts_match_header(pt):
     import ctypes as C
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
-    assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2 + 8 * 2
+    assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2 + 8 * 2 + 4 * 2   # + redone_batches, reserved_
     assert C.sizeof(pt.SceneInfo) == 4 * 8 + 4 * 6 + 4 + 4 + 8  # one pad dword before the u64
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
