@@ -1041,3 +1041,24 @@ def test_full_term_log_spills_to_the_pool_or_the_batch_is_redone_exactly(pt, orc
         os.environ.pop("PT_TUNE_TERM_OCAP", None)
         os.environ.pop("PT_TUNE_TERM_SPILL", None)
         gs.close()
+
+
+def test_spill_pool_at_full_size_two_pipelines(pt, gpu_ctx, cornell_gpu):
+    """1080p, 4 frames x 4 sample groups (33 M slots, two pipelines) with a one-entry overflow log: tens of thousands of
+    slots chain terms into the shared pool.  Same film and ray count as the single-group render, nothing redone."""
+    kw = dict(width=1920, height=1080, spp_per_frame=32, max_depth=8, frame=0, frame_count=4)
+    a, b = pt.Film(gpu_ctx, 1920, 1080), pt.Film(gpu_ctx, 1920, 1080)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, a, pt.default_params(sample_groups=1, **kw))
+    rays = gpu_ctx.stats().rays
+    os.environ["PT_TUNE_TERM_OCAP"] = "1"
+    try:
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, b, pt.default_params(sample_groups=4, **kw))
+    finally:
+        os.environ.pop("PT_TUNE_TERM_OCAP", None)
+    st = gpu_ctx.stats()
+    assert st.sample_groups == 4 and st.redone_batches == 0 and st.rays == rays
+    assert a.read_f32().tobytes() == b.read_f32().tobytes()
+    assert a.read_bgra8().tobytes() == b.read_bgra8().tobytes()
+    a.close(); b.close()
