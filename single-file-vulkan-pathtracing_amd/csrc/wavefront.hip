@@ -789,7 +789,9 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
                         &per_cu_i, pl.lds_scene ? reinterpret_cast<const void *>(k_extend_inst<false, true>)
                                                 : reinterpret_cast<const void *>(k_extend_inst<false, false>), TB, pl.smem));
         per_cu_i = std::max(1, std::min(per_cu_i, 8));
-        pl.refill = 32;  // measured on C4: 16: -4 %, 24: -1 %, 40: -1 %
+        pl.refill = 64;  // a wave takes new rays only when all its lanes are done: entering an instance (ray transform, three
+                         // divides) and the TLAS root are too expensive to run for a few refilled lanes.  C4: 16: 8.2, 32: 8.85,
+                         // 48: 9.26, 56: 9.2, 64: 9.38 Grays/s
         if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
         pl.grid = ctx->num_cus * per_cu_i;
         // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk
