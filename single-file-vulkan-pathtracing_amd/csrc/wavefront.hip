@@ -399,8 +399,15 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
             else cur = pop();
         }
         // ---- leaf phase
+        // entering an instance costs ~130 VALU instructions (ray transform, three true divides, slab set-up): lanes that
+        // want to wait until ENTER_MIN of them do, or until no other lane of the wave has triangle work left
+        // (extend -6 %, C4 +1.5 %; 8, 16 and 32 measured alike)
+        constexpr int ENTER_MIN = 16;
+        const int n_enter = __popcll(__ballot(have && cur != SENTINEL && !in_blas));
+        const bool others = __ballot(have && cur != SENTINEL && in_blas) != 0ull;
+        const bool do_enter = n_enter >= ENTER_MIN || !others;
         if (have) {
-            if (cur != SENTINEL) {
+            if (cur != SENTINEL && (in_blas || do_enter)) {
                 const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
                 if (in_blas) {
                     if (COUNT) c_tris += cnt;
