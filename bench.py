@@ -204,6 +204,7 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 4),
+            "ms_per_1spp_pass": round(dt * 1e3 / args.steps / args.spp, 5),   # also per sample-per-pixel pass
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
