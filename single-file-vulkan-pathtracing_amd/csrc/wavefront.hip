@@ -526,8 +526,15 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
 }
 
 // ---- shade: closesthit / miss + the bounce logic of raygen.rgen:76-83, regeneration, compaction
+// k_shade: paths per thread and waves per SIMD asked of the compiler.  Measured (C2 / C5 Mrays/s, same box): 4 x 4 waves
+// (105 VGPRs) 22 050 / 2 266; 4 x 5 (96 VGPRs, 14 spilled since the term-log tiers) 22 060 / 2 258; 3 x 5 22 260 / 2 271;
+// 3 x 6 22 280 / 2 270; 2 x 7 (72 VGPRs, no spills) 22 630 / 2 281 -- all within the run-to-run noise, so the one without
+// spills and with the most waves in flight is used.  One queue-tail atomic per 512 paths.
+#ifndef PT_SHADE_ITEMS
+#define PT_SHADE_ITEMS 2
+#endif
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 5  // 96 VGPRs instead of 105, no spills: five waves per SIMD keep more queue loads in flight (C2 +2.3 %; 6: 77 spills)
+#define PT_SHADE_WAVES 7
 #endif
 template <int SH_ITEMS, bool LDS_TABLES>
 __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
@@ -1269,8 +1276,8 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
                           &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst, s->d_shade64, s->d_ke4)
-                    if (shade_lds) { PT_LAUNCH_SHADE(4, true); }
-                    else { PT_LAUNCH_SHADE(4, false); }
+                    if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true); }
+                    else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false); }
 #undef PT_LAUNCH_SHADE
                     if (profile) {
                         ev_extend.push_back(x0); ev_extend.push_back(x1);
