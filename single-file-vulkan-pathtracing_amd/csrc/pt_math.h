@@ -20,8 +20,11 @@
 #define PT_LEAF 0x80000000u
 // primitives per BVH4 leaf (count-1 lives in bits 28..30 of a leaf word, so <= 8).  Measured on MI355X
 // (Grays/s for leaf sizes 1/2/3/4/8): Cornell 11.5/14.3/14.6/13.8/12.7, 1M soup 1.11/1.17/1.17/1.15/1.02,
-// 10k-instance grid (both levels) 5.7/5.1/4.8/3.9/2.7 -> 2 triangles per BLAS leaf, 1 instance per TLAS leaf
-#define PT_BLAS_LEAF_MAX 2u
+// 10k-instance grid (both levels) 5.7/5.1/4.8/3.9/2.7 -> then 2 triangles per BLAS leaf, 1 instance per TLAS leaf.
+// Re-measured with the final HBM kernel (64-B nodes in four 16-B loads: a node visit costs 4 L1 look-ups per lane,
+// a triangle 3): 1M soup 2.43/2.28/2.12/1.99 Grays/s for 1/2/3/4 -> 1 triangle per leaf of the collapsed LBVH.
+// (Scenes <= 2048 triangles are traversed through the surface-area BVH4 below unless FAST_BUILD is asked for.)
+#define PT_BLAS_LEAF_MAX 1u
 #define PT_TLAS_LEAF_MAX 1u
 #define PT_SAH_LEAF_MAX 4u  // surface-area BVH4 of small scenes: leaves up to 4 where splitting does not pay (C2 +1.3 % over 2)
 
