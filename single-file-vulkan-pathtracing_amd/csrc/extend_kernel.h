@@ -135,11 +135,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     // Scenes in HBM (deep trees, incoherent rays): inside the classic while-while loop the node phase ran
     // at 18 % lane occupancy on the 1M-triangle soup (device counters) -- lanes that already hold a leaf wait
     // for the last lane to finish descending.  There the wave instead takes ONE step per iteration, of the
-    // kind (node or leaf) that more of its lanes are waiting for, node steps counting double: node occupancy
+    // kind (node or leaf) that more of its lanes are waiting for (node steps counted double until the leaves went to 1 triangle): node occupancy
     // 36 %, triangle steps 36 %, C5 +11 %.  The LDS-resident Cornell box loses 5 % to the extra votes, so it
     // keeps the inner loop.
     constexpr bool VOTE = !LDS_SCENE;
-    constexpr int VOTE_NODE_NUM = 2, VOTE_NODE_DEN = 1;
+    constexpr int VOTE_NODE_NUM = 1, VOTE_NODE_DEN = 1;  // plain majority (with 1-triangle leaves: 2:1 -1 %, 3:1 -3 %, 1:2 .. 3:4 equal)
     // COMPACT (scene in LDS and its exact stack bound fits: the Cornell box): child words are re-coded to 14 bits
     // when the nodes are staged (leaf: bit 13 | (count-1) << 11 | first; inner: node index; done: 0x3FFF) and a
     // stack entry is ONE dword, the entry distance truncated to its top 18 bits above the child word
