@@ -33,12 +33,14 @@ BYTES_SHADE = 104.0
 BYTES_PER_PATH = 96.0
 
 
-def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0):
+def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, instances=None):
     """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
     bounded sample of the same workload: the same image, all cores, as many samples per pixel as fit
     into ~budget_s seconds (calibrated with a 1-spp pass, at most spp_max)."""
     from oracle import pt_oracle as orc
     osc = orc.Scene(*arrays)
+    if instances is not None:
+        osc.set_instances(instances)      # two-level scene (config C4): the oracle walks its own TLAS
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
     osc.render_frame(orc.default_params(width=width, height=height, spp_per_frame=1, max_depth=depth), mode=1, nthreads=cores)
@@ -231,12 +233,8 @@ def main():
             out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
         base = None
         if not args.no_cpu_baseline and world == 1:
-            if args.config == "c4":
-                base = None        # the oracle binding used here has no instance set-up in cpu_baseline: skipped for C4
-            elif args.config == "c2":
-                base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth)
-            else:
-                base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth)
+            base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth,
+                                      instances=pt.cornell_grid_instances() if args.config == "c4" else None)
         # traversal work per ray, counted by an instrumented build of the same kernel on the same
         # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
         nodes_per_ray = tris_per_ray = 0.0
