@@ -76,6 +76,9 @@ def main():
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0,
+                    help="seconds of oracle time for cpu_baseline (it renders as many spp of frame 0 as fit; when that is the "
+                         "whole frame, film and ray count are compared with the GPU's)")
     args = ap.parse_args()
 
     import torch
@@ -233,7 +236,7 @@ def main():
             out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
         base = None
         if not args.no_cpu_baseline and world == 1:
-            base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth,
+            base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth, budget_s=args.cpu_budget_s,
                                       instances=pt.cornell_grid_instances() if args.config == "c4" else None)
         # traversal work per ray, counted by an instrumented build of the same kernel on the same
         # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
