@@ -1137,7 +1137,26 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
     s->ctx->stats.frames_in_flight = sh.lanes;
     s->ctx->stats.sample_groups = sh.groups;
-    return rc_;
+    if (rc_ != PT_OK) return rc_;
+    // the other one-time objects of a render: pipeline streams, fork / join events and, with PT_FLAG_PROFILE, the
+    // pooled (start, stop) events of every extend / shade launch of one batch (4 per round and pipeline)
+    pt_ctx *ctx = s->ctx;
+    for (int k = 1; k < 2; k++)
+        if (!ctx->pipe_stream[k]) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[k], hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+        }
+    if (!ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (p->flags & PT_FLAG_PROFILE) {
+        const size_t batches = ((size_t)p->frame_count + sh.lanes - 1) / sh.lanes;
+        const size_t want = std::min<size_t>(4ull * sh.group_size * p->max_depth * 2ull * batches, 1u << 16);
+        while (ctx->ev_pool.size() < want) {
+            hipEvent_t e = nullptr;
+            PT_HIP(ctx, hipEventCreate(&e));
+            ctx->ev_pool.push_back(e);
+        }
+    }
+    return PT_OK;
 }
 
 static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool nested)
