@@ -172,9 +172,10 @@ def main():
     # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
         pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, **common))
-        if world > 1:
-            tmp = film_t.clone()
-            reduce_film(tmp)
+    if world > 1:      # communicator set-up (the first RCCL collective of a process) is not a step: always outside the timed region
+        tmp = film_t.clone()
+        reduce_film(tmp)
+        del tmp
     film.clear()
     ctx.reset_stats()
 
