@@ -29,9 +29,17 @@ typedef struct pth_scene {
 /* Returns 0 on success; on failure returns nonzero and writes a message into err (the
  * reference throws std::runtime_error(warn + err), main.cpp:35).  mtl_dir may be NULL = the
  * OBJ's directory (the reference passes "../assets", main.cpp:34).
- * Polygons are fan-triangulated; faces with no material get Kd = 0.6 grey, Ke = 0 (the
+ * Polygons are fan-triangulated; a declared material starts Kd = Ke = 0 and missing components of a Kd/Ke line
+ * stay 0 (tinyobjloader's InitMaterial / parseReal3); faces with NO material get Kd = 0.6 grey, Ke = 0 (the
  * reference would index materials[-1], main.cpp:49 -- undefined there, defined here).      */
 int  pth_load_obj(const char *obj_path, const char *mtl_dir, pth_scene *out, char *err, size_t err_len);
+/* flags: PTH_QUAD_SHORTER_DIAGONAL cuts 4-gons along their shorter diagonal -- (0,1,2)(0,2,3) if |v0v2|^2 < |v1v3|^2,
+ * else (0,1,3)(1,2,3) -- as newer tinyobjloader releases are understood to do (the reference's submodule is unpinned
+ * and empty in the checkout, so which rule it was built with is unknown).  On the Cornell box both rules give the
+ * same surfaces and, within the stated tolerance, the same image; only gl_PrimitiveID numbering and the last bits of
+ * hit positions differ.  pth_load_obj = flags 0 = fan, which all fixtures use.                          */
+enum { PTH_QUAD_SHORTER_DIAGONAL = 1u };
+int  pth_load_obj_ex(const char *obj_path, const char *mtl_dir, uint32_t flags, pth_scene *out, char *err, size_t err_len);
 void pth_free_scene(pth_scene *s);
 
 /* bgra: w*h*4 bytes as read by pt_film_read_bgra8 -> binary PPM (P6, RGB).                 */
@@ -42,6 +50,10 @@ int pth_write_pfm(const char *path, const float *rgb, uint32_t w, uint32_t h);
 /* Writes <path> (OBJ) and <path minus .obj>.mtl: n_tris random triangles, frozen recipe in
  * BASELINE.md section 4 / DESIGN.md section 9 (PCG stream seeded with `seed`).                     */
 int pth_write_soup_obj(const char *obj_path, uint32_t n_tris, uint32_t seed);
+
+/* The arrays pth_load_obj would return for that file, generated directly (free with pth_free_scene): scenes
+ * larger than the Infinity Cache (bench.py --config c5x) without a gigabyte of OBJ text in between.      */
+int pth_make_soup(uint32_t n_tris, uint32_t seed, pth_scene *out);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,10 @@ class Function:
 class Module:
     """parsed SPIR-V module (only what the three reference shaders use; anything else raises)"""
 
-    def __init__(self, path):
+    def __init__(self, path, int_const_override=None):
+        """int_const_override: {value: new value} applied to scalar OpConstants of integer type -- the one use is
+        specialising `int maxSamples = 32` (raygen.rgen:43, a single OpStore of that constant) to another sample
+        count so a launch can be compared at 1 spp; the instruction stream is untouched."""
         blob = open(path, "rb").read()
         w = struct.unpack("<%dI" % (len(blob) // 4), blob)
         if w[0] != 0x07230203:
@@ -136,6 +139,8 @@ class Module:
             elif op == 43:
                 t = self.types[o[0]]
                 self.const[o[1]] = F32(struct.unpack("<f", struct.pack("<I", o[2]))[0]) if t[0] == "float" else o[2]
+                if t[0] == "int" and int_const_override and o[2] in int_const_override:
+                    self.const[o[1]] = int_const_override[o[2]] & M32
             elif op == 44:
                 self.const[o[1]] = [self.const[c] for c in o[2:]]
             elif op == 54:
@@ -206,8 +211,12 @@ class Pipeline:
     """the ray-tracing pipeline of main.cpp:540-608: one raygen, one miss, one closest-hit group, and the
     descriptor set of main.cpp:610-641 (bindings 2/3/4 = vertices / indices / faces as flat arrays)."""
 
-    def __init__(self, rgen, rchit, rmiss, vertices, indices, faces, driver):
-        self.rgen, self.rchit, self.rmiss, self.drv = Module(rgen), Module(rchit), Module(rmiss), driver
+    def __init__(self, rgen, rchit, rmiss, vertices, indices, faces, driver, contract=False, rgen_int_const_override=None):
+        """contract: evaluate every OpFAdd / OpFSub one of whose operands is the result of an OpFMul /
+        OpVectorTimesScalar of the same function as ONE fused multiply-add (product exact, one rounding) -- what a
+        Vulkan compiler may do to these shaders, none of whose results is decorated NoContraction."""
+        self.rgen, self.rchit, self.rmiss, self.drv = Module(rgen, rgen_int_const_override), Module(rchit), Module(rmiss), driver
+        self.contract = contract
         self.buffers = {2: [[F32(x) for x in vertices]], 3: [[int(x) for x in indices]], 4: [[F32(x) for x in faces]]}
         self.n_traces = 0
         self.n_instructions = 0
@@ -266,6 +275,16 @@ class Pipeline:
         drv = self.drv
         label = fn.entry
         count = 0
+        prod = {}  # contract: result id of a multiply -> its operands
+
+        def fused(pid, c, sign_p, sign_c):  # sign_p * (a * b) + sign_c * c with one rounding
+            a, b = prod[pid]
+            f = lambda x, y, z: F32(sign_p * (np.float64(x) * np.float64(y)) + sign_c * np.float64(z))  # noqa: E731
+            if isinstance(a, list):
+                bb = b if isinstance(b, list) else [b] * len(a)
+                return [f(x, y, z) for x, y, z in zip(a, bb, c)]
+            return f(a, b, c)
+
         while True:
             for op, o in fn.blocks[label]:
                 count += 1
@@ -279,14 +298,23 @@ class Pipeline:
                 elif op == 59:  # OpVariable (Function storage)
                     pointee = m.types[o[0]][2]
                     vals[o[1]] = Ptr(Cell(_copy(vals[o[3]]) if len(o) > 3 else m.zero(pointee)))
-                elif op == 133: vals[o[1]] = _ew2(lambda a, b: a * b, vals[o[2]], vals[o[3]])  # OpFMul
-                elif op == 129: vals[o[1]] = _ew2(lambda a, b: a + b, vals[o[2]], vals[o[3]])  # OpFAdd
-                elif op == 131: vals[o[1]] = _ew2(lambda a, b: a - b, vals[o[2]], vals[o[3]])  # OpFSub
+                elif op == 133:  # OpFMul
+                    vals[o[1]] = _ew2(lambda a, b: a * b, vals[o[2]], vals[o[3]])
+                    if self.contract: prod[o[1]] = (vals[o[2]], vals[o[3]])
+                elif op == 129:  # OpFAdd
+                    if self.contract and o[2] in prod: vals[o[1]] = fused(o[2], vals[o[3]], 1.0, 1.0)
+                    elif self.contract and o[3] in prod: vals[o[1]] = fused(o[3], vals[o[2]], 1.0, 1.0)
+                    else: vals[o[1]] = _ew2(lambda a, b: a + b, vals[o[2]], vals[o[3]])
+                elif op == 131:  # OpFSub
+                    if self.contract and o[2] in prod: vals[o[1]] = fused(o[2], vals[o[3]], 1.0, -1.0)
+                    elif self.contract and o[3] in prod: vals[o[1]] = fused(o[3], vals[o[2]], -1.0, 1.0)
+                    else: vals[o[1]] = _ew2(lambda a, b: a - b, vals[o[2]], vals[o[3]])
                 elif op == 136: vals[o[1]] = _ew2(lambda a, b: a / b, vals[o[2]], vals[o[3]])  # OpFDiv
                 elif op == 127: vals[o[1]] = _ew1(lambda a: -a, vals[o[2]])  # OpFNegate
                 elif op == 142:  # OpVectorTimesScalar
                     s = vals[o[3]]
                     vals[o[1]] = [a * s for a in vals[o[2]]]
+                    if self.contract: prod[o[1]] = (vals[o[2]], s)
                 elif op == 148: vals[o[1]] = drv.dot(vals[o[2]], vals[o[3]])  # OpDot
                 elif op == 128: vals[o[1]] = _ew2(lambda a, b: (a + b) & M32, vals[o[2]], vals[o[3]])  # OpIAdd
                 elif op == 132: vals[o[1]] = _ew2(lambda a, b: (a * b) & M32, vals[o[2]], vals[o[3]])  # OpIMul

@@ -84,7 +84,7 @@ API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "p
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render",
                "pt_render_prepare", "pt_trace",
                "pt_get_stats", "pt_reset_stats"]
-HOST_SYMBOLS = ["pth_load_obj", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj"]
+HOST_SYMBOLS = ["pth_load_obj", "pth_load_obj_ex", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj", "pth_make_soup"]
 
 _amd = None
 _host = None
@@ -146,22 +146,27 @@ def lib_host():
             raise ImportError(f"{path} is missing: run __graft_entry__.build()")
         L = C.CDLL(path)
         L.pth_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(HostScene), C.c_char_p, C.c_size_t]
+        L.pth_load_obj_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(HostScene), C.c_char_p, C.c_size_t]
         L.pth_free_scene.argtypes = [C.POINTER(HostScene)]
         L.pth_free_scene.restype = None
         L.pth_write_ppm_bgra8.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.pth_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.pth_write_soup_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
+        L.pth_make_soup.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(HostScene)]
         _host = L
     return _host
 
 
 # ---- host side: scene ingest / image output ---------------------------------------------------
-def load_obj(path, mtl_dir=None):
-    """-> (vertices f32[3*nv], indices u32[3*nt], faces f32[6*nt]) exactly as the reference's
-    loadFromFile fills them (main.cpp:28-58)."""
+QUAD_SHORTER_DIAGONAL = 1
+
+
+def load_obj(path, mtl_dir=None, flags=0):
+    """-> (vertices f32[3*nv], indices u32[3*nt], faces f32[6*nt]) as the reference's loadFromFile fills them
+    (main.cpp:28-58); flags: QUAD_SHORTER_DIAGONAL (include/pt_host.h)."""
     hs = HostScene()
     err = C.create_string_buffer(512)
-    rc = lib_host().pth_load_obj(os.fsencode(path), os.fsencode(mtl_dir) if mtl_dir else None, C.byref(hs), err, 512)
+    rc = lib_host().pth_load_obj_ex(os.fsencode(path), os.fsencode(mtl_dir) if mtl_dir else None, flags, C.byref(hs), err, 512)
     if rc != 0:
         raise RuntimeError(f"load_obj({path}): {err.value.decode()}")  # reference: throw std::runtime_error (main.cpp:35)
     try:
@@ -190,6 +195,20 @@ def write_pfm(path, rgb):
 def write_soup_obj(path, n_tris, seed=1):
     if lib_host().pth_write_soup_obj(os.fsencode(path), n_tris, seed) != 0:
         raise RuntimeError(f"cannot write {path}")
+
+
+def make_soup(n_tris, seed=1):
+    """-> the arrays load_obj(write_soup_obj(...)) would return, without the OBJ text in between."""
+    hs = HostScene()
+    if lib_host().pth_make_soup(n_tris, seed, C.byref(hs)) != 0:
+        raise RuntimeError("pth_make_soup failed")
+    try:
+        v = np.ctypeslib.as_array(hs.vertices, shape=(3 * hs.n_verts,)).copy()
+        i = np.ctypeslib.as_array(hs.indices, shape=(3 * hs.n_tris,)).copy()
+        f = np.ctypeslib.as_array(hs.faces, shape=(6 * hs.n_tris,)).copy()
+    finally:
+        lib_host().pth_free_scene(C.byref(hs))
+    return v, i, f
 
 
 def cornell_grid_instances(n=100, cell=0.02, scale=0.009):

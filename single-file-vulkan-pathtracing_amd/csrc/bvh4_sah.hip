@@ -48,7 +48,11 @@ struct Builder {
             hi[k] = std::max(hi[k], (double)thi[3 * (size_t)t + k]);
         }
     }
-    int build(uint32_t first, uint32_t count)
+    // depth: the sweep has no balance term -- n coincident triangles cost the same at every split position and the
+    // lowest one wins, a chain of depth n.  Below SAH_MAX_DEPTH the node is split at the median of the best axis'
+    // centroid order instead, which bounds the height (and the traversal stack) by SAH_MAX_DEPTH + log2(n).
+    static constexpr int SAH_MAX_DEPTH = 24;
+    int build(uint32_t first, uint32_t count, int depth = 0)
     {
         const int me = (int)nodes.size();
         nodes.emplace_back();
@@ -85,9 +89,10 @@ struct Builder {
         }
         const double a_node = area(nodes[me].lo, nodes[me].hi);
         if (count <= leaf_max && 0.6 * (double)count * a_node <= 1.0 * a_node + 0.6 * best) return me;  // leaf
+        if (depth >= SAH_MAX_DEPTH) best_k = count / 2 - 1;
         std::copy(sorted[best_axis].begin(), sorted[best_axis].end(), ids.begin() + first);
-        const int l = build(first, best_k + 1);
-        const int r = build(first + best_k + 1, count - best_k - 1);
+        const int l = build(first, best_k + 1, depth + 1);
+        const int r = build(first + best_k + 1, count - best_k - 1, depth + 1);
         nodes[me].left = l; nodes[me].right = r;
         return me;
     }

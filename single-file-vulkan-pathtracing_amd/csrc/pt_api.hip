@@ -2,6 +2,8 @@
 #include "pt_internal.h"
 #include "pt_math.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -54,6 +56,7 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *mb = getenv("PT_MEM_BUDGET_MB")) ctx->mem_budget = (size_t)std::max(0ll, atoll(mb)) << 20;
     if (stream) {
         ctx->stream = reinterpret_cast<hipStream_t>(stream);
     } else {
@@ -102,7 +105,8 @@ pt_status pt_scene_create(pt_ctx *ctx, const float *vertices, uint32_t n_verts, 
     if (!out || !vertices || !indices || !faces) { ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
     *out = nullptr;
     if (n_tris == 0 || n_verts == 0) { ctx->err = "empty scene"; return PT_ERR_INVALID_ARG; }
-    if (n_tris >= 0x7FFFFFFFu / 4u) { ctx->err = "too many triangles"; return PT_ERR_INVALID_ARG; }
+    // BVH4 leaf words keep the first sorted position in bits 0..27 and (count - 1) in bits 28..30
+    if (n_tris >= (1u << 28)) { ctx->err = "too many triangles (the BVH4 leaf encoding holds 2^28 - 1)"; return PT_ERR_INVALID_ARG; }
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
         if (indices[i] >= n_verts) { ctx->err = "vertex index out of range"; return PT_ERR_INVALID_ARG; }
     PT_HIP(ctx, hipSetDevice(ctx->device));

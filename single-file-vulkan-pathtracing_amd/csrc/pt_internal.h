@@ -36,6 +36,10 @@ struct pt_ctx {
     std::vector<hipEvent_t> ev_pool;  // PT_FLAG_PROFILE start/stop events, reused across pt_render calls
     void *d_spill = nullptr;   // HBM overflow of the traversal short stack: [level][thread] uint2
     size_t spill_bytes = 0;
+    // Upper bound on the wavefront workspace of a film (0 = what hipMemGetInfo reports as free).  Set from the
+    // environment variable PT_MEM_BUDGET_MB at pt_ctx_create: for processes that share the GPU with another
+    // allocator (torch), and for the out-of-memory tests.
+    size_t mem_budget = 0;
 };
 
 struct pt_scene {
@@ -104,6 +108,7 @@ struct pt_film {
         uint32_t *d_hit_inst = nullptr;               // instance (TLAS sorted position); only for two-level scenes
         uint32_t *d_count = nullptr;                  // [2] queue sizes
         size_t cap_slots = 0, cap_color = 0, cap_terms = 0, cap_terms_over = 0;  // allocated capacities (buffers only grow)
+        size_t bytes = 0;                             // device bytes held by the buffers above
     } work;
 };
 

@@ -808,8 +808,11 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
                          // 48: 9.26, 56: 9.2, 64: 9.38 Grays/s
         if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
         pl.grid = ctx->num_cus * per_cu_i;
-        // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk
-        const uint32_t bound_i = 3u * (s->tlas_height / 2u + 1u) + 4u + 3u * (s->height / 2u + 1u) + 2u;
+        // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk: the exact bound of the
+        // BVH4 that is TRAVERSED when the builder gave one (the surface-area BVH4 of a small scene can be deeper
+        // than the balanced LBVH whose height s->height is), else 3 per level of the collapsed LBVH
+        const uint32_t blas_bound = s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u);
+        const uint32_t bound_i = 3u * (s->tlas_height / 2u + 1u) + 4u + blas_bound + 2u;
         pl.spill_levels = bound_i > (uint32_t)LDS_STACK ? bound_i - (uint32_t)LDS_STACK : 0u;
         const size_t need_i = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
         if (need_i > ctx->spill_bytes) {
@@ -863,8 +866,10 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     pl.refill = pl.lds_scene ? REFILL_MIN_IDLE : 32;  // big scenes (vote-scheduled steps): 32 idle lanes measured best on C5 (16: -2.5 %, 48: -3 %)
     if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
     pl.grid = ctx->num_cus * per_cu;
-    // stack bound: a BVH4 node pushes <= 3 entries per level; wide height <= binary height/2 + 1
-    const uint32_t bound = std::min(3u * (s->height / 2u + 1u) + 1u, s->stack_need);
+    // stack bound: the exact one of the BVH4 that is traversed when its builder computed it (small scenes; the
+    // surface-area BVH4 is not bounded by the LBVH's height), else a BVH4 node pushes <= 3 entries per level and the
+    // collapsed LBVH's wide height is <= binary height/2 + 1
+    const uint32_t bound = s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u) + 1u;
     pl.spill_levels = bound > (uint32_t)pl.lds_stack ? bound - (uint32_t)pl.lds_stack : 0u;
     const size_t need = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
     if (need > ctx->spill_bytes) {
@@ -936,8 +941,63 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 #undef PT_LAUNCH_EXTEND
 }
 
+// Bytes of workspace per path slot that do not depend on the sample-group shape: two queue sets
+// (id 8 + state 16 + rayA 16 + rayB 8), hit 16 + instance 4, term count 4, pool head 4.
+constexpr size_t SLOT_BYTES = 2 * (8 + 16 + 16 + 8) + 16 + 4 + 4 + 4;
+
+struct WorkNeed { size_t slots, color, terms, terms_over, total; };
+WorkNeed work_need(uint64_t n_slots, uint32_t groups, uint32_t term_cap, uint32_t term_pcap)
+{
+    WorkNeed n{};
+    n.slots = (size_t)std::max<uint64_t>(n_slots, 1);
+    n.color = groups == 1 ? n.slots : 0;
+    n.terms = groups > 1 ? n.slots * (size_t)term_pcap : 0;
+    n.terms_over = groups > 1 ? n.slots * (size_t)(term_cap - term_pcap) : 0;
+    n.total = n.slots * SLOT_BYTES + sizeof(float4) * (n.color + n.terms + n.terms_over) +
+              (groups > 1 ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0);
+    return n;
+}
+
+// One workspace allocation.  Out of memory (the device's, or the context's PT_MEM_BUDGET_MB) is PT_ERR_OOM, and HIP's
+// sticky error is cleared so that the context stays usable.
+pt_status work_alloc(pt_ctx *ctx, pt_film::Work &w, void **p, size_t bytes, size_t limit)
+{
+    *p = nullptr;
+    if (limit && w.bytes + bytes > limit) {
+        ctx->err = "wavefront workspace exceeds the memory budget (" + std::to_string((w.bytes + bytes) >> 20) + " MB wanted, " +
+                   std::to_string(limit >> 20) + " MB allowed): fewer frames_in_flight / sample_groups fit";
+        return PT_ERR_OOM;
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        ctx->err = std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MB of wavefront workspace: " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP;
+    }
+    w.bytes += bytes;
+    return PT_OK;
+}
+
+// Frees the shape-dependent buffers (everything but the tile list and the counters) and zeroes their capacities:
+// the state after a failed grow -- the film itself (d_rgb / d_bgra) is untouched and the next render re-allocates.
+void free_shape_buffers(pt_film::Work &w)
+{
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(w.d_qid[i]); (void)hipFree(w.d_qstate[i]); (void)hipFree(w.d_qrayA[i]); (void)hipFree(w.d_qrayB[i]);
+        w.d_qid[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
+    }
+    (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst); (void)hipFree(w.d_nterm); (void)hipFree(w.d_spill_head);
+    (void)hipFree(w.d_color); (void)hipFree(w.d_terms); (void)hipFree(w.d_terms_over); (void)hipFree(w.d_spill);
+    w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr; w.d_spill_head = nullptr;
+    w.d_color = nullptr; w.d_terms = nullptr; w.d_terms_over = nullptr; w.d_spill = nullptr;
+    w.cap_slots = w.cap_color = w.cap_terms = w.cap_terms_over = 0;
+    w.bytes = 0;
+}
+
 // Workspace for (rank, world) tiles, `lanes` frames in flight and `groups` sample groups.  Buffers only
 // ever grow: a later call with a smaller shape reuses them (hipMalloc of tens of GB costs 100s of ms).
+// A grow that does not fit returns PT_ERR_OOM and leaves the film WITHOUT shape buffers (all freed, capacities 0).
 pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap,
                       uint32_t term_pcap)
 {
@@ -962,54 +1022,67 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         ctx->err = "too many path slots (frames_in_flight x sample_groups x pixels >= 2^31)";
         return PT_ERR_INVALID_ARG;
     }
-    w.lanes = lanes; w.groups = groups; w.term_cap = term_cap;
-    w.n_slots = (uint32_t)n_slots64;
-    const size_t ns = std::max<size_t>(w.n_slots, 1);
+    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
+    const WorkNeed need = work_need(n_slots64, groups, term_cap, term_pcap);
+    const size_t ns = need.slots;
+    const size_t limit = ctx->mem_budget;
+    pt_status rc = PT_OK;
+#define PT_WORK_ALLOC(PTR, BYTES) \
+    if (rc == PT_OK) rc = work_alloc(ctx, w, (void **)&(PTR), (BYTES), limit)
     if (ns > w.cap_slots) {
+        // the queue set goes as a whole: free first (peak = the new size, not old + new)
+        const size_t keep_color = w.cap_color, keep_terms = w.cap_terms, keep_over = w.cap_terms_over;
+        float4 *const color = w.d_color, *const terms = w.d_terms, *const over = w.d_terms_over, *const pool = w.d_spill;
+        w.d_color = w.d_terms = w.d_terms_over = w.d_spill = nullptr;
+        free_shape_buffers(w);
+        w.d_color = color; w.d_terms = terms; w.d_terms_over = over; w.d_spill = pool;
+        w.cap_color = keep_color; w.cap_terms = keep_terms; w.cap_terms_over = keep_over;
+        w.bytes = sizeof(float4) * (keep_color + keep_terms + keep_over) + (pool ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0);
         for (int i = 0; i < 2; i++) {
-            (void)hipFree(w.d_qid[i]); (void)hipFree(w.d_qstate[i]);
-            (void)hipFree(w.d_qrayA[i]); (void)hipFree(w.d_qrayB[i]);
-            w.d_qid[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
+            PT_WORK_ALLOC(w.d_qid[i], sizeof(uint2) * ns);
+            PT_WORK_ALLOC(w.d_qstate[i], sizeof(float4) * ns);
+            PT_WORK_ALLOC(w.d_qrayA[i], sizeof(float4) * ns);
+            PT_WORK_ALLOC(w.d_qrayB[i], sizeof(float2) * ns);
         }
-        (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst); (void)hipFree(w.d_nterm); (void)hipFree(w.d_spill_head);
-        w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr; w.d_spill_head = nullptr;
-        w.cap_slots = 0;
-        for (int i = 0; i < 2; i++) {
-            PT_HIP(ctx, hipMalloc((void **)&w.d_qid[i], sizeof(uint2) * ns));
-            PT_HIP(ctx, hipMalloc((void **)&w.d_qstate[i], sizeof(float4) * ns));
-            PT_HIP(ctx, hipMalloc((void **)&w.d_qrayA[i], sizeof(float4) * ns));
-            PT_HIP(ctx, hipMalloc((void **)&w.d_qrayB[i], sizeof(float2) * ns));
-        }
-        PT_HIP(ctx, hipMalloc((void **)&w.d_hit, sizeof(float4) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_hit_inst, sizeof(uint32_t) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_nterm, sizeof(uint32_t) * ns));
-        PT_HIP(ctx, hipMalloc((void **)&w.d_spill_head, sizeof(uint32_t) * ns));
-        w.cap_slots = ns;
+        PT_WORK_ALLOC(w.d_hit, sizeof(float4) * ns);
+        PT_WORK_ALLOC(w.d_hit_inst, sizeof(uint32_t) * ns);
+        PT_WORK_ALLOC(w.d_nterm, sizeof(uint32_t) * ns);
+        PT_WORK_ALLOC(w.d_spill_head, sizeof(uint32_t) * ns);
+        if (rc == PT_OK) w.cap_slots = ns;
     }
-    if (groups == 1 && ns > w.cap_color) {
+    if (rc == PT_OK && need.color > w.cap_color) {
         (void)hipFree(w.d_color);
+        w.bytes -= sizeof(float4) * w.cap_color;
         w.d_color = nullptr; w.cap_color = 0;
-        PT_HIP(ctx, hipMalloc((void **)&w.d_color, sizeof(float4) * ns));
-        w.cap_color = ns;
+        PT_WORK_ALLOC(w.d_color, sizeof(float4) * need.color);
+        if (rc == PT_OK) w.cap_color = need.color;
     }
     // primary log: term_pcap entries per slot (dense, what is normally touched); overflow: the rest of the
     // worst case (one entry per ray), allocated but rarely touched
-    const size_t n_prim = groups > 1 ? ns * (size_t)term_pcap : 0;
-    const size_t n_over = groups > 1 ? ns * (size_t)(term_cap - term_pcap) : 0;
-    if (n_prim > w.cap_terms) {
+    if (rc == PT_OK && need.terms > w.cap_terms) {
         (void)hipFree(w.d_terms);
+        w.bytes -= sizeof(float4) * w.cap_terms;
         w.d_terms = nullptr; w.cap_terms = 0;
-        PT_HIP(ctx, hipMalloc((void **)&w.d_terms, sizeof(float4) * n_prim));
-        w.cap_terms = n_prim;
+        PT_WORK_ALLOC(w.d_terms, sizeof(float4) * need.terms);
+        if (rc == PT_OK) w.cap_terms = need.terms;
     }
-    if (n_over > w.cap_terms_over) {
+    if (rc == PT_OK && need.terms_over > w.cap_terms_over) {
         (void)hipFree(w.d_terms_over);
+        w.bytes -= sizeof(float4) * w.cap_terms_over;
         w.d_terms_over = nullptr; w.cap_terms_over = 0;
-        PT_HIP(ctx, hipMalloc((void **)&w.d_terms_over, sizeof(float4) * n_over));
-        w.cap_terms_over = n_over;
+        PT_WORK_ALLOC(w.d_terms_over, sizeof(float4) * need.terms_over);
+        if (rc == PT_OK) w.cap_terms_over = need.terms_over;
     }
-    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
-    if (groups > 1 && !w.d_spill) PT_HIP(ctx, hipMalloc((void **)&w.d_spill, sizeof(float4) * SPILL_POOL_ENTRIES));
+    if (rc == PT_OK && groups > 1 && !w.d_spill) PT_WORK_ALLOC(w.d_spill, sizeof(float4) * (size_t)SPILL_POOL_ENTRIES);
+#undef PT_WORK_ALLOC
+    if (rc != PT_OK) {
+        free_shape_buffers(w);
+        w.lanes = w.groups = w.term_cap = 0;
+        w.n_slots = 0;
+        return rc;
+    }
+    w.lanes = lanes; w.groups = groups; w.term_cap = term_cap;
+    w.n_slots = (uint32_t)n_slots64;
     return PT_OK;
 }
 
@@ -1020,7 +1093,9 @@ struct RenderShape {
 
 // frames in flight x sample groups: enough live paths (~32M) to fill the chip several times over, and slots that
 // do not live longer than they have to
-RenderShape choose_shape(const pt_film *f, const pt_params *p)
+// `shrink`: 0 for the first try; pt_render retries with 1, 2, ... after an out-of-memory workspace grow, each step
+// halving the memory the AUTO shape may plan for (explicit frames_in_flight / sample_groups are never overridden).
+RenderShape choose_shape(const pt_film *f, const pt_params *p, int shrink = 0)
 {
     RenderShape sh;
     const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
@@ -1039,7 +1114,13 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
     const bool can_redo = (p->flags & PT_FLAG_ASYNC) == 0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    // what the workspace may occupy: the device's free memory plus what this film already holds, within the
+    // context's budget (PT_MEM_BUDGET_MB), 7/8 of it planned for
+    uint64_t avail = (uint64_t)free_b + f->work.bytes;
+    if (f->ctx->mem_budget) avail = std::min<uint64_t>(avail, f->ctx->mem_budget);
+    avail = (avail - avail / 8) >> std::min(shrink, 40);
     const uint64_t have_log = f->work.cap_terms_over * sizeof(float4);  // already ours: counts as free
+    if (f->ctx->mem_budget) free_b = (size_t)std::min<uint64_t>(free_b, avail);
     // sample groups: split each pixel's samples over several slots; the term logs keep the sum order exact.
     //  (a) few frames asked for: the frames in flight alone cannot fill the chip;
     //  (b) a slot lives group_size x depth rounds and every round costs ~27 us of launch-bound time per pipeline
@@ -1069,6 +1150,24 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
         }
     }
     groups = std::max(1u, std::min(groups, p->spp_per_frame));
+    // AUTO shapes have to fit the memory there is (queues + primary log; the overflow log is budgeted below): first
+    // fewer sample groups (the next smaller divisor of spp), then fewer frames in flight
+    auto planned = [&](uint32_t l, uint32_t g) {
+        const uint32_t gs = (p->spp_per_frame + g - 1) / g;
+        return work_need((uint64_t)l * g * pixels_local, g, g > 1 ? std::min(gs * p->max_depth, gs + 2u) : 0u,
+                         g > 1 ? std::min(gs * p->max_depth, gs + 2u) : 0u).total;
+    };
+    while (planned(lanes, groups) > avail) {
+        if (p->sample_groups == 0 && groups > 1) {
+            uint32_t g = groups - 1;
+            while (g > 1 && p->spp_per_frame % g) g--;
+            groups = g;
+        } else if (p->frames_in_flight == 0 && lanes > 1) {
+            lanes = (lanes + 1) / 2;
+        } else {
+            break;  // explicit shape (or one frame, one group): ensure_work reports PT_ERR_OOM if it does not fit
+        }
+    }
     sh.group_size = (p->spp_per_frame + groups - 1) / groups;
     sh.groups = (p->spp_per_frame + sh.group_size - 1) / sh.group_size;  // no empty groups
     const uint32_t worst = sh.groups > 1 ? sh.group_size * p->max_depth : 0u;  // every ray of a slot adds a term
@@ -1078,7 +1177,8 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
         // overflow log within a budget (16 GB, a quarter of the free memory) instead of the worst case (136 GB for
         // 16 frames x 4 groups at 1080p); a slot that fills it raises a flag and the batch is redone with groups == 1
         const uint64_t n_slots = (uint64_t)lanes * sh.groups * pixels_local;
-        const uint64_t budget = std::min<uint64_t>(16ull << 30, (have_log + free_b) / 4);
+        const uint64_t room = avail > planned(lanes, sh.groups) ? avail - planned(lanes, sh.groups) : 0;
+        const uint64_t budget = std::min<uint64_t>(std::min<uint64_t>(16ull << 30, (have_log + free_b) / 4), room);
         uint64_t ocap = std::min<uint64_t>(worst - sh.term_pcap, budget / std::max<uint64_t>(n_slots * sizeof(float4), 1));
         if (const char *e = getenv("PT_TUNE_TERM_OCAP")) ocap = std::min<uint64_t>(ocap, (uint64_t)std::max(0, atoi(e)));  // tests
         sh.term_cap = sh.term_pcap + (uint32_t)ocap;
@@ -1086,6 +1186,22 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p)
     }
     sh.lanes = lanes;
     return sh;
+}
+
+// The shape of a render and its workspace.  An AUTO shape that does not fit after all (another allocator took the
+// memory between hipMemGetInfo and hipMalloc) is planned again for half the memory, down to one frame and one group;
+// an explicit shape that does not fit is PT_ERR_OOM.  Either way a failure leaves the film usable.
+pt_status shape_and_work(pt_film *f, const pt_params *p, RenderShape &sh)
+{
+    pt_status rc = PT_OK;
+    for (int attempt = 0; attempt < 12; attempt++) {
+        sh = choose_shape(f, p, attempt);
+        rc = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
+        if (rc != PT_ERR_OOM) return rc;
+        const bool can_shrink = (p->frames_in_flight == 0 && sh.lanes > 1) || (p->sample_groups == 0 && sh.groups > 1);
+        if (!can_shrink) return rc;
+    }
+    return rc;
 }
 
 pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
@@ -1133,8 +1249,8 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     ExtendPlan pl;
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
-    const RenderShape sh = choose_shape(f, p);
-    rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
+    RenderShape sh;
+    rc_ = shape_and_work(f, p, sh);
     s->ctx->stats.frames_in_flight = sh.lanes;
     s->ctx->stats.sample_groups = sh.groups;
     if (rc_ != PT_OK) return rc_;
@@ -1168,10 +1284,10 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     ExtendPlan pl;
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
-    const RenderShape sh = choose_shape(f, p);
-    const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
-    rc_ = ensure_work(f, p->rank, p->world, lanes, groups, term_cap, sh.term_pcap);
+    RenderShape sh;
+    rc_ = shape_and_work(f, p, sh);
     if (rc_ != PT_OK) return rc_;
+    const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
     if (!nested) {
         ctx->stats.frames_in_flight = lanes;
         ctx->stats.sample_groups = groups;

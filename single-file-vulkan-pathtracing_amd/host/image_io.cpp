@@ -2,6 +2,7 @@
 // the generator of the synthetic triangle soup (BASELINE.json config 5).
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,56 @@ struct Pcg {
     }
     float uni() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // [0,1), 24 bits
 };
+const char *const kSoupNames[8] = { "white", "red", "green", "blue", "yellow", "cyan", "magenta", "grey" };
+const float kSoupKd[8][3] = { { .725f, .71f, .68f }, { .63f, .065f, .05f }, { .14f, .45f, .091f }, { .1f, .2f, .7f },
+                              { .7f, .7f, .1f },     { .1f, .7f, .7f },    { .7f, .1f, .7f },      { .4f, .4f, .4f } };
+const float kSoupLightKd[3] = { 0.78f, 0.78f, 0.78f }, kSoupLightKe[3] = { 17.f, 12.f, 4.f };
+
+// one triangle of the soup (OBJ space), consuming the generator exactly as the recipe below says
+void soup_triangle(Pcg &rng, float (&v)[3][3])
+{
+    for (;;) {
+        const float c[3] = { rng.uni() * 2.f - 1.f, rng.uni() * 2.f, rng.uni() * 2.f - 1.f };
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) v[k][a] = c[a] + 0.02f * (rng.uni() - 0.5f);
+        const float e1[3] = { v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2] };
+        const float e2[3] = { v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2] };
+        const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        if (cx * cx + cy * cy + cz * cz >= 1e-16f) return;
+    }
+}
 }  // namespace
+
+// The same soup as pth_write_soup_obj + pth_load_obj would give, without the detour through ~140 bytes of text per
+// triangle: for the scenes larger than the Infinity Cache (bench.py --config c5x, 8 M triangles = 1.1 GB of OBJ).
+extern "C" int pth_make_soup(uint32_t n_tris, uint32_t seed, pth_scene *out)
+{
+    if (!out || !n_tris || n_tris > 0x0FFFFFFFu) return 1;
+    *out = pth_scene{};
+    float *vert = static_cast<float *>(std::malloc(sizeof(float) * 9 * (size_t)n_tris));
+    uint32_t *idx = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * 3 * (size_t)n_tris));
+    float *faces = static_cast<float *>(std::malloc(sizeof(float) * 6 * (size_t)n_tris));
+    if (!vert || !idx || !faces) { std::free(vert); std::free(idx); std::free(faces); return 2; }
+    Pcg rng{ seed };
+    for (uint32_t i = 0; i < n_tris; i++) {
+        float v[3][3];
+        soup_triangle(rng, v);
+        for (int k = 0; k < 3; k++) {
+            vert[9 * (size_t)i + 3 * k + 0] = v[k][0];
+            vert[9 * (size_t)i + 3 * k + 1] = -v[k][1];  // main.cpp:42
+            vert[9 * (size_t)i + 3 * k + 2] = v[k][2];
+            idx[3 * (size_t)i + k] = 3u * i + (uint32_t)k;
+        }
+        const bool light = i % 64u == 7u;
+        const float *kd = light ? kSoupLightKd : kSoupKd[i % 8u];
+        for (int a = 0; a < 3; a++) {
+            faces[6 * (size_t)i + a] = kd[a];
+            faces[6 * (size_t)i + 3 + a] = light ? kSoupLightKe[a] : 0.f;
+        }
+    }
+    out->vertices = vert; out->n_verts = 3u * n_tris; out->indices = idx; out->n_tris = n_tris; out->faces = faces;
+    return 0;
+}
 
 // Recipe (frozen): centre c ~ U([-1,1] x [0,2] x [-1,1]) in OBJ space (Y is negated at load, so
 // the soup fills the Cornell box volume [-1,1] x [-2,0] x [-1,1] the camera looks into); the
@@ -63,9 +113,8 @@ extern "C" int pth_write_soup_obj(const char *obj_path, uint32_t n_tris, uint32_
     const std::string mtl_name = slash == std::string::npos ? mtl : mtl.substr(slash + 1);
     FILE *fm = std::fopen(mtl.c_str(), "w");
     if (!fm) return 2;
-    static const char *names[8] = { "white", "red", "green", "blue", "yellow", "cyan", "magenta", "grey" };
-    static const float kd[8][3] = { { .725f, .71f, .68f }, { .63f, .065f, .05f }, { .14f, .45f, .091f }, { .1f, .2f, .7f },
-                                    { .7f, .7f, .1f },     { .1f, .7f, .7f },    { .7f, .1f, .7f },      { .4f, .4f, .4f } };
+    const char *const *names = kSoupNames;
+    const float (&kd)[8][3] = kSoupKd;
     for (int i = 0; i < 8; i++) std::fprintf(fm, "newmtl %s\nKd %g %g %g\nKe 0 0 0\n\n", names[i], kd[i][0], kd[i][1], kd[i][2]);
     std::fprintf(fm, "newmtl light\nKd 0.78 0.78 0.78\nKe 17 12 4\n");
     std::fclose(fm);
@@ -79,15 +128,7 @@ extern "C" int pth_write_soup_obj(const char *obj_path, uint32_t n_tris, uint32_
     int last = -1;
     for (uint32_t i = 0; i < n_tris; i++) {
         float v[3][3];
-        for (;;) {
-            const float c[3] = { rng.uni() * 2.f - 1.f, rng.uni() * 2.f, rng.uni() * 2.f - 1.f };
-            for (int k = 0; k < 3; k++)
-                for (int a = 0; a < 3; a++) v[k][a] = c[a] + 0.02f * (rng.uni() - 0.5f);
-            const float e1[3] = { v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2] };
-            const float e2[3] = { v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2] };
-            const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
-            if (cx * cx + cy * cy + cz * cz >= 1e-16f) break;
-        }
+        soup_triangle(rng, v);
         const int m = (i % 64u == 7u) ? 8 : (int)(i % 8u);
         if (m != last) {
             std::fprintf(f, "usemtl %s\n", m == 8 ? "light" : names[m]);

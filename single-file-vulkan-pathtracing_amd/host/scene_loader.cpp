@@ -2,8 +2,8 @@
 //
 // Mirrors loadFromFile (main.cpp:28-58).  tinyobjloader is not vendored in the reference
 // checkout, so its behaviour on this path is restated: `v`, `f` with 1-based or negative
-// indices and v/vt/vn forms, fan triangulation of polygons, `mtllib`, `usemtl`, and from the
-// MTL `newmtl`, `Kd`, `Ke`.  Shapes/groups do not matter: the reference concatenates all
+// indices and v/vt/vn forms, fan triangulation of polygons (PTH_QUAD_SHORTER_DIAGONAL: the quad rule of
+// newer tinyobjloader releases), `mtllib`, `usemtl`, and from the MTL `newmtl`, `Kd`, `Ke`.  Shapes/groups do not matter: the reference concatenates all
 // shapes in file order (main.cpp:38-57) and material ids are per face.
 #include <cerrno>
 #include <cstdio>
@@ -20,10 +20,15 @@
 
 namespace {
 
+// A material DECLARED by newmtl starts all-zero, as tinyobjloader's InitMaterial leaves it, and a Kd / Ke line with
+// fewer than three numbers leaves the missing ones 0 (its parseReal3 defaults).  Faces with NO material
+// (material id -1: no usemtl yet, unknown name, missing MTL file) make the reference index materials[-1]
+// (main.cpp:49, undefined); here they get kNoMaterial.
 struct Material {
-    float kd[3] = { 0.6f, 0.6f, 0.6f };
+    float kd[3] = { 0.f, 0.f, 0.f };
     float ke[3] = { 0.f, 0.f, 0.f };
 };
+constexpr Material kNoMaterial = { { 0.6f, 0.6f, 0.6f }, { 0.f, 0.f, 0.f } };
 
 bool read_file(const std::string &path, std::string &out)
 {
@@ -80,14 +85,10 @@ bool load_mtl(const std::string &path, std::vector<Material> &mats, std::unorder
             cur = &mats.back();
         } else if ((k == "Kd" || k == "Ke") && cur) {
             float *dst = k == "Kd" ? cur->kd : cur->ke;
-            float v[3];
+            float v[3] = { 0.f, 0.f, 0.f };
             int got = 0;
             while (got < 3 && parse_float(p, e, v[got])) got++;
-            if (got >= 1) {  // a single value means grey, as OBJ/MTL readers do
-                if (got == 1) v[1] = v[2] = v[0];
-                else if (got == 2) v[2] = v[1];
-                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
-            }
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
         }
         next_line(p, e);
     }
@@ -102,6 +103,11 @@ void set_err(char *err, size_t n, const std::string &msg)
 }  // namespace
 
 extern "C" int pth_load_obj(const char *obj_path, const char *mtl_dir, pth_scene *out, char *err, size_t err_len)
+{
+    return pth_load_obj_ex(obj_path, mtl_dir, 0u, out, err, err_len);
+}
+
+extern "C" int pth_load_obj_ex(const char *obj_path, const char *mtl_dir, uint32_t flags, pth_scene *out, char *err, size_t err_len)
 {
     if (!obj_path || !out) { set_err(err, err_len, "null argument"); return 1; }
     std::memset(out, 0, sizeof(*out));
@@ -152,6 +158,23 @@ extern "C" int pth_load_obj(const char *obj_path, const char *mtl_dir, pth_scene
                 poly.push_back(vi);
             }
             if (poly.size() < 3) { set_err(err, err_len, "face with < 3 vertices at line " + std::to_string(line_no)); return 3; }
+            if (poly.size() == 4 && (flags & PTH_QUAD_SHORTER_DIAGONAL)) {
+                // tinyobjloader >= v2.0.0rc9 (as far as it is known here; the reference's submodule is an unpinned,
+                // empty directory): a quad is cut along its SHORTER diagonal, (0,1,2)(0,2,3) when |v0v2|^2 < |v1v3|^2,
+                // else (0,1,3)(1,2,3)
+                auto d2 = [&](long a, long b) {
+                    float s2 = 0.f;
+                    for (int c = 0; c < 3; c++) { const float d = pos[3 * (size_t)a + c] - pos[3 * (size_t)b + c]; s2 += d * d; }
+                    return s2;
+                };
+                const bool fan = d2(poly[0], poly[2]) < d2(poly[1], poly[3]);
+                const int order[2][6] = { { 0, 1, 3, 1, 2, 3 }, { 0, 1, 2, 0, 2, 3 } };
+                for (int c = 0; c < 6; c++) tri_idx.push_back((uint32_t)poly[(size_t)order[fan ? 1 : 0][c]]);
+                tri_mat.push_back(cur_mat);
+                tri_mat.push_back(cur_mat);
+                next_line(p, e);
+                continue;
+            }
             for (size_t c = 1; c + 1 < poly.size(); c++) {  // fan: (0,1,2) (0,2,3) ...
                 tri_idx.push_back((uint32_t)poly[0]);
                 tri_idx.push_back((uint32_t)poly[c]);
@@ -190,9 +213,8 @@ extern "C" int pth_load_obj(const char *obj_path, const char *mtl_dir, pth_scene
         out->vertices[3 * i + 2] = pos[3 * (size_t)vi + 2];
         out->indices[i] = (uint32_t)i;
     }
-    const Material none;
     for (size_t t = 0; t < nt; t++) {  // main.cpp:47-56
-        const Material &m = tri_mat[t] >= 0 ? mats[(size_t)tri_mat[t]] : none;
+        const Material &m = tri_mat[t] >= 0 ? mats[(size_t)tri_mat[t]] : kNoMaterial;
         for (int c = 0; c < 3; c++) {
             out->faces[6 * t + c] = m.kd[c];
             out->faces[6 * t + 3 + c] = m.ke[c];

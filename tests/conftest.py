@@ -14,6 +14,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_box():
+    if not os.path.exists("/dev/kfd"):
+        return False
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    """On a box WITH a GPU every test carries the `gpu` marker, so `pytest -m gpu` there also runs the host-side
+    parity tests (OBJ ingest, C-ABI, the oracle against its fixtures, the gloo world-2 reduce): the box that renders
+    is the box whose libc / locale / compiler those have to pass on.  Without a GPU (the build container) only the
+    tests that need one carry it, and `-m "not gpu"` runs the rest."""
+    if _gpu_box():
+        for it in items:
+            if "gpu" not in it.keywords:
+                it.add_marker(pytest.mark.gpu)
+
+
 @pytest.fixture(scope="session")
 def pt():
     """The product package (directory name has '-', hence importlib)."""

@@ -10,7 +10,9 @@ implementation -- is the closest-hit query behind OpTraceRayKHR (`orc_trace`), G
 correctly rounded sqrt, the evaluation order of dot/cross/normalize, and the unorm8 conversion of the storage
 image.  Everything else is the reference's instruction stream.
 
-Usage (repo root):  python tests/golden/make_spirv_goldens.py
+Usage (repo root):  python tests/golden/make_spirv_goldens.py                  (spirv_pixels.npz, canonical driver)
+                    python tests/golden/make_spirv_goldens.py --independent    (spirv_independent.npz: a driver that shares
+                                                                                no code with oracle/, see IndependentDriver)
 """
 import multiprocessing as mp
 import os
@@ -58,6 +60,73 @@ class CanonicalDriver(vm.Driver):
             self.img[(x, y)] = [F32(c) for c in texel]
 
 
+class IndependentDriver(vm.Driver):
+    """A second evaluation of the implementation-defined pieces that shares NO code with oracle/ (pt_oracle.c's
+    watertight test, its sin/cos polynomials, its operation order): what an idealised conforming driver could do.
+      * traceRayEXT: brute force over all triangles with the Moeller-Trumbore test in binary64 (inputs are the
+        shader's binary32 values), tmin < t < tmax, no culling, closest t, equal t -> lowest primitive id; the
+        barycentrics are rounded once to binary32.  `log` collects every query with its margins for the hit test.
+      * sin / cos / sqrt: numpy binary64, rounded once;  dot / cross / normalize: binary64, rounded once.
+    `tests/golden/spirv_independent.npz` is made with it, once with the instruction stream as written and once with
+    every multiply-add fused (Pipeline(contract=True))."""
+
+    def __init__(self, arrays, log=None):
+        super().__init__(lambda a: (F32(np.sin(np.float64(a))), F32(np.cos(np.float64(a)))))
+        v, i, _ = arrays
+        p = np.asarray(v, np.float64).reshape(-1, 3)[np.asarray(i, np.int64).reshape(-1, 3)]  # [tri][corner][xyz]
+        self.v0, self.e1, self.e2 = p[:, 0], p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+        # triangles with identical corner sets (the OBJ repeats two quads): a tie between them is decided by the id rule
+        key = [tuple(sorted(map(tuple, t))) for t in p]
+        self.twin = np.array([[key[a] == key[b] for b in range(len(p))] for a in range(len(p))])
+        self.img, self.log = {}, log
+
+    def sqrt(self, a): return F32(np.sqrt(np.float64(a)))
+    def dot(self, a, b): return F32(sum(np.float64(x) * np.float64(y) for x, y in zip(a, b)))
+
+    def cross(self, a, b):
+        a, b = [np.float64(x) for x in a], [np.float64(x) for x in b]
+        return [F32(a[1] * b[2] - b[1] * a[2]), F32(a[2] * b[0] - b[2] * a[0]), F32(a[0] * b[1] - b[0] * a[1])]
+
+    def normalize(self, v):
+        v = np.array([np.float64(x) for x in v])
+        return [F32(x) for x in v / np.sqrt((v * v).sum())]
+
+    def trace(self, origin, tmin, direction, tmax):
+        o, d = np.array(origin, np.float64), np.array(direction, np.float64)
+        with np.errstate(all="ignore"):
+            pv = np.cross(d, self.e2)
+            det = (self.e1 * pv).sum(1)
+            tv = o - self.v0
+            u = (tv * pv).sum(1) / det
+            qv = np.cross(tv, self.e1)
+            vv = (qv * d).sum(1) / det
+            t = (qv * self.e2).sum(1) / det
+        w = 1.0 - u - vv
+        inside = (det != 0) & (u >= 0) & (vv >= 0) & (w >= 0) & (t > np.float64(tmin)) & (t < np.float64(tmax))
+        best = int(np.argmin(np.where(inside, t, np.inf))) if inside.any() else -1  # argmin: first (lowest id) of equal t
+        if self.log is not None:
+            # clear = no other decision is within 1e-5 of flipping: edges of every triangle that could be the closest
+            # hit, the tmin plane, and the runner-up's distance (identical twins excepted)
+            eps = 1e-5
+            tb = t[best] if best >= 0 else np.inf
+            near = (det != 0) & (np.minimum(np.minimum(u, vv), w) > -eps) & (t > np.float64(tmin) - eps) & (t < tb + eps)
+            near_edge = near & (np.minimum(np.minimum(u, vv), w) < eps)
+            near_tmin = near & (np.abs(t - np.float64(tmin)) < eps)
+            rivals = near.copy()
+            if best >= 0:
+                rivals &= ~self.twin[best]
+            clear = not (near_edge.any() or near_tmin.any() or rivals.any())
+            self.log.append((*[F32(x) for x in origin], *[F32(x) for x in direction], best, F32(tb if best >= 0 else 0),
+                             F32(u[best]) if best >= 0 else F32(0), F32(vv[best]) if best >= 0 else F32(0), clear))
+        return None if best < 0 else (best, F32(u[best]), F32(vv[best]))
+
+    def image_load(self, x, y):
+        return self.img.get((x, y), [F32(0)] * 4)
+
+    def image_store(self, x, y, texel):
+        self.img[(x, y)] = [F32(c) for c in texel]
+
+
 _state = {}
 
 
@@ -82,6 +151,57 @@ def run_pixel(job):
             tex.append(list(drv.img[(x, y)]))
             rays.append(pipe.n_traces - n0)
     return tex, rays
+
+
+def run_pixel_independent(job):
+    """job = (x, y, width, height, n_frames, spp (None = the shader's 32), contract, log rays?) ->
+    (texel after each frame [n,4], traces per frame [n], ray log)"""
+    x, y, w, h, n_frames, spp, contract, want_log = job
+    if not _state:
+        _init()
+    log = [] if want_log else None
+    drv = IndependentDriver(_state["arrays"], log)
+    pipe = vm.Pipeline(REF + "raygen.rgen.spv", REF + "closesthit.rchit.spv", REF + "miss.rmiss.spv", *_state["arrays"], drv,
+                       contract=contract, rgen_int_const_override=None if spp is None else {32: spp})
+    tex, rays = [], []
+    with np.errstate(all="ignore"):
+        for frame in range(n_frames):
+            n0 = pipe.n_traces
+            pipe.launch(x, y, w, h, frame)
+            tex.append(list(drv.img[(x, y)]))
+            rays.append(pipe.n_traces - n0)
+    return tex, rays, log
+
+
+def main_independent():
+    """tests/golden/spirv_independent.npz: the reference's shaders over the INDEPENDENT driver (no oracle code)."""
+    t0 = time.time()
+    out = {}
+    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+        # E: a complete 240x136 launch at ONE sample per pixel (maxSamples specialised 32 -> 1), frame 0
+        w, h = 240, 136
+        for name, contract in (("ideal", False), ("fma", True)):
+            res = pool.map(run_pixel_independent, [(x, y, w, h, 1, 1, contract, name == "ideal" and x % 4 == 0 and y % 2 == 0)
+                                                   for y in range(h) for x in range(w)], chunksize=64)
+            out["e_texels_" + name] = np.array([r[0][0] for r in res], np.float32).reshape(h, w, 4)
+            out["e_traces_" + name] = np.array([r[1][0] for r in res], np.int32).reshape(h, w)
+            if name == "ideal":
+                log = [e for r in res if r[2] for e in r[2]]
+                out["e_rays6"] = np.array([e[:6] for e in log], np.float32)
+                out["e_prim"] = np.array([e[6] for e in log], np.int32)
+                out["e_tuv"] = np.array([e[7:10] for e in log], np.float32)
+                out["e_clear"] = np.array([e[10] for e in log], bool)
+            print("E", name, w, "x", h, "1 spp, traces", out["e_traces_" + name].sum(), "%.0f s" % (time.time() - t0), flush=True)
+        out["e_launch"] = np.array([w, h], np.int32)
+        # F: the launch of fixture C (120x68, the shader's own 32 spp, frames 0 and 1 = 64 spp)
+        w, h = 120, 68
+        for name, contract in (("ideal", False), ("fma", True)):
+            res = pool.map(run_pixel_independent, [(x, y, w, h, 2, None, contract, False) for y in range(h) for x in range(w)], chunksize=8)
+            out["f_texels_" + name] = np.array([r[0] for r in res], np.float32).reshape(h, w, 2, 4).transpose(2, 0, 1, 3)
+            out["f_traces_" + name] = np.array([r[1] for r in res], np.int64).reshape(h, w, 2).transpose(2, 0, 1)
+            print("F", name, "traces", out["f_traces_" + name].sum(axis=(1, 2)), "%.0f s" % (time.time() - t0), flush=True)
+        out["f_launch"] = np.array([w, h], np.int32)
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "spirv_independent.npz"), **out)
 
 
 def pixel_set(w, h, nx, ny, seed):
@@ -135,4 +255,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--independent" in sys.argv:
+        main_independent()
+    elif "--all" in sys.argv:
+        main()
+        main_independent()
+    else:
+        main()

@@ -22,11 +22,11 @@ def load_mtl(path):
             if not line:
                 continue
             if line[0] == "newmtl":
-                cur = {"Kd": [0.6, 0.6, 0.6], "Ke": [0.0, 0.0, 0.0]}  # tinyobj defaults
+                cur = {"Kd": [0.0, 0.0, 0.0], "Ke": [0.0, 0.0, 0.0]}  # tinyobj InitMaterial: all zero
                 names[line[1]] = len(mats)
                 mats.append(cur)
             elif line[0] in ("Kd", "Ke") and cur is not None:
-                cur[line[0]] = [float(x) for x in line[1:4]]
+                cur[line[0]] = ([float(x) for x in line[1:4]] + [0.0, 0.0, 0.0])[:3]  # parseReal3: missing -> 0
     return mats, names
 
 

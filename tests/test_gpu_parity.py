@@ -1062,3 +1062,78 @@ def test_spill_pool_at_full_size_two_pipelines(pt, gpu_ctx, cornell_gpu):
     assert a.read_f32().tobytes() == b.read_f32().tobytes()
     assert a.read_bgra8().tobytes() == b.read_bgra8().tobytes()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n_coincident", [500, 2048])
+def test_coincident_triangles_deep_sah_tree_keeps_the_stack_in_bounds(pt, orc, gpu_ctx, n_coincident):
+    """n copies of ONE triangle (+ a few others): every split of the surface-area sweep costs the same, which used to give
+    a chain n/3 deep whose traversal stack overran a spill region sized from the balanced LBVH's height.  The sweep now
+    falls back to median splits below depth 24 and the spill region is sized from the stack bound of the BVH4 that is
+    traversed.  Hits (closest t, lowest primitive id among the coincident ones) equal the oracle's on every variant,
+    for both builders, also as a BLAS under instances."""
+    rng = np.random.default_rng(5)
+    one = np.array([[-0.5, -0.4, 0.1], [0.6, -0.3, 0.0], [0.0, 0.7, -0.1]], np.float32)
+    extra = rng.uniform(-1, 1, (16, 3, 3)).astype(np.float32)
+    tris = np.concatenate([np.repeat(one[None], n_coincident - 16, 0), extra])
+    v = tris.reshape(-1)
+    i = np.arange(v.size // 3, dtype=np.uint32)
+    f = rng.uniform(0, 1, (len(tris), 6)).astype(np.float32).reshape(-1)
+    n = 30000
+    org = rng.uniform(-1.5, 1.5, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    osc = orc.Scene(v, i, f)
+    want, _ = osc.trace(rays, tmin=0.001, tmax=100.0, mode=0)
+    assert (want["prim"] == 0).sum() > 1000        # the coincident stack is hit, and its lowest id wins
+    gs = pt.Scene(gpu_ctx, v, i, f)
+    for quality in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD):
+        gs.set_bvh_quality(quality)
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS if n_coincident <= 500 else pt.EXTEND_AUTO, pt.EXTEND_HBM):
+            got = gs.trace(rays, tmin=0.001, tmax=100.0, extend=variant)
+            assert got.tobytes() == want.tobytes(), (quality, variant)
+    gs.set_bvh_quality(pt.BVH_PREFER_FAST_TRACE)
+    xf = np.zeros((3, 3, 4), np.float32)
+    for k in range(3):
+        xf[k, 0, 0] = xf[k, 1, 1] = xf[k, 2, 2] = 0.5
+        xf[k, :, 3] = [k - 1.0, 0.1 * k, 0.0]
+    gs.set_instances(xf)
+    osc.set_instances(xf)
+    want, _ = osc.trace(rays, tmin=0.001, tmax=100.0, mode=1)
+    assert gs.trace(rays, tmin=0.001, tmax=100.0).tobytes() == want.tobytes()
+    gs.close()
+
+
+def test_workspace_out_of_memory_is_reported_and_the_film_stays_usable(pt, orc, cornell_arrays, cornell_oracle):
+    """PT_MEM_BUDGET_MB (read at pt_ctx_create) caps the wavefront workspace.  An explicit shape that does not fit is
+    PT_ERR_OOM with nothing rendered; the film keeps its content and the next render -- AUTO shape, which plans for
+    the memory there is -- continues it bit-exactly."""
+    w, h = 256, 160
+    kw = dict(width=w, height=h, spp_per_frame=8, max_depth=8)
+    ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 3, **kw)
+    os.environ["PT_MEM_BUDGET_MB"] = "48"
+    try:
+        ctx = pt.Context(0)
+    finally:
+        os.environ.pop("PT_MEM_BUDGET_MB", None)
+    scene = pt.Scene(ctx, *cornell_arrays)
+    film = pt.Film(ctx, w, h)
+    pt.render(scene, film, pt.default_params(frame=0, frame_count=1, **kw))              # fits: 41 k slots
+    before = film.read_f32()
+    with pytest.raises(pt.PtError) as e:                                                   # 64 frames x 8 groups: 2.6 GB
+        pt.render(scene, film, pt.default_params(frame=1, frame_count=64, frames_in_flight=64, sample_groups=8, **kw))
+    assert e.value.status == 4 and "budget" in str(e.value)                                # PT_ERR_OOM
+    with pytest.raises(pt.PtError) as e:
+        pt.render_prepare(scene, film, pt.default_params(frame=1, frame_count=64, frames_in_flight=64, sample_groups=8, **kw))
+    assert e.value.status == 4
+    assert film.read_f32().tobytes() == before.tobytes()                                   # nothing was blended
+    ctx.reset_stats()
+    pt.render(scene, film, pt.default_params(frame=1, frame_count=2, **kw))                # AUTO shrinks to the budget
+    st = ctx.stats()
+    assert st.frames_in_flight * st.sample_groups * w * h * 124 <= 48 << 20
+    assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes()
+    # a long AUTO render under the same budget: many small batches, same bits as one frame at a time
+    a = pt.Film(ctx, w, h)
+    pt.render(scene, a, pt.default_params(frame=0, frame_count=3, **kw))
+    assert a.read_f32().tobytes() == ofilm.tobytes()
+    a.close(); film.close(); scene.close(); ctx.close()

@@ -36,10 +36,43 @@ def test_loader_ragged_inputs(pt, tmp_path):
     assert faces.shape[0] == 6
     np.testing.assert_allclose(faces[0], [0.6, 0.6, 0.6, 0, 0, 0])
     np.testing.assert_allclose(faces[1], [0.1, 0.2, 0.3, 1, 2, 3])
-    np.testing.assert_allclose(faces[4], [0.5, 0.5, 0.5, 0, 0, 0])
+    np.testing.assert_allclose(faces[4], [0.5, 0, 0, 0, 0, 0])   # `Kd 0.5`: missing components stay 0 (tinyobj parseReal3)
     np.testing.assert_allclose(faces[5], [0.6, 0.6, 0.6, 0, 0, 0])
     tri = v.reshape(-1, 3, 3)
     np.testing.assert_allclose(tri[3], [[0, 0, 0], [0, -1, 0], [0.5, -2, 0]])  # fan (0,3,4), y flipped
+
+
+def test_loader_quad_rules(pt, tmp_path, orc):
+    """fan (default, what every fixture uses) against the shorter-diagonal rule of newer tinyobjloader releases: a
+    non-rectangular quad is cut along the other diagonal; a declared material without Kd is black (InitMaterial);
+    on the Cornell box the two rules differ in 16 of 18 quads yet give the same image within the stated tolerance."""
+    (tmp_path / "m.mtl").write_text("newmtl bare\nKe 1 1 1\n")
+    obj = tmp_path / "q.obj"
+    obj.write_text("mtllib m.mtl\nusemtl bare\nv 0 0 0\nv 1 0 0\nv 3 2 0\nv 0 1 0\nf 1 2 3 4\n")   # |v0v2|^2 = 13 > |v1v3|^2 = 2
+    v, _, f = pt.load_obj(str(obj))
+    tri = v.reshape(-1, 3, 3)
+    np.testing.assert_allclose(tri[0], [[0, 0, 0], [1, 0, 0], [3, -2, 0]])
+    np.testing.assert_allclose(f.reshape(-1, 6)[0], [0, 0, 0, 1, 1, 1])
+    v2, _, _ = pt.load_obj(str(obj), flags=pt.QUAD_SHORTER_DIAGONAL)
+    tri2 = v2.reshape(-1, 3, 3)
+    np.testing.assert_allclose(tri2[0], [[0, 0, 0], [1, 0, 0], [0, -1, 0]])      # (0,1,3)
+    np.testing.assert_allclose(tri2[1], [[1, 0, 0], [3, -2, 0], [0, -1, 0]])     # (1,2,3)
+    a = pt.load_obj(pt.ASSET_CORNELL)
+    b = pt.load_obj(pt.ASSET_CORNELL, flags=pt.QUAD_SHORTER_DIAGONAL)
+    ta, tb = a[0].reshape(-1, 2, 3, 3), b[0].reshape(-1, 2, 3, 3)
+    assert ta.shape == tb.shape and sum(not np.array_equal(x, y) for x, y in zip(ta, tb)) == 16
+    p = orc.default_params(width=96, height=64, spp_per_frame=4, max_depth=8)
+    ia, ra, _, _ = orc.Scene(*a).render_frame(p)
+    ib, rb, _, _ = orc.Scene(*b).render_frame(p)
+    d = np.linalg.norm(ia.astype(np.float64) - ib, axis=-1) / np.maximum(1.0, np.linalg.norm(ib.astype(np.float64), axis=-1))
+    assert (d <= 1e-4).mean() >= 0.99 and abs(ra - rb) <= 0.002 * ra
+
+
+def test_make_soup_equals_the_obj_round_trip(pt, tmp_path):
+    path = str(tmp_path / "s.obj")
+    pt.write_soup_obj(path, 3000, 7)
+    a, b = pt.load_obj(path), pt.make_soup(3000, 7)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
 
 
 def test_loader_errors(pt, tmp_path):
