@@ -10,10 +10,20 @@ A *step* is one frame = one reference launch (traceRaysKHR(W,H,1), main.cpp:659)
 pixel, <= 8 rays each, blended into the film (raygen.rgen:41-91).  K steps = 32*K spp; K=2 is
 exactly config C2 (64 spp); the default K=16 (512 spp) lets the device keep 16 frames in flight.  The scene + LBVH are resident in HBM before the timed
 region; the timed region is the K frames (all kernels: generate, extend, shade/compact, resolve)
-plus, for N>1, the one RCCL reduce of the float film to rank 0.  Rank 0 prints ONE JSON line.
+plus, for N>1, the one RCCL collective that assembles the presented image on rank 0.  Rank 0 prints ONE JSON line.
 
 N>1 shards the 8x8 pixel tiles of the SAME image over the ranks (config C3's decomposition), so
 the total work per step is fixed: "scaling": "strong".
+
+Beside the headline the default single-GPU run appends, OUTSIDE the timed region, the legs VERDICT r01 asked for:
+  * `c2_exact`            K = 2 (= 64 spp, exactly BASELINE config C2) in one call;
+  * `latency_ms_1frame`   the reference's own dispatch shape: one blocking pt_render per frame (main.cpp:647-685);
+  * `roofline.valu_*`     the VALU-issue side of the Cornell traversal kernel from LIVE block counters;
+  * `roofline_c5`         the traversal kernel on the 1M-triangle soup (BASELINE config C5), the one config whose
+                          scene does not fit LDS/L2: algorithmic bytes per ray x rays per launch / average launch
+                          time / 8 TB/s, every factor measured in this run (`--config c5` runs it as the headline,
+                          `--config c5x` an 8M-triangle soup that does not fit the 256 MiB Infinity Cache either);
+  * `cpu_baseline`        the oracle on all host cores and on one, with the CPU model.
 """
 import argparse
 import importlib
@@ -27,16 +37,36 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+# VALU issue peak of the chip in wave64 instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (a SIMD
+# issues a wave64 VALU op over two passes of its 32 lanes at best: v_add/v_mul; fma-class ops take 4)
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2
 # algorithmic bytes per ray of the wavefront pipeline (SURVEY.md section 8d / DESIGN.md section 7)
 BYTES_EXTEND = 40.0    # read ray 28 (index-free dense queue: 24 + 4 slot id passed along), write hit 12
 BYTES_SHADE = 104.0
 BYTES_PER_PATH = 96.0
 
+# VALU instructions of the blocks of k_extend_lds7 (the Cornell instantiation of extend_body), counted in the ISA of
+# the shipped library by scripts/isa_blocks.py (re-run it after any change to extend_kernel.h; the table names the
+# git revision it was read at).  A launch's VALU wave-instructions = sum over blocks of (wave executions counted
+# live by the instrumented instantiation of the same template, PT_FLAG_COUNT_VISITS) x (instructions of the block).
+ISA_VALU_MODEL = json.load(open(os.path.join(REPO, "profiles", "isa_valu_model.json"))) \
+    if os.path.exists(os.path.join(REPO, "profiles", "isa_valu_model.json")) else None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
 
 def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, instances=None):
     """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
     bounded sample of the same workload: the same image, all cores, as many samples per pixel as fit
-    into ~budget_s seconds (calibrated with a 1-spp pass, at most spp_max)."""
+    into ~budget_s seconds (calibrated with a 1-spp pass, at most spp_max); then ONE thread on a crop."""
     from oracle import pt_oracle as orc
     osc = orc.Scene(*arrays)
     if instances is not None:
@@ -50,10 +80,187 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
     t0 = time.perf_counter()
     img, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
     dt = time.perf_counter() - t0
+    # single thread: the central 1/16 of the image (a quarter of each side) at 1 spp, scaled to ~budget_s / 4
+    cw, ch = max(width // 4, 1), max(height // 4, 1)
+    p1 = orc.default_params(width=width, height=height, spp_per_frame=1, max_depth=depth)
+    t0 = time.perf_counter()
+    _, r1 = orc.render_rect(osc, p1, (width - cw) // 2, (height - ch) // 2, cw, ch, mode=1, nthreads=1)
+    d1 = time.perf_counter() - t0
+    spp1 = int(max(1, min(spp_max, budget_s / 4 / max(d1, 1e-3))))
+    if spp1 > 1:
+        p1 = orc.default_params(width=width, height=height, spp_per_frame=spp1, max_depth=depth)
+        t0 = time.perf_counter()
+        _, r1 = orc.render_rect(osc, p1, (width - cw) // 2, (height - ch) // 2, cw, ch, mode=1, nthreads=1)
+        d1 = time.perf_counter() - t0
     base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
+            "cpu_model": cpu_model(), "single_thread_mrays": round(r1 / d1 / 1e6, 4),
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
-                      f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads"}
+                      f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads; "
+                      f"single thread: central {cw}x{ch} crop, {spp1} spp, {r1} rays in {d1:.2f} s"}
     return base, cnt.nodes_visited / max(rays, 1), cnt.tris_tested / max(rays, 1)
+
+
+def extend_kernel_name(pt, st, info, config):
+    if config == "c4":
+        return "k_extend_inst"
+    return {1: "k_extend_flat", 2: "k_extend_lds7" if info.n_wide_nodes <= 8191 else "k_extend<lds>", 3: "k_extend<hbm>"}.get(st.extend_variant, "?")
+
+
+def count_visits(pt, ctx, scene, W, H, common):
+    """One extra, untimed frame through the instrumented instantiation of the same traversal kernel."""
+    ctx.reset_stats()
+    scratch = pt.Film(ctx, W, H)
+    pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, flags=pt.FLAG_COUNT_VISITS, **common))
+    cst = ctx.stats()
+    film = scratch.read_f32()
+    scratch.close()
+    return cst, film
+
+
+def valu_model(cst, kernel):
+    """VALU wave-instructions per 64 rays of the single-level traversal kernel from live wave-level block counts."""
+    m = (ISA_VALU_MODEL or {}).get(kernel)
+    if not m or not cst.wave_iterations:
+        return None
+    b = m["valu_per_block"]
+    total = (cst.wave_iterations * b["outer_iteration"] + cst.wave_refills * b["refill"] + cst.node_steps * b["node_step"] +
+             cst.wave_pops * b["pop_iteration"] + cst.tri_steps * b["triangle_step"] + cst.wave_hit_blocks * b["hit_block"] +
+             cst.wave_finishes * b["finish"])
+    return {"wave_instr": total, "per_64_rays": total / max(cst.rays, 1) * 64.0, "revision": m.get("revision"),
+            "blocks": {"outer_iterations": cst.wave_iterations, "refills": cst.wave_refills, "node_steps": cst.node_steps,
+                       "pop_iterations": cst.wave_pops, "triangle_steps": cst.tri_steps, "hit_blocks": cst.wave_hit_blocks,
+                       "finishes": cst.wave_finishes}}
+
+
+def roofline_block(pt, st, cst, info, config, mean_len, note):
+    """`roofline` for the dominant kernel (the closest-hit traversal) of a leg: every number from this run."""
+    nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
+    tris_per_ray = cst.tris_tested / max(cst.rays, 1)
+    node_occ = cst.nodes_visited / (64.0 * cst.node_steps) if cst.node_steps else None
+    tri_occ = cst.tris_tested / (64.0 * cst.tri_steps) if cst.tri_steps else None
+    scene_bytes = info.device_bytes
+    # one BVH4 node visit of the HBM variant = 64 B (4 fp16 child boxes 48 B + 4 child words 16 B; the two-level
+    # kernel reads fp32 nodes, 128 B); one triangle = 36 B of positions.  Counted only when the scene exceeds the
+    # 32 MiB of L2 (SURVEY 8d); smaller scenes are LDS / L2 resident and HBM sees the queue I/O only.
+    node_bytes = 128.0 if config == "c4" else 64.0
+    gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
+    bytes_extend = BYTES_EXTEND + gather
+    gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
+    kernel = extend_kernel_name(pt, st, info, config)
+    r = {
+        "bound": "hbm", "kernel": kernel,
+        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "launches": st.launches_extend, "rays_per_launch": round(st.rays / st.launches_extend, 1),
+        "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
+        "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
+        "algorithmic_bytes_per_ray": round(bytes_extend, 1),
+        "gather": {"bvh4_nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                   "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
+                   "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
+        "active_lanes": {"node_steps": round(64 * node_occ, 1) if node_occ else None,
+                         "triangle_steps": round(64 * tri_occ, 1) if tri_occ else None},
+        "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
+        "note": note,
+    }
+    # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure is the
+    # bytes per ray of this round's committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs; 2 x FETCH +
+    # WRITE per the gfx950 correction of MI355X_MICROARCH.md) x this run's rays per launch
+    prof = os.path.join(REPO, "profiles", f"r02_pmc_extend_{config}.json")
+    if os.path.exists(prof):
+        try:
+            pmc = json.load(open(prof))
+            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
+            r["pmc_profile"] = {k: (round(pmc[k], 3) if isinstance(pmc[k], float) else pmc[k]) for k in
+                                ("hbm_bytes_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays", "valu_active_lanes_per_instr",
+                                 "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "rocprof_avg_launch_us") if k in pmc}
+            r["pmc_profile"]["source"] = os.path.relpath(prof, REPO)
+        except Exception:
+            pass
+    vm = valu_model(cst, kernel)
+    if vm:
+        rays_per_s = st.rays / (st.ms_extend * 1e-3)   # the kernel's own rate (its launches overlap the other pipeline's shade)
+        r["valu_wave_instr_per_64_rays"] = round(vm["per_64_rays"], 1)
+        r["valu_frac"] = round(vm["per_64_rays"] / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4)
+        r["valu_model"] = {"peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "isa_revision": vm["revision"], "wave_block_counts_1_frame": vm["blocks"],
+                           "source": "live wave-level block counts (PT_FLAG_COUNT_VISITS) x VALU instructions per block of the shipped ISA "
+                                     "(profiles/isa_valu_model.json, scripts/isa_blocks.py)"}
+    return r
+
+
+def build_scene(pt, ctx, config, soup_tris, rank, bvh_quality):
+    ingest = tlas_ms = None
+    if config in ("c5", "c5x"):
+        t0 = time.perf_counter()
+        if config == "c5":
+            obj = f"/tmp/pt_soup_{soup_tris}_rank{rank}.obj"     # generated, not committed (139 MB of text)
+            pt.write_soup_obj(obj, soup_tris, 1)
+            t1 = time.perf_counter()
+            arrays = pt.load_obj(obj)
+            ingest = {"generate_s": round(t1 - t0, 3), "load_obj_s": round(time.perf_counter() - t1, 3), "obj_bytes": os.path.getsize(obj)}
+            os.remove(obj)
+            os.remove(obj[:-4] + ".mtl")
+        else:
+            arrays = pt.make_soup(soup_tris, 1)                  # the same soup without the OBJ text in between
+            ingest = {"generate_s": round(time.perf_counter() - t0, 3), "source": "pth_make_soup (arrays, no OBJ text)"}
+        name = f"soup {soup_tris} triangles (PCG seed 1)"
+    else:
+        arrays = pt.load_obj(pt.ASSET_CORNELL)
+        name = "CornellBox-Original.obj"
+    scene = pt.Scene(ctx, *arrays)          # upload + on-device LBVH build (untimed, reported apart)
+    if bvh_quality == "fast_build":
+        scene.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)
+    if config == "c4":
+        t0 = time.perf_counter()
+        scene.set_instances(pt.cornell_grid_instances())      # TLAS build on device
+        ctx.sync()
+        tlas_ms = (time.perf_counter() - t0) * 1e3
+        name = "CornellBox-Original.obj x 10 000 instances (100x100 grid, scale 0.009)"
+    return scene, arrays, name, ingest, tlas_ms
+
+
+NOTES = {
+    "c2": "Cornell (<8 KB scene+BVH) never leaves LDS: extend is VALU-issue bound (valu_frac), HBM sees only queue I/O; "
+          "the HBM fraction is physically meaningful on configs C5 / C5x only (roofline_c5)",
+    "c4": "TLAS (10k instances) + BLAS fit in L2: traversal is VALU/latency bound, HBM sees queue I/O only",
+    "c5": "scene + BVH4 = 160 MB > L2 (32 MiB) but < Infinity Cache (256 MiB): every node/triangle fetch is a 64/48-B gather "
+          "through L1/L2/MALL; FETCH_SIZE counts MALL hits too",
+    "c5x": "8M-triangle soup: the traversal working set (BVH4 64-B nodes + triangles) exceeds the 256 MiB Infinity Cache, "
+           "gathers reach HBM",
+}
+
+
+def c5_leg(pt, ctx, W, H, config, soup_tris, frames, rank):
+    """The traversal kernel on the soup: `frames` warm-up frames, then the same `frames` frames timed with per-launch
+    events (identical launches, so rocprofv3's average over the whole process equals this leg's), then one
+    instrumented frame for the visit counts."""
+    scene, arrays, name, ingest, _ = build_scene(pt, ctx, config, soup_tris, rank, "fast_trace")
+    info = scene.info()
+    film = pt.Film(ctx, W, H)
+    common = dict(width=W, height=H, spp_per_frame=16, max_depth=16)
+    timed = pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_PROFILE, **common)
+    pt.render_prepare(scene, film, timed)
+    shape = ctx.stats()
+    common.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups)
+    timed = pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_PROFILE, **common)
+    pt.render(scene, film, timed)              # warm-up: the same call
+    film.clear()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    pt.render(scene, film, timed)
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    cst, _ = count_visits(pt, ctx, scene, W, H, common)
+    r = roofline_block(pt, st, cst, info, config, st.rays / max(st.paths, 1), NOTES[config])
+    out = {"workload": f"{config.upper()}: {name} {W}x{H}, 16 spp/frame x {frames} frames, 16 bounces",
+           "mrays_per_s": round(st.rays / dt / 1e6, 2), "ms_per_frame": round(dt * 1e3 / frames, 3),
+           "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups,
+           "bvh": {"triangles": info.n_tris, "bvh4_nodes": info.n_wide_nodes, "height": info.bvh_height, "build_ms": round(info.build_ms, 3)},
+           "ingest": ingest}
+    out.update(r)
+    film.close()
+    scene.close()
+    return out
 
 
 def main():
@@ -63,12 +270,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c4", "c5", "c5x"], default="c2",
                     help="c2 = Cornell box (the headline), c4 = Cornell x 10 000 instances (two-level BVH), "
-                         "c5 = 1M-triangle soup, 16 spp/frame, depth 16")
+                         "c5 = 1M-triangle soup, 16 spp/frame, depth 16; c5x = the same recipe with 8M triangles (> Infinity Cache)")
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--soup-tris", type=int, default=1000000)
+    ap.add_argument("--soup-tris", type=int, default=None)
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--sample-groups", type=int, default=0)
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm"], default="auto", help="closest-hit kernel variant")
@@ -76,6 +283,8 @@ def main():
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c5 legs")
+    ap.add_argument("--c5-frames", type=int, default=4, help="frames of the roofline_c5 leg")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0,
                     help="seconds of oracle time for cpu_baseline (it renders as many spp of frame 0 as fit; when that is the "
                          "whole frame, film and ray count are compared with the GPU's)")
@@ -108,51 +317,24 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    def reduce_film(t):
-        if emulate:
-            h = t.cpu()
-            ptd.reduce_film(h, dst=0)
-            if rank == 0:
-                t.copy_(h)
-        else:
-            ptd.reduce_film(t, dst=0)
-
     pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
     ptd = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
 
     W, H = args.width, args.height
-    if args.config == "c5":
+    if args.config in ("c5", "c5x"):
         args.spp = args.spp or 16
         args.depth = args.depth or 16
-        obj = f"/tmp/pt_soup_{args.soup_tris}_rank{rank}.obj"     # generated, not committed (139 MB of text)
-        t0 = time.perf_counter()
-        pt.write_soup_obj(obj, args.soup_tris, 1)
-        t1 = time.perf_counter()
-        arrays = pt.load_obj(obj)
-        ingest = {"generate_s": round(t1 - t0, 3), "load_obj_s": round(time.perf_counter() - t1, 3),
-                  "obj_bytes": os.path.getsize(obj)}
-        os.remove(obj)
-        scene_name = f"soup {args.soup_tris} triangles (PCG seed 1)"
+        args.soup_tris = args.soup_tris or (1000000 if args.config == "c5" else 8000000)
     else:
         args.spp = args.spp or 32
         args.depth = args.depth or 8
-        arrays = pt.load_obj(pt.ASSET_CORNELL)
-        ingest = None
-        scene_name = "CornellBox-Original.obj"
     stream = torch.cuda.current_stream(dev)
     ctx = pt.Context(local_rank, stream=stream.cuda_stream)
-    scene = pt.Scene(ctx, *arrays)          # upload + on-device LBVH build (untimed, reported apart)
-    if args.bvh_quality == "fast_build":
-        scene.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)
-    if args.config == "c4":
-        t0 = time.perf_counter()
-        scene.set_instances(pt.cornell_grid_instances())      # TLAS build on device
-        ctx.sync()
-        tlas_ms = (time.perf_counter() - t0) * 1e3
-        scene_name = "CornellBox-Original.obj x 10 000 instances (100x100 grid, scale 0.009)"
+    scene, arrays, scene_name, ingest, tlas_ms = build_scene(pt, ctx, args.config, args.soup_tris, rank, args.bvh_quality)
     info = scene.info()
-    film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # torch owns the film: RCCL reduces it in place
+    film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # this rank's accumulation film (torch owns the memory)
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
+    presenter = ptd.Presenter(pt, ctx, film, film_t, rank, world, cdev, emulate) if world > 1 else None
     flags = 0 if args.no_kernel_events else pt.FLAG_PROFILE
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
                   frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
@@ -172,17 +354,15 @@ def main():
     # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
         pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, **common))
-    if world > 1:      # communicator set-up (the first RCCL collective of a process) is not a step: always outside the timed region
-        tmp = film_t.clone()
-        reduce_film(tmp)
-        del tmp
+    if presenter:      # communicator set-up (the first collective of a process) is not a step: always outside the timed region
+        presenter.present()
     film.clear()
     ctx.reset_stats()
 
     barrier()
     t0 = time.perf_counter()
     pt.render(scene, film, timed)
-    reduce_film(film_t)                 # the one collective per presented image (no-op for N=1)
+    presented = presenter.present() if presenter else film_t   # the one collective per presented image (none for N=1)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -205,7 +385,8 @@ def main():
         out = {
             "metric": {"c2": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)",
                        "c4": "Mrays/s, Cornell Box x 10k instances (two-level BVH) 1920x1080 @ 8 bounces (BASELINE config C4)",
-                       "c5": "Mrays/s, 1M-triangle soup 1920x1080 @ 16 bounces (BASELINE config C5)"}[args.config],
+                       "c5": "Mrays/s, 1M-triangle soup 1920x1080 @ 16 bounces (BASELINE config C5)",
+                       "c5x": "Mrays/s, 8M-triangle soup (> Infinity Cache) 1920x1080 @ 16 bounces"}[args.config],
             "value": round(rays_total / dt / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,11 +397,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": ("CornellBox-Original.obj (the reference's own scene, 36 triangles)" if args.config in ("c2", "c4") else
-                     "synthetic triangle soup (generator pth_write_soup_obj, seed 1), written as OBJ+MTL and parsed by the host loader")
+                     "synthetic triangle soup (generator pth_write_soup_obj / pth_make_soup, seed 1)"
+                     + (", written as OBJ+MTL and parsed by the host loader" if args.config == "c5" else ""))
                     + "; rays are generated on device",
             "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
                                    f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
-                       "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" + (", RCCL reduce to rank 0" if world > 1 else ""),
+                       "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
+                                         (f", {presenter.describe()}" if presenter else ""),
                        "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups},
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
@@ -231,82 +414,70 @@ def main():
         }
         if rays_minmax:
             out["rays_per_rank_min_max"] = rays_minmax
+        if presenter:
+            out["rccl_ranks"] = presenter.ranks_seen
+        # sum of the presented image (N = 1: the film; N > 1: what the gather assembled on rank 0), order-insensitive in float64
+        out["presented_checksum"] = float(presented.double().sum().item())
         if ingest:
             out["ingest"] = ingest
         if args.config == "c4":
             out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
+        # traversal work per ray, counted by an instrumented build of the same kernel on the same
+        # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes and the VALU model
+        frame0_rays_gpu = frame0_film_gpu = None
+        cst = None
+        if st.extend_variant != pt.EXTEND_FLAT:
+            cst, frame0_film_gpu = count_visits(pt, ctx, scene, W, H, common)   # (rank 0's shard when N > 1)
+            frame0_rays_gpu = cst.rays
+        if flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
+            out["roofline"] = roofline_block(pt, st, cst, info, args.config, mean_len, NOTES[args.config])
+            bytes_extend = out["roofline"]["algorithmic_bytes_per_ray"]
+            pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
+            out["roofline"]["pipeline_algorithmic_GBps"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2)
+        if world == 1 and not args.no_extra_legs and args.config == "c2":
+            # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
+            ctx.reset_stats()
+            film.clear()
+            exact = pt.default_params(frame=0, frame_count=2, width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth)
+            pt.render_prepare(scene, film, exact)
+            pt.render(scene, film, exact)                          # warm-up of this shape
+            film.clear()
+            ctx.reset_stats()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            pt.render(scene, film, exact)
+            d2 = time.perf_counter() - t0
+            s2 = ctx.stats()
+            out["c2_exact"] = {"workload": f"BASELINE config C2 exactly: {W}x{H}, 64 spp = 2 frames x 32, {args.depth} bounces, one pt_render",
+                               "mrays_per_s": round(s2.rays / d2 / 1e6, 2), "ms_total": round(d2 * 1e3, 3), "ms_per_frame": round(d2 * 1e3 / 2, 3),
+                               "rays": s2.rays, "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups}
+            one = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, frame_count=1)
+            pt.render_prepare(scene, film, pt.default_params(frame=0, **one))
+            film.clear()
+            pt.render(scene, film, pt.default_params(frame=0, **one))
+            lat = []
+            ctx.reset_stats()
+            for k in range(1, 9):                                  # one blocking pt_render per frame, as main.cpp:647-685
+                t0 = time.perf_counter()
+                pt.render(scene, film, pt.default_params(frame=k, **one))
+                lat.append((time.perf_counter() - t0) * 1e3)
+            s1 = ctx.stats()
+            lat.sort()
+            out["latency_ms_1frame"] = round(lat[len(lat) // 2], 3)
+            out["latency_1frame"] = {"median_ms": round(lat[len(lat) // 2], 3), "min_ms": round(lat[0], 3), "max_ms": round(lat[-1], 3),
+                                     "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 2), "frames": len(lat),
+                                     "sample_groups": s1.sample_groups,
+                                     "shape": "K = 1: one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle, main.cpp:656-683)"}
+            # ---- the traversal kernel where HBM-side bandwidth is the bound: config C5 -------------------------
+            film.clear()
+            try:
+                out["roofline_c5"] = c5_leg(pt, ctx, W, H, "c5", 1000000, args.c5_frames, rank)
+            except Exception as e:      # never lose the headline to the extra leg
+                out["roofline_c5"] = {"error": repr(e)}
         base = None
         if not args.no_cpu_baseline and world == 1:
             base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth, budget_s=args.cpu_budget_s,
                                       instances=pt.cornell_grid_instances() if args.config == "c4" else None)
-        # traversal work per ray, counted by an instrumented build of the same kernel on the same
-        # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes
-        nodes_per_ray = tris_per_ray = 0.0
-        node_occ = tri_occ = None
-        frame0_rays_gpu = frame0_film_gpu = None
-        if st.extend_variant != pt.EXTEND_FLAT:
-            ctx.reset_stats()
-            scratch = pt.Film(ctx, W, H)
-            pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, flags=pt.FLAG_COUNT_VISITS, **common))
-            cst = ctx.stats()
-            nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
-            tris_per_ray = cst.tris_tested / max(cst.rays, 1)
-            node_occ = cst.nodes_visited / (64.0 * cst.node_steps) if cst.node_steps else None
-            tri_occ = cst.tris_tested / (64.0 * cst.tri_steps) if cst.tri_steps else None
-            frame0_rays_gpu = cst.rays
-            frame0_film_gpu = scratch.read_f32()
-            scratch.close()
-        if flags and st.launches_extend and st.ms_extend > 0:
-            # dominant kernel = k_extend (closest-hit traversal).  Algorithmic bytes: 40 B/ray; the
-            # 36-triangle scene + LBVH are LDS-resident so there is no scene-gather term.
-            # scene gather: counted only when the scene exceeds the 32 MiB of L2
-            scene_bytes = info.device_bytes
-            # one BVH4 node visit of the HBM variant = 64 B (4 fp16 child boxes 48 B + 4 child words 16 B; the
-            # two-level kernel reads fp32 nodes, 128 B); one triangle = 36 B of positions
-            node_bytes = 128.0 if args.config == "c4" else 64.0
-            gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
-            bytes_extend = BYTES_EXTEND + gather
-            gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
-            pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
-            traffic = None
-            prof = os.path.join(REPO, "profiles", {"c2": "r01_pmc_extend.json", "c4": "r01_pmc_extend_c4.json",
-                                                   "c5": "r01_pmc_extend_c5.json"}[args.config])
-            pmc = None
-            if os.path.exists(prof):
-                try:   # PMC HBM bytes per ray of the same kernel (committed rocprofv3 run) x this run's rays per launch
-                    pmc = json.load(open(prof))
-                    traffic = round(pmc["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
-                except Exception:
-                    traffic = pmc = None
-            out["roofline"] = {
-                "bound": "hbm", "kernel": {1: "k_extend_flat", 2: "k_extend<lds>", 3: "k_extend<hbm>"}.get(st.extend_variant, "?"),
-                "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "launches": st.launches_extend,
-                "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
-                "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
-                "algorithmic_bytes_per_ray": round(bytes_extend, 1),
-                "gather": {"bvh4_nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
-                           "lane_occupancy_node_steps": round(node_occ, 3) if node_occ else None,
-                           "lane_occupancy_triangle_steps": round(tri_occ, 3) if tri_occ else None,
-                           "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
-                           "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
-                "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
-                "pmc_profile": None if not pmc else {   # from the committed rocprofv3 PMC passes of this kernel
-                    "valu_busy_fraction": round(pmc["valu_busy_fraction"], 3),
-                    "valu_wave_instr_per_64_rays": round(pmc["valu_wave_instr_per_64_rays"], 1),
-                    "wait_any_fraction_of_wave_cycles": round(pmc["wait_any_fraction_of_wave_cycles"], 3),
-                    "l2_hit_rate": round(pmc["l2_hit_rate"], 3), "hbm_bytes_per_ray": round(pmc["hbm_bytes_per_ray"], 1),
-                    "source": os.path.relpath(prof, REPO)},
-                "pipeline_algorithmic_GBps": round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2),
-                "note": ("Cornell (<8 KB scene+BVH) never leaves SGPRs/LDS: extend is VALU-issue bound, HBM sees only "
-                         "queue I/O; the HBM fraction is physically meaningful on config C5 (1M triangles) only")
-                        if args.config == "c2" else
-                        ("TLAS (10k instances) + BLAS fit in L2: traversal is VALU/latency bound, HBM sees queue I/O only"
-                         if args.config == "c4" else
-                         "scene + BVH4 = 118 MB > L2: every node/triangle fetch is a 128/48-B gather through L2/MALL/HBM"),
-            }
-        if base and not args.no_cpu_baseline and world == 1:
             cpu_rays, cpu_spp, cpu_img = base.pop("_rays"), base.pop("_spp"), base.pop("_img")
             out["cpu_baseline"] = base
             if cpu_spp == args.spp and frame0_rays_gpu is not None:
@@ -316,6 +487,8 @@ def main():
                 out["frame0_film_bit_exact"] = bool(frame0_film_gpu.tobytes() == cpu_img.tobytes())
         print(json.dumps(out), flush=True)
 
+    if presenter:
+        presenter.close()
     film.close()
     scene.close()
     ctx.close()

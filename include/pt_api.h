@@ -16,13 +16,14 @@
 #ifndef PT_API_H
 #define PT_API_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PT_API_VERSION 1
+#define PT_API_VERSION 2
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -178,6 +179,38 @@ typedef struct pt_hit {
 pt_status pt_trace(pt_scene *scene, const float *rays6, uint32_t n, float tmin, float tmax,
                    uint32_t extend /* PT_EXTEND_* */, pt_hit *hits);
 
+/* ---- multi-GPU: assembling the presented image of a tile-sharded render ---------- */
+/* The reference renders on physical device 0 (main.cpp:105) and copies its storage image to the swapchain
+ * (main.cpp:661-667).  Here N ranks -- processes or host threads, one context and one GPU each -- render the
+ * interleaved 8x8 tiles of one image (pt_params.rank / .world); pt_film_present stands in for that copy: ONE RCCL
+ * gather of the packed tiles to the root per presented image (W*H*12/N bytes per rank over xGMI), written to a
+ * separate image, so every rank's accumulation film stays valid for further progressive frames.
+ * RCCL is loaded at run time (dlopen) by the first pt_comm_* call: PT_ERR_UNSUPPORTED when it is not installed. */
+typedef struct pt_comm pt_comm;
+typedef struct pt_unique_id { char internal[128]; } pt_unique_id; /* = ncclUniqueId */
+/* One rank makes the id (ncclGetUniqueId) and hands the 128 bytes to the others by any means (the launcher's
+ * store, MPI, a file); then every rank creates its communicator (ncclCommInitRank; collective: returns when all
+ * `world` ranks have called it).  One communicator per context.                                                   */
+pt_status pt_comm_unique_id(pt_unique_id *id);
+pt_status pt_comm_create(pt_ctx *ctx, const pt_unique_id *id, uint32_t world, uint32_t rank, pt_comm **out);
+pt_status pt_comm_ranks(const pt_comm *comm, uint32_t *n); /* ncclCommCount: the ranks RCCL actually connected */
+void pt_comm_destroy(pt_comm *comm);
+/* Called by every rank once per presented image, with the film it rendered as (rank, world) of the communicator.
+ * d_image: DEVICE memory for width*height*3 floats on the root (ignored elsewhere).  Blocking.               */
+pt_status pt_film_present(pt_film *film, pt_comm *comm, uint32_t root, float *d_image);
+/* The two kernels of that path alone (no communicator): a rank's tiles <-> a dense device buffer
+ * [tile][64 pixels][rgb], tiles in row-major order of the tile grid.  pt_film_tile_count gives its length / 192.  */
+pt_status pt_film_tile_count(const pt_film *film, uint32_t rank, uint32_t world, uint32_t *n_tiles);
+pt_status pt_film_pack_tiles(pt_film *film, uint32_t rank, uint32_t world, float *d_packed);
+pt_status pt_film_unpack_tiles(pt_film *film, uint32_t rank, uint32_t world, const float *d_packed, float *d_image);
+
+/* Device memory for the buffers a caller hands to the library (pt_film_create_external, pt_film_present), for hosts
+ * that do not link HIP themselves (host/pt_main.cpp is plain g++): hipMalloc / hipFree / a blocking device->host copy
+ * ordered after the context's stream.                                                                            */
+pt_status pt_device_alloc(pt_ctx *ctx, size_t bytes, void **out);
+pt_status pt_device_free(pt_ctx *ctx, void *device_ptr);
+pt_status pt_device_read(pt_ctx *ctx, const void *device_src, void *host_dst, size_t bytes);
+
 /* ---- statistics ------------------------------------------------------------------------ */
 typedef struct pt_stats {
     uint64_t rays;             /* closest-hit queries (= traceRayEXT calls) since last reset, exact */
@@ -197,6 +230,11 @@ typedef struct pt_stats {
     uint64_t node_steps, tri_steps;
     /* batches whose sample-group term log filled up and that were rendered again with one group (exact either way) */
     uint32_t redone_batches, reserved_;
+    /* PT_FLAG_COUNT_VISITS, single-level extend kernel: how often a WAVE executed the other blocks of the kernel --
+     * the refill block, one iteration of the stack-pop loop, the hit block of the triangle test (the true divide),
+     * the block that writes a hit record, one iteration of the outer loop.  With the per-block instruction counts
+     * of the shipped ISA (bench.py) these give the VALU instructions a launch issues without a PMC run.     */
+    uint64_t wave_refills, wave_pops, wave_hit_blocks, wave_finishes, wave_iterations;
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

@@ -15,6 +15,7 @@ bench = None
 for line in open(os.path.join(root, "stats.log")):
     if line.startswith("{") and '"metric"' in line:
         bench = json.loads(line)
+# the k_extend* kernel of the headline leg (the roofline_c5 leg of a default run uses another instantiation)
 # dominant extend kernel of the timed region = the k_extend* kernel with most total time (the counting
 # instantiation only runs the one extra untimed frame)
 name = max((k for k in s["kernels"] if k.startswith("k_extend")), key=lambda k: s["kernels"][k]["total_ns"])

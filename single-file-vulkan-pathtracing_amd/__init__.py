@@ -67,7 +67,9 @@ class Stats(C.Structure):
                 ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("frames_in_flight", C.c_uint32), ("sample_groups", C.c_uint32),
                 ("node_steps", C.c_uint64), ("tri_steps", C.c_uint64),
-                ("redone_batches", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("redone_batches", C.c_uint32), ("reserved_", C.c_uint32),
+                ("wave_refills", C.c_uint64), ("wave_pops", C.c_uint64), ("wave_hit_blocks", C.c_uint64),
+                ("wave_finishes", C.c_uint64), ("wave_iterations", C.c_uint64)]
 
 
 class HostScene(C.Structure):
@@ -83,7 +85,10 @@ API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "p
                "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_film_create", "pt_film_create_external", "pt_film_clear",
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render",
                "pt_render_prepare", "pt_trace",
-               "pt_get_stats", "pt_reset_stats"]
+               "pt_get_stats", "pt_reset_stats",
+               "pt_comm_unique_id", "pt_comm_create", "pt_comm_ranks", "pt_comm_destroy", "pt_film_present",
+               "pt_film_tile_count", "pt_film_pack_tiles", "pt_film_unpack_tiles",
+               "pt_device_alloc", "pt_device_free", "pt_device_read"]
 HOST_SYMBOLS = ["pth_load_obj", "pth_load_obj_ex", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj", "pth_make_soup"]
 
 _amd = None
@@ -134,6 +139,18 @@ def lib_amd():
         L.pt_trace.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, vp]
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_reset_stats.argtypes = [vp]
+        L.pt_comm_unique_id.argtypes = [vp]
+        L.pt_comm_create.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.pt_comm_ranks.argtypes = [vp, C.POINTER(C.c_uint32)]
+        L.pt_comm_destroy.argtypes = [vp]
+        L.pt_comm_destroy.restype = None
+        L.pt_film_present.argtypes = [vp, vp, C.c_uint32, vp]
+        L.pt_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.pt_device_free.argtypes = [vp, vp]
+        L.pt_device_read.argtypes = [vp, vp, vp, C.c_size_t]
+        L.pt_film_tile_count.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.pt_film_pack_tiles.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        L.pt_film_unpack_tiles.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
         _amd = L
     return _amd
 
@@ -375,6 +392,78 @@ class Film:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """One rank's RCCL communicator for presenting tile-sharded renders (include/pt_api.h: pt_comm_*)."""
+
+    def __init__(self, ctx, unique_id, world, rank):
+        self.ctx, self.world, self.rank = ctx, world, rank
+        self.h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        ctx._check(lib_amd().pt_comm_create(ctx.h, buf, world, rank, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib_amd().pt_comm_unique_id(buf)
+        if rc != PT_OK:
+            raise PtError(rc, "pt_comm_unique_id (is RCCL installed?)")
+        return buf.raw
+
+    def ranks(self):
+        n = C.c_uint32()
+        self.ctx._check(lib_amd().pt_comm_ranks(self.h, C.byref(n)))
+        return n.value
+
+    def present(self, film, device_image_ptr, root=0):
+        self.ctx._check(lib_amd().pt_film_present(film.h, self.h, root, C.c_void_p(device_image_ptr)))
+
+    def close(self):
+        if self.h:
+            lib_amd().pt_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """hipMalloc'ed memory through the C-ABI (for callers without torch): .ptr, .read(dtype, shape)"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._check(lib_amd().pt_device_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def read(self, dtype, shape):
+        a = np.zeros(shape, dtype=dtype)
+        assert a.nbytes <= self.nbytes
+        self.ctx._check(lib_amd().pt_device_read(self.ctx.h, C.c_void_p(self.ptr), a.ctypes.data, a.nbytes))
+        return a
+
+    def close(self):
+        if self.ptr:
+            lib_amd().pt_device_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+def film_tile_count(film, rank, world):
+    n = C.c_uint32()
+    film.ctx._check(lib_amd().pt_film_tile_count(film.h, rank, world, C.byref(n)))
+    return n.value
+
+
+def film_pack_tiles(film, rank, world, device_ptr):
+    film.ctx._check(lib_amd().pt_film_pack_tiles(film.h, rank, world, C.c_void_p(device_ptr)))
+
+
+def film_unpack_tiles(film, rank, world, device_packed_ptr, device_image_ptr):
+    film.ctx._check(lib_amd().pt_film_unpack_tiles(film.h, rank, world, C.c_void_p(device_packed_ptr), C.c_void_p(device_image_ptr)))
 
 
 def render(scene, film, params):

@@ -208,6 +208,10 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     uint32_t cur = DONE;
     int sp = 0;
     unsigned long long c_nodes = 0, c_tris = 0, c_node_steps = 0, c_tri_steps = 0;
+    unsigned long long c_refills = 0, c_pops = 0, c_hit_blocks = 0, c_finishes = 0, c_iters = 0;  // wave executions of the other blocks
+    // one lane per wave counts a block the wave executes (exec mask of the moment)
+#define PT_COUNT_WAVE(C) \
+    if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) (C)++
 
     auto push = [&](uint32_t w, float t) {
         if (COMPACT) {
@@ -223,6 +227,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     auto pop = [&]() -> uint32_t {  // next subtree that can still contain the closest hit
         if (COMPACT) {
             while (sp > 0) {
+                PT_COUNT_WAVE(c_pops);
                 sp--;
                 const uint32_t e = my_stack32[sp * TB];
                 if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
@@ -230,6 +235,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             return DONE;
         }
         while (sp > 0) {
+            PT_COUNT_WAVE(c_pops);
             sp--;
             unsigned long long e;
             if (!SPILL || sp < lds_stack) e = my_stack[sp * TB];
@@ -241,6 +247,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
 
     for (;;) {
         // ---- refill idle lanes from the queue head
+        PT_COUNT_WAVE(c_iters);
         const unsigned long long idle = __ballot(!have);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= refill_min_idle) {
@@ -248,6 +255,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
+                    PT_COUNT_WAVE(c_refills);
                     q = qq;
                     const float4 ra = rayA[q];
                     const float2 rb = rayB[q];
@@ -368,9 +376,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : 3 * (size_t)pos;
                     const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
                     float t, V, W, det;
+                    bool divided = false;
                     const bool th = LDS_SCENE
-                        ? ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)
-                        : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det);
+                        ? ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr)
+                        : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr);
+                    if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
                     if (th) {
                         const uint32_t prim = __float_as_uint(a.w);
                         // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
@@ -382,6 +392,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 cur = pop();
             }
             if (cur == DONE) {  // traversal finished: emit the hit record, the lane becomes idle
+                PT_COUNT_WAVE(c_finishes);
                 const bool miss = best_pos == PT_MISS;
                 // raw_hit (render path): (V, W, det) go out undivided and k_shade takes the two quotients at
                 // full lane occupancy; here they would run once per finishing lane group
@@ -392,18 +403,29 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             }
         }
     }
+#undef PT_COUNT_WAVE
     if (COUNT) {
         for (int o = 32; o > 0; o >>= 1) {
             c_nodes += __shfl_xor(c_nodes, o, 64);
             c_tris += __shfl_xor(c_tris, o, 64);
             c_node_steps += __shfl_xor(c_node_steps, o, 64);
             c_tri_steps += __shfl_xor(c_tri_steps, o, 64);
+            c_refills += __shfl_xor(c_refills, o, 64);
+            c_pops += __shfl_xor(c_pops, o, 64);
+            c_hit_blocks += __shfl_xor(c_hit_blocks, o, 64);
+            c_finishes += __shfl_xor(c_finishes, o, 64);
+            c_iters += __shfl_xor(c_iters, o, 64);
         }
         if (lane == 0 && stats) {
             atomicAdd(stats + 2, c_nodes);
             atomicAdd(stats + 3, c_tris);
             atomicAdd(stats + 4, c_node_steps);
             atomicAdd(stats + 5, c_tri_steps);
+            atomicAdd(stats + 8, c_refills);
+            atomicAdd(stats + 9, c_pops);
+            atomicAdd(stats + 10, c_hit_blocks);
+            atomicAdd(stats + 11, c_finishes);
+            atomicAdd(stats + 12, c_iters);
         }
     }
 }

@@ -65,8 +65,8 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     }
     if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return fail("hipEventCreate", e);
-    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * 8)) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * PT_N_STATS)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS)) != hipSuccess) return fail("hipMemset", e);
     *out = ctx;
     return PT_OK;
 }
@@ -286,10 +286,44 @@ pt_status pt_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, floa
     return guarded(s->ctx, [&] { return ptw_trace(s, rays6, n, tmin, tmax, extend, hits); });
 }
 
+pt_status pt_device_alloc(pt_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return PT_ERR_INVALID_ARG;
+    *out = nullptr;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP;
+    }
+    return PT_OK;
+}
+
+pt_status pt_device_free(pt_ctx *ctx, void *p)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipFree(p));
+    return PT_OK;
+}
+
+pt_status pt_device_read(pt_ctx *ctx, const void *src, void *dst, size_t bytes)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!src || !dst) { ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
 {
     if (!ctx || !out) return PT_ERR_INVALID_ARG;
-    unsigned long long h[8];
+    unsigned long long h[PT_N_STATS];
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     ctx->stats.rays = h[0];
@@ -297,6 +331,8 @@ pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
     ctx->stats.tris_tested = h[3];
     ctx->stats.node_steps = h[4];
     ctx->stats.tri_steps = h[5];
+    ctx->stats.wave_refills = h[8]; ctx->stats.wave_pops = h[9]; ctx->stats.wave_hit_blocks = h[10];
+    ctx->stats.wave_finishes = h[11]; ctx->stats.wave_iterations = h[12];
     *out = ctx->stats;
     return PT_OK;
 }
@@ -305,7 +341,7 @@ pt_status pt_reset_stats(pt_ctx *ctx)
 {
     if (!ctx) return PT_ERR_INVALID_ARG;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8));
+    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS));
     ctx->stats = pt_stats{};
     return PT_OK;
 }

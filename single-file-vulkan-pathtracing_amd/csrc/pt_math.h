@@ -215,7 +215,8 @@ __device__ __forceinline__ RayPre ray_setup(const f3 org, const f3 dir)
 // v2 = attribs.y).  The two divides are deferred to the hit that finally wins (same operands,
 // same bits, fewer IEEE divides).
 __device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 v1, const f3 v2, float tmin,
-                                         float tmax, float &t, float &Vn, float &Wn, float &detn)
+                                         float tmax, float &t, float &Vn, float &Wn, float &detn,
+                                         bool *reached_divide = nullptr)  // instrumented builds only
 {
     const f3 A = { v0.x - r.org.x, v0.y - r.org.y, v0.z - r.org.z };
     const f3 B = { v1.x - r.org.x, v1.y - r.org.y, v1.z - r.org.z };
@@ -234,6 +235,7 @@ __device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     const float det = (U + V) + W;
     if (det == 0.0f) return false;
+    if (reached_divide) *reached_divide = true;
     const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
     const float T = (U * Az + V * Bz) + W * Cz;
     const float tt = fdiv(T, det);
@@ -257,7 +259,8 @@ __device__ __forceinline__ float safe_inv(float d)
 // origin permuted the same way: the per-vertex component selects of tri_test() disappear, every
 // remaining operation has the same operands, so the result is bit-identical.
 __device__ __forceinline__ bool tri_test_perm(const RayPre &r, const f3 orgp, const f3 v0, const f3 v1, const f3 v2,
-                                              float tmin, float tmax, float &t, float &Vn, float &Wn, float &detn)
+                                              float tmin, float tmax, float &t, float &Vn, float &Wn, float &detn,
+                                              bool *reached_divide = nullptr)  // instrumented builds only
 {
     const f3 A = { v0.x - orgp.x, v0.y - orgp.y, v0.z - orgp.z };
     const f3 B = { v1.x - orgp.x, v1.y - orgp.y, v1.z - orgp.z };
@@ -271,6 +274,7 @@ __device__ __forceinline__ bool tri_test_perm(const RayPre &r, const f3 orgp, co
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     const float det = (U + V) + W;
     if (det == 0.0f) return false;
+    if (reached_divide) *reached_divide = true;
     const float Az = r.Sz * A.z, Bz = r.Sz * B.z, Cz = r.Sz * C.z;
     const float T = (U * Az + V * Bz) + W * Cz;
     const float tt = fdiv(T, det);

@@ -1,13 +1,18 @@
 """Multi-GPU sharding of the radiance loop: one process per GPU, pixel tiles interleaved over the
-ranks, ONE collective per presented image (a sum-reduce of the zero-padded float films to rank 0
-over RCCL/xGMI; `gloo` on CPU for the tests).
+ranks, ONE collective per presented image.
 
 The path shards with no data-path exchange: a pixel's radiance depends only on (pixel, sample
 index, scene) (raygen.rgen:47-48, 88-90 touch nothing but the own texel).  Every rank holds the
 whole scene and builds the same LBVH; rank r renders the 8x8 pixel tiles with
 (tile_x + tile_y) % world == r -- interleaved, because contiguous bands are badly unbalanced
-(44 % of the image, the border, terminates after one ray).  Outside its tiles a rank's film is
-exactly 0, so the sum over ranks reproduces the single-GPU film bit for bit (x + 0 == x).
+(44 % of the image, the border, terminates after one ray).
+
+Presenting: `pt_film_present` (csrc/present_rccl.hip) packs the tiles a rank owns, gathers them on
+the root with ncclSend / ncclRecv over the library's OWN RCCL communicator (W*H*12/N bytes per rank)
+and unpacks them into a separate image; a rank's accumulation film is never written by the
+collective, so progressive rendering can continue and present again.  `Presenter` below is the glue
+under `torch.distributed`: the launcher's process group only carries the 128-byte RCCL unique id
+to the ranks (and, in the CPU emulation of the tests, the packed tiles over gloo).
 """
 import numpy as np
 
@@ -25,13 +30,115 @@ def owned_mask(width, height, rank, world):
     return tile_owner(width, height, world) == rank
 
 
-def reduce_film(film_tensor, dst=0, group=None):
-    """Sum the per-rank films into rank `dst` (in place). film_tensor: torch tensor [H, W, 3] f32
-    living where the process group's backend expects it (cuda for nccl/RCCL, cpu for gloo)."""
+def tile_list(width, height, rank, world):
+    """-> [(tile_x, tile_y)] of a rank in the order the device enumerates them (row major)."""
+    tiles_x, tiles_y = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    return [(tx, ty) for ty in range(tiles_y) for tx in range(tiles_x) if (tx + ty) % world == rank]
+
+
+def pack_tiles_host(film, rank, world):
+    """numpy mirror of k_pack_tiles: [n_tiles, 64, 3] float32 (pixels beyond the image edge are 0)."""
+    h, w = film.shape[:2]
+    tl = tile_list(w, h, rank, world)
+    out = np.zeros((len(tl), TILE, TILE, 3), np.float32)
+    for k, (tx, ty) in enumerate(tl):
+        blk = film[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE]
+        out[k, :blk.shape[0], :blk.shape[1]] = blk
+    return out.reshape(len(tl), TILE * TILE, 3)
+
+
+def unpack_tiles_host(packed, image, rank, world):
+    """numpy mirror of k_unpack_tiles: scatter a rank's packed tiles into `image` [H, W, 3]."""
+    h, w = image.shape[:2]
+    for k, (tx, ty) in enumerate(tile_list(w, h, rank, world)):
+        blk = packed[k].reshape(TILE, TILE, 3)
+        y1, x1 = min((ty + 1) * TILE, h), min((tx + 1) * TILE, w)
+        image[ty * TILE:y1, tx * TILE:x1] = blk[:y1 - ty * TILE, :x1 - tx * TILE]
+    return image
+
+
+def gather_present_host(film, rank, world, dst=0, group=None):
+    """The presentation collective on host arrays over any torch.distributed backend (the world-2 gloo test): every
+    rank packs its tiles, the root gathers them and unpacks.  -> the presented image on `dst`, None elsewhere;
+    `film` is not modified."""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(film_tensor, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return film_tensor
+    mine = torch.from_numpy(pack_tiles_host(film, rank, world))
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return unpack_tiles_host(mine.numpy(), np.zeros_like(film), rank, world)
+    h, w = film.shape[:2]
+    counts = [len(tile_list(w, h, r, world)) for r in range(world)]
+    if rank == dst:
+        bufs = [torch.zeros((counts[r], TILE * TILE, 3), dtype=torch.float32) for r in range(world)]
+        bufs[dst] = mine
+        reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(world) if r != dst and counts[r]]
+        for q in reqs:
+            q.wait()
+        image = np.zeros_like(film)
+        for r in range(world):
+            unpack_tiles_host(bufs[r].numpy(), image, r, world)
+        return image
+    if counts[rank]:
+        dist.send(mine, dst=dst, group=group)
+    return None
+
+
+class Presenter:
+    """bench.py's glue: this rank's film -> the presented image on rank 0, once per call.
+
+    Real run: the library's own RCCL communicator (`Comm`), created from a unique id that rank 0 makes and
+    torch.distributed broadcasts.  PT_BENCH_EMULATE (all ranks on GPU 0, gloo): the same pack / unpack kernels with
+    the packed tiles carried by gloo -- RCCL cannot put two ranks on one device."""
+
+    def __init__(self, pt, ctx, film, film_tensor, rank, world, cdev, emulate):
+        import torch
+        import torch.distributed as dist
+        self.pt, self.ctx, self.film, self.rank, self.world, self.emulate = pt, ctx, film, rank, world, emulate
+        self.torch, self.dist = torch, dist
+        dev = film_tensor.device
+        self.image = torch.zeros_like(film_tensor) if rank == 0 else None
+        self.comm = None
+        self.ranks_seen = None
+        if emulate:
+            self.counts = [pt.film_tile_count(film, r, world) for r in range(world)]
+            self.packed = torch.zeros((max(self.counts[rank], 1), 64, 3), dtype=torch.float32, device=dev)
+            self.ranks_seen = dist.get_world_size()
+        else:
+            box = [pt.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.comm = pt.Comm(ctx, box[0], world, rank)
+            self.ranks_seen = self.comm.ranks()
+
+    def describe(self):
+        return ("packed tiles gathered over gloo (emulation)" if self.emulate else
+                "one RCCL gather of the packed tiles to rank 0 (pt_film_present: ncclSend/ncclRecv, own communicator)")
+
+    def present(self):
+        pt, torch, dist = self.pt, self.torch, self.dist
+        if not self.emulate:
+            self.comm.present(self.film, self.image.data_ptr() if self.rank == 0 else 0, root=0)
+            return self.image
+        pt.film_pack_tiles(self.film, self.rank, self.world, self.packed.data_ptr())
+        host = self.packed.cpu()
+        if self.rank == 0:
+            for r in range(self.world):
+                if r == 0:
+                    buf = host
+                else:
+                    buf = torch.zeros((max(self.counts[r], 1), 64, 3), dtype=torch.float32)
+                    if self.counts[r]:
+                        dist.recv(buf, src=r)
+                d = buf.to(self.image.device)
+                pt.film_unpack_tiles(self.film, r, self.world, d.data_ptr(), self.image.data_ptr())
+            return self.image
+        if self.counts[self.rank]:
+            dist.send(host, dst=0)
+        return None
+
+    def close(self):
+        if self.comm:
+            self.comm.close()
+            self.comm = None
 
 
 def sum_counters(values, device, group=None):

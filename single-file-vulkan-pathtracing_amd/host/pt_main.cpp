@@ -6,12 +6,18 @@
 //   pt_main [--obj assets/CornellBox-Original.obj] [--width 1024] [--height 1024]
 //           [--frames 1] [--spp 32] [--depth 8] [--device 0] [--batch N]
 //           [--ppm out.ppm] [--pfm out.pfm]
+//           [--ranks N [--devices 0,1,...]]
+// --ranks N renders with N GPUs: one host thread and one context per GPU, the 8x8 pixel tiles interleaved over the
+// ranks (pt_params.rank/world), and ONE RCCL gather of the packed tiles to rank 0 per presented image
+// (pt_film_present); the image written is the presented one.
 // Prints one JSON line with ray count, ms/frame and Mrays/s.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pt_api.h"
@@ -23,80 +29,185 @@ namespace {
     std::fprintf(stderr, "pt_main: %s\n", msg.c_str());
     std::exit(1);
 }
+
+struct Options {
+    std::string obj = "assets/CornellBox-Original.obj", ppm, pfm;
+    uint32_t width = 1024, height = 1024, frames = 1, spp = 32, depth = 8, batch = 0;
+    int device = 0;
+    uint32_t ranks = 1;          // --ranks N: one host thread + one GPU per rank, tiles interleaved, RCCL gather to rank 0
+    std::vector<int> devices;    // --devices a,b,...: HIP ordinals of the ranks (default 0..N-1)
+};
+
+struct RankResult {
+    pt_stats st{};
+    pt_scene_info info{};
+    uint32_t rccl_ranks = 0;
+    double render_ms = 0.0, present_ms = 0.0;
+    std::string error;
+};
+
+// What one rank does: the reference's main() from the scene upload on (main.cpp:492-685), for its share of the
+// tiles; then the one collective per presented image.  Rank 0 returns the image in `image` (device -> host).
+void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_unique_id *id, RankResult &res,
+              std::vector<float> *image_f32, std::vector<uint8_t> *image_bgra8)
+{
+    pt_ctx *ctx = nullptr;
+    pt_scene *scene = nullptr;
+    pt_film *film = nullptr;
+    pt_comm *comm = nullptr;
+    float *d_image = nullptr;
+    auto fail = [&](const char *what) {
+        res.error = std::string(what) + ": " + (ctx ? pt_last_error(ctx) : pt_last_error(nullptr));
+    };
+    const int device = o.ranks > 1 ? o.devices[rank] : o.device;
+    do {
+        if (pt_ctx_create(device, nullptr, &ctx) != PT_OK) { fail("pt_ctx_create"); break; }
+        if (pt_scene_create(ctx, hs.vertices, hs.n_verts, hs.indices, hs.n_tris, hs.faces, &scene) != PT_OK) { fail("pt_scene_create"); break; }
+        pt_scene_get_info(scene, &res.info);
+        if (pt_film_create(ctx, o.width, o.height, &film) != PT_OK) { fail("pt_film_create"); break; }
+        if (o.ranks > 1) {
+            if (pt_comm_create(ctx, id, o.ranks, rank, &comm) != PT_OK) { fail("pt_comm_create"); break; }
+            pt_comm_ranks(comm, &res.rccl_ranks);
+        }
+        pt_params p;
+        pt_params_default(&p);
+        p.width = o.width; p.height = o.height; p.spp_per_frame = o.spp; p.max_depth = o.depth;
+        p.frames_in_flight = o.batch;
+        p.rank = rank; p.world = o.ranks;
+        // the reference dispatches one frame per loop iteration (main.cpp:647-685); frames are
+        // independent until the blend, so they are handed over in one call and batched on the device
+        p.frame = 0; p.frame_count = o.frames;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (pt_render(scene, film, &p) != PT_OK) { fail("pt_render"); break; }
+        const auto t1 = std::chrono::steady_clock::now();
+        res.render_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        pt_get_stats(ctx, &res.st);
+        if (o.ranks > 1) {
+            // the presented image lives in its own device buffer on rank 0 (main.cpp:661-667 copies the storage image)
+            if (rank == 0 && pt_device_alloc(ctx, sizeof(float) * 3 * (size_t)o.width * o.height, (void **)&d_image) != PT_OK) { fail("pt_device_alloc"); break; }
+            if (pt_film_present(film, comm, 0, d_image) != PT_OK) { fail("pt_film_present"); break; }
+            res.present_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            if (rank == 0 && image_f32) {
+                image_f32->resize(3 * (size_t)o.width * o.height);
+                if (pt_device_read(ctx, d_image, image_f32->data(), sizeof(float) * image_f32->size()) != PT_OK) { fail("pt_device_read"); break; }
+            }
+        } else {
+            if (image_f32) {
+                image_f32->resize(3 * (size_t)o.width * o.height);
+                if (pt_film_read_f32(film, image_f32->data()) != PT_OK) { fail("pt_film_read_f32"); break; }
+            }
+            if (image_bgra8) {
+                image_bgra8->resize(4 * (size_t)o.width * o.height);
+                if (pt_film_read_bgra8(film, image_bgra8->data()) != PT_OK) { fail("pt_film_read_bgra8"); break; }
+            }
+        }
+    } while (false);
+    if (d_image) pt_device_free(ctx, d_image);
+    pt_comm_destroy(comm);
+    pt_film_destroy(film);
+    pt_scene_destroy(scene);
+    pt_ctx_destroy(ctx);
+}
 }  // namespace
 
 int main(int argc, char **argv)
 {
-    std::string obj = "assets/CornellBox-Original.obj", ppm, pfm;
-    uint32_t width = 1024, height = 1024, frames = 1, spp = 32, depth = 8, batch = 0;
-    int device = 0;
+    Options o;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * {
             if (i + 1 >= argc) die("missing value for " + a);
             return argv[++i];
         };
-        if (a == "--obj") obj = val();
-        else if (a == "--width") width = (uint32_t)std::atoi(val());
-        else if (a == "--height") height = (uint32_t)std::atoi(val());
-        else if (a == "--frames") frames = (uint32_t)std::atoi(val());
-        else if (a == "--spp") spp = (uint32_t)std::atoi(val());
-        else if (a == "--depth") depth = (uint32_t)std::atoi(val());
-        else if (a == "--device") device = std::atoi(val());
-        else if (a == "--batch") batch = (uint32_t)std::atoi(val());
-        else if (a == "--ppm") ppm = val();
-        else if (a == "--pfm") pfm = val();
+        if (a == "--obj") o.obj = val();
+        else if (a == "--width") o.width = (uint32_t)std::atoi(val());
+        else if (a == "--height") o.height = (uint32_t)std::atoi(val());
+        else if (a == "--frames") o.frames = (uint32_t)std::atoi(val());
+        else if (a == "--spp") o.spp = (uint32_t)std::atoi(val());
+        else if (a == "--depth") o.depth = (uint32_t)std::atoi(val());
+        else if (a == "--device") o.device = std::atoi(val());
+        else if (a == "--batch") o.batch = (uint32_t)std::atoi(val());
+        else if (a == "--ranks") o.ranks = (uint32_t)std::max(1, std::atoi(val()));
+        else if (a == "--devices") {
+            std::string v = val();
+            for (size_t b = 0; b <= v.size();) {
+                const size_t e = std::min(v.find(',', b), v.size());
+                o.devices.push_back(std::atoi(v.substr(b, e - b).c_str()));
+                b = e + 1;
+            }
+        }
+        else if (a == "--ppm") o.ppm = val();
+        else if (a == "--pfm") o.pfm = val();
         else die("unknown option " + a);
+    }
+    if (o.ranks > 1) {
+        if (o.devices.empty()) for (uint32_t r = 0; r < o.ranks; r++) o.devices.push_back((int)r);
+        if (o.devices.size() != o.ranks) die("--devices needs one ordinal per rank");
     }
 
     char err[512] = { 0 };
     pth_scene hs{};
     const auto t0 = std::chrono::steady_clock::now();
-    if (pth_load_obj(obj.c_str(), nullptr, &hs, err, sizeof(err)) != 0) die(err);
+    if (pth_load_obj(o.obj.c_str(), nullptr, &hs, err, sizeof(err)) != 0) die(err);
     const auto t1 = std::chrono::steady_clock::now();
 
-    pt_ctx *ctx = nullptr;
-    if (pt_ctx_create(device, nullptr, &ctx) != PT_OK) die(pt_last_error(nullptr));
-    pt_scene *scene = nullptr;
-    if (pt_scene_create(ctx, hs.vertices, hs.n_verts, hs.indices, hs.n_tris, hs.faces, &scene) != PT_OK) die(pt_last_error(ctx));
-    pt_scene_info info{};
-    pt_scene_get_info(scene, &info);
-    pt_film *film = nullptr;
-    if (pt_film_create(ctx, width, height, &film) != PT_OK) die(pt_last_error(ctx));
-
-    pt_params p;
-    pt_params_default(&p);
-    p.width = width; p.height = height; p.spp_per_frame = spp; p.max_depth = depth;
-    p.frames_in_flight = batch;
-    // the reference dispatches one frame per loop iteration (main.cpp:647-685); frames are
-    // independent until the blend, so they are handed over in one call and batched on the device
-    p.frame = 0; p.frame_count = frames;
-    if (pt_render(scene, film, &p) != PT_OK) die(pt_last_error(ctx));
-    pt_stats st{};
-    pt_get_stats(ctx, &st);
-
-    if (!ppm.empty()) {
-        std::vector<uint8_t> img(4 * (size_t)width * height);
-        if (pt_film_read_bgra8(film, img.data()) != PT_OK) die(pt_last_error(ctx));
-        if (pth_write_ppm_bgra8(ppm.c_str(), img.data(), width, height) != 0) die("cannot write " + ppm);
+    std::vector<RankResult> res(o.ranks);
+    std::vector<float> image_f32;
+    std::vector<uint8_t> image_bgra8;
+    const bool want_f32 = !o.pfm.empty() || (o.ranks > 1 && !o.ppm.empty());
+    const auto t2 = std::chrono::steady_clock::now();
+    if (o.ranks == 1) {
+        run_rank(o, hs, 0, nullptr, res[0], want_f32 ? &image_f32 : nullptr, !o.ppm.empty() ? &image_bgra8 : nullptr);
+    } else {
+        // one host thread per GPU (north star: host code stays C++; the reference has one device, main.cpp:105)
+        pt_unique_id id{};
+        if (pt_comm_unique_id(&id) != PT_OK) die("RCCL is not available (pt_comm_unique_id)");
+        std::vector<std::thread> th;
+        for (uint32_t r = 0; r < o.ranks; r++)
+            th.emplace_back([&, r] { run_rank(o, hs, r, &id, res[r], r == 0 && want_f32 ? &image_f32 : nullptr, nullptr); });
+        for (auto &t : th) t.join();
     }
-    if (!pfm.empty()) {
-        std::vector<float> img(3 * (size_t)width * height);
-        if (pt_film_read_f32(film, img.data()) != PT_OK) die(pt_last_error(ctx));
-        if (pth_write_pfm(pfm.c_str(), img.data(), width, height) != 0) die("cannot write " + pfm);
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+    for (uint32_t r = 0; r < o.ranks; r++)
+        if (!res[r].error.empty()) die("rank " + std::to_string(r) + ": " + res[r].error);
+
+    if (!o.ppm.empty()) {
+        if (o.ranks > 1) {  // display transform of the presented float image: clamp + unorm8 (one frame's worth of main.cpp:481-484)
+            image_bgra8.resize(4 * (size_t)o.width * o.height);
+            for (size_t i = 0; i < (size_t)o.width * o.height; i++) {
+                for (int c = 0; c < 3; c++) {
+                    float v = image_f32[3 * i + (size_t)c];
+                    v = !(v > 0.f) ? 0.f : (v > 1.f ? 1.f : v);
+                    image_bgra8[4 * i + (size_t)(2 - c)] = (uint8_t)(v * 255.0f + 0.5f);
+                }
+                image_bgra8[4 * i + 3] = 255;
+            }
+        }
+        if (pth_write_ppm_bgra8(o.ppm.c_str(), image_bgra8.data(), o.width, o.height) != 0) die("cannot write " + o.ppm);
     }
+    if (!o.pfm.empty() && pth_write_pfm(o.pfm.c_str(), image_f32.data(), o.width, o.height) != 0) die("cannot write " + o.pfm);
+
+    unsigned long long rays = 0, paths = 0, rays_min = ~0ull, rays_max = 0;
+    double render_ms = 0.0, present_ms = 0.0;
+    for (const RankResult &r : res) {
+        rays += r.st.rays; paths += r.st.paths;
+        rays_min = std::min<unsigned long long>(rays_min, r.st.rays);
+        rays_max = std::max<unsigned long long>(rays_max, r.st.rays);
+        render_ms = std::max(render_ms, r.render_ms);
+        present_ms = std::max(present_ms, r.present_ms);
+    }
+    const pt_stats &st = res[0].st;
+    const pt_scene_info &info = res[0].info;
     const double load_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    const double ms = o.ranks > 1 ? render_ms + present_ms : (double)st.ms_total;
     std::printf("{\"obj\": \"%s\", \"triangles\": %u, \"bvh_nodes\": %u, \"bvh_height\": %u, \"load_ms\": %.3f, "
                 "\"bvh_build_ms\": %.3f, \"width\": %u, \"height\": %u, \"frames\": %u, \"spp_per_frame\": %u, "
-                "\"max_depth\": %u, \"rays\": %llu, \"paths\": %llu, \"rounds\": %u, \"ms_total\": %.3f, "
-                "\"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f}\n",
-                obj.c_str(), info.n_tris, info.n_nodes, info.bvh_height, load_ms, info.build_ms, width, height, frames, spp,
-                depth, (unsigned long long)st.rays, (unsigned long long)st.paths, st.rounds, st.ms_total,
-                st.ms_total / frames, st.ms_total > 0 ? (double)st.rays / (st.ms_total * 1e3) : 0.0);
-
-    pt_film_destroy(film);
-    pt_scene_destroy(scene);
-    pt_ctx_destroy(ctx);
+                "\"max_depth\": %u, \"ranks\": %u, \"rccl_ranks\": %u, \"rays\": %llu, \"paths\": %llu, "
+                "\"rays_per_rank_min\": %llu, \"rays_per_rank_max\": %llu, \"rounds\": %u, \"ms_total\": %.3f, "
+                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f}\n",
+                o.obj.c_str(), info.n_tris, info.n_nodes, info.bvh_height, load_ms, info.build_ms, o.width, o.height, o.frames, o.spp,
+                o.depth, o.ranks, res[0].rccl_ranks, rays, paths, rays_min, rays_max, st.rounds, ms, present_ms, wall_ms,
+                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0);
     pth_free_scene(&hs);
     return 0;
 }

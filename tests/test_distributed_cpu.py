@@ -1,11 +1,14 @@
-"""world_size-2 test of the multi-GPU path on CPU (gloo): tile ownership is a partition, and
-summing the zero-padded per-rank films reproduces the single-device film bit for bit."""
+"""world_size-2 test of the multi-GPU path on CPU (gloo): tile ownership is a partition, and the presentation
+collective -- every rank packs the tiles it owns, the root gathers and unpacks them (the host mirror of
+pt_film_present's kernels, csrc/present_rccl.hip) -- reproduces the single-device film bit for bit without touching
+any rank's accumulation film."""
 import importlib
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -34,18 +37,38 @@ def _worker(rank, world, port, w, h, out):
     full = np.load(out + ".full.npy")
     # what a rank's film holds: its own tiles, exact zeros elsewhere
     mine = np.where(d.owned_mask(w, h, rank, world)[..., None], full, np.float32(0)).astype(np.float32)
-    t = torch.from_numpy(mine.copy())
-    d.reduce_film(t, dst=0)
+    keep = mine.copy()
+    first = d.gather_present_host(mine, rank, world, dst=0)
+    # the collective leaves the rank's accumulation film alone, so presenting twice gives the same image
+    assert mine.tobytes() == keep.tobytes()
+    again = d.gather_present_host(mine, rank, world, dst=0)
     rays = d.sum_counters([1000 + rank, 7], "cpu")
     if rank == 0:
-        np.save(out + ".reduced.npy", t.numpy())
+        assert first.tobytes() == again.tobytes()
+        np.save(out + ".reduced.npy", again)
         np.save(out + ".rays.npy", np.array(rays))
+    else:
+        assert first is None and again is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gloo_world2_reduce_is_bit_exact(orc, cornell_oracle, tmp_path):
-    w, h = 64, 40
+def test_pack_unpack_round_trip_on_ragged_sizes(pt):
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    rng = np.random.default_rng(3)
+    for (w, h, world) in [(64, 40, 2), (61, 37, 3), (7, 5, 4), (200, 9, 8)]:
+        full = rng.uniform(0, 4, (h, w, 3)).astype(np.float32)
+        image = np.zeros_like(full)
+        n = 0
+        for r in range(world):
+            packed = d.pack_tiles_host(full, r, world)
+            n += len(packed)
+            d.unpack_tiles_host(packed, image, r, world)
+        assert n == ((w + 7) // 8) * ((h + 7) // 8) and image.tobytes() == full.tobytes()
+
+
+@pytest.mark.parametrize("w,h", [(64, 40), (61, 37)])
+def test_gloo_world2_gather_present_is_bit_exact(orc, cornell_oracle, tmp_path, w, h):
     p = orc.default_params(width=w, height=h, spp_per_frame=2, max_depth=4)
     full, _, _, _ = cornell_oracle.render_frame(p)
     out = str(tmp_path / "x")

@@ -807,7 +807,7 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     import subprocess
     import sys
     repo = os.path.dirname(HERE)
-    args = ["--steps", "2", "--warmup", "1", "--width", "320", "--height", "184", "--no-cpu-baseline"]
+    args = ["--steps", "2", "--warmup", "1", "--width", "320", "--height", "184", "--no-cpu-baseline", "--no-extra-legs"]
     one = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     j1 = json.loads(one.stdout.strip().splitlines()[-1])
@@ -819,6 +819,8 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     j2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["steps"] == 2
     assert j2["rays"] == j1["rays"] and j2["paths"] == j1["paths"]
+    assert j2["rccl_ranks"] == 2                                   # (gloo ranks in the emulation)
+    assert abs(j2["presented_checksum"] - j1["presented_checksum"]) <= 1e-9 * abs(j1["presented_checksum"])   # same image assembled
     lo, hi = j2["rays_per_rank_min_max"]
     assert lo + hi == j2["rays"] and hi - lo < 0.02 * hi          # interleaved tiles balance the ranks
     for k in ("metric", "value", "unit", "ms_per_step", "roofline", "config"):
@@ -1137,3 +1139,85 @@ def test_workspace_out_of_memory_is_reported_and_the_film_stays_usable(pt, orc, 
     pt.render(scene, a, pt.default_params(frame=0, frame_count=3, **kw))
     assert a.read_f32().tobytes() == ofilm.tobytes()
     a.close(); film.close(); scene.close(); ctx.close()
+
+
+def test_present_pack_unpack_kernels_assemble_the_single_device_film(pt, gpu_ctx, cornell_gpu):
+    """pt_film_present's two kernels without a communicator: the shards of world = 3 and 8 (ragged 250x131 image, partial
+    edge tiles) are packed per rank and unpacked into one image = the single-device film, bit for bit; the device
+    kernels agree with their numpy mirrors (what the gloo world-2 test runs on the CPU)."""
+    import importlib
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    w, h = 250, 131
+    kw = dict(width=w, height=h, spp_per_frame=4, max_depth=8, frame=0, frame_count=2)
+    full = pt.Film(gpu_ctx, w, h)
+    pt.render(cornell_gpu, full, pt.default_params(**kw))
+    want = full.read_f32()
+    for world in (3, 8):
+        image = pt.DeviceBuffer(gpu_ctx, w * h * 12)
+        n_total = 0
+        for rank in range(world):
+            film = pt.Film(gpu_ctx, w, h)
+            pt.render(cornell_gpu, film, pt.default_params(rank=rank, world=world, **kw))
+            n = pt.film_tile_count(film, rank, world)
+            assert n == len(d.tile_list(w, h, rank, world))
+            n_total += n
+            packed = pt.DeviceBuffer(gpu_ctx, max(n, 1) * 192 * 4)
+            pt.film_pack_tiles(film, rank, world, packed.ptr)
+            host = packed.read(np.float32, (n, 64, 3))
+            assert host.tobytes() == d.pack_tiles_host(film.read_f32(), rank, world).tobytes()
+            pt.film_unpack_tiles(film, rank, world, packed.ptr, image.ptr)
+            packed.close(); film.close()
+        assert n_total == ((w + 7) // 8) * ((h + 7) // 8)
+        assert image.read(np.float32, (h, w, 3)).tobytes() == want.tobytes()
+        image.close()
+    full.close()
+
+
+def test_present_through_rccl_world_1(pt, gpu_ctx, cornell_gpu):
+    """The library's own RCCL communicator (dlopen'ed librccl, ncclCommInitRank) with one rank: pt_film_present packs,
+    has nothing to gather, and unpacks into a SEPARATE image equal to the film; the film itself is untouched and can be
+    rendered further and presented again (the old in-place reduce could not)."""
+    w, h = 200, 120
+    kw = dict(width=w, height=h, spp_per_frame=4, max_depth=8)
+    film = pt.Film(gpu_ctx, w, h)
+    comm = pt.Comm(gpu_ctx, pt.Comm.unique_id(), 1, 0)
+    assert comm.ranks() == 1
+    image = pt.DeviceBuffer(gpu_ctx, w * h * 12)
+    for frame in range(3):
+        pt.render(cornell_gpu, film, pt.default_params(frame=frame, frame_count=1, **kw))
+        comm.present(film, image.ptr, root=0)
+        assert image.read(np.float32, (h, w, 3)).tobytes() == film.read_f32().tobytes()
+    ref = pt.Film(gpu_ctx, w, h)
+    pt.render(cornell_gpu, ref, pt.default_params(frame=0, frame_count=3, **kw))
+    assert film.read_f32().tobytes() == ref.read_f32().tobytes()
+    with pytest.raises(pt.PtError):                                    # rendered as (0, 1), presented as another shape
+        other = pt.Film(gpu_ctx, w, h)
+        pt.render(cornell_gpu, other, pt.default_params(frame=0, frame_count=1, rank=1, world=2, **kw))
+        comm.present(other, image.ptr, root=0)
+    image.close(); comm.close(); film.close(); ref.close()
+
+
+def _two_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count() >= 2
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs >= 2 GPUs (RCCL cannot place two ranks on one device)")
+def test_pt_main_two_ranks_over_rccl_equals_one_rank(tmp_path):
+    """host/pt_main --ranks 2: two host threads, two GPUs, tiles interleaved, one RCCL gather of the packed tiles to rank
+    0 -- the presented image equals the single-GPU image bit for bit, the ray counts add up."""
+    import json
+    import subprocess
+    repo = os.path.dirname(HERE)
+    exe = os.path.join(repo, "single-file-vulkan-pathtracing_amd", "pt_main")
+    args = ["--obj", os.path.join(repo, "assets", "CornellBox-Original.obj"), "--width", "320", "--height", "200", "--frames", "2",
+            "--spp", "8"]
+    one = subprocess.run([exe] + args + ["--pfm", str(tmp_path / "one.pfm")], capture_output=True, text=True, timeout=600)
+    two = subprocess.run([exe] + args + ["--ranks", "2", "--pfm", str(tmp_path / "two.pfm")], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr, two.stderr)
+    j1, j2 = json.loads(one.stdout), json.loads(two.stdout)
+    assert j2["ranks"] == 2 and j2["rccl_ranks"] == 2 and j2["rays"] == j1["rays"] and j2["paths"] == j1["paths"]
+    assert open(tmp_path / "one.pfm", "rb").read() == open(tmp_path / "two.pfm", "rb").read()

@@ -145,7 +145,7 @@ def test_abi_exports_every_declared_symbol(pt):
 def test_struct_layouts_match_header(pt):
     import ctypes as C
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
-    assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2 + 8 * 2 + 4 * 2   # + redone_batches, reserved_
+    assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2 + 8 * 2 + 4 * 2 + 8 * 5   # + redone_batches, reserved_, wave-level block counts
     assert C.sizeof(pt.SceneInfo) == 4 * 8 + 4 * 6 + 4 + 4 + 8  # one pad dword before the u64
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
@@ -191,6 +191,14 @@ def test_abi_is_null_safe_without_a_gpu(pt):
     assert L.pt_trace(None, None, 0, C.c_float(0), C.c_float(1), 0, None) == 1
     assert L.pt_get_stats(None, None) == 1 and L.pt_reset_stats(None) == 1
     assert L.pt_ctx_create(0, None, None) == 1
+    assert L.pt_comm_unique_id(None) == 1 and L.pt_comm_create(None, None, 1, 0, C.byref(out)) == 1
+    assert L.pt_comm_ranks(None, None) == 1 and L.pt_film_present(None, None, 0, None) == 1
+    L.pt_comm_destroy(None)
+    n = C.c_uint32()
+    assert L.pt_film_tile_count(None, 0, 1, C.byref(n)) == 1 and L.pt_film_pack_tiles(None, 0, 1, None) == 1
+    assert L.pt_film_unpack_tiles(None, 0, 1, None, None) == 1
+    assert L.pt_device_alloc(None, 16, C.byref(out)) == 1 and L.pt_device_free(None, None) == 1
+    assert L.pt_device_read(None, None, None, 0) == 1
     assert out.value is None and null.value is None
     H = pt.lib_host()
     err = C.create_string_buffer(64)
