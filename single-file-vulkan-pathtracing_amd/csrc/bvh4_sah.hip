@@ -12,6 +12,11 @@
 //     until it has four;
 //   * same node format and the same box padding as the collapsed LBVH (pt_internal.h), so the traversal
 //     kernels do not know the difference.  Hits do not depend on the BVH (closest t, lowest primitive id).
+//   * PRIMITIVES are single triangles or FAN PAIRS (pair_with_next: triangle i+1 is (v0, v2, v3) of a quad whose first
+//     half (v0, v1, v2) is triangle i -- what a loader makes of a quad): with pair leaves every leaf holds exactly one
+//     primitive, the two halves of a quad stay adjacent in the leaf order, and the LDS traversal kernel tests them
+//     with shared vertex transforms and edge function (extend_kernel.h: PAIRS).  Every other kernel sees an ordinary
+//     1- or 2-triangle leaf.
 // Everything is deterministic: double arithmetic, stable sorts, first minimum wins.
 #include <algorithm>
 #include <cmath>
@@ -30,9 +35,12 @@ struct BNode {
 };
 
 struct Builder {
-    const float *tlo, *thi;
-    uint32_t leaf_max;
-    std::vector<uint32_t> ids;
+    const float *tlo, *thi;      // per TRIANGLE
+    uint32_t leaf_max;           // primitives per leaf
+    std::vector<uint32_t> prim_first;  // primitive -> its first triangle; a primitive is 1 triangle or 2 consecutive ones
+    std::vector<uint8_t> prim_tris;
+    std::vector<double> plo, phi;      // per primitive box (3 each)
+    std::vector<uint32_t> ids;         // primitive ids, permuted by the sweep
     std::vector<BNode> nodes;
     std::vector<double> area_l;
 
@@ -41,11 +49,26 @@ struct Builder {
         const double x = std::max(hi[0] - lo[0], 0.0), y = std::max(hi[1] - lo[1], 0.0), z = std::max(hi[2] - lo[2], 0.0);
         return 2.0 * (x * y + y * z + z * x);
     }
-    void grow(double *lo, double *hi, uint32_t t) const
+    void grow(double *lo, double *hi, uint32_t prim) const
     {
         for (int k = 0; k < 3; k++) {
-            lo[k] = std::min(lo[k], (double)tlo[3 * (size_t)t + k]);
-            hi[k] = std::max(hi[k], (double)thi[3 * (size_t)t + k]);
+            lo[k] = std::min(lo[k], plo[3 * (size_t)prim + k]);
+            hi[k] = std::max(hi[k], phi[3 * (size_t)prim + k]);
+        }
+    }
+    void init_prims(uint32_t n, const uint8_t *pair_with_next)
+    {
+        for (uint32_t t = 0; t < n;) {
+            const uint32_t cnt = (pair_with_next && t + 1 < n && pair_with_next[t]) ? 2u : 1u;
+            prim_first.push_back(t);
+            prim_tris.push_back((uint8_t)cnt);
+            for (int k = 0; k < 3; k++) {
+                double lo = tlo[3 * (size_t)t + k], hi = thi[3 * (size_t)t + k];
+                if (cnt == 2) { lo = std::min(lo, (double)tlo[3 * (size_t)(t + 1) + k]); hi = std::max(hi, (double)thi[3 * (size_t)(t + 1) + k]); }
+                plo.push_back(lo);
+                phi.push_back(hi);
+            }
+            t += cnt;
         }
     }
     // depth: the sweep has no balance term -- n coincident triangles cost the same at every split position and the
@@ -71,8 +94,8 @@ struct Builder {
             std::vector<uint32_t> &o = sorted[ax];
             o.assign(ids.begin() + first, ids.begin() + first + count);
             std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) {
-                const double ca = (double)tlo[3 * (size_t)a + ax] + (double)thi[3 * (size_t)a + ax];
-                const double cb = (double)tlo[3 * (size_t)b + ax] + (double)thi[3 * (size_t)b + ax];
+                const double ca = plo[3 * (size_t)a + ax] + phi[3 * (size_t)a + ax];
+                const double cb = plo[3 * (size_t)b + ax] + phi[3 * (size_t)b + ax];
                 return ca < cb || (ca == cb && a < b);
             });
             area_l.assign(count, 0.0);
@@ -133,15 +156,17 @@ uint32_t pt_wide_stack_need(const std::vector<uint32_t> &w)
     return need[0];
 }
 
-void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, float pad, uint32_t leaf_max,
-                       std::vector<uint32_t> &rows, std::vector<uint32_t> &order)
+void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
+                       uint32_t leaf_max, std::vector<uint32_t> &rows, std::vector<uint32_t> &order)
 {
     Builder b;
     b.tlo = tlo; b.thi = thi; b.leaf_max = std::max(leaf_max, 1u);
-    b.ids.resize(n);
-    for (uint32_t i = 0; i < n; i++) b.ids[i] = i;
-    b.nodes.reserve(2 * (size_t)n);
-    b.build(0, n);
+    b.init_prims(n, pair_with_next);
+    const uint32_t np = (uint32_t)b.prim_first.size();
+    b.ids.resize(np);
+    for (uint32_t i = 0; i < np; i++) b.ids[i] = i;
+    b.nodes.reserve(2 * (size_t)np);
+    b.build(0, np);
     rows.clear();
     order.clear();
     order.reserve(n);
@@ -185,17 +210,24 @@ void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, float pad
         for (int j = 0; j < m; j++) {
             const BNode &k = b.nodes[kids[j]];
             float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+            uint32_t n_tri = 0;
             for (uint32_t t = 0; t < k.count; t++) {
-                const uint32_t tri = b.ids[k.first + t];
-                for (int c = 0; c < 3; c++) {
-                    lo[c] = std::min(lo[c], tlo[3 * (size_t)tri + c] - pad);  // float, like k_refit
-                    hi[c] = std::max(hi[c], thi[3 * (size_t)tri + c] + pad);
+                const uint32_t prim = b.ids[k.first + t];
+                for (uint32_t h = 0; h < b.prim_tris[prim]; h++, n_tri++) {
+                    const uint32_t tri = b.prim_first[prim] + h;
+                    for (int c = 0; c < 3; c++) {
+                        lo[c] = std::min(lo[c], tlo[3 * (size_t)tri + c] - pad);  // float, like k_refit
+                        hi[c] = std::max(hi[c], thi[3 * (size_t)tri + c] + pad);
+                    }
                 }
             }
             uint32_t word;
             if (k.left < 0) {
-                word = PT_LEAF | ((k.count - 1u) << 28) | (uint32_t)order.size();
-                for (uint32_t t = 0; t < k.count; t++) order.push_back(b.ids[k.first + t]);
+                word = PT_LEAF | ((n_tri - 1u) << 28) | (uint32_t)order.size();  // n_tri <= 8 (leaf_max <= 4 primitives)
+                for (uint32_t t = 0; t < k.count; t++) {
+                    const uint32_t prim = b.ids[k.first + t];
+                    for (uint32_t h = 0; h < b.prim_tris[prim]; h++) order.push_back(b.prim_first[prim] + h);
+                }
             } else {
                 word = new_row();
                 todo.push_back({ kids[j], word });

@@ -122,7 +122,7 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // at ~88 atomics/us on this chip, which short Cornell traversals (3.6 nodes/ray) exceed 3x over.
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
-template <bool LDS_SCENE, bool COUNT, bool SPILL>
+template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false>
 __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
                                                NormBox nb, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
@@ -146,7 +146,13 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     // (sign, exponent, 9 mantissa bits: rounds a non-negative distance DOWN, so the pop test stays conservative).
     // Half the stack bytes in LDS: 15 KB instead of 25 KB per block for the Cornell box, which lifts the LDS cap
     // on resident blocks from 6 to 10 per CU.  The host only picks it for tmin >= 0.
+    // PAIRS (a COMPACT variant): every leaf holds ONE primitive -- a triangle, or the two halves (v0,v1,v2),(v0,v2,v3)
+    // of a quad at consecutive positions (bvh4_sah.hip, pair_with_next).  The leaf step is then one straight piece of
+    // code for all lanes that hold a leaf (no per-lane triangle count to loop over: that loop ran at 31 % lane
+    // occupancy on the Cornell box), and the second half re-uses the first one's sheared v0, v2 and the products of
+    // their shared edge function: 44 instead of 60 VALU for the two edge tests, bit for bit the per-triangle results.
     constexpr bool COMPACT = LDS_SCENE && !SPILL;
+    static_assert(!PAIRS || COMPACT, "pair leaves are implemented for the compact LDS kernel");
     constexpr uint32_t LEAF_BIT = COMPACT ? 0x2000u : PT_LEAF;
     constexpr uint32_t DONE = COMPACT ? 0x3FFFu : SENTINEL;
 
@@ -338,6 +344,29 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 PT_SLAB4H(t2, y, 0)
                 PT_SLAB4H(t3, y, 1)
             }
+            if (COMPACT) {
+                // One-dword keys (entry distance truncated to its top 18 bits | 14-bit child word) are what the stack holds
+                // anyway; formed BEFORE the sort they order like the distances (non-negative floats compare like their bit
+                // patterns; a miss is +inf | word, above every hit), so a compare-exchange is v_min_u32 + v_max_u32
+                // instead of a compare and four selects: 14 VALU for the network instead of 25, and the pushes store the
+                // key as it is.  Children closer together than 2^-9 of their distance may swap places -- the visit order
+                // is not part of the result (closest t, lowest primitive id).  The host runs this kernel for tmin > 0 only
+                // (entry distances >= tmin: no -0, whose bit pattern would sort last).
+                uint32_t k0 = (__float_as_uint(t0) & 0xFFFFC000u) | w0, k1 = (__float_as_uint(t1) & 0xFFFFC000u) | w1,
+                         k2 = (__float_as_uint(t2) & 0xFFFFC000u) | w2, k3 = (__float_as_uint(t3) & 0xFFFFC000u) | w3;
+#define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
+                PT_KSWAP(k0, k1)
+                PT_KSWAP(k2, k3)
+                PT_KSWAP(k0, k2)
+                PT_KSWAP(k1, k3)
+                PT_KSWAP(k1, k2)
+#undef PT_KSWAP
+                constexpr uint32_t KINF = 0x7F800000u;
+                if (k3 < KINF) { my_stack32[sp * TB] = k3; sp++; }  // farthest first, so the nearest pending pops first
+                if (k2 < KINF) { my_stack32[sp * TB] = k2; sp++; }
+                if (k1 < KINF) { my_stack32[sp * TB] = k1; sp++; }
+                cur = k0 < KINF ? (k0 & 0x3FFFu) : pop();
+            } else {
 #define PT_CSWAP(TA, WA, TB_, WB)                            \
     {                                                        \
         const bool sw = TB_ < TA;                            \
@@ -355,6 +384,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             if (t2 < INF) push(w2, t2);
             if (t1 < INF) push(w1, t1);
             cur = t0 < INF ? w0 : pop();
+            }
             do_node = !VOTE && !(cur & LEAF_BIT);
             if (!VOTE) {
                 // fewer than 1/6 of the wave's rays still descending while the rest waits with a leaf: let the
@@ -366,6 +396,45 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         }
         // ---- leaf phase
         if (have) {
+            if (PAIRS) {
+                if (cur != DONE && (cur & LEAF_BIT)) {
+                    const uint32_t first = cur & 0x7FFu;
+                    const bool two = ((cur >> 11) & 3u) != 0u;  // count - 1: a fan pair at positions first, first + 1
+                    if (COUNT) c_tris += two ? 2u : 1u;
+                    PT_COUNT_WAVE(c_tri_steps);
+                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
+                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
+                    // the sheared vertices and the products of the edge v0-v2 serve both halves (ptm::tri_test_perm, same
+                    // operands in the same order: bit-identical numerators)
+                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
+                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
+                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
+                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
+                    const float pAC = Ax * Cy, qAC = Ay * Cx;
+                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
+                        if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+                        const float det = (U + V) + W;
+                        if (det == 0.0f) return;
+                        PT_COUNT_WAVE(c_hit_blocks);
+                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
+                        const float t = ptm::fdiv(T, det);
+                        if (!(t > tmin && t < tmax)) return;
+                        // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
+                        if (t < best_t || (t == best_t && prim < best_prim)) {
+                            best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                        }
+                    };
+                    finish(Cx * By - Cy * Bx, pAC - qAC, Bx * Ay - By * Ax, Az_, Bz_, Cz_, first, __float_as_uint(a.w));
+                    if (two) {
+                        const float4 d = tri4[ti + 5];  // third vertex of the second half; .w = its primitive id (k_pack)
+                        const float Dz_ = d.z - orgp.z;
+                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
+                        // (v0, v2, v3): U = Dx*Cy - Dy*Cx, V = Ax*Dy - Ay*Dx, W = Cx*Ay - Cy*Ax = qAC - pAC
+                        finish(Dx * Cy - Dy * Cx, Ax * Dy - Ay * Dx, qAC - pAC, Az_, Cz_, Dz_, first + 1u, __float_as_uint(d.w));
+                    }
+                    cur = pop();
+                }
+            } else
             if (cur != DONE && (cur & LEAF_BIT) && (!VOTE || do_leaf)) {
                 const uint32_t first = COMPACT ? (cur & 0x7FFu) : (cur & 0x0FFFFFFFu);
                 const uint32_t cnt = (COMPACT ? ((cur >> 11) & 3u) : ((cur >> 28) & 7u)) + 1u;
@@ -439,10 +508,10 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
 #define PT_EXTEND_ARGS                                                                                               \
     g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
         refill_min_idle, tmin, tmax, lds_stack, raw_hit
-template <bool LDS_SCENE, bool COUNT, bool SPILL>
+template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false>
 __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 {
-    extend_body<LDS_SCENE, COUNT, SPILL>(PT_EXTEND_ARGS);
+    extend_body<LDS_SCENE, COUNT, SPILL, PAIRS>(PT_EXTEND_ARGS);
 }
 // The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
 // asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations
@@ -450,6 +519,11 @@ __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 __global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7(PT_EXTEND_PARAMS)
 {
     extend_body<true, false, false>(PT_EXTEND_ARGS);
+}
+// ... and the same over a BVH4 with one primitive (triangle or fan pair) per leaf: what the Cornell box runs by default
+__global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7p(PT_EXTEND_PARAMS)
+{
+    extend_body<true, false, false, true>(PT_EXTEND_ARGS);
 }
 #undef PT_EXTEND_PARAMS
 #undef PT_EXTEND_ARGS

@@ -17,6 +17,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -489,7 +491,8 @@ __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig
                  c = tri_orig[3 * (size_t)prim + 2];
     tri4[3 * (size_t)pos + 0] = a;  // .w = bits(prim)
     tri4[3 * (size_t)pos + 1] = b;
-    tri4[3 * (size_t)pos + 2] = c;
+    tri4[3 * (size_t)pos + 2] = make_float4(c.x, c.y, c.z, a.w);  // .w = bits(prim) again: the pair-leaf test of k_extend
+                                                                  // reads only this vertex of a quad's second triangle
     // closesthit.rchit:43-48 normal (never flipped), :60 brdf = Kd / pi (true divide), :61 emission
     const ptm::f3 nrm = ptm::tri_normal({ a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z });
     const float *f = faces + 6 * (size_t)prim;
@@ -754,6 +757,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
     s->d_wide_lbvh = s->d_wide; s->n_wide_lbvh = s->n_wide; s->stack_need_lbvh = s->stack_need;
     s->bvh4_builder = 0;
+    s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;
     s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
     if (n <= PT_SAH_MAX_TRIS) {
         // small scene: keep what a rebuild of the BVH4 in another leaf order needs, then apply the default
@@ -766,6 +770,14 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
         for (uint32_t i = 0; i < n; i++) {
             s->h_tlo[3 * i + 0] = lo[i].x; s->h_tlo[3 * i + 1] = lo[i].y; s->h_tlo[3 * i + 2] = lo[i].z;
             s->h_thi[3 * i + 0] = hi[i].x; s->h_thi[3 * i + 1] = hi[i].y; s->h_thi[3 * i + 2] = hi[i].z;
+        }
+        // fan pairs as a loader emits them for quads: the next triangle starts at the same vertex and continues from
+        // this one's third (bitwise equal coordinates); greedy, non-overlapping
+        s->h_pair.assign(n, 0);
+        auto vtx = [&](uint32_t tri, int k) { return h_vertices + 3 * (size_t)h_indices[3 * (size_t)tri + k]; };
+        for (uint32_t i = 0; i + 1 < n; i++) {
+            const bool same = std::memcmp(vtx(i, 0), vtx(i + 1, 0), 12) == 0 && std::memcmp(vtx(i, 2), vtx(i + 1, 1), 12) == 0;
+            if (same) { s->h_pair[i] = 1; i++; }
         }
         s->d_tri_orig = d_tri_orig.release();
         s->d_faces = d_faces.release();
@@ -790,7 +802,13 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
         for (int k = 0; k < 3; k++) scale = fmaxf(scale, fmaxf(fabsf(s->bmin[k]), fabsf(s->bmax[k])));
         const float pad = scale * 3.814697265625e-06f;
         std::vector<uint32_t> rows, order;
-        pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pad, PT_SAH_LEAF_MAX, rows, order);
+        // one primitive per leaf, a primitive being a triangle or a quad's two halves (PT_TUNE_PAIR_LEAVES=0: the former
+        // rule, up to PT_SAH_LEAF_MAX independent triangles per leaf where splitting does not pay)
+        const char *pe = getenv("PT_TUNE_PAIR_LEAVES");
+        const bool pairs = !(pe && atoi(pe) == 0);
+        pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad, pairs ? 1u : PT_SAH_LEAF_MAX,
+                          rows, order);
+        s->sah_pair_leaves = pairs;
         if (order.size() != n || rows.empty()) { ctx->err = "internal: SAH build lost triangles"; return PT_ERR_HIP; }
         s->n_wide_sah = (uint32_t)(rows.size() / 32);
         s->stack_need_sah = pt_wide_stack_need(rows);
@@ -802,8 +820,10 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
     PT_HIP(ctx, hipStreamSynchronize(st));  // nothing may still be traversing the old tables
     if (want_sah) {
         s->d_wide = s->d_wide_sah; s->n_wide = s->n_wide_sah; s->stack_need = s->stack_need_sah; s->bvh4_builder = 1;
+        s->pair_leaves = s->sah_pair_leaves;
     } else {
         s->d_wide = s->d_wide_lbvh; s->n_wide = s->n_wide_lbvh; s->stack_need = s->stack_need_lbvh; s->bvh4_builder = 0;
+        s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;  // 1-triangle leaves are the degenerate case of the pair kernel
     }
     k_pack<<<(n + TB - 1) / TB, TB, 0, st>>>(s->d_tri_orig, s->d_faces, want_sah ? s->d_prim_of_sah : s->d_prim_of, n, s->d_tri4,
                                            s->d_shade4, s->d_shade64, s->d_ke4);

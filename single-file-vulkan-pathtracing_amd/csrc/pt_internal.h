@@ -71,6 +71,9 @@ struct pt_scene {
     float4 *d_tri_orig = nullptr;           // small scenes keep the unsorted triangles + materials so the
     float *d_faces = nullptr;               // per-triangle tables can be re-packed in another leaf order
     std::vector<float> h_tlo, h_thi;        // small scenes: unpadded triangle boxes (3 floats each)
+    std::vector<uint8_t> h_pair;            // small scenes: [n] triangle i+1 = (v0, v2, v3) of the quad whose (v0, v1, v2) is triangle i
+    bool sah_pair_leaves = false;           // ... of the surface-area BVH4 (d_wide_sah)
+    bool pair_leaves = false;               // the traversed BVH4 has exactly one primitive (triangle or such a pair) per leaf
     unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
     uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
     uint64_t device_bytes = 0;
@@ -130,8 +133,9 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality);
 void ptb_free_scene_buffers(pt_scene *s);
 constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
 // bvh4_sah.hip: host surface-area sweep -> BVH4 rows (32 dwords each) + leaf order
-void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, float pad, uint32_t leaf_max,
-                       std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
+// pair_with_next (nullable): [n] flags, triangle i and i+1 are the two halves (v0,v1,v2),(v0,v2,v3) of a quad and form ONE primitive
+void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
+                       uint32_t leaf_max_prims, std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
 uint32_t pt_wide_stack_need(const std::vector<uint32_t> &rows32);
 void ptb_free_instances(pt_scene *s);
 // wavefront.hip

@@ -785,6 +785,7 @@ struct ExtendPlan {
     int lds_stack = LDS_STACK;  // stack entries per lane kept in LDS (single-level kernel)
     bool spill = true;          // false: the scene's exact stack bound fits lds_stack, kernel without spill path
                                 // (and with one-dword stack entries: COMPACT in k_extend)
+    bool pairs = false;         // ... and every leaf of the BVH4 is one triangle or one fan pair: the PAIRS kernel
     size_t smem_wide_entries = 0;  // LDS bytes of the same plan run by the 8-byte-entry kernel (negative tmin)
 };
 
@@ -845,16 +846,19 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     // (the no-spill kernel packs child words into 14 bits: <= 2047 triangles, <= 8191 nodes, leaves of <= 4)
     pl.spill = !(pl.lds_scene && s->stack_need <= 16u && s->n_tris <= 2047u && s->n_wide <= 8191u);
     if (!pl.spill) pl.lds_stack = (int)std::max(s->stack_need, 1u);
+    pl.pairs = !pl.spill && s->pair_leaves && !(getenv("PT_TUNE_PAIR_KERNEL") && atoi(getenv("PT_TUNE_PAIR_KERNEL")) == 0);
     pl.smem_wide_entries = (size_t)pl.lds_stack * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
     pl.smem = pl.spill ? pl.smem_wide_entries : (size_t)pl.lds_stack * TB * sizeof(uint32_t) + scene_bytes;
     if (!pl.spill && pl.smem_wide_entries > 48 * 1024) {
         PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem_wide_entries));
         PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem_wide_entries));
     }
-    const void *fn = !pl.spill ? reinterpret_cast<const void *>(k_extend_lds7)
+    const void *fn = pl.pairs ? reinterpret_cast<const void *>(k_extend_lds7p)
+                     : !pl.spill ? reinterpret_cast<const void *>(k_extend_lds7)
                      : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false, true>)
                                     : ptw_extend_hbm_fn(false);
-    const void *fn_count = !pl.spill ? reinterpret_cast<const void *>(k_extend<true, true, false>)
+    const void *fn_count = pl.pairs ? reinterpret_cast<const void *>(k_extend<true, true, false, true>)
+                           : !pl.spill ? reinterpret_cast<const void *>(k_extend<true, true, false>)
                            : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, true, true>)
                                           : ptw_extend_hbm_fn(true);
     if (pl.smem > 48 * 1024)
@@ -916,16 +920,26 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     const uint32_t stride = (uint32_t)pl.grid * TB;
     const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],
                            s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
-    // one-dword stack entries truncate the entry distance toward zero, which is only conservative for t >= 0:
-    // a negative tmin (not valid in Vulkan, accepted here) runs the same plan through the 8-byte-entry kernel
-    const bool no_spill = !pl.spill && tmin >= 0.f;
+    // one-dword stack entries truncate the entry distance toward zero, which is only conservative for t >= 0, and the
+    // sort of the one-dword keys takes entry distances for positive floats (tmin = 0 could make one -0): a tmin <= 0
+    // (not valid in Vulkan, accepted here) runs the same plan through the 8-byte-entry kernel
+    const bool no_spill = !pl.spill && tmin > 0.f;
     const size_t smem = (!pl.spill && !no_spill) ? pl.smem_wide_entries : pl.smem;
 #define PT_LAUNCH_EXTEND(L, C, S)                                                                                     \
     hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, \
                           s->d_wide16, nbox,                                                                          \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
                           pl.refill, tmin, tmax, pl.lds_stack, raw)
-    if (no_spill) {
+    if (no_spill && pl.pairs) {
+        if (count)
+            hipExtLaunchKernelGGL((k_extend<true, true, false, true>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide,
+                                  s->d_wide16, nbox, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill,
+                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw);
+        else
+            hipExtLaunchKernelGGL(k_extend_lds7p, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
+                                  s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw);
+    } else if (no_spill) {
         if (count) PT_LAUNCH_EXTEND(true, true, false);
         else
             hipExtLaunchKernelGGL(k_extend_lds7, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,

@@ -1083,6 +1083,8 @@ def test_coincident_triangles_deep_sah_tree_keeps_the_stack_in_bounds(pt, orc, g
     n = 30000
     org = rng.uniform(-1.5, 1.5, (n, 3))
     d = rng.normal(size=(n, 3))
+    bary = rng.dirichlet([1, 1, 1], n // 2)                       # half of the rays aim at the coincident stack
+    d[:n // 2] = bary @ one.astype(np.float64) - org[:n // 2]
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays = np.concatenate([org, d], 1).astype(np.float32)
     osc = orc.Scene(v, i, f)
@@ -1221,3 +1223,70 @@ def test_pt_main_two_ranks_over_rccl_equals_one_rank(tmp_path):
     j1, j2 = json.loads(one.stdout), json.loads(two.stdout)
     assert j2["ranks"] == 2 and j2["rccl_ranks"] == 2 and j2["rays"] == j1["rays"] and j2["paths"] == j1["paths"]
     assert open(tmp_path / "one.pfm", "rb").read() == open(tmp_path / "two.pfm", "rb").read()
+
+
+def test_pair_leaves_fan_quads_share_work_but_not_bits(pt, orc, gpu_ctx, cornell_arrays, cornell_oracle):
+    """The surface-area BVH4 of small scenes holds ONE primitive per leaf, a primitive being a triangle or the two halves
+    (v0,v1,v2),(v0,v2,v3) of a quad, and the LDS kernel tests such a pair with shared vertex transforms and edge products.
+    (a) Cornell: 18 two-triangle leaves, each a fan pair in input order.  (b) a scene mixing fan quads, lone triangles,
+    a reversed-winding 'pair' that must NOT be paired, and duplicated quads: hit records equal the oracle's on every
+    kernel variant, for rays through the shared diagonals (where the shared edge function is exactly 0 on both halves),
+    through vertices, and random ones; tmin <= 0 takes the 8-byte-entry kernel over the same tree."""
+    sc = pt.Scene(gpu_ctx, *cornell_arrays)
+    wide = sc.read_bvh4()
+    words = wide[:, 24:28].ravel()
+    leaves = words[(words != 0xFFFFFFFF) & (words & 0x80000000 != 0)]
+    assert len(leaves) == 18 and all(int((w >> 28) & 7) == 1 for w in leaves)
+    sc.close()
+    rng = np.random.default_rng(21)
+    tris = []
+    quads = []
+    for k in range(40):                                  # planar and non-planar fan quads
+        c = rng.uniform(-1, 1, 3)
+        e1, e2 = rng.normal(size=3) * 0.4, rng.normal(size=3) * 0.4
+        q = np.array([c, c + e1, c + e1 + e2 + rng.normal(size=3) * (0.05 if k % 3 == 0 else 0.0), c + e2])
+        quads.append(q)
+        tris += [q[[0, 1, 2]], q[[0, 2, 3]]]
+        if k % 10 == 0:                                   # duplicated quad: coincident, lowest primitive id wins
+            tris += [q[[0, 1, 2]], q[[0, 2, 3]]]
+    for k in range(25):
+        tris.append(rng.uniform(-1, 1, (3, 3)))           # lone triangles
+    q = quads[0] + np.array([0.0, 0.0, 2.5])
+    tris += [q[[0, 1, 2]], q[[2, 3, 0]]]                  # shares the diagonal but is not the fan pattern
+    tris = np.array(tris, np.float32)
+    v = tris.reshape(-1)
+    i = np.arange(v.size // 3, dtype=np.uint32)
+    f = rng.uniform(0, 1, (len(tris), 6)).astype(np.float32).reshape(-1)
+    rays = []
+    for q in quads:
+        q = q.astype(np.float32).astype(np.float64)
+        for s in rng.uniform(0.02, 0.98, 40):
+            target = q[0] * (1 - s) + q[2] * s            # a point on the shared diagonal
+            o = target + rng.normal(size=3)
+            rays.append(np.concatenate([o, target - o]))
+        for k in range(4):                                # through the vertices
+            o = q[k] + rng.normal(size=3)
+            rays.append(np.concatenate([o, q[k] - o]))
+    rays = np.array(rays)
+    rnd = np.concatenate([rng.uniform(-2, 2, (40000, 3)), rng.normal(size=(40000, 3))], 1)
+    rays = np.concatenate([rays, rnd]).astype(np.float32)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    assert gs.info().bvh4_builder == 1
+    wide = gs.read_bvh4()
+    words = wide[:, 24:28].ravel()
+    leaves = words[(words != 0xFFFFFFFF) & (words & 0x80000000 != 0)]
+    n_pair = sum(int((w >> 28) & 7) == 1 for w in leaves)
+    assert n_pair == 44 and len(leaves) == 44 + 25 + 2    # 40 quads + 4 duplicates paired; the reversed one is two singles
+    for tmin in (0.001, 0.0, -0.5):
+        want, _ = osc.trace(rays, tmin=tmin, tmax=100.0, mode=0)
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_FLAT):
+            got = gs.trace(rays, tmin=tmin, tmax=100.0, extend=variant)
+            assert got.tobytes() == want.tobytes(), (tmin, variant)
+    assert (want["prim"] != 0xFFFFFFFF).sum() > 5000
+    os.environ["PT_TUNE_PAIR_KERNEL"] = "0"               # the per-triangle kernel over the same pair-leaf tree
+    try:
+        want, _ = osc.trace(rays, tmin=0.001, tmax=100.0, mode=0)
+        assert gs.trace(rays, tmin=0.001, tmax=100.0).tobytes() == want.tobytes()
+    finally:
+        os.environ.pop("PT_TUNE_PAIR_KERNEL", None)
+    gs.close()
