@@ -103,7 +103,10 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
 def extend_kernel_name(pt, st, info, config):
     if config == "c4":
         return "k_extend_inst"
-    return {1: "k_extend_flat", 2: "k_extend_lds7" if info.n_wide_nodes <= 8191 else "k_extend<lds>", 3: "k_extend<hbm>"}.get(st.extend_variant, "?")
+    lds = "k_extend<lds>"
+    if info.n_wide_nodes <= 8191 and info.n_tris <= 2047:     # the compact no-spill instantiations (plan_extend)
+        lds = "k_extend_lds7" if os.environ.get("PT_TUNE_PAIR_KERNEL") == "0" or os.environ.get("PT_TUNE_PAIR_LEAVES") == "0" else "k_extend_lds7p"
+    return {1: "k_extend_flat", 2: lds, 3: "k_extend<hbm>"}.get(st.extend_variant, "?")
 
 
 def count_visits(pt, ctx, scene, W, H, common):

@@ -18,7 +18,9 @@ for line in open(os.path.join(root, "stats.log")):
 # the k_extend* kernel of the headline leg (the roofline_c5 leg of a default run uses another instantiation)
 # dominant extend kernel of the timed region = the k_extend* kernel with most total time (the counting
 # instantiation only runs the one extra untimed frame)
-name = max((k for k in s["kernels"] if k.startswith("k_extend")), key=lambda k: s["kernels"][k]["total_ns"])
+import re
+counting = re.compile(r"k_extend<\w+, true|k_extend_inst<true")   # the instrumented instantiations (PT_FLAG_COUNT_VISITS frame)
+name = max((k for k in s["kernels"] if k.startswith("k_extend") and not counting.match(k)), key=lambda k: s["kernels"][k]["total_ns"])
 e, kt = s["pmc"][name], s["kernels"][name]
 pl = lambda c: e[c + "_per_launch"]
 rays_per_launch = bench["rays"] / bench["roofline"]["launches"]

@@ -1066,7 +1066,7 @@ def test_spill_pool_at_full_size_two_pipelines(pt, gpu_ctx, cornell_gpu):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("n_coincident", [500, 2048])
+@pytest.mark.parametrize("n_coincident", [150, 500, 2048])
 def test_coincident_triangles_deep_sah_tree_keeps_the_stack_in_bounds(pt, orc, gpu_ctx, n_coincident):
     """n copies of ONE triangle (+ a few others): every split of the surface-area sweep costs the same, which used to give
     a chain n/3 deep whose traversal stack overran a spill region sized from the balanced LBVH's height.  The sweep now
@@ -1093,7 +1093,7 @@ def test_coincident_triangles_deep_sah_tree_keeps_the_stack_in_bounds(pt, orc, g
     gs = pt.Scene(gpu_ctx, v, i, f)
     for quality in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD):
         gs.set_bvh_quality(quality)
-        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS if n_coincident <= 500 else pt.EXTEND_AUTO, pt.EXTEND_HBM):
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS if n_coincident <= 150 else pt.EXTEND_AUTO, pt.EXTEND_HBM):
             got = gs.trace(rays, tmin=0.001, tmax=100.0, extend=variant)
             assert got.tobytes() == want.tobytes(), (quality, variant)
     gs.set_bvh_quality(pt.BVH_PREFER_FAST_TRACE)
