@@ -106,7 +106,7 @@ def extend_kernel_name(pt, st, info, config):
     lds = "k_extend<lds>"
     if info.n_wide_nodes <= 8191 and info.n_tris <= 2047:     # the compact no-spill instantiations (plan_extend)
         lds = "k_extend_lds7" if os.environ.get("PT_TUNE_PAIR_KERNEL") == "0" or os.environ.get("PT_TUNE_PAIR_LEAVES") == "0" else "k_extend_lds7p"
-    return {1: "k_extend_flat", 2: lds, 3: "k_extend<hbm>"}.get(st.extend_variant, "?")
+    return {1: "k_extend_flat", 2: lds, 3: "k_extend<hbm>", 4: "k_extend8"}.get(st.extend_variant, "?")
 
 
 def count_visits(pt, ctx, scene, W, H, common):
@@ -145,7 +145,10 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
     # one BVH4 node visit of the HBM variant = 64 B (4 fp16 child boxes 48 B + 4 child words 16 B; the two-level
     # kernel reads fp32 nodes, 128 B); one triangle = 36 B of positions.  Counted only when the scene exceeds the
     # 32 MiB of L2; smaller scenes are LDS / L2 resident and HBM sees the queue I/O only.
-    node_bytes = 128.0 if config == "c4" else 64.0
+    bvh8 = st.extend_variant == 4       # one 128-B line per node visit (8 fp16 child boxes + child / triangle bases and masks)
+    node_bytes = 128.0 if (config == "c4" or bvh8) else 64.0
+    if bvh8:
+        scene_bytes = info.device_bytes8
     gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
     bytes_extend = BYTES_EXTEND + gather
     gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
@@ -158,7 +161,7 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
         "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
         "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
         "algorithmic_bytes_per_ray": round(bytes_extend, 1),
-        "gather": {"bvh4_nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+        "gather": {"bvh_nodes_per_ray": round(nodes_per_ray, 2), "node_bytes": node_bytes, "tris_per_ray": round(tris_per_ray, 2),
                    "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
                    "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
         "active_lanes": {"node_steps": round(64 * node_occ, 1) if node_occ else None,
@@ -258,7 +261,8 @@ def c5_leg(pt, ctx, W, H, config, soup_tris, frames, rank):
     out = {"workload": f"{config.upper()}: {name} {W}x{H}, 16 spp/frame x {frames} frames, 16 bounces",
            "mrays_per_s": round(st.rays / dt / 1e6, 2), "ms_per_frame": round(dt * 1e3 / frames, 3),
            "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups,
-           "bvh": {"triangles": info.n_tris, "bvh4_nodes": info.n_wide_nodes, "height": info.bvh_height, "build_ms": round(info.build_ms, 3)},
+           "bvh": {"triangles": info.n_tris, "bvh4_nodes": info.n_wide_nodes, "bvh8_nodes": info.n_wide8_nodes, "bvh8_levels": info.wide8_levels,
+                   "height": info.bvh_height, "build_ms": round(info.build_ms, 3), "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant)},
            "ingest": ingest}
     out.update(r)
     film.close()
@@ -281,7 +285,7 @@ def main():
     ap.add_argument("--soup-tris", type=int, default=None)
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--sample-groups", type=int, default=0)
-    ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm"], default="auto", help="closest-hit kernel variant")
+    ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm", "hbm8"], default="auto", help="closest-hit kernel variant")
     ap.add_argument("--bvh-quality", choices=["fast_trace", "fast_build"], default="fast_trace",
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
@@ -341,7 +345,7 @@ def main():
     flags = 0 if args.no_kernel_events else pt.FLAG_PROFILE
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
                   frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
-                  extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM}[args.extend])
+                  extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM, "hbm8": pt.EXTEND_HBM8}[args.extend])
 
     def barrier():
         if world > 1:
@@ -411,7 +415,7 @@ def main():
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
-                    "build_ms": round(info.build_ms, 3), "bvh4_nodes": info.n_wide_nodes,
+                    "build_ms": round(info.build_ms, 3), "bvh4_nodes": info.n_wide_nodes, "bvh8_nodes": info.n_wide8_nodes,
                     "bvh4_builder": ["collapsed LBVH", "surface-area sweep (<= 2048 triangles, ePreferFastTrace)"][info.bvh4_builder],
                     "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant, str(st.extend_variant))},
         }

@@ -81,7 +81,10 @@ typedef struct pt_scene_info {
     uint32_t bvh4_builder;    /* which BVH4 is traversed: 0 collapsed LBVH, 1 surface-area sweep   */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
-    uint64_t device_bytes;    /* resident scene + BVH bytes                                     */
+    uint64_t device_bytes;    /* resident scene + BVH bytes of the BVH4 path                    */
+    uint32_t n_wide8_nodes;   /* BVH8 nodes (128 B each) of the PT_EXTEND_HBM8 path, levels of that tree */
+    uint32_t wide8_levels;
+    uint64_t device_bytes8;   /* resident triangle tables + BVH8 bytes of that path             */
 } pt_scene_info;
 pt_status pt_scene_get_info(const pt_scene *scene, pt_scene_info *info);
 
@@ -103,6 +106,10 @@ pt_status pt_scene_read_bvh(const pt_scene *scene, uint64_t *keys, uint32_t *pri
  * hi.z[4] child[4] 0[4]}; child = 0xFFFFFFFF empty | node index | bit31: leaf,
  * (count-1)<<28 | first sorted position.                                                     */
 pt_status pt_scene_read_bvh4(const pt_scene *scene, uint32_t *nodes32);
+/* The BVH8 of big scenes: n_wide8_nodes x 32 dwords {lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8] as fp16 of
+ * (x - c) / s with c, s the centre and half extent of the scene box, child_base, tri_base, imask | lmask << 8, 0, 0[4]}
+ * and prim_of_pos8: n_tris entries, BVH8 triangle position -> gl_PrimitiveID.  Either pointer may be NULL.        */
+pt_status pt_scene_read_bvh8(const pt_scene *scene, uint32_t *nodes32, uint32_t *prim_of_pos8);
 
 /* ---- film: descriptor binding 1 (raygen.rgen:7, main.cpp:481-484) ---------------------- */
 /* float32 running-mean radiance (the canonical result) plus the reference's rgba8 display
@@ -133,7 +140,8 @@ enum {
     PT_EXTEND_AUTO = 0,
     PT_EXTEND_FLAT = 1, /* <= 1024 triangles: one wide leaf scanned wave-uniformly (SGPR stream); never AUTO  */
     PT_EXTEND_LDS = 2,  /* BVH4 + triangles staged in LDS (scenes <= 24 KB by AUTO), lane refill             */
-    PT_EXTEND_HBM = 3   /* BVH4 + triangles read through L1/L2/MALL from HBM, LDS short stack + HBM spill    */
+    PT_EXTEND_HBM = 3,  /* BVH4 + triangles read through L1/L2/MALL from HBM, LDS short stack + HBM spill    */
+    PT_EXTEND_HBM8 = 4  /* BVH8 (one 128-B line per node, one stack entry per node); never AUTO (measured slower)  */
 };
 
 typedef struct pt_params {

@@ -11,7 +11,7 @@ for r in $(seq 1 ${AB_ROUNDS:-3}); do
     echo -n "$NAME: "
     env $(echo $ENVS | tr ',' ' ') python bench.py --no-cpu-baseline --no-extra-legs $ARGS 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{}); g=r.get('gather',{}); a=r.get('active_lanes',{})
-print(d['value'], d['ms_per_step'], 'nodes/ray', g.get('bvh4_nodes_per_ray'), 'tris/ray', g.get('tris_per_ray'), 'lanes node', a.get('node_steps'), 'tri', a.get('triangle_steps'), 'ext_ms', r.get('extend_ms'), 'sh_ms', r.get('shade_ms'), 'bvh4', d['bvh']['bvh4_nodes'])"
+print(d['value'], d['ms_per_step'], 'nodes/ray', g.get('bvh_nodes_per_ray'), 'tris/ray', g.get('tris_per_ray'), 'lanes node', a.get('node_steps'), 'tri', a.get('triangle_steps'), 'ext_ms', r.get('extend_ms'), 'sh_ms', r.get('shade_ms'), 'bvh4', d['bvh']['bvh4_nodes'])"
   done
 done
 cp /tmp/keep.so $L

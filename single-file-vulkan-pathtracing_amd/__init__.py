@@ -29,9 +29,10 @@ PIPELINE_WAVEFRONT = 0
 FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4
-EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM = 0, 1, 2, 3
+EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM, EXTEND_HBM8 = 0, 1, 2, 3, 4
 BVH_PREFER_FAST_TRACE, BVH_PREFER_FAST_BUILD = 0, 1
-EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4, scene staged in LDS", 3: "BVH4, scene in HBM/L2"}
+EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4, scene staged in LDS", 3: "BVH4, scene in HBM/L2",
+                4: "BVH8 (128-B nodes, one stack entry per node), scene in HBM/L2"}
 MISS = 0xFFFFFFFF
 
 
@@ -57,7 +58,8 @@ class SceneInfo(C.Structure):
                 ("n_wide_nodes", C.c_uint32), ("n_instances", C.c_uint32), ("n_tlas_nodes", C.c_uint32),
                 ("leaf_max", C.c_uint32), ("bvh4_builder", C.c_uint32),
                 ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("n_wide8_nodes", C.c_uint32), ("wide8_levels", C.c_uint32),
+                ("device_bytes8", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -82,7 +84,7 @@ HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"),
 # every symbol include/pt_api.h and include/pt_host.h declare
 API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "pt_scene_create", "pt_scene_destroy",
                "pt_scene_set_instances", "pt_scene_set_bvh_quality",
-               "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_film_create", "pt_film_create_external", "pt_film_clear",
+               "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_scene_read_bvh8", "pt_film_create", "pt_film_create_external", "pt_film_clear",
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render",
                "pt_render_prepare", "pt_trace",
                "pt_get_stats", "pt_reset_stats",
@@ -125,6 +127,7 @@ def lib_amd():
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.pt_scene_read_bvh.argtypes = [vp, vp, vp, vp]
         L.pt_scene_read_bvh4.argtypes = [vp, vp]
+        L.pt_scene_read_bvh8.argtypes = [vp, vp, vp]
         L.pt_film_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.pt_film_create_external.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(vp)]
         L.pt_film_clear.argtypes = [vp]
@@ -337,6 +340,14 @@ class Scene:
         nodes = np.zeros((self.info().n_wide_nodes, 32), dtype=np.uint32)
         self.ctx._check(lib_amd().pt_scene_read_bvh4(self.h, nodes.ctypes.data))
         return nodes
+
+    def read_bvh8(self):
+        """-> (nodes [n_wide8, 32] u32, prim_of_pos8 [n_tris] u32) of the BVH8 (include/pt_api.h: pt_scene_read_bvh8)"""
+        i = self.info()
+        nodes = np.zeros((i.n_wide8_nodes, 32), dtype=np.uint32)
+        prim = np.zeros(i.n_tris, dtype=np.uint32)
+        self.ctx._check(lib_amd().pt_scene_read_bvh8(self.h, nodes.ctypes.data, prim.ctypes.data))
+        return nodes, prim
 
     def trace(self, rays6, tmin=0.001, tmax=10000.0, extend=EXTEND_AUTO):
         """Closest-hit query alone (traceRayEXT, raygen.rgen:63-75)."""

@@ -11,9 +11,26 @@
 // at 72 VGPRs) -- hence two translation units rather than one flag.  Other strategies tried: max-memory-clause
 // +6 % C5 / -7 % C2, iterative-ilp -1.5 % / -13 %, iterative-maxocc 0 / -6 %.
 #include "extend_kernel.h"
+#include "extend8_kernel.h"
+
+#include <cstdlib>
+
+// PT_TUNE_UNIFIED=1 selects the unified-fetch step (extend_kernel.h: every lane fetches what its `cur` points to, the
+// wave waits once per iteration) instead of the vote-scheduled one.  Measured on MI355X, C5: 26 % fewer iterations and
+// node-step lane occupancy 24 -> 28 of 64, extend 290 -> 311 ms and the overlapped shade 105 -> 83 ms per 4 frames: the
+// same total (beyond L2 the kernel is bound by distinct 128-B lines per second, scripts/ubench/gather_rate.hip, not by
+// the number of waits), so the established kernel stays the default.
+static bool unified_step()
+{
+    static const bool on = getenv("PT_TUNE_UNIFIED") && atoi(getenv("PT_TUNE_UNIFIED")) == 1;
+    return on;
+}
 
 const void *ptw_extend_hbm_fn(bool count)
 {
+    if (unified_step())
+        return count ? reinterpret_cast<const void *>(k_extend<false, true, true, false, true>)
+                     : reinterpret_cast<const void *>(k_extend<false, false, true, false, true>);
     return count ? reinterpret_cast<const void *>(k_extend<false, true, true>)
                  : reinterpret_cast<const void *>(k_extend<false, false, true>);
 }
@@ -26,12 +43,34 @@ void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hi
                            float tmax, int lds_stack, int raw_hit)
 {
     const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
+#define PT_LAUNCH_HBM(C, U)                                                                                                  \
+    hipExtLaunchKernelGGL((k_extend<false, C, true, false, U>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, wide, wide16, \
+                          nb, tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill, tmin, \
+                          tmax, lds_stack, raw_hit)
+    if (unified_step()) {
+        if (count) PT_LAUNCH_HBM(true, true); else PT_LAUNCH_HBM(false, true);
+    } else {
+        if (count) PT_LAUNCH_HBM(true, false); else PT_LAUNCH_HBM(false, false);
+    }
+#undef PT_LAUNCH_HBM
+}
+
+// ---- BVH8 kernel (extend8_kernel.h), same translation unit for the same scheduler --------------------------------
+const void *ptw_extend8_fn(bool count)
+{
+    return count ? reinterpret_cast<const void *>(k_extend8<true>) : reinterpret_cast<const void *>(k_extend8<false>);
+}
+
+void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
+                        const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
+                        const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
+                        uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit)
+{
+    const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
     if (count)
-        hipExtLaunchKernelGGL((k_extend<false, true, true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, wide, wide16,
-                              nb, tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride,
-                              refill, tmin, tmax, lds_stack, raw_hit);
+        hipExtLaunchKernelGGL((k_extend8<true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rayA, rayB, hit,
+                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit);
     else
-        hipExtLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, wide, wide16,
-                              nb, tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride,
-                              refill, tmin, tmax, lds_stack, raw_hit);
+        hipExtLaunchKernelGGL((k_extend8<false>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rayA, rayB, hit,
+                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit);
 }

@@ -512,6 +512,150 @@ __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig
     ke4[pos] = make_float4(f[3], f[4], f[5], 0.f);
 }
 
+
+// ---- BVH8 (scenes walked out of L2 / MALL / HBM) ------------------------------------------------------------------
+// Measured on MI355X (scripts/ubench/gather_rate.hip): beyond L2 a wave's divergent loads cost per distinct 128-B LINE
+// (~56 G lines/s for the chip), not per byte or per load instruction -- four 16-B loads of one line cost what one does.
+// So the wide node of big scenes is one whole line holding EIGHT children, and a ray fetches a third fewer lines than
+// with four children per 64-B node (22 instead of 35 node visits on a 100k-triangle soup of C5's density).
+//   node = 8 x uint4:  lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8] as fp16 of coordinates normalised to the scene
+//          box (rounded outwards, empty slot = +inf), then {child_base, tri_base, imask | lmask << 8, 0}, then a spare.
+//   Internal children are CONTIGUOUS nodes (child of slot s = child_base + popcount(imask below s)) and the triangles
+//   of a node's leaf children are contiguous positions of the BVH8's own triangle order (tri_base + popcount(lmask
+//   below s)), so a traversal stack entry is {child_base, pending-children mask} for a whole node -- one push per visit
+//   instead of one per child, and no child words to keep.
+//   Children sit in the slot of their OCTANT about the node's centre where it is free, so "slot xor ray octant" visits
+//   them roughly front to back without sorting (Ylitie, Karras, Laine 2017).
+// Built top-down, one level per pass, from the binary LBVH: a wide node starts with the two children of its binary
+// node and keeps opening the internal one of LARGEST SURFACE AREA until it has eight (the area-guided collapse that
+// stands in for ePreferFastTrace, main.cpp:419, on big scenes).  Scans give every level's nodes and triangles their
+// places, so the result is deterministic.
+__device__ __forceinline__ float box_area(const float4 lo, const float4 hi)
+{
+    const float x = hi.x - lo.x, y = hi.y - lo.y, z = hi.z - lo.z;
+    return (x * y + y * z) + z * x;
+}
+
+// one thread per wide node of this level: its up-to-8 children as binary references in slot order (PT_MISS = empty)
+__global__ __launch_bounds__(TB) void k_w8_expand(uint32_t count, const uint32_t *__restrict__ front, int n,
+                                                  const uint2 *__restrict__ topo, const float4 *__restrict__ box_lo,
+                                                  const float4 *__restrict__ box_hi, uint32_t *__restrict__ kids,
+                                                  uint32_t *__restrict__ n_int, uint32_t *__restrict__ n_leaf)
+{
+    const uint32_t j = blockIdx.x * TB + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t b = front[j];
+    uint32_t ref[8];
+    int m = 2;
+    { const uint2 ch = topo[b]; ref[0] = ch.x; ref[1] = ch.y; }
+    while (m < 8) {
+        int pick = -1;
+        float pa = -1.f;
+        for (int k = 0; k < m; k++) {
+            if (ref[k] & PT_LEAF) continue;
+            const float a = box_area(box_lo[(size_t)n + ref[k]], box_hi[(size_t)n + ref[k]]);
+            if (a > pa) { pa = a; pick = k; }  // first maximum wins
+        }
+        if (pick < 0) break;
+        const uint2 ch = topo[ref[pick]];
+        ref[pick] = ch.x;
+        ref[m++] = ch.y;
+    }
+    // slots by octant of the child's centre about the centre of this node's box; taken -> the free slot with the
+    // fewest differing octant bits (lowest index among equals)
+    const float4 nlo = box_lo[(size_t)n + b], nhi = box_hi[(size_t)n + b];
+    const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
+    uint32_t slot_ref[8];
+    for (int k = 0; k < 8; k++) slot_ref[k] = PT_MISS;
+    uint32_t used = 0, ni = 0, nl = 0;
+    for (int k = 0; k < m; k++) {
+        const bool leaf = (ref[k] & PT_LEAF) != 0u;
+        const size_t bi = leaf ? (size_t)(ref[k] & ~PT_LEAF) : (size_t)n + ref[k];
+        const float4 lo = box_lo[bi], hi = box_hi[bi];
+        const uint32_t want = (0.5f * (lo.x + hi.x) > cx ? 1u : 0u) | (0.5f * (lo.y + hi.y) > cy ? 2u : 0u) | (0.5f * (lo.z + hi.z) > cz ? 4u : 0u);
+        uint32_t best = 8, bd = 9;
+        for (uint32_t sl = 0; sl < 8; sl++) {
+            if (used & (1u << sl)) continue;
+            const uint32_t d = (uint32_t)__popc(sl ^ want);
+            if (d < bd) { bd = d; best = sl; }
+        }
+        used |= 1u << best;
+        slot_ref[best] = ref[k];
+        if (leaf) nl++; else ni++;
+    }
+    for (int k = 0; k < 8; k++) kids[8 * (size_t)j + k] = slot_ref[k];
+    n_int[j] = ni;
+    n_leaf[j] = nl;
+}
+
+// writes the level's nodes, the next level's frontier and the triangle order
+// Triangle order: a wide node's subtree covers the same contiguous range of positions as its binary node does in the
+// sorted (Morton) order; inside it come first the node's own leaf triangles, then the subtrees of its internal children
+// in slot order -- so the order stays spatially coherent at every scale (k_shade and the triangle fetches gather from it)
+// AND a node's leaf triangles are contiguous.  tri_start = first position of the node's range.
+__global__ __launch_bounds__(TB) void k_w8_emit(uint32_t count, uint32_t level_base, uint32_t next_base, int n,
+                                                const uint32_t *__restrict__ kids, const uint32_t *__restrict__ int_off,
+                                                const uint32_t *__restrict__ tri_start, const uint2 *__restrict__ range,
+                                                const float4 *__restrict__ box_lo,
+                                                const float4 *__restrict__ box_hi, float cx, float cy, float cz, float rsx,
+                                                float rsy, float rsz, uint4 *__restrict__ wide8, uint32_t *__restrict__ next_front,
+                                                uint32_t *__restrict__ next_start, uint32_t *__restrict__ order8)
+{
+    const uint32_t j = blockIdx.x * TB + threadIdx.x;
+    if (j >= count) return;
+    const float c[3] = { cx, cy, cz }, rs[3] = { rsx, rsy, rsz };
+    uint32_t hl[3][8], hh[3][8];
+    uint32_t imask = 0, lmask = 0, ni = 0, nl = 0;
+    const uint32_t child_base = next_base + int_off[j], tri_base = tri_start[j];
+    uint32_t sub_start = tri_base;  // where the next internal child's range begins: behind this node's own leaves
+    for (int k = 0; k < 8; k++) {
+        const uint32_t r = kids[8 * (size_t)j + k];
+        if (r != PT_MISS && (r & PT_LEAF)) sub_start++;
+    }
+    for (int k = 0; k < 8; k++) {
+        const uint32_t r = kids[8 * (size_t)j + k];
+        if (r == PT_MISS) {
+            for (int ax = 0; ax < 3; ax++) hl[ax][k] = hh[ax][k] = 0x7C00u;  // +inf: no slab interval
+            continue;
+        }
+        const bool leaf = (r & PT_LEAF) != 0u;
+        const size_t bi = leaf ? (size_t)(r & ~PT_LEAF) : (size_t)n + r;
+        const float4 lo = box_lo[bi], hi = box_hi[bi];
+        const float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
+        for (int ax = 0; ax < 3; ax++) {  // as k_wide_half: every fp16 box contains its fp32 box
+            hl[ax][k] = __half_as_ushort(__float2half_rd((l[ax] - c[ax]) * rs[ax] - 3.814697265625e-06f));
+            hh[ax][k] = __half_as_ushort(__float2half_ru((h[ax] - c[ax]) * rs[ax] + 3.814697265625e-06f));
+        }
+        if (leaf) {
+            lmask |= 1u << k;
+            order8[tri_base + nl] = r & ~PT_LEAF;  // BVH8 triangle position -> sorted (Morton) position
+            nl++;
+        } else {
+            imask |= 1u << k;
+            next_front[int_off[j] + ni] = r;
+            next_start[int_off[j] + ni] = sub_start;
+            const uint2 rg = range[r];
+            sub_start += rg.y - rg.x + 1u;
+            ni++;
+        }
+    }
+    uint4 *o = wide8 + 8 * (size_t)(level_base + j);
+    for (int ax = 0; ax < 3; ax++) {
+        o[ax] = make_uint4(hl[ax][0] | (hl[ax][1] << 16), hl[ax][2] | (hl[ax][3] << 16), hl[ax][4] | (hl[ax][5] << 16), hl[ax][6] | (hl[ax][7] << 16));
+        o[3 + ax] = make_uint4(hh[ax][0] | (hh[ax][1] << 16), hh[ax][2] | (hh[ax][3] << 16), hh[ax][4] | (hh[ax][5] << 16), hh[ax][6] | (hh[ax][7] << 16));
+    }
+    o[6] = make_uint4(child_base, tri_base, imask | (lmask << 8), 0u);
+    o[7] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// order8 o sorted order: BVH8 position -> primitive id
+__global__ __launch_bounds__(TB) void k_compose(const uint32_t *__restrict__ order8, const uint32_t *__restrict__ prim_of, uint32_t n,
+                                                uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i < n) out[i] = prim_of[order8[i]];
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -531,7 +675,25 @@ struct BvhOut {
     uint32_t n_nodes = 0, n_wide = 0, height = 0;
     uint32_t stack_need = 0;               // most entries a depth-first walk of the BVH4 can have pending
     float bmin[3]{}, bmax[3]{};
+    // BVH8 (want8): 128-B nodes, the triangle order that goes with them (position -> sorted position), levels
+    uint4 *d_wide8 = nullptr;
+    uint32_t *d_order8 = nullptr;
+    uint32_t n_wide8 = 0, levels8 = 0;
+    float norm_c[3]{}, norm_s[3]{1.f, 1.f, 1.f}, norm_rs[3]{1.f, 1.f, 1.f};
 };
+
+// the normalisation of the fp16 node formats: x' = (x - c) * rs with c the centre and 1/rs the half extent of the scene box
+static void norm_box(const float *bmin, const float *bmax, float *c, float *sv, float *rs)
+{
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) ext = fmaxf(ext, bmax[k] - bmin[k]);
+    for (int k = 0; k < 3; k++) {
+        c[k] = 0.5f * (bmin[k] + bmax[k]);
+        // half extent, never degenerate (flat scenes) and never so small that the padded boxes leave fp16's range
+        sv[k] = fmaxf(0.5f * (bmax[k] - bmin[k]), fmaxf(ext * 0x1p-10f, 1e-30f));
+        rs[k] = 1.0f / sv[k];
+    }
+}
 
 __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n,
                                                uint32_t *__restrict__ scene_ord)
@@ -567,7 +729,8 @@ static void exclusive_scan(uint32_t *d_data, uint32_t total, uint32_t *d_sums, h
     k_scan_apply<<<tiles, TB, 0, st>>>(d_data, total, d_sums);
 }
 
-static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, uint32_t leaf_max, BvhOut &out)
+static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, uint32_t leaf_max, BvhOut &out,
+                          bool want8 = false)
 {
     hipStream_t st = ctx->stream;
     const uint32_t gt = (n + TB - 1) / TB;
@@ -660,6 +823,53 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         out.bmax[k] = ord2f(ord[3 + k]);
     }
     PT_HIP(ctx, hipGetLastError());
+    norm_box(out.bmin, out.bmax, out.norm_c, out.norm_s, out.norm_rs);
+    if (want8 && n > 1) {
+        // BVH8, level by level from the root (see k_w8_expand).  Worst case every wide node has two children: n - 1 nodes.
+        const uint32_t n_int = n - 1;
+        DevBuf<uint32_t> d_front[2], d_start[2], d_kids, d_ni, d_nl;
+        for (int k = 0; k < 2; k++) {
+            PT_HIP(ctx, d_front[k].alloc(n_int));
+            PT_HIP(ctx, d_start[k].alloc(n_int));
+        }
+        PT_HIP(ctx, d_kids.alloc(8 * (size_t)n_int));
+        PT_HIP(ctx, d_ni.alloc(n_int));
+        PT_HIP(ctx, d_nl.alloc(n_int));
+        PT_HIP(ctx, hipMalloc((void **)&out.d_wide8, 128 * (size_t)n_int));
+        PT_HIP(ctx, hipMalloc((void **)&out.d_order8, sizeof(uint32_t) * (size_t)n));
+        PT_HIP(ctx, hipMemsetAsync(d_front[0].p, 0, sizeof(uint32_t), st));  // level 0: the binary root, whose range starts at 0
+        PT_HIP(ctx, hipMemsetAsync(d_start[0].p, 0, sizeof(uint32_t), st));
+        uint32_t count = 1, level_base = 0, tri_run = 0, levels = 0;
+        int cf = 0;
+        while (count > 0) {
+            const uint32_t g = (count + TB - 1) / TB;
+            k_w8_expand<<<g, TB, 0, st>>>(count, d_front[cf].p, (int)n, d_topo.p, d_blo.p, d_bhi.p, d_kids.p, d_ni.p, d_nl.p);
+            uint32_t last[2] = { 0, 0 }, tot[2] = { 0, 0 };
+            PT_HIP(ctx, hipMemcpyAsync(&last[0], d_ni.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipMemcpyAsync(&last[1], d_nl.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            exclusive_scan(d_ni.p, count, d_sums.p, st);
+            exclusive_scan(d_nl.p, count, d_sums.p, st);  // (only its total is used: the leaf triangles this level places)
+            PT_HIP(ctx, hipMemcpyAsync(&tot[0], d_ni.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipMemcpyAsync(&tot[1], d_nl.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            const uint32_t next_count = tot[0] + last[0], leaves = tot[1] + last[1];
+            const uint32_t next_base = level_base + count;
+            if ((uint64_t)next_base + next_count > n_int || (uint64_t)tri_run + leaves > n) { ctx->err = "internal: BVH8 build overran its bounds"; return PT_ERR_HIP; }
+            k_w8_emit<<<g, TB, 0, st>>>(count, level_base, next_base, (int)n, d_kids.p, d_ni.p, d_start[cf].p, d_range.p, d_blo.p, d_bhi.p,
+                                        out.norm_c[0], out.norm_c[1], out.norm_c[2], out.norm_rs[0], out.norm_rs[1], out.norm_rs[2],
+                                        out.d_wide8, d_front[cf ^ 1].p, d_start[cf ^ 1].p, out.d_order8);
+            level_base = next_base;
+            tri_run += leaves;
+            count = next_count;
+            cf ^= 1;
+            levels++;
+        }
+        if (tri_run != n) { ctx->err = "internal: BVH8 build lost triangles"; return PT_ERR_HIP; }
+        out.n_wide8 = level_base;
+        out.levels8 = levels;
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        PT_HIP(ctx, hipGetLastError());
+    }
     return PT_OK;
 }
 
@@ -698,14 +908,7 @@ static pt_status make_wide16(pt_scene *s)
 {
     pt_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
-    float ext = 0.f;
-    for (int k = 0; k < 3; k++) ext = fmaxf(ext, s->bmax[k] - s->bmin[k]);
-    for (int k = 0; k < 3; k++) {
-        s->norm_c[k] = 0.5f * (s->bmin[k] + s->bmax[k]);
-        // half extent, never degenerate (flat scenes) and never so small that the padded boxes leave fp16's range
-        s->norm_s[k] = fmaxf(0.5f * (s->bmax[k] - s->bmin[k]), fmaxf(ext * 0x1p-10f, 1e-30f));
-        s->norm_rs[k] = 1.0f / s->norm_s[k];
-    }
+    norm_box(s->bmin, s->bmax, s->norm_c, s->norm_s, s->norm_rs);
     (void)hipFree(s->d_wide16);
     s->d_wide16 = nullptr;
     PT_HIP(ctx, hipMalloc((void **)&s->d_wide16, 64 * (size_t)s->n_wide));
@@ -733,7 +936,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, d_tlo.alloc(n));
     PT_HIP(ctx, d_thi.alloc(n));
     s->n_tris = n;
-    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * 3 * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * (3 * (size_t)n + 1)));  // + 16 B: the unified fetch of k_extend reads 64 B at a 48-B record
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade64, sizeof(float4) * 4 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_ke4, sizeof(float4) * (size_t)n));
@@ -745,12 +948,26 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p);
     BvhOut o;
-    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o);
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o, true);
     s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
+    s->d_wide8 = o.d_wide8; s->n_wide8 = o.n_wide8; s->levels8 = o.levels8;
+    DevBuf<uint32_t> d_order8;
+    d_order8.p = o.d_order8;
     if (rc != PT_OK) return rc;
     s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height; s->stack_need = o.stack_need;
     for (int k = 0; k < 3; k++) { s->bmin[k] = o.bmin[k]; s->bmax[k] = o.bmax[k]; }
     k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4, s->d_shade64, s->d_ke4);
+    if (s->d_wide8) {  // the BVH8's own triangle order: its per-triangle tables (the LDS-sized shade4 is never used with it)
+        PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of8, sizeof(uint32_t) * (size_t)n));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_tri4_8, sizeof(float4) * (3 * (size_t)n + 1)));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_shade64_8, sizeof(float4) * 4 * (size_t)n));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_ke4_8, sizeof(float4) * (size_t)n));
+        DevBuf<float4> d_shade4_scratch;
+        PT_HIP(ctx, d_shade4_scratch.alloc(3 * (size_t)n));
+        k_compose<<<gt, TB, 0, st>>>(d_order8.p, s->d_prim_of, n, s->d_prim_of8);
+        k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of8, n, s->d_tri4_8, d_shade4_scratch.p, s->d_shade64_8, s->d_ke4_8);
+        PT_HIP(ctx, hipStreamSynchronize(st));
+    }
     PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
@@ -759,6 +976,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     s->bvh4_builder = 0;
     s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;
     s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
+    s->device_bytes8 = sizeof(float4) * 8 * (uint64_t)n + 128ull * s->n_wide8;  // tri4_8 + shade64_8 + ke4_8 + nodes
     if (n <= PT_SAH_MAX_TRIS) {
         // small scene: keep what a rebuild of the BVH4 in another leaf order needs, then apply the default
         // quality (ePreferFastTrace, main.cpp:419)
@@ -843,6 +1061,8 @@ void ptb_free_scene_buffers(pt_scene *s)
     (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
     (void)hipFree(s->d_tri_orig); (void)hipFree(s->d_faces); (void)hipFree(s->d_wide16);
     s->d_wide16 = nullptr;
+    (void)hipFree(s->d_wide8); (void)hipFree(s->d_prim_of8); (void)hipFree(s->d_tri4_8); (void)hipFree(s->d_shade64_8); (void)hipFree(s->d_ke4_8);
+    s->d_wide8 = nullptr; s->d_prim_of8 = nullptr; s->d_tri4_8 = s->d_shade64_8 = s->d_ke4_8 = nullptr;
     s->d_tri4 = s->d_shade4 = s->d_nodes = s->d_wide = s->d_wide_lbvh = s->d_wide_sah = s->d_tri_orig = nullptr;
     s->d_prim_of_sah = s->d_prim_of = nullptr; s->d_keys = nullptr; s->d_faces = nullptr;
 }

@@ -151,6 +151,7 @@ pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
     info->n_instances = s->n_inst;
     info->n_tlas_nodes = s->n_tlas_wide;
     info->leaf_max = PT_BLAS_LEAF_MAX;
+    info->n_wide8_nodes = s->n_wide8; info->wide8_levels = s->levels8; info->device_bytes8 = s->device_bytes8;
     info->bvh4_builder = s->bvh4_builder;
     for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
     info->build_ms = s->build_ms;
@@ -175,6 +176,17 @@ pt_status pt_scene_read_bvh4(const pt_scene *s, uint32_t *nodes32)
     pt_ctx *ctx = s->ctx;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide, 128 * (size_t)s->n_wide, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_scene_read_bvh8(const pt_scene *s, uint32_t *nodes32, uint32_t *prim_of_pos8)
+{
+    if (!s) return PT_ERR_INVALID_ARG;
+    pt_ctx *ctx = s->ctx;
+    if (!s->d_wide8) { ctx->err = "the scene has no BVH8 (a single triangle)"; return PT_ERR_UNSUPPORTED; }
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nodes32) PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide8, 128 * (size_t)s->n_wide8, hipMemcpyDeviceToHost));
+    if (prim_of_pos8) PT_HIP(ctx, hipMemcpy(prim_of_pos8, s->d_prim_of8, sizeof(uint32_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

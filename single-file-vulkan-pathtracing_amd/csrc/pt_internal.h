@@ -65,6 +65,14 @@ struct pt_scene {
     // boxes as fp16 of coordinates normalised to the scene box, rounded outwards; halves the bytes per node
     uint2 *d_wide16 = nullptr;
     float norm_c[3]{}, norm_s[3]{1.f, 1.f, 1.f}, norm_rs[3]{1.f, 1.f, 1.f};  // x' = (x - c) * rs,  s = 1/rs
+    // BVH8 of the same LBVH for scenes walked out of L2 / MALL / HBM (lbvh_build.hip k_w8_*): 128-B nodes, and the
+    // per-triangle tables in ITS triangle order (a node's leaf triangles are contiguous), used instead of
+    // d_tri4 / d_shade64 / d_ke4 whenever the BVH8 kernel traverses
+    uint4 *d_wide8 = nullptr;
+    uint32_t n_wide8 = 0, levels8 = 0;
+    uint32_t *d_prim_of8 = nullptr;
+    float4 *d_tri4_8 = nullptr, *d_shade64_8 = nullptr, *d_ke4_8 = nullptr;
+    uint64_t device_bytes8 = 0;
     float4 *d_wide_lbvh = nullptr; uint32_t n_wide_lbvh = 0, stack_need_lbvh = 0xFFFFFFFFu;
     float4 *d_wide_sah = nullptr;  uint32_t n_wide_sah = 0, stack_need_sah = 0xFFFFFFFFu;
     uint32_t *d_prim_of_sah = nullptr;      // leaf order of the SAH BVH4 (position -> prim id)

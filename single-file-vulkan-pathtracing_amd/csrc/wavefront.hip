@@ -39,6 +39,13 @@ void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hi
                            unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
                            float tmax, int lds_stack, int raw_hit);
 
+// extend_hbm.hip: k_extend8 (BVH8)
+const void *ptw_extend8_fn(bool count);
+void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
+                        const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
+                        const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
+                        uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit);
+
 namespace {
 
 // Exact unsigned division by a run-time constant without the ~28-instruction v_rcp sequence
@@ -786,13 +793,15 @@ struct ExtendPlan {
     bool spill = true;          // false: the scene's exact stack bound fits lds_stack, kernel without spill path
                                 // (and with one-dword stack entries: COMPACT in k_extend)
     bool pairs = false;         // ... and every leaf of the BVH4 is one triangle or one fan pair: the PAIRS kernel
+    bool bvh8 = false;          // PT_EXTEND_HBM8: the BVH8 and ITS triangle order (s->d_tri4_8, d_shade64_8, d_ke4_8)
     size_t smem_wide_entries = 0;  // LDS bytes of the same plan run by the 8-byte-entry kernel (negative tmin)
 };
 
 pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
-    if (want > PT_EXTEND_HBM) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
+    if (want > PT_EXTEND_HBM8) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
+    if (want == PT_EXTEND_HBM8 && (s->n_inst || !s->d_wide8)) { ctx->err = "no BVH8 for this scene (instanced, or a single triangle)"; return PT_ERR_UNSUPPORTED; }
     if (s->n_inst) {  // two-level scenes: one kernel variant (BVH4s read through L1/L2)
         if (want == PT_EXTEND_FLAT || want == PT_EXTEND_LDS) { ctx->err = "instanced scenes only have the HBM extend variant"; return PT_ERR_UNSUPPORTED; }
         pl.variant = PT_EXTEND_HBM;
@@ -835,6 +844,37 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         return PT_OK;
     }
     const size_t scene_bytes = 16 * LDS_NODE_F4 * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;  // 3 permuted triangle copies
+    // AUTO keeps the BVH4 (64-B nodes) for scenes that do not fit LDS: measured on MI355X (1M / 8M-triangle soups) the
+    // BVH8 visits 26 % fewer nodes but fetches as many 128-B LINES (two 64-B BVH4 siblings share one), and lines are
+    // what the memory system charges beyond L2 -- extend + shade kernel time 458 vs 395 ms per 4 frames of C5, equal on
+    // C5x.  PT_EXTEND_HBM8 (or PT_TUNE_BVH8=1 under AUTO) selects it.
+    const bool auto8 = want == PT_EXTEND_AUTO && scene_bytes > 24 * 1024 && s->d_wide8 && getenv("PT_TUNE_BVH8") && atoi(getenv("PT_TUNE_BVH8")) == 1;
+    if (want == PT_EXTEND_HBM8 || auto8) {
+        pl.variant = PT_EXTEND_HBM8;
+        pl.bvh8 = true;
+        pl.lds_scene = false;
+        pl.lds_stack = 12;
+        if (const char *e = getenv("PT_TUNE_LDS_STACK")) pl.lds_stack = std::max(1, std::min(atoi(e), 32));
+        pl.smem = (size_t)pl.lds_stack * TB * sizeof(uint2);
+        int per_cu8 = 0;
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, ptw_extend8_fn(false), TB, pl.smem));
+        per_cu8 = std::max(1, std::min(per_cu8, 8));
+        pl.refill = 32;
+        if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+        pl.grid = ctx->num_cus * per_cu8;
+        // one stack entry per visited node: at most one per level of the BVH8
+        const uint32_t bound8 = s->levels8 + 1u;
+        pl.spill_levels = bound8 > (uint32_t)pl.lds_stack ? bound8 - (uint32_t)pl.lds_stack : 0u;
+        const size_t need8 = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
+        if (need8 > ctx->spill_bytes) {
+            (void)hipFree(ctx->d_spill);
+            ctx->d_spill = nullptr;
+            ctx->spill_bytes = 0;
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_spill, need8));
+            ctx->spill_bytes = need8;
+        }
+        return PT_OK;
+    }
     if (want == PT_EXTEND_LDS && scene_bytes > 96 * 1024) { ctx->err = "scene does not fit LDS"; return PT_ERR_UNSUPPORTED; }
     pl.lds_scene = want == PT_EXTEND_LDS || (want == PT_EXTEND_AUTO && scene_bytes <= 24 * 1024);
     pl.variant = pl.lds_scene ? PT_EXTEND_LDS : PT_EXTEND_HBM;
@@ -918,6 +958,11 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     }
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
+    if (pl.bvh8) {
+        ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, rayA, rayB, hit,
+                           count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw);
+        return;
+    }
     const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],
                            s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
     // one-dword stack entries truncate the entry distance toward zero, which is only conservative for t >= 0, and the
@@ -1344,7 +1389,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     // 1 path/thread is 40 % slower, 2 equal, grid size flat between 4 and 16 blocks per CU
     const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 6 * (size_t)s->n_tris;
-    const bool shade_lds = shade_smem <= 16 * 1024;  // per-triangle tables of small scenes are staged in LDS
+    const bool shade_lds = shade_smem <= 16 * 1024 && !pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
     // Several pipelines on separate streams: the slot lanes of a batch are split into parts that run their
     // rounds independently, so the VALU-bound extend of one overlaps the HBM-bound shade of another
     // (measured on MI355X, Cornell box: 1 pipeline 13.4, 2: 15.2, 3: 15.0, 4: 14.1 Grays/s; restricting the
@@ -1424,7 +1469,8 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
 #define PT_LAUNCH_SHADE(N, L)                                                                                                  \
     hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
-                          &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst, s->d_shade64, s->d_ke4)
+                          &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst,                    \
+                          pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4)
                     if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true); }
                     else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false); }
 #undef PT_LAUNCH_SHADE
@@ -1558,7 +1604,7 @@ pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, flo
         (void)hipEventRecord(ctx->ev_a, st);
         launch_extend(pl, s, d_a, d_b, d_hit, d_hi, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, false, st);
         (void)hipEventRecord(ctx->ev_b, st);
-        k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, s->d_tri4, s->n_inst ? d_hi : nullptr, s->d_tlas_prim_of, n, d_out);
+        k_hits_to_api<<<(n + TB - 1) / TB, TB, 0, st>>>(d_hit, pl.bvh8 ? s->d_tri4_8 : s->d_tri4, s->n_inst ? d_hi : nullptr, s->d_tlas_prim_of, n, d_out);
         (void)hipMemcpyAsync(hits, d_out, sizeof(pt_hit) * n, hipMemcpyDeviceToHost, st);
         if ((e = hipStreamSynchronize(st)) != hipSuccess) fail(e, "pt_trace");
         else if ((e = hipGetLastError()) != hipSuccess) fail(e, "pt_trace");

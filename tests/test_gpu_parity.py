@@ -323,7 +323,7 @@ def test_sample_groups_keep_the_sum_order_bit_exact(pt, orc, gpu_ctx, cornell_gp
     film.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_every_extend_variant_renders_the_same_bits(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle, variant):
     kw = dict(width=72, height=56, spp_per_frame=6, max_depth=8)
     film = pt.Film(gpu_ctx, 72, 56)
@@ -1289,4 +1289,101 @@ def test_pair_leaves_fan_quads_share_work_but_not_bits(pt, orc, gpu_ctx, cornell
         assert gs.trace(rays, tmin=0.001, tmax=100.0).tobytes() == want.tobytes()
     finally:
         os.environ.pop("PT_TUNE_PAIR_KERNEL", None)
+    gs.close()
+
+
+def _half(u16):
+    return np.asarray(u16, np.uint16).view(np.float16).astype(np.float64)
+
+
+def _check_bvh8(pt, gs, v, n):
+    """structure of the BVH8: contiguous children, every triangle in exactly one leaf slot, fp16 child boxes that contain
+    their triangles (through every level)"""
+    info = gs.info()
+    nodes, prim8 = gs.read_bvh8()
+    assert nodes.shape[0] == info.n_wide8_nodes >= 1 and sorted(prim8.tolist()) == list(range(n))
+    bmin, bmax = np.array(list(info.bbox_min), np.float64), np.array(list(info.bbox_max), np.float64)
+    ext = (bmax - bmin).max()
+    c, s = 0.5 * (bmin + bmax), np.maximum(0.5 * (bmax - bmin), max(ext * 2.0 ** -10, 1e-30))
+    tri = np.asarray(v, np.float64).reshape(-1, 3, 3)
+    halves = nodes[:, :24].copy().view(np.uint16).reshape(-1, 6, 8)          # [node][lo.x lo.y lo.z hi.x hi.y hi.z][slot]
+    lo = _half(halves[:, 0:3, :]) * s[None, :, None] + c[None, :, None]
+    hi = _half(halves[:, 3:6, :]) * s[None, :, None] + c[None, :, None]
+    child_base, tri_base, masks = nodes[:, 24], nodes[:, 25], nodes[:, 26]
+    imask, lmask = masks & 0xFF, (masks >> 8) & 0xFF
+    assert ((imask & lmask) == 0).all()
+    seen_node = np.zeros(len(nodes), np.int64)
+    seen_tri = np.zeros(n, np.int64)
+    # subtree boxes bottom-up: nodes of a level come after their parents, so walk the array backwards
+    sub_lo = np.full((len(nodes), 3), np.inf)
+    sub_hi = np.full((len(nodes), 3), -np.inf)
+    tol = 1e-6 * max(ext, 1e-30)
+    for i in range(len(nodes) - 1, -1, -1):
+        ni = nl = 0
+        for sl in range(8):
+            if imask[i] >> sl & 1:
+                ch = child_base[i] + ni
+                ni += 1
+                assert i < ch < len(nodes)
+                seen_node[ch] += 1
+                assert (lo[i, :, sl] <= sub_lo[ch] + tol).all() and (hi[i, :, sl] >= sub_hi[ch] - tol).all()
+                sub_lo[i] = np.minimum(sub_lo[i], sub_lo[ch]); sub_hi[i] = np.maximum(sub_hi[i], sub_hi[ch])
+            elif lmask[i] >> sl & 1:
+                pos = tri_base[i] + nl
+                nl += 1
+                seen_tri[pos] += 1
+                t = tri[prim8[pos]]
+                assert (lo[i, :, sl] <= t.min(0) + tol).all() and (hi[i, :, sl] >= t.max(0) - tol).all()
+                sub_lo[i] = np.minimum(sub_lo[i], t.min(0)); sub_hi[i] = np.maximum(sub_hi[i], t.max(0))
+            else:
+                assert np.isinf(lo[i, :, sl]).all() and np.isinf(hi[i, :, sl]).all()   # empty slot: no slab interval
+    assert (seen_tri == 1).all() and seen_node[0] == 0 and (seen_node[1:] == 1).all()
+    return info
+
+
+@pytest.mark.parametrize("n,seed,spread", [(0, 0, 0), (2, 2, 0.3), (3, 3, 0.3), (9, 4, 0.3), (100, 5, 0.3), (5000, 6, 0.1), (60000, 7, 0.02)])
+def test_bvh8_structure_and_hits(pt, orc, gpu_ctx, cornell_arrays, n, seed, spread):
+    """The BVH8 of scenes that are walked out of L2 / MALL / HBM (n = 0: the Cornell box, which AUTO keeps in LDS but which
+    has one all the same): valid tree, and PT_EXTEND_HBM8 returns the oracle's hit records bit for bit -- random rays, rays
+    along the axes (zero direction components) and from inside the boxes; a negative tmin too."""
+    v, i, f = cornell_arrays if n == 0 else _soup(n, seed, spread=spread)
+    nt = len(i) // 3
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    info = _check_bvh8(pt, gs, v, nt)
+    assert info.wide8_levels >= 1 and info.n_wide8_nodes <= max(nt - 1, 1)
+    rng = np.random.default_rng(seed)
+    m = 40000
+    org = rng.uniform(-1.3, 1.3, (m, 3))
+    d = rng.normal(size=(m, 3))
+    d[:300] = np.eye(3)[rng.integers(0, 3, 300)] * rng.choice([-1.0, 1.0], (300, 1))     # axis-parallel
+    tri = np.asarray(v, np.float64).reshape(-1, 3, 3)
+    tgt = tri[rng.integers(0, nt, m // 2)].mean(1)                                          # half aim at triangles
+    d[m // 2:] = tgt - org[m // 2:]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    for tmin in (0.001, -0.25):
+        want, _ = osc.trace(rays, tmin=tmin, tmax=50.0)
+        got = gs.trace(rays, tmin=tmin, tmax=50.0, extend=pt.EXTEND_HBM8)
+        assert got.tobytes() == want.tobytes(), (n, tmin)
+    assert (want["prim"] != 0xFFFFFFFF).sum() > m // 4
+    gs.close()
+
+
+def test_bvh8_render_bit_exact_and_auto_selection(pt, orc, gpu_ctx):
+    """A 30 000-triangle soup (does not fit LDS): AUTO and PT_EXTEND_HBM walk the BVH4, PT_EXTEND_HBM8 the BVH8; all render the oracle's
+    film and ray count, progressive frames, sample groups and two pipelines included (k_shade reads the per-triangle tables in
+    the order of whichever tree was walked)."""
+    v, i, f = _soup(30000, 11, spread=0.05)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    kw = dict(width=160, height=96, spp_per_frame=4, max_depth=6)
+    ofilm, obgra, orays = _render_oracle(orc, osc, 3, **kw)
+    for extend, name in ((pt.EXTEND_AUTO, 3), (pt.EXTEND_HBM8, 4), (pt.EXTEND_HBM, 3)):
+        film = pt.Film(gpu_ctx, 160, 96)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(frame=0, frame_count=1, extend=extend, **kw))
+        pt.render(gs, film, pt.default_params(frame=1, frame_count=2, extend=extend, sample_groups=2, flags=pt.FLAG_COUNT_VISITS, **kw))
+        st = gpu_ctx.stats()
+        assert st.extend_variant == name and st.rays == orays and st.nodes_visited > 0 and st.tris_tested > 0
+        assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes()
+        film.close()
     gs.close()

@@ -146,7 +146,7 @@ def test_struct_layouts_match_header(pt):
     import ctypes as C
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
     assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2 + 8 * 2 + 4 * 2 + 8 * 5   # + redone_batches, reserved_, wave-level block counts
-    assert C.sizeof(pt.SceneInfo) == 4 * 8 + 4 * 6 + 4 + 4 + 8  # one pad dword before the u64
+    assert C.sizeof(pt.SceneInfo) == 4 * 8 + 4 * 6 + 4 + 4 + 8 + 4 * 2 + 8  # one pad dword before the first u64
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
     assert list(p.cam_origin) == [0.0, -1.0, 5.0] and list(p.cam_target) == [0.0, -1.0, 2.0]
@@ -183,6 +183,7 @@ def test_abi_is_null_safe_without_a_gpu(pt):
     assert L.pt_scene_get_info(None, None) == 1
     assert L.pt_scene_read_bvh(None, None, None, None) == 1
     assert L.pt_scene_read_bvh4(None, None) == 1
+    assert L.pt_scene_read_bvh8(None, None, None) == 1
     assert L.pt_film_create(None, 4, 4, C.byref(out)) == 1
     assert L.pt_film_create_external(None, 4, 4, None, C.byref(out)) == 1
     assert L.pt_film_clear(None) == 1 and L.pt_film_read_f32(None, None) == 1 and L.pt_film_read_bgra8(None, None) == 1
