@@ -536,7 +536,8 @@ __device__ __forceinline__ float box_area(const float4 lo, const float4 hi)
     return (x * y + y * z) + z * x;
 }
 
-// one thread per wide node of this level: its up-to-8 children as binary references in slot order (PT_MISS = empty)
+// one thread per wide node of this level: its up-to-W children as binary references in slot order (PT_MISS = empty)
+template <int W>
 __global__ __launch_bounds__(TB) void k_w8_expand(uint32_t count, const uint32_t *__restrict__ front, int n,
                                                   const uint2 *__restrict__ topo, const float4 *__restrict__ box_lo,
                                                   const float4 *__restrict__ box_hi, uint32_t *__restrict__ kids,
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(TB) void k_w8_expand(uint32_t count, const uint32_t
     uint32_t ref[8];
     int m = 2;
     { const uint2 ch = topo[b]; ref[0] = ch.x; ref[1] = ch.y; }
-    while (m < 8) {
+    while (m < W) {
         int pick = -1;
         float pa = -1.f;
         for (int k = 0; k < m; k++) {
@@ -570,6 +571,11 @@ __global__ __launch_bounds__(TB) void k_w8_expand(uint32_t count, const uint32_t
     uint32_t used = 0, ni = 0, nl = 0;
     for (int k = 0; k < m; k++) {
         const bool leaf = (ref[k] & PT_LEAF) != 0u;
+        if (W < 8) {  // four-wide nodes are sorted by entry distance at traversal time: slots in the order found
+            slot_ref[k] = ref[k];
+            if (leaf) nl++; else ni++;
+            continue;
+        }
         const size_t bi = leaf ? (size_t)(ref[k] & ~PT_LEAF) : (size_t)n + ref[k];
         const float4 lo = box_lo[bi], hi = box_hi[bi];
         const uint32_t want = (0.5f * (lo.x + hi.x) > cx ? 1u : 0u) | (0.5f * (lo.y + hi.y) > cy ? 2u : 0u) | (0.5f * (lo.z + hi.z) > cz ? 4u : 0u);
@@ -648,6 +654,51 @@ __global__ __launch_bounds__(TB) void k_w8_emit(uint32_t count, uint32_t level_b
     o[7] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// The same level-by-level build with FOUR children per node, in the 64-B format k_extend<hbm> walks (fp16 planes +
+// child words; leaves point into the usual sorted triangle order): area-guided collapse, and the children of a node
+// are contiguous -- 4 x 64 B = two 128-B lines, so the siblings a ray visits after one another share lines and the
+// levels of the tree are dense in memory (the chip charges per line beyond L2, not per node).
+__global__ __launch_bounds__(TB) void k_w4_emit(uint32_t count, uint32_t level_base, uint32_t next_base, int n,
+                                                const uint32_t *__restrict__ kids, const uint32_t *__restrict__ int_off,
+                                                const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi, float cx,
+                                                float cy, float cz, float rsx, float rsy, float rsz, uint4 *__restrict__ wide16,
+                                                uint32_t *__restrict__ next_front)
+{
+    const uint32_t j = blockIdx.x * TB + threadIdx.x;
+    if (j >= count) return;
+    const float c[3] = { cx, cy, cz }, rs[3] = { rsx, rsy, rsz };
+    uint32_t hl[3][4], hh[3][4], word[4];
+    uint32_t ni = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t r = kids[8 * (size_t)j + k];
+        if (r == PT_MISS) {
+            for (int ax = 0; ax < 3; ax++) hl[ax][k] = hh[ax][k] = 0x7C00u;
+            word[k] = PT_MISS;
+            continue;
+        }
+        const bool leaf = (r & PT_LEAF) != 0u;
+        const size_t bi = leaf ? (size_t)(r & ~PT_LEAF) : (size_t)n + r;
+        const float4 lo = box_lo[bi], hi = box_hi[bi];
+        const float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
+        for (int ax = 0; ax < 3; ax++) {
+            hl[ax][k] = __half_as_ushort(__float2half_rd((l[ax] - c[ax]) * rs[ax] - 3.814697265625e-06f));
+            hh[ax][k] = __half_as_ushort(__float2half_ru((h[ax] - c[ax]) * rs[ax] + 3.814697265625e-06f));
+        }
+        if (leaf) {
+            word[k] = r;  // PT_LEAF | sorted position, count 1
+        } else {
+            word[k] = next_base + int_off[j] + ni;
+            next_front[int_off[j] + ni] = r;
+            ni++;
+        }
+    }
+    uint4 *o = wide16 + 4 * (size_t)(level_base + j);
+    o[0] = make_uint4(hl[0][0] | (hl[0][1] << 16), hl[0][2] | (hl[0][3] << 16), hl[1][0] | (hl[1][1] << 16), hl[1][2] | (hl[1][3] << 16));
+    o[1] = make_uint4(hl[2][0] | (hl[2][1] << 16), hl[2][2] | (hl[2][3] << 16), hh[0][0] | (hh[0][1] << 16), hh[0][2] | (hh[0][3] << 16));
+    o[2] = make_uint4(hh[1][0] | (hh[1][1] << 16), hh[1][2] | (hh[1][3] << 16), hh[2][0] | (hh[2][1] << 16), hh[2][2] | (hh[2][3] << 16));
+    o[3] = make_uint4(word[0], word[1], word[2], word[3]);
+}
+
 // order8 o sorted order: BVH8 position -> primitive id
 __global__ __launch_bounds__(TB) void k_compose(const uint32_t *__restrict__ order8, const uint32_t *__restrict__ prim_of, uint32_t n,
                                                 uint32_t *__restrict__ out)
@@ -679,6 +730,8 @@ struct BvhOut {
     uint4 *d_wide8 = nullptr;
     uint32_t *d_order8 = nullptr;
     uint32_t n_wide8 = 0, levels8 = 0;
+    uint4 *d_wide16t = nullptr;            // BVH4, 64-B nodes, built top-down with contiguous children (k_w4_emit)
+    uint32_t n_wide16t = 0, levels4t = 0;
     float norm_c[3]{}, norm_s[3]{1.f, 1.f, 1.f}, norm_rs[3]{1.f, 1.f, 1.f};
 };
 
@@ -843,7 +896,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         int cf = 0;
         while (count > 0) {
             const uint32_t g = (count + TB - 1) / TB;
-            k_w8_expand<<<g, TB, 0, st>>>(count, d_front[cf].p, (int)n, d_topo.p, d_blo.p, d_bhi.p, d_kids.p, d_ni.p, d_nl.p);
+            k_w8_expand<8><<<g, TB, 0, st>>>(count, d_front[cf].p, (int)n, d_topo.p, d_blo.p, d_bhi.p, d_kids.p, d_ni.p, d_nl.p);
             uint32_t last[2] = { 0, 0 }, tot[2] = { 0, 0 };
             PT_HIP(ctx, hipMemcpyAsync(&last[0], d_ni.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             PT_HIP(ctx, hipMemcpyAsync(&last[1], d_nl.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -867,6 +920,29 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         if (tri_run != n) { ctx->err = "internal: BVH8 build lost triangles"; return PT_ERR_HIP; }
         out.n_wide8 = level_base;
         out.levels8 = levels;
+        // ... and the four-wide tree in the 64-B format, same passes
+        PT_HIP(ctx, hipMalloc((void **)&out.d_wide16t, 64 * (size_t)n_int));
+        PT_HIP(ctx, hipMemsetAsync(d_front[0].p, 0, sizeof(uint32_t), st));
+        count = 1; level_base = 0; levels = 0; cf = 0;
+        while (count > 0) {
+            const uint32_t g = (count + TB - 1) / TB;
+            k_w8_expand<4><<<g, TB, 0, st>>>(count, d_front[cf].p, (int)n, d_topo.p, d_blo.p, d_bhi.p, d_kids.p, d_ni.p, d_nl.p);
+            uint32_t last = 0, tot = 0;
+            PT_HIP(ctx, hipMemcpyAsync(&last, d_ni.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            exclusive_scan(d_ni.p, count, d_sums.p, st);
+            PT_HIP(ctx, hipMemcpyAsync(&tot, d_ni.p + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            const uint32_t next_count = tot + last, next_base = level_base + count;
+            if ((uint64_t)next_base + next_count > n_int) { ctx->err = "internal: BVH4 (top-down) build overran its bounds"; return PT_ERR_HIP; }
+            k_w4_emit<<<g, TB, 0, st>>>(count, level_base, next_base, (int)n, d_kids.p, d_ni.p, d_blo.p, d_bhi.p, out.norm_c[0], out.norm_c[1],
+                                        out.norm_c[2], out.norm_rs[0], out.norm_rs[1], out.norm_rs[2], out.d_wide16t, d_front[cf ^ 1].p);
+            level_base = next_base;
+            count = next_count;
+            cf ^= 1;
+            levels++;
+        }
+        out.n_wide16t = level_base;
+        out.levels4t = levels;
         PT_HIP(ctx, hipStreamSynchronize(st));
         PT_HIP(ctx, hipGetLastError());
     }
@@ -951,6 +1027,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o, true);
     s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
     s->d_wide8 = o.d_wide8; s->n_wide8 = o.n_wide8; s->levels8 = o.levels8;
+    s->d_wide16t = o.d_wide16t; s->n_wide16t = o.n_wide16t; s->levels4t = o.levels4t;
     DevBuf<uint32_t> d_order8;
     d_order8.p = o.d_order8;
     if (rc != PT_OK) return rc;
@@ -1061,6 +1138,8 @@ void ptb_free_scene_buffers(pt_scene *s)
     (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);
     (void)hipFree(s->d_tri_orig); (void)hipFree(s->d_faces); (void)hipFree(s->d_wide16);
     s->d_wide16 = nullptr;
+    (void)hipFree(s->d_wide16t);
+    s->d_wide16t = nullptr;
     (void)hipFree(s->d_wide8); (void)hipFree(s->d_prim_of8); (void)hipFree(s->d_tri4_8); (void)hipFree(s->d_shade64_8); (void)hipFree(s->d_ke4_8);
     s->d_wide8 = nullptr; s->d_prim_of8 = nullptr; s->d_tri4_8 = s->d_shade64_8 = s->d_ke4_8 = nullptr;
     s->d_tri4 = s->d_shade4 = s->d_nodes = s->d_wide = s->d_wide_lbvh = s->d_wide_sah = s->d_tri_orig = nullptr;

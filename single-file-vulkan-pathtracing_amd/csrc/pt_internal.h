@@ -70,6 +70,10 @@ struct pt_scene {
     // d_tri4 / d_shade64 / d_ke4 whenever the BVH8 kernel traverses
     uint4 *d_wide8 = nullptr;
     uint32_t n_wide8 = 0, levels8 = 0;
+    // BVH4 in the 64-B format built top-down (area-guided collapse, the children of a node contiguous): what
+    // k_extend<hbm> walks for scenes whose traversed BVH4 is the collapsed LBVH (lbvh_build.hip k_w4_emit)
+    uint4 *d_wide16t = nullptr;
+    uint32_t n_wide16t = 0, levels4t = 0;
     uint32_t *d_prim_of8 = nullptr;
     float4 *d_tri4_8 = nullptr, *d_shade64_8 = nullptr, *d_ke4_8 = nullptr;
     uint64_t device_bytes8 = 0;

@@ -794,6 +794,7 @@ struct ExtendPlan {
                                 // (and with one-dword stack entries: COMPACT in k_extend)
     bool pairs = false;         // ... and every leaf of the BVH4 is one triangle or one fan pair: the PAIRS kernel
     bool bvh8 = false;          // PT_EXTEND_HBM8: the BVH8 and ITS triangle order (s->d_tri4_8, d_shade64_8, d_ke4_8)
+    bool topdown4 = false;      // HBM variant over the top-down BVH4 with contiguous children (s->d_wide16t)
     size_t smem_wide_entries = 0;  // LDS bytes of the same plan run by the 8-byte-entry kernel (negative tmin)
 };
 
@@ -910,10 +911,13 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     pl.refill = pl.lds_scene ? REFILL_MIN_IDLE : 32;  // big scenes (vote-scheduled steps): 32 idle lanes measured best on C5 (16: -2.5 %, 48: -3 %)
     if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
     pl.grid = ctx->num_cus * per_cu;
+    // the HBM variant of a scene whose traversed BVH4 is the collapsed LBVH walks the top-down layout of it
+    pl.topdown4 = !pl.lds_scene && s->bvh4_builder == 0 && s->d_wide16t && !(getenv("PT_TUNE_TOPDOWN4") && atoi(getenv("PT_TUNE_TOPDOWN4")) == 0);
     // stack bound: the exact one of the BVH4 that is traversed when its builder computed it (small scenes; the
     // surface-area BVH4 is not bounded by the LBVH's height), else a BVH4 node pushes <= 3 entries per level and the
     // collapsed LBVH's wide height is <= binary height/2 + 1
-    const uint32_t bound = s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u) + 1u;
+    const uint32_t bound = pl.topdown4 ? 3u * s->levels4t + 1u
+                           : s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u) + 1u;
     pl.spill_levels = bound > (uint32_t)pl.lds_stack ? bound - (uint32_t)pl.lds_stack : 0u;
     const size_t need = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
     if (need > ctx->spill_bytes) {
@@ -993,7 +997,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
-        ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
+        ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
                               s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
                               tmax, pl.lds_stack, raw);
     }
