@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm", "hbm8"], default="auto", help="closest-hit kernel variant")
     ap.add_argument("--bvh-quality", choices=["fast_trace", "fast_build"], default="fast_trace",
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
+    ap.add_argument("--sort-rays", choices=["auto", "on", "off"], default="auto",
+                    help="per-round device sort of the extend queue by (origin cell, octant); auto = scenes beyond the Infinity Cache")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c5 legs")
@@ -343,6 +345,8 @@ def main():
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
     presenter = ptd.Presenter(pt, ctx, film, film_t, rank, world, cdev, emulate) if world > 1 else None
     flags = 0 if args.no_kernel_events else pt.FLAG_PROFILE
+    sort_flag = {"auto": 0, "on": pt.FLAG_SORT_RAYS, "off": pt.FLAG_NO_SORT_RAYS}[args.sort_rays]
+    flags |= sort_flag
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
                   frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
                   extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM, "hbm8": pt.EXTEND_HBM8}[args.extend])
@@ -360,7 +364,7 @@ def main():
     timed = pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common)
     # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
-        pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, **common))
+        pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, flags=sort_flag, **common))
     if presenter:      # communicator set-up (the first collective of a process) is not a step: always outside the timed region
         presenter.present()
     film.clear()
@@ -411,7 +415,7 @@ def main():
                                    f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
-                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups},
+                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "sort_rays": args.sort_rays},
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,

@@ -131,8 +131,12 @@ enum { PT_PIPELINE_WAVEFRONT = 0 /* generate / extend / shade queues */ };
 enum {
     PT_FLAG_PROFILE = 1u,      /* hipEvent-time every extend/shade launch (adds events to the stream)       */
     PT_FLAG_COUNT_VISITS = 2u, /* instrumented traversal: count BVH4 nodes / triangles visited (slower)      */
-    PT_FLAG_ASYNC = 4u         /* pt_render only queues the work (no waitIdle, main.cpp:683); pt_sync and the */
+    PT_FLAG_ASYNC = 4u,        /* pt_render only queues the work (no waitIdle, main.cpp:683); pt_sync and the */
                                /* film read-backs wait for it.  No timing statistics; not with PT_FLAG_PROFILE */
+    /* Ray sorting (scenes walked out of HBM): before every extend pass after the first the queue is put in (origin cell,
+     * direction octant) order by a device radix sort of a permutation.  AUTO (neither flag): on when the traversal
+     * working set (BVH4 nodes + triangles) exceeds the 256 MiB Infinity Cache.  Results do not depend on it.        */
+    PT_FLAG_SORT_RAYS = 8u, PT_FLAG_NO_SORT_RAYS = 16u
 };
 /* Which closest-hit kernel runs.  All variants implement the same closest-hit definition and
  * return identical bits; AUTO picks by scene size. */

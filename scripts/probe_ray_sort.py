@@ -1,17 +1,17 @@
-"""dev probe: upper bound of what ray sorting can buy on the 1M-triangle soup (config C5).
+"""dev probe: upper bound of what ray sorting can buy on the triangle soup (config C5; `probe_ray_sort.py 8000000` = C5x,
+whose traversal working set exceeds the 256 MiB Infinity Cache).
 Traces the same incoherent rays (origins on random triangles, uniform hemisphere directions) in random
 order and pre-sorted on the host by (origin cell Morton code, direction octant); prints extend-kernel ms."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
-obj = "/tmp/probe_soup.obj"
-pt.write_soup_obj(obj, 1000000, 1)
-v, i, f = pt.load_obj(obj); os.remove(obj)
+NT = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+v, i, f = pt.make_soup(NT, 1)
 ctx = pt.Context(0); sc = pt.Scene(ctx, v, i, f)
 rng = np.random.default_rng(1)
 n = 4_000_000
-tri = v.reshape(-1, 3, 3)[rng.integers(0, 1000000, n)]
+tri = v.reshape(-1, 3, 3)[rng.integers(0, NT, n)]
 b = rng.dirichlet([1, 1, 1], n).astype(np.float32)
 org = (tri * b[:, :, None]).sum(1).astype(np.float32)
 d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
@@ -28,6 +28,7 @@ def run(r, label):
     sc.trace(r[:1000])            # warm
     ctx.reset_stats(); sc.trace(r); ms = ctx.stats().ms_extend
     print(f"{label:40s} extend {ms:8.2f} ms  {n/ms/1e3:8.1f} Mrays/s")
+print(f"{NT} triangles, {n} rays, extend variant AUTO")
 run(rays, "random order")
 for bits in (3, 4, 5, 6, 8):
     run(rays[np.argsort(key(bits), kind='stable')], f"sorted: {bits} bits/axis cell + octant")

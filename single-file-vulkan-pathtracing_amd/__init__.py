@@ -29,6 +29,8 @@ PIPELINE_WAVEFRONT = 0
 FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4
+FLAG_SORT_RAYS = 8
+FLAG_NO_SORT_RAYS = 16
 EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM, EXTEND_HBM8 = 0, 1, 2, 3, 4
 BVH_PREFER_FAST_TRACE, BVH_PREFER_FAST_BUILD = 0, 1
 EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4, scene staged in LDS", 3: "BVH4, scene in HBM/L2",

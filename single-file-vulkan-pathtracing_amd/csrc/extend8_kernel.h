@@ -24,7 +24,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                                              float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                              uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
                                              uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
-                                             int raw_hit)
+                                             int raw_hit, const uint32_t *__restrict__ perm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t n = *count_in;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
-                    q = qq;
+                    q = perm ? perm[qq] : qq;  // ray_sort.hip
                     const float4 ra = rayA[q];
                     const float2 rb = rayB[q];
                     const ptm::f3 org = { ra.x, ra.y, ra.z };
@@ -239,10 +239,10 @@ __global__ __launch_bounds__(TB, PT_EXTEND8_WAVES) void k_extend8(const uint4 *_
                                                 float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                                 uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
                                                 uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
-                                                int raw_hit)
+                                                int raw_hit, const uint32_t *__restrict__ perm)
 {
     extend8_body<COUNT>(nodes8, nb, tri4, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
-                        tmax, lds_stack, raw_hit);
+                        tmax, lds_stack, raw_hit, perm);
 }
 
 }  // namespace

@@ -130,7 +130,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
                                                unsigned long long *stats, uint2 *__restrict__ spill,
                                                uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
-                                               int lds_stack, int raw_hit)
+                                               int lds_stack, int raw_hit, const uint32_t *__restrict__ perm)
 {
     // Scenes in HBM (deep trees, incoherent rays): inside the classic while-while loop the node phase ran
     // at 18 % lane occupancy on the 1M-triangle soup (device counters) -- lanes that already hold a leaf wait
@@ -269,7 +269,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
-                    q = qq;
+                    q = (!LDS_SCENE && perm) ? perm[qq] : qq;  // ray_sort.hip: the queue is walked in (cell, octant) order
                     const float4 ra = rayA[q];
                     const float2 rb = rayB[q];
                     const ptm::f3 org = { ra.x, ra.y, ra.z };
@@ -593,10 +593,10 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         const float4 *__restrict__ g_tri4, uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,       \
         const float2 *__restrict__ rayB, float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,           \
         uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill, uint32_t spill_stride,          \
-        int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit
+        int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit, const uint32_t *__restrict__ perm
 #define PT_EXTEND_ARGS                                                                                               \
     g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
-        refill_min_idle, tmin, tmax, lds_stack, raw_hit
+        refill_min_idle, tmin, tmax, lds_stack, raw_hit, perm
 template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false>
 __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 {

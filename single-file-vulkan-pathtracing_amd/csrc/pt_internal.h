@@ -125,6 +125,8 @@ struct pt_film {
         uint32_t *d_count = nullptr;                  // [2] queue sizes
         size_t cap_slots = 0, cap_color = 0, cap_terms = 0, cap_terms_over = 0;  // allocated capacities (buffers only grow)
         size_t bytes = 0;                             // device bytes held by the buffers above
+        void *d_sort = nullptr;                       // ray_sort.hip scratch for all pipelines (ptw_ray_sort_bytes per slot range)
+        size_t sort_bytes = 0;
     } work;
 };
 

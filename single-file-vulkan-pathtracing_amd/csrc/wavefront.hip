@@ -37,14 +37,20 @@ void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hi
                            const float *norm_rs, const float4 *tri4, uint32_t n_wide, uint32_t n_tris, const float4 *rayA,
                            const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
                            unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
-                           float tmax, int lds_stack, int raw_hit);
+                           float tmax, int lds_stack, int raw_hit, const uint32_t *perm);
 
 // extend_hbm.hip: k_extend8 (BVH8)
 const void *ptw_extend8_fn(bool count);
 void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
                         const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
-                        uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit);
+                        uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
+                        const uint32_t *perm);
+
+// ray_sort.hip
+size_t ptw_ray_sort_bytes(size_t cap);
+const uint32_t *ptw_sort_rays(hipStream_t st, const float4 *rayA, const float2 *rayB, const uint32_t *count, size_t cap,
+                              const float *bmin, const float *bmax, int bits, int num_cus, void *scratch);
 
 namespace {
 
@@ -933,7 +939,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
                    uint32_t *hit_inst, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                    float tmin, float tmax, bool count, bool raw_hit, hipStream_t st, int pipe = 0,
-                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const uint32_t *perm = nullptr)
 {
     const int raw = raw_hit ? 1 : 0;  // hit records as (pos, V, W, det) for k_shade instead of (pos, t, u, v)
     // hipExtLaunchKernelGGL stamps THIS kernel's start/stop into ev0/ev1 (null = plain launch): under
@@ -964,7 +970,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     const uint32_t stride = (uint32_t)pl.grid * TB;
     if (pl.bvh8) {
         ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, rayA, rayB, hit,
-                           count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw);
+                           count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw, perm);
         return;
     }
     const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],
@@ -978,28 +984,28 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, \
                           s->d_wide16, nbox,                                                                          \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
-                          pl.refill, tmin, tmax, pl.lds_stack, raw)
+                          pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr)
     if (no_spill && pl.pairs) {
         if (count)
             hipExtLaunchKernelGGL((k_extend<true, true, false, true>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide,
                                   s->d_wide16, nbox, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill,
-                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw);
+                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr);
         else
             hipExtLaunchKernelGGL(k_extend_lds7p, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
                                   s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
-                                  pl.refill, tmin, tmax, pl.lds_stack, raw);
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr);
     } else if (no_spill) {
         if (count) PT_LAUNCH_EXTEND(true, true, false);
         else
             hipExtLaunchKernelGGL(k_extend_lds7, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
                                   s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
-                                  pl.refill, tmin, tmax, pl.lds_stack, raw);
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr);
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
         ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
                               s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
-                              tmax, pl.lds_stack, raw);
+                              tmax, pl.lds_stack, raw, perm);
     }
 #undef PT_LAUNCH_EXTEND
 }
@@ -1055,7 +1061,7 @@ void free_shape_buffers(pt_film::Work &w)
     w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr; w.d_spill_head = nullptr;
     w.d_color = nullptr; w.d_terms = nullptr; w.d_terms_over = nullptr; w.d_spill = nullptr;
     w.cap_slots = w.cap_color = w.cap_terms = w.cap_terms_over = 0;
-    w.bytes = 0;
+    w.bytes = w.sort_bytes;  // (the ray-sort scratch is not a shape buffer)
 }
 
 // Workspace for (rank, world) tiles, `lanes` frames in flight and `groups` sample groups.  Buffers only
@@ -1100,7 +1106,7 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         free_shape_buffers(w);
         w.d_color = color; w.d_terms = terms; w.d_terms_over = over; w.d_spill = pool;
         w.cap_color = keep_color; w.cap_terms = keep_terms; w.cap_terms_over = keep_over;
-        w.bytes = sizeof(float4) * (keep_color + keep_terms + keep_over) + (pool ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0);
+        w.bytes = sizeof(float4) * (keep_color + keep_terms + keep_over) + (pool ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0) + w.sort_bytes;
         for (int i = 0; i < 2; i++) {
             PT_WORK_ALLOC(w.d_qid[i], sizeof(uint2) * ns);
             PT_WORK_ALLOC(w.d_qstate[i], sizeof(float4) * ns);
@@ -1302,6 +1308,7 @@ void ptw_free_work(pt_film *f)
     (void)hipFree(w.d_hit);
     (void)hipFree(w.d_hit_inst);
     (void)hipFree(w.d_count);
+    (void)hipFree(w.d_sort);
     w = pt_film::Work{};
 }
 
@@ -1418,6 +1425,31 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
         }
     if (n_pipes > 1 && !ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
 
+    // ray sorting (ray_sort.hip): the HBM kernels only; AUTO when the traversal working set does not fit the Infinity Cache
+    bool sort_rays = false;
+    if ((pl.variant == PT_EXTEND_HBM || pl.variant == PT_EXTEND_HBM8) && !s->n_inst) {
+        const uint64_t working_set = pl.bvh8 ? 128ull * s->n_wide8 + 48ull * s->n_tris
+                                             : 64ull * (pl.topdown4 ? s->n_wide16t : s->n_wide) + 48ull * s->n_tris;
+        sort_rays = working_set > (256ull << 20);
+        if (p->flags & PT_FLAG_SORT_RAYS) sort_rays = true;
+        if (p->flags & PT_FLAG_NO_SORT_RAYS) sort_rays = false;
+    }
+    int sort_bits = 4;  // 4 bits per axis + octant = 15-bit keys = two 8-bit passes (C5x: 6 bits, three passes: +0 %, 4 bits: +3.5 %)
+    if (const char *e = getenv("PT_TUNE_SORT_BITS")) sort_bits = std::max(1, std::min(atoi(e), 9));
+    if (sort_rays) {
+        // one scratch area per pipeline, sized for that pipeline's share of the slots (+ slack for the uneven split)
+        const size_t per_pipe = ptw_ray_sort_bytes((size_t)w.n_slots / (size_t)n_pipes + (size_t)rc.slots_per_lane + 1);
+        const size_t need = per_pipe * (size_t)n_pipes;
+        if (need > w.sort_bytes) {
+            (void)hipFree(w.d_sort);
+            w.d_sort = nullptr;
+            w.bytes -= w.sort_bytes;
+            w.sort_bytes = 0;
+            const hipError_t e = hipMalloc(&w.d_sort, need);
+            if (e != hipSuccess) { (void)hipGetLastError(); sort_rays = false; }  // no room: render unsorted
+            else { w.sort_bytes = need; w.bytes += need; }
+        }
+    }
     ctx->stats.extend_variant = pl.variant;
     if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     if (w.n_slots > 0) {
@@ -1468,8 +1500,15 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                     const int cur = pp.cur;
                     hipEvent_t x0 = nullptr, x1 = nullptr, h0 = nullptr, h1 = nullptr;
                     if (profile) { x0 = new_event(); x1 = new_event(); h0 = new_event(); h1 = new_event(); }
+                    const uint32_t *perm = nullptr;
+                    if (sort_rays && round > 0) {  // (round 0 is the primary rays: one origin, generated tile by tile)
+                        const size_t per_pipe = w.sort_bytes / (size_t)n_pipes;
+                        perm = ptw_sort_rays(pp.st, pp.qv[cur].rayA, pp.qv[cur].rayB, &pp.count[cur], pp.n_slots, s->bmin, s->bmax, sort_bits,
+                                             ctx->num_cus, static_cast<char *>(w.d_sort) + per_pipe * (size_t)k);
+                        ctx->stats.launches_other += 1 + 5 * (uint32_t)((3 * sort_bits + 3 + 7) / 8);
+                    }
                     launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
-                                  ctx->d_stats, p->tmin, p->tmax, count_visits, true, pp.st, k, x0, x1);
+                                  ctx->d_stats, p->tmin, p->tmax, count_visits, true, pp.st, k, x0, x1, perm);
 #define PT_LAUNCH_SHADE(N, L)                                                                                                  \
     hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \

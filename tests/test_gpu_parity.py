@@ -1387,3 +1387,32 @@ def test_bvh8_render_bit_exact_and_auto_selection(pt, orc, gpu_ctx):
         assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes()
         film.close()
     gs.close()
+
+
+@pytest.mark.parametrize("extend", [3, 4])
+def test_ray_sorting_changes_no_bit(pt, orc, gpu_ctx, extend):
+    """PT_FLAG_SORT_RAYS: before every extend pass after the first the queue is walked in (origin cell, direction octant)
+    order through a permutation sorted on the device.  Film, display image and ray count equal the oracle's and the
+    unsorted render's -- one pipeline and two, sample groups, progressive frames, BVH4 and BVH8 kernels."""
+    v, i, f = _soup(30000, 17, spread=0.05)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    kw = dict(width=160, height=96, spp_per_frame=4, max_depth=6)
+    ofilm, obgra, orays = _render_oracle(orc, osc, 3, **kw)
+    for flags, groups in ((pt.FLAG_SORT_RAYS, 0), (pt.FLAG_SORT_RAYS | pt.FLAG_COUNT_VISITS, 2), (pt.FLAG_NO_SORT_RAYS, 0)):
+        film = pt.Film(gpu_ctx, 160, 96)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(frame=0, frame_count=1, extend=extend, flags=flags, **kw))
+        pt.render(gs, film, pt.default_params(frame=1, frame_count=2, extend=extend, flags=flags, sample_groups=groups, **kw))
+        assert gpu_ctx.stats().rays == orays
+        assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes()
+        film.close()
+    # two pipelines (>= 4 M slots): 1080p, 1 spp x 2 groups... a large launch, compared with its unsorted twin
+    kw = dict(width=1920, height=1080, spp_per_frame=2, max_depth=5, frame=0, frame_count=2, extend=extend)
+    a, b = pt.Film(gpu_ctx, 1920, 1080), pt.Film(gpu_ctx, 1920, 1080)
+    gpu_ctx.reset_stats()
+    pt.render(gs, a, pt.default_params(flags=pt.FLAG_NO_SORT_RAYS, **kw))
+    rays = gpu_ctx.stats().rays
+    gpu_ctx.reset_stats()
+    pt.render(gs, b, pt.default_params(flags=pt.FLAG_SORT_RAYS, **kw))
+    assert gpu_ctx.stats().rays == rays and a.read_f32().tobytes() == b.read_f32().tobytes()
+    a.close(); b.close(); gs.close()
