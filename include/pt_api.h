@@ -127,7 +127,15 @@ pt_status pt_film_read_bgra8(pt_film *film, uint8_t *bgra);
 void pt_film_destroy(pt_film *film);
 
 /* ---- dispatch: pushConstants + traceRaysKHR (main.cpp:656-659) ------------------------- */
-enum { PT_PIPELINE_WAVEFRONT = 0 /* generate / extend / shade queues */ };
+enum {
+    PT_PIPELINE_WAVEFRONT = 0,     /* generate / extend / shade queues: the reference's estimator, bit for bit        */
+    /* NOT the reference's estimator (opt-in, no parity with the reference's images at equal sample counts, only in
+     * expectation): next-event estimation.  At every hit one point on one emitter (chosen by area) is sampled and a
+     * SHADOW ray queued -- a third queue, compacted like the others and traced by the same extend kernels as an
+     * any-hit query; the emission of a surface the path runs into counts for camera rays only.  Same random stream
+     * otherwise (three more numbers per hit).  Fully specified arithmetic like the reference path's (the tests' CPU checker restates it bit for bit).  Single-level scenes. */
+    PT_PIPELINE_WAVEFRONT_NEE = 1
+};
 enum {
     PT_FLAG_PROFILE = 1u,      /* hipEvent-time every extend/shade launch (adds events to the stream)       */
     PT_FLAG_COUNT_VISITS = 2u, /* instrumented traversal: count BVH4 nodes / triangles visited (slower)      */

@@ -145,6 +145,11 @@ struct orc_scene {
     uint32_t n_inst;
     orc_instance *inst;
     orc_bvh tlas;  /* LBVH over the instances' world boxes */
+    /* emitters (Ke != 0) in primitive order, for the NEE estimator: 16 floats each
+     * {A.xyz, B.xyz, C.xyz, N.xyz, Ke.rgb, cdf} and the sum of their areas */
+    uint32_t n_lights;
+    float *lights;
+    float light_area;
 };
 
 static inline uint64_t expand21(uint32_t v)
@@ -367,13 +372,42 @@ orc_scene *orc_scene_create(const float *vertices, uint32_t n_verts, const uint3
                 s->tri[9 * (size_t)t + 3 * c + k] = vertices[3 * (size_t)indices[3 * (size_t)t + c] + k];
     memcpy(s->face, faces, sizeof(float) * 6 * (size_t)n_tris);
     build_blas(s);
+    /* emitters for the NEE estimator (pt_api: PT_PIPELINE_WAVEFRONT_NEE): every triangle with Ke != 0, in primitive
+     * order; normal as closesthit.rchit:43-48; area = |cross| / 2; cdf = running float sum of the areas */
+    for (uint32_t t = 0; t < n_tris; t++) {
+        const float *f = s->face + 6 * (size_t)t;
+        if (f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f) s->n_lights++;
+    }
+    if (s->n_lights) {
+        s->lights = malloc(sizeof(float) * 16 * (size_t)s->n_lights);
+        uint32_t k = 0;
+        float run = 0.0f;
+        for (uint32_t t = 0; t < n_tris; t++) {
+            const float *f = s->face + 6 * (size_t)t;
+            if (!(f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f)) continue;
+            const float *tv = s->tri + 9 * (size_t)t;
+            float *L = s->lights + 16 * (size_t)k++;
+            float e1[3], e2[3];
+            for (int c = 0; c < 9; c++) L[c] = tv[c];
+            for (int c = 0; c < 3; c++) { e1[c] = tv[3 + c] - tv[c]; e2[c] = tv[6 + c] - tv[c]; }
+            float cx = e1[1] * e2[2] - e1[2] * e2[1];
+            float cy = e1[2] * e2[0] - e1[0] * e2[2];
+            float cz = e1[0] * e2[1] - e1[1] * e2[0];
+            float len = sqrtf((cx * cx + cy * cy) + cz * cz);
+            L[9] = -(cx / len); L[10] = -(cy / len); L[11] = -(cz / len);
+            L[12] = f[3]; L[13] = f[4]; L[14] = f[5];
+            run = run + 0.5f * len;
+            L[15] = run;
+        }
+        s->light_area = run;
+    }
     return s;
 }
 
 void orc_scene_destroy(orc_scene *s)
 {
     if (!s) return;
-    free(s->tri); free(s->face); free(s->inst); bvh_free(&s->blas); bvh_free(&s->tlas); free(s);
+    free(s->tri); free(s->face); free(s->inst); free(s->lights); bvh_free(&s->blas); bvh_free(&s->tlas); free(s);
 }
 
 void orc_scene_bvh_info(const orc_scene *s, orc_bvh_info *info)
@@ -700,7 +734,35 @@ static void render_pixel(job *jb, uint32_t px, uint32_t py)
             }
             float pos[3], n[3], brdf[3], emi[3];
             orc_shade_hit(s, &h, pos, n, brdf, emi);
-            for (int k = 0; k < 3; k++) color[k] = color[k] + weight[k] * emi[k]; /* :76 */
+            if (!p->nee || depth == 0)
+                for (int k = 0; k < 3; k++) color[k] = color[k] + weight[k] * emi[k]; /* :76 */
+            if (p->nee && s->n_lights && !s->n_inst) {
+                /* next-event estimation (not in the reference): one point on one emitter, chosen by area; the
+                 * contribution weight * brdf * Ke * cos_s |cos_l| / d^2 * total_area if the shadow ray is free */
+                const float rl = orc_rand(&seed), ru = orc_rand(&seed), rv = orc_rand(&seed);
+                const float pick = rl * s->light_area;
+                uint32_t li = 0;
+                while (li + 1 < s->n_lights && !(s->lights[16 * (size_t)li + 15] > pick)) li++;
+                const float *L = s->lights + 16 * (size_t)li;
+                const float su = sqrtf(ru);
+                const float b0 = 1.0f - su, b1 = su * (1.0f - rv), b2 = su * rv;
+                float d[3];
+                for (int k = 0; k < 3; k++) d[k] = ((L[k] * b0 + L[3 + k] * b1) + L[6 + k] * b2) - pos[k];
+                const float d2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+                if (d2 > 0.0f) {
+                    const float dist = sqrtf(d2);
+                    float wi[3] = { d[0] / dist, d[1] / dist, d[2] / dist };
+                    const float cs = (wi[0] * n[0] + wi[1] * n[1]) + wi[2] * n[2];
+                    const float cl = fabsf((wi[0] * L[9] + wi[1] * L[10]) + wi[2] * L[11]);
+                    if (cs > 0.0f && cl > 0.0f) {
+                        const float fgeo = ((cs * cl) / d2) * s->light_area;
+                        orc_hit sh;
+                        orc_trace(s, jb->mode, pos, wi, p->tmin, dist * 0.999f, &sh, &jb->cnt);
+                        if (sh.prim == ORC_MISS)
+                            for (int k = 0; k < 3; k++) color[k] = color[k] + ((weight[k] * brdf[k]) * L[12 + k]) * fgeo;
+                    }
+                }
+            }
             for (int k = 0; k < 3; k++) org[k] = pos[k];                            /* :77 */
             float r1 = orc_rand(&seed); /* cos(theta) first, azimuth second (appendix B.3) */
             float r2 = orc_rand(&seed);

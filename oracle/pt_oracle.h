@@ -62,6 +62,9 @@ typedef struct orc_params {
     float    cam_target[3];    /* target = (d.x+tx, d.y+ty, tz), (0,-1,2), raygen.rgen:56 */
     float    env[3];           /* (0.7,0.6,0.5), miss.rmiss:10                          */
     uint32_t libm_sincos;      /* 0 = canonical polynomial, 1 = libm sinf/cosf (tolerance study) */
+    uint32_t nee;              /* 1 = the product's opt-in PT_PIPELINE_WAVEFRONT_NEE estimator (NOT the reference's):
+                                  next-event estimation, one light sample + one shadow ray per hit; emission of a hit
+                                  counts for camera rays only.  Same expectation, other variance and other random numbers. */
 } orc_params;
 void orc_params_default(orc_params *p);
 

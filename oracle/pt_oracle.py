@@ -21,7 +21,7 @@ class Params(C.Structure):
         ("spp_per_frame", C.c_uint32), ("max_depth", C.c_uint32),
         ("tmin", C.c_float), ("tmax", C.c_float),
         ("cam_origin", C.c_float * 3), ("cam_target", C.c_float * 3), ("env", C.c_float * 3),
-        ("libm_sincos", C.c_uint32),
+        ("libm_sincos", C.c_uint32), ("nee", C.c_uint32),
     ]
 
 

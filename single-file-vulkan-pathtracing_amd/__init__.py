@@ -26,6 +26,7 @@ PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_OOM",
                 5: "PT_ERR_UNSUPPORTED"}
 PIPELINE_WAVEFRONT = 0
+PIPELINE_WAVEFRONT_NEE = 1
 FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4

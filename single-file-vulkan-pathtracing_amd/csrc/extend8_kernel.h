@@ -24,7 +24,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                                              float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                              uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
                                              uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
-                                             int raw_hit, const uint32_t *__restrict__ perm)
+                                             int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t n = *count_in;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                     ay = inv.y < 0.f ? 48u : 0u;
                     az = inv.z < 0.f ? 48u : 0u;
                     oct = (inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u);
-                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_t = ray_tmax ? ray_tmax[q] : tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;  // (shadow rays: extend_kernel.h)
                     best_pos = PT_MISS; best_prim = PT_MISS;
                     // the root as the only child (slot `oct`, so priority 0) of a virtual parent
                     ng_base = 0u;
@@ -172,6 +172,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 // closest t; equal t -> lowest gl_PrimitiveID
                 if (t < best_t || (t == best_t && prim < best_prim)) {
                     best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                    if (ray_tmax) { sp = 0; tg_hits = 0u; ng_meta &= 0xFFFFFF00u; }  // any hit ends a shadow ray
                 }
             }
             if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
@@ -239,10 +240,10 @@ __global__ __launch_bounds__(TB, PT_EXTEND8_WAVES) void k_extend8(const uint4 *_
                                                 float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                                 uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
                                                 uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
-                                                int raw_hit, const uint32_t *__restrict__ perm)
+                                                int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
     extend8_body<COUNT>(nodes8, nb, tri4, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
-                        tmax, lds_stack, raw_hit, perm);
+                        tmax, lds_stack, raw_hit, perm, ray_tmax);
 }
 
 }  // namespace

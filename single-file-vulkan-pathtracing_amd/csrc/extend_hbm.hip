@@ -40,13 +40,13 @@ void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hi
                            const float *norm_rs, const float4 *tri4, uint32_t n_wide, uint32_t n_tris, const float4 *rayA,
                            const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
                            unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
-                           float tmax, int lds_stack, int raw_hit, const uint32_t *perm)
+                           float tmax, int lds_stack, int raw_hit, const uint32_t *perm, const float *ray_tmax)
 {
     const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
 #define PT_LAUNCH_HBM(C, U)                                                                                                  \
     hipExtLaunchKernelGGL((k_extend<false, C, true, false, U>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, wide, wide16, \
                           nb, tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill, tmin, \
-                          tmax, lds_stack, raw_hit, perm)
+                          tmax, lds_stack, raw_hit, perm, ray_tmax)
     if (unified_step()) {
         if (count) PT_LAUNCH_HBM(true, true); else PT_LAUNCH_HBM(false, true);
     } else {
@@ -65,13 +65,13 @@ void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEv
                         const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                         uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
-                        const uint32_t *perm)
+                        const uint32_t *perm, const float *ray_tmax)
 {
     const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
     if (count)
         hipExtLaunchKernelGGL((k_extend8<true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rayA, rayB, hit,
-                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm);
+                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax);
     else
         hipExtLaunchKernelGGL((k_extend8<false>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rayA, rayB, hit,
-                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm);
+                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax);
 }

@@ -130,8 +130,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
                                                unsigned long long *stats, uint2 *__restrict__ spill,
                                                uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
-                                               int lds_stack, int raw_hit, const uint32_t *__restrict__ perm)
+                                               int lds_stack, int raw_hit, const uint32_t *__restrict__ perm,
+                                               const float *__restrict__ ray_tmax)
 {
+    // ray_tmax (shadow rays of the NEE pipeline): a per-ray upper bound instead of `tmax`, and ANY hit below it ends
+    // the walk (the record then only says hit or miss)
     // Scenes in HBM (deep trees, incoherent rays): inside the classic while-while loop the node phase ran
     // at 18 % lane occupancy on the 1M-triangle soup (device counters) -- lanes that already hold a leaf wait
     // for the last lane to finish descending.  There the wave instead takes ONE step per iteration, of the
@@ -292,7 +295,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                         orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y),
                                  ptm::sel3(pre.kz, org.x, org.y, org.z) };
                     }
-                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_t = ray_tmax ? ray_tmax[q] : tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS;
                     cur = 0u;  // wide root
                     sp = 0;
@@ -362,6 +365,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                             // closest t; equal t -> lowest gl_PrimitiveID
                             if (t < best_t || (t == best_t && prim < best_prim)) {
                                 best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                                if (ray_tmax) sp = 0;
                             }
                         }
                         if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
@@ -511,6 +515,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                         // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
                         if (t < best_t || (t == best_t && prim < best_prim)) {
                             best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                            if (ray_tmax) sp = 0;  // any hit will do: nothing pending any more
                         }
                     };
                     finish(Cx * By - Cy * Bx, pAC - qAC, Bx * Ay - By * Ax, Az_, Bz_, Cz_, first, __float_as_uint(a.w));
@@ -544,6 +549,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                         // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
                         if (t < best_t || (t == best_t && prim < best_prim)) {
                             best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                            if (ray_tmax) sp = 0;
                         }
                     }
                 }
@@ -593,10 +599,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         const float4 *__restrict__ g_tri4, uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,       \
         const float2 *__restrict__ rayB, float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,           \
         uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill, uint32_t spill_stride,          \
-        int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit, const uint32_t *__restrict__ perm
+        int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit, const uint32_t *__restrict__ perm,       \
+        const float *__restrict__ ray_tmax
 #define PT_EXTEND_ARGS                                                                                               \
     g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
-        refill_min_idle, tmin, tmax, lds_stack, raw_hit, perm
+        refill_min_idle, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax
 template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false>
 __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 {
@@ -605,15 +612,29 @@ __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 // The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
 // asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations
 // keep the plain launch bounds they were tuned with.
+// (perm / ray_tmax as literal null pointers: the hot instantiations must not carry the shadow-ray branches -- with them
+// as run-time arguments the 72-VGPR kernels spilled two registers and lost 8 %; shadow rays run the _sh twins)
+#define PT_EXTEND_ARGS_PLAIN                                                                                         \
+    g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
+        refill_min_idle, tmin, tmax, lds_stack, raw_hit, nullptr, nullptr
 __global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7(PT_EXTEND_PARAMS)
+{
+    extend_body<true, false, false>(PT_EXTEND_ARGS_PLAIN);
+}
+__global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7_sh(PT_EXTEND_PARAMS)
 {
     extend_body<true, false, false>(PT_EXTEND_ARGS);
 }
 // ... and the same over a BVH4 with one primitive (triangle or fan pair) per leaf: what the Cornell box runs by default
 __global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7p(PT_EXTEND_PARAMS)
 {
+    extend_body<true, false, false, true>(PT_EXTEND_ARGS_PLAIN);
+}
+__global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7p_sh(PT_EXTEND_PARAMS)
+{
     extend_body<true, false, false, true>(PT_EXTEND_ARGS);
 }
+#undef PT_EXTEND_ARGS_PLAIN
 #undef PT_EXTEND_PARAMS
 #undef PT_EXTEND_ARGS
 

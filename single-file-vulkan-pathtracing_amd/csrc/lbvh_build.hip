@@ -19,6 +19,7 @@
 
 #include "device_scan.h"  // block_exclusive_scan, k_scan_*, exclusive_scan
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -971,6 +972,32 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
+    {   // emitters for the NEE pipeline: normal as closesthit.rchit:43-48, area = |cross| / 2, cdf = running float sum of the
+        // areas in primitive order (this file is compiled with -ffp-contract=off on the host side too)
+        std::vector<float4> lights;
+        float run = 0.f;
+        for (uint32_t t = 0; t < n; t++) {
+            const float *f = h_faces + 6 * (size_t)t;
+            if (!(f[3] != 0.f || f[4] != 0.f || f[5] != 0.f)) continue;
+            const float *a = h_vertices + 3 * (size_t)h_indices[3 * (size_t)t + 0], *b = h_vertices + 3 * (size_t)h_indices[3 * (size_t)t + 1],
+                        *c = h_vertices + 3 * (size_t)h_indices[3 * (size_t)t + 2];
+            const float e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+            const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const float len = sqrtf((cx * cx + cy * cy) + cz * cz);
+            run = run + 0.5f * len;
+            lights.push_back(make_float4(a[0], a[1], a[2], run));
+            lights.push_back(make_float4(b[0], b[1], b[2], 0.f));
+            lights.push_back(make_float4(c[0], c[1], c[2], 0.f));
+            lights.push_back(make_float4(-(cx / len), -(cy / len), -(cz / len), 0.f));
+            lights.push_back(make_float4(f[3], f[4], f[5], 0.f));
+        }
+        s->n_lights = (uint32_t)(lights.size() / 5);
+        s->light_area = run;
+        if (s->n_lights) {
+            PT_HIP(ctx, hipMalloc((void **)&s->d_lights, sizeof(float4) * lights.size()));
+            PT_HIP(ctx, hipMemcpy(s->d_lights, lights.data(), sizeof(float4) * lights.size(), hipMemcpyHostToDevice));
+        }
+    }
     s->d_wide_lbvh = s->d_wide; s->n_wide_lbvh = s->n_wide; s->stack_need_lbvh = s->stack_need;
     s->bvh4_builder = 0;
     s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;
@@ -1062,6 +1089,8 @@ void ptb_free_scene_buffers(pt_scene *s)
     s->d_wide16 = nullptr;
     (void)hipFree(s->d_wide16t);
     s->d_wide16t = nullptr;
+    (void)hipFree(s->d_lights);
+    s->d_lights = nullptr; s->n_lights = 0;
     (void)hipFree(s->d_wide8); (void)hipFree(s->d_prim_of8); (void)hipFree(s->d_tri4_8); (void)hipFree(s->d_shade64_8); (void)hipFree(s->d_ke4_8);
     s->d_wide8 = nullptr; s->d_prim_of8 = nullptr; s->d_tri4_8 = s->d_shade64_8 = s->d_ke4_8 = nullptr;
     s->d_tri4 = s->d_shade4 = s->d_nodes = s->d_wide = s->d_wide_lbvh = s->d_wide_sah = s->d_tri_orig = nullptr;

@@ -89,6 +89,11 @@ struct pt_scene {
     unsigned long long *d_keys = nullptr;  // sorted Morton keys (kept for parity read-back)
     uint32_t *d_prim_of = nullptr;         // sorted position -> prim id
     uint64_t device_bytes = 0;
+    // emitters (Ke != 0) in primitive order for PT_PIPELINE_WAVEFRONT_NEE: 5 float4 each {A, cdf} {B, 0} {C, 0} {N, 0} {Ke, 0}
+    // (cdf = running float sum of the triangle areas, light_area its total)
+    float4 *d_lights = nullptr;
+    uint32_t n_lights = 0;
+    float light_area = 0.f;
     // two-level scenes: instances in TLAS leaf order, 6 float4 each {object->world rows, world->object rows}
     uint32_t n_inst = 0, n_tlas_wide = 0, tlas_height = 0;
     float4 *d_inst6 = nullptr;
@@ -125,6 +130,10 @@ struct pt_film {
         uint32_t *d_count = nullptr;                  // [2] queue sizes
         size_t cap_slots = 0, cap_color = 0, cap_terms = 0, cap_terms_over = 0;  // allocated capacities (buffers only grow)
         size_t bytes = 0;                             // device bytes held by the buffers above
+        // shadow queue of the NEE pipeline (one entry per hit whose light sample faces it)
+        float4 *d_sq_rayA = nullptr; float2 *d_sq_rayB = nullptr; float4 *d_sq_contrib = nullptr;  // {r, g, b, tmax}
+        uint32_t *d_sq_slot = nullptr; float *d_sq_tmax = nullptr; float4 *d_sq_hit = nullptr; uint32_t *d_sq_count = nullptr;
+        size_t cap_sq = 0;
         void *d_sort = nullptr;                       // ray_sort.hip scratch for all pipelines (ptw_ray_sort_bytes per slot range)
         size_t sort_bytes = 0;
     } work;

@@ -37,7 +37,7 @@ void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hi
                            const float *norm_rs, const float4 *tri4, uint32_t n_wide, uint32_t n_tris, const float4 *rayA,
                            const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
                            unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
-                           float tmax, int lds_stack, int raw_hit, const uint32_t *perm);
+                           float tmax, int lds_stack, int raw_hit, const uint32_t *perm, const float *ray_tmax);
 
 // extend_hbm.hip: k_extend8 (BVH8)
 const void *ptw_extend8_fn(bool count);
@@ -45,7 +45,7 @@ void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEv
                         const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                         uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
-                        const uint32_t *perm);
+                        const uint32_t *perm, const float *ray_tmax);
 
 // ray_sort.hip
 size_t ptw_ray_sort_bytes(size_t cap);
@@ -538,6 +538,58 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
     }
 }
 
+// ---- next-event estimation (PT_PIPELINE_WAVEFRONT_NEE; NOT the reference's estimator, see include/pt_api.h) ----------
+// The third queue: one shadow ray per hit whose light sample faces the surface.  contrib = the radiance the path gains if
+// the ray reaches the light: ((weight * brdf) * Ke) * (cos_s |cos_l| / d^2 * total light area), .w = the ray's tmax.
+struct ShadowQueue {
+    float4 *rayA;     // {org.xyz, dir.x}
+    float2 *rayB;     // {dir.y, dir.z}
+    float4 *contrib;  // {r, g, b, tmax}
+    float *tmax;      // the same tmax as a plain array: what the extend kernels read (ray_tmax)
+    uint32_t *slot;
+};
+
+// One light sample for the hit at `pos` (normal n, brdf, path weight w); the operations and their order are part of the
+// pipeline's definition (the CPU checker of the tests restates them, and the two agree bit for bit).  Returns false when no shadow ray is needed.
+__device__ __forceinline__ bool nee_sample(const float4 *__restrict__ lights, uint32_t n_lights, float light_area, uint32_t &seed,
+                                           const ptm::f3 pos, const ptm::f3 n, float br, float bg, float bb, float wr, float wg,
+                                           float wb, ptm::f3 &wi, float4 &contrib)
+{
+    const float rl = ptm::rnd(seed), ru = ptm::rnd(seed), rv = ptm::rnd(seed);
+    const float pick = rl * light_area;
+    uint32_t li = 0;
+    while (li + 1u < n_lights && !(lights[5 * (size_t)li].w > pick)) li++;
+    const float4 A = lights[5 * (size_t)li + 0], B = lights[5 * (size_t)li + 1], C = lights[5 * (size_t)li + 2],
+                 N = lights[5 * (size_t)li + 3], Ke = lights[5 * (size_t)li + 4];
+    const float su = ptm::fsqrt(ru);
+    const float b0 = 1.0f - su, b1 = su * (1.0f - rv), b2 = su * rv;
+    const float dx = ((A.x * b0 + B.x * b1) + C.x * b2) - pos.x, dy = ((A.y * b0 + B.y * b1) + C.y * b2) - pos.y,
+                dz = ((A.z * b0 + B.z * b1) + C.z * b2) - pos.z;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (!(d2 > 0.0f)) return false;
+    const float dist = ptm::fsqrt(d2);
+    wi = { ptm::fdiv(dx, dist), ptm::fdiv(dy, dist), ptm::fdiv(dz, dist) };
+    const float cs = (wi.x * n.x + wi.y * n.y) + wi.z * n.z;
+    const float cl = fabsf((wi.x * N.x + wi.y * N.y) + wi.z * N.z);
+    if (!(cs > 0.0f && cl > 0.0f)) return false;
+    const float fgeo = ptm::fdiv(cs * cl, d2) * light_area;
+    contrib = make_float4(((wr * br) * Ke.x) * fgeo, ((wg * bg) * Ke.y) * fgeo, ((wb * bb) * Ke.z) * fgeo, dist * 0.999f);
+    return true;
+}
+
+// after the shadow rays were traced: the contributions of those that reached their light
+__global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad, const float4 *__restrict__ sq_hit,
+                                                   const float4 *__restrict__ contrib, const uint32_t *__restrict__ slot,
+                                                   const uint32_t *__restrict__ count)
+{
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) {
+        if (__float_as_uint(sq_hit[i].x) != PT_MISS) continue;  // occluded
+        const float4 c = contrib[i];
+        add_radiance(rc, rad, slot[i], c.x, c.y, c.z);
+    }
+}
+
 // ---- shade: closesthit / miss + the bounce logic of raygen.rgen:76-83, regeneration, compaction
 // k_shade: paths per thread and waves per SIMD asked of the compiler.  Measured (C2 / C5 Mrays/s, same box): 4 x 4 waves
 // (105 VGPRs) 22 050 / 2 266; 4 x 5 (96 VGPRs, 14 spilled since the term-log tiers) 22 060 / 2 258; 3 x 5 22 260 / 2 271;
@@ -549,14 +601,16 @@ __global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ t
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 7
 #endif
-template <int SH_ITEMS, bool LDS_TABLES>
-__global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
+template <int SH_ITEMS, bool LDS_TABLES, bool NEE = false>
+__global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
                                               uint32_t n_tris,
                                               const float4 *__restrict__ hit, Radiance rad, QueueView in,
                                               QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out,
                                               const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst,
-                                              const float4 *__restrict__ shade64, const float4 *__restrict__ ke4)
+                                              const float4 *__restrict__ shade64, const float4 *__restrict__ ke4,
+                                              const float4 *__restrict__ lights, uint32_t n_lights, float light_area,
+                                              ShadowQueue sq, uint32_t *sq_count)
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
@@ -581,10 +635,14 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
         uint32_t o_slot[SH_ITEMS], o_ctr[SH_ITEMS];
         float4 o_state[SH_ITEMS], o_rayA[SH_ITEMS];
         float2 o_rayB[SH_ITEMS];
+        bool s_alive[SH_ITEMS];          // NEE: a shadow ray for this item
+        float4 s_rayA[SH_ITEMS], s_contrib[SH_ITEMS];
+        float2 s_rayB[SH_ITEMS];
 #pragma unroll
         for (int it = 0; it < SH_ITEMS; it++) {
             const uint32_t q = base + it * TB + threadIdx.x;
             alive[it] = false;
+            if (NEE) { s_alive[it] = false; o_slot[it] = 0u; }
             if (q >= n) continue;
             const uint2 id = in.id[q];
             const uint32_t slot = id.x, ctr = id.y;
@@ -617,10 +675,11 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
                 // non-negative accumulator, so the read-modify-write is skipped for non-emitters
                 // (NaN compares false and still takes the add).
                 const float er = wr * s1.z, eg = wg * s1.w, eb = wb * s2.x;
-                if (!(er == 0.f && eg == 0.f && eb == 0.f)) add_radiance(rc, rad, slot, er, eg, eb);
+                // (NEE: the emitters are sampled explicitly, so running into one counts for camera rays only)
+                if ((!NEE || depth == 0u) && !(er == 0.f && eg == 0.f && eb == 0.f)) add_radiance(rc, rad, slot, er, eg, eb);
                 depth++;
                 terminated = depth >= rc.max_depth;  // raygen.rgen:62 loop bound
-                if (!terminated) {
+                if (!terminated || (NEE && n_lights)) {
                     if (LDS_TABLES) {
                         a = tri4[3 * pos + 0]; b = tri4[3 * pos + 1]; c = tri4[3 * pos + 2];
                     } else {
@@ -649,6 +708,16 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
                         const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
                         org = pw;
                         nrm = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
+                    }
+                    if (NEE && n_lights) {  // one light sample -> shadow queue (three random numbers, drawn before the bounce's)
+                        ptm::f3 wi;
+                        float4 cb;
+                        if (nee_sample(lights, n_lights, light_area, seed, org, nrm, s0.w, s1.x, s1.y, wr, wg, wb, wi, cb)) {
+                            s_alive[it] = true;
+                            s_rayA[it] = make_float4(org.x, org.y, org.z, wi.x);
+                            s_rayB[it] = make_float2(wi.y, wi.z);
+                            s_contrib[it] = cb;
+                        }
                     }
                     const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
                     const float r2 = ptm::rnd(seed);
@@ -683,6 +752,20 @@ __global__ __launch_bounds__(TB, PT_SHADE_WAVES) void k_shade(RenderConst rc, co
             o_rayB[it] = make_float2(dir.y, dir.z);
         }
         uint32_t dst[SH_ITEMS];
+        if (NEE) {  // the shadow queue, compacted like the path queue (its entries outlive this path's regeneration: own slot copy)
+            uint32_t sdst[SH_ITEMS];
+            chunk_offsets<SH_ITEMS>(s_alive, sdst, sq_count, s_wcnt, &s_base);
+#pragma unroll
+            for (int it = 0; it < SH_ITEMS; it++) {
+                if (s_alive[it]) {
+                    sq.rayA[sdst[it]] = s_rayA[it];
+                    sq.rayB[sdst[it]] = s_rayB[it];
+                    sq.contrib[sdst[it]] = s_contrib[it];
+                    sq.tmax[sdst[it]] = s_contrib[it].w;
+                    sq.slot[sdst[it]] = o_slot[it];
+                }
+            }
+        }
         chunk_offsets<SH_ITEMS>(alive, dst, count_out, s_wcnt, &s_base);
 #pragma unroll
         for (int it = 0; it < SH_ITEMS; it++) {
@@ -939,7 +1022,8 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const float2 *rayB, float4 *hit,
                    uint32_t *hit_inst, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                    float tmin, float tmax, bool count, bool raw_hit, hipStream_t st, int pipe = 0,
-                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const uint32_t *perm = nullptr)
+                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const uint32_t *perm = nullptr,
+                   const float *ray_tmax = nullptr)
 {
     const int raw = raw_hit ? 1 : 0;  // hit records as (pos, V, W, det) for k_shade instead of (pos, t, u, v)
     // hipExtLaunchKernelGGL stamps THIS kernel's start/stop into ev0/ev1 (null = plain launch): under
@@ -970,7 +1054,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     const uint32_t stride = (uint32_t)pl.grid * TB;
     if (pl.bvh8) {
         ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, rayA, rayB, hit,
-                           count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw, perm);
+                           count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw, perm, ray_tmax);
         return;
     }
     const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],
@@ -984,28 +1068,28 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, \
                           s->d_wide16, nbox,                                                                          \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
-                          pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr)
+                          pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax)
     if (no_spill && pl.pairs) {
         if (count)
             hipExtLaunchKernelGGL((k_extend<true, true, false, true>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide,
                                   s->d_wide16, nbox, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill,
-                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr);
+                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax);
         else
-            hipExtLaunchKernelGGL(k_extend_lds7p, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
+            hipExtLaunchKernelGGL(ray_tmax ? k_extend_lds7p_sh : k_extend_lds7p, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
                                   s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
-                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr);
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax);
     } else if (no_spill) {
         if (count) PT_LAUNCH_EXTEND(true, true, false);
         else
-            hipExtLaunchKernelGGL(k_extend_lds7, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
+            hipExtLaunchKernelGGL(ray_tmax ? k_extend_lds7_sh : k_extend_lds7, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
                                   s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
-                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr);
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax);
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
         ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
                               s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
-                              tmax, pl.lds_stack, raw, perm);
+                              tmax, pl.lds_stack, raw, perm, ray_tmax);
     }
 #undef PT_LAUNCH_EXTEND
 }
@@ -1260,9 +1344,12 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, int shrink = 0)
 // The shape of a render and its workspace.  An AUTO shape that does not fit after all (another allocator took the
 // memory between hipMemGetInfo and hipMalloc) is planned again for half the memory, down to one frame and one group;
 // an explicit shape that does not fit is PT_ERR_OOM.  Either way a failure leaves the film usable.
-pt_status shape_and_work(pt_film *f, const pt_params *p, RenderShape &sh)
+pt_status shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh)
 {
     pt_status rc = PT_OK;
+    pt_params p_local = *p_in;
+    if (p_local.pipeline == PT_PIPELINE_WAVEFRONT_NEE) p_local.sample_groups = 1;  // up to max_depth + 1 radiance terms per sample: the plain accumulator
+    const pt_params *p = &p_local;
     for (int attempt = 0; attempt < 12; attempt++) {
         sh = choose_shape(f, p, attempt);
         rc = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
@@ -1283,7 +1370,12 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
         return PT_ERR_INVALID_ARG;
     }
     if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
-    if (p->pipeline != PT_PIPELINE_WAVEFRONT) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+    if (p->pipeline > PT_PIPELINE_WAVEFRONT_NEE) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT_NEE) {
+        if (s->n_inst) { ctx->err = "the NEE pipeline renders single-level scenes only"; return PT_ERR_UNSUPPORTED; }
+        if (p->extend == PT_EXTEND_FLAT) { ctx->err = "the NEE pipeline has no flat extend variant (shadow rays need a per-ray tmax)"; return PT_ERR_UNSUPPORTED; }
+        if (p->sample_groups > 1) { ctx->err = "the NEE pipeline runs one sample group per pixel"; return PT_ERR_UNSUPPORTED; }
+    }
     return PT_OK;
 }
 
@@ -1309,6 +1401,8 @@ void ptw_free_work(pt_film *f)
     (void)hipFree(w.d_hit_inst);
     (void)hipFree(w.d_count);
     (void)hipFree(w.d_sort);
+    (void)hipFree(w.d_sq_rayA); (void)hipFree(w.d_sq_rayB); (void)hipFree(w.d_sq_contrib); (void)hipFree(w.d_sq_slot);
+    (void)hipFree(w.d_sq_tmax); (void)hipFree(w.d_sq_hit); (void)hipFree(w.d_sq_count);
     w = pt_film::Work{};
 }
 
@@ -1450,6 +1544,22 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
             else { w.sort_bytes = need; w.bytes += need; }
         }
     }
+    const bool nee = p->pipeline == PT_PIPELINE_WAVEFRONT_NEE;
+    if (nee && (size_t)w.n_slots > w.cap_sq) {  // the shadow queue: at most one entry per live path and round
+        (void)hipFree(w.d_sq_rayA); (void)hipFree(w.d_sq_rayB); (void)hipFree(w.d_sq_contrib); (void)hipFree(w.d_sq_slot);
+        (void)hipFree(w.d_sq_tmax); (void)hipFree(w.d_sq_hit);
+        w.d_sq_rayA = w.d_sq_contrib = w.d_sq_hit = nullptr; w.d_sq_rayB = nullptr; w.d_sq_slot = nullptr; w.d_sq_tmax = nullptr;
+        w.cap_sq = 0;
+        const size_t ns = w.n_slots;
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_rayA, sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_rayB, sizeof(float2) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_contrib, sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_slot, sizeof(uint32_t) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_tmax, sizeof(float) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_hit, sizeof(float4) * ns));
+        if (!w.d_sq_count) PT_HIP(ctx, hipMalloc((void **)&w.d_sq_count, sizeof(uint32_t) * PT_MAX_PIPES));
+        w.cap_sq = ns;
+    }
     ctx->stats.extend_variant = pl.variant;
     if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     if (w.n_slots > 0) {
@@ -1509,13 +1619,33 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                     }
                     launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
                                   ctx->d_stats, p->tmin, p->tmax, count_visits, true, pp.st, k, x0, x1, perm);
-#define PT_LAUNCH_SHADE(N, L)                                                                                                  \
-    hipExtLaunchKernelGGL((k_shade<N, L>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
+                    ShadowQueue sq{};
+                    uint32_t *sq_count = nullptr;
+                    if (nee) {
+                        sq = { w.d_sq_rayA + pp.slot_begin, w.d_sq_rayB + pp.slot_begin, w.d_sq_contrib + pp.slot_begin,
+                               w.d_sq_tmax + pp.slot_begin, w.d_sq_slot + pp.slot_begin };
+                        sq_count = w.d_sq_count + k;
+                        PT_HIP(ctx, hipMemsetAsync(sq_count, 0, sizeof(uint32_t), pp.st));
+                    }
+#define PT_LAUNCH_SHADE(N, L, E)                                                                                               \
+    hipExtLaunchKernelGGL((k_shade<N, L, E>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
                           &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst,                    \
-                          pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4)
-                    if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true); }
-                    else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false); }
+                          pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4, s->d_lights, s->n_lights,   \
+                          s->light_area, sq, sq_count)
+                    if (nee) {
+                        if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, true); }
+                        else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, true); }
+                        if (s->n_lights) {
+                            // the shadow rays of this round: any-hit queries with their own tmax, then the unoccluded terms
+                            launch_extend(pl, s, sq.rayA, sq.rayB, w.d_sq_hit + pp.slot_begin, nullptr, sq_count, nullptr, ctx->d_stats,
+                                          p->tmin, p->tmax, false, true, pp.st, k, nullptr, nullptr, nullptr, sq.tmax);
+                            k_shadow_add<<<shade_grid, TB, 0, pp.st>>>(rc, rad, w.d_sq_hit + pp.slot_begin, sq.contrib, sq.slot, sq_count);
+                            ctx->stats.launches_extend++;
+                            ctx->stats.launches_other++;
+                        }
+                    } else if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, false); }
+                    else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, false); }
 #undef PT_LAUNCH_SHADE
                     if (profile) {
                         ev_extend.push_back(x0); ev_extend.push_back(x1);
