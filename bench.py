@@ -109,15 +109,22 @@ def extend_kernel_name(pt, st, info, config):
     return {1: "k_extend_flat", 2: lds, 3: "k_extend<hbm>", 4: "k_extend8"}.get(st.extend_variant, "?")
 
 
-def count_visits(pt, ctx, scene, W, H, common):
-    """One extra, untimed frame through the instrumented instantiation of the same traversal kernel."""
-    ctx.reset_stats()
+def count_visits(pt, ctx, scene, W, H, common, frames=1):
+    """The same `frames` frames once more, untimed, through the instrumented instantiation of the same traversal kernel
+    (the wave-level block counts depend on how full the queues are, so the shape has to be the timed one: counted on a
+    single frame the Cornell kernel shows 1075 VALU instructions per 64 rays, on the 16 of the timed run 930, which is what
+    SQ_INSTS_VALU measures there); then frame 0 alone for the film / ray-count comparison with the CPU oracle."""
     scratch = pt.Film(ctx, W, H)
-    pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, flags=pt.FLAG_COUNT_VISITS, **common))
+    ctx.reset_stats()
+    pt.render(scene, scratch, pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_COUNT_VISITS, **common))
     cst = ctx.stats()
+    scratch.clear()
+    ctx.reset_stats()
+    pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, **common))
+    rays0 = ctx.stats().rays
     film = scratch.read_f32()
     scratch.close()
-    return cst, film
+    return cst, film, rays0
 
 
 def valu_model(cst, kernel):
@@ -163,7 +170,7 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
         "algorithmic_bytes_per_ray": round(bytes_extend, 1),
         "gather": {"bvh_nodes_per_ray": round(nodes_per_ray, 2), "node_bytes": node_bytes, "tris_per_ray": round(tris_per_ray, 2),
                    "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
-                   "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), 1 extra frame"},
+                   "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), the timed frames once more, untimed"},
         "active_lanes": {"node_steps": round(64 * node_occ, 1) if node_occ else None,
                          "triangle_steps": round(64 * tri_occ, 1) if tri_occ else None},
         "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
@@ -188,7 +195,7 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
         rays_per_s = st.rays / (st.ms_extend * 1e-3)   # the kernel's own rate (its launches overlap the other pipeline's shade)
         r["valu_wave_instr_per_64_rays"] = round(vm["per_64_rays"], 1)
         r["valu_frac"] = round(vm["per_64_rays"] / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4)
-        r["valu_model"] = {"peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "isa_revision": vm["revision"], "wave_block_counts_1_frame": vm["blocks"],
+        r["valu_model"] = {"peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "isa_revision": vm["revision"], "wave_block_counts": vm["blocks"],
                            "source": "live wave-level block counts (PT_FLAG_COUNT_VISITS) x VALU instructions per block of the shipped ISA "
                                      "(profiles/isa_valu_model.json, scripts/isa_blocks.py)"}
     return r
@@ -256,7 +263,7 @@ def c5_leg(pt, ctx, W, H, config, soup_tris, frames, rank):
     pt.render(scene, film, timed)
     dt = time.perf_counter() - t0
     st = ctx.stats()
-    cst, _ = count_visits(pt, ctx, scene, W, H, common)
+    cst, _, _ = count_visits(pt, ctx, scene, W, H, common, frames)
     r = roofline_block(pt, st, cst, info, config, st.rays / max(st.paths, 1), NOTES[config])
     out = {"workload": f"{config.upper()}: {name} {W}x{H}, 16 spp/frame x {frames} frames, 16 bounces",
            "mrays_per_s": round(st.rays / dt / 1e6, 2), "ms_per_frame": round(dt * 1e3 / frames, 3),
@@ -438,8 +445,7 @@ def main():
         frame0_rays_gpu = frame0_film_gpu = None
         cst = None
         if st.extend_variant != pt.EXTEND_FLAT:
-            cst, frame0_film_gpu = count_visits(pt, ctx, scene, W, H, common)   # (rank 0's shard when N > 1)
-            frame0_rays_gpu = cst.rays
+            cst, frame0_film_gpu, frame0_rays_gpu = count_visits(pt, ctx, scene, W, H, common, args.steps)   # (rank 0's shard when N > 1)
         if flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
             out["roofline"] = roofline_block(pt, st, cst, info, args.config, mean_len, NOTES[args.config])
             bytes_extend = out["roofline"]["algorithmic_bytes_per_ray"]

@@ -413,7 +413,8 @@ __global__ void k_wide_single(const float4 *__restrict__ nodes, float4 *__restri
 __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig, const float *__restrict__ faces,
                                              const uint32_t *__restrict__ prim_of, uint32_t n,
                                              float4 *__restrict__ tri4, float4 *__restrict__ shade4,
-                                             float4 *__restrict__ shade64, float4 *__restrict__ ke4)
+                                             float4 *__restrict__ shade64, float4 *__restrict__ ke4,
+                                             float4 *__restrict__ frame4 = nullptr)
 {
     const uint32_t pos = blockIdx.x * TB + threadIdx.x;
     if (pos >= n) return;
@@ -432,6 +433,12 @@ __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig
     shade4[3 * (size_t)pos + 0] = make_float4(nrm.x, nrm.y, nrm.z, br);
     shade4[3 * (size_t)pos + 1] = make_float4(bg, bb, f[3], f[4]);
     shade4[3 * (size_t)pos + 2] = make_float4(f[5], 0.f, 0.f, 0.f);
+    if (frame4) {  // raygen.rgen:14-21 for this triangle's normal: {T.xyz, B.x} {B.yz, 0, 0}
+        ptm::f3 T, B;
+        ptm::tangent_frame(nrm, T, B);
+        frame4[2 * (size_t)pos + 0] = make_float4(T.x, T.y, T.z, B.x);
+        frame4[2 * (size_t)pos + 1] = make_float4(B.y, B.z, 0.f, 0.f);
+    }
     // the same values regrouped for scenes whose tables stay in HBM (k_shade<.., false>): one 64-B record instead of
     // two 48-B ones (4 divergent 16-B loads per hit instead of 6, 1 instead of 3 for a path that ends at this hit),
     // the emission apart because almost no triangle has one
@@ -939,6 +946,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade64, sizeof(float4) * 4 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_ke4, sizeof(float4) * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_frame4, sizeof(float4) * 2 * (size_t)n));
     PT_HIP(ctx, hipMemcpyAsync(d_vert.p, h_vertices, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d_idx.p, h_indices, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d_faces.p, h_faces, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -956,7 +964,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     if (rc != PT_OK) return rc;
     s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height; s->stack_need = o.stack_need;
     for (int k = 0; k < 3; k++) { s->bmin[k] = o.bmin[k]; s->bmax[k] = o.bmax[k]; }
-    k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4, s->d_shade64, s->d_ke4);
+    k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4, s->d_shade64, s->d_ke4, s->d_frame4);
     if (s->d_wide8) {  // the BVH8's own triangle order: its per-triangle tables (the LDS-sized shade4 is never used with it)
         PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of8, sizeof(uint32_t) * (size_t)n));
         PT_HIP(ctx, hipMalloc((void **)&s->d_tri4_8, sizeof(float4) * (3 * (size_t)n + 1)));
@@ -1070,7 +1078,7 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
         s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;  // 1-triangle leaves are the degenerate case of the pair kernel
     }
     k_pack<<<(n + TB - 1) / TB, TB, 0, st>>>(s->d_tri_orig, s->d_faces, want_sah ? s->d_prim_of_sah : s->d_prim_of, n, s->d_tri4,
-                                           s->d_shade4, s->d_shade64, s->d_ke4);
+                                           s->d_shade4, s->d_shade64, s->d_ke4, s->d_frame4);
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
@@ -1080,8 +1088,8 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
 void ptb_free_scene_buffers(pt_scene *s)
 {
     (void)hipFree(s->d_tri4); (void)hipFree(s->d_shade4); (void)hipFree(s->d_nodes);
-    (void)hipFree(s->d_shade64); (void)hipFree(s->d_ke4);
-    s->d_shade64 = s->d_ke4 = nullptr;
+    (void)hipFree(s->d_shade64); (void)hipFree(s->d_ke4); (void)hipFree(s->d_frame4);
+    s->d_shade64 = s->d_ke4 = s->d_frame4 = nullptr;
     (void)hipFree(s->d_wide_lbvh ? s->d_wide_lbvh : s->d_wide);  // d_wide aliases d_wide_lbvh or d_wide_sah
     (void)hipFree(s->d_wide_sah); (void)hipFree(s->d_prim_of_sah);
     (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of);

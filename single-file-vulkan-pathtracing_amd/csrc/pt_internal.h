@@ -52,6 +52,7 @@ struct pt_scene {
     float4 *d_shade4 = nullptr;
     float4 *d_shade64 = nullptr;  // 4 x float4 per leaf position {v0, n.x} {v1, n.y} {v2, n.z} {brdf, emits ? 1 : 0}: what k_shade gathers when the tables are not in LDS
     float4 *d_ke4 = nullptr;      // float4 per leaf position {Ke, 0}: read for emitters only
+    float4 *d_frame4 = nullptr;   // 2 x float4 per leaf position {T.xyz, B.x} {B.yz, 0, 0}: the tangent frame of the normal (raygen.rgen:14-21), for k_shade's LDS tables
     float4 *d_nodes = nullptr;            // binary LBVH (parity read-back; the collapse reads it)
     float4 *d_wide = nullptr;             // BVH4, 8 x float4 = 128 B per node: what traversal walks
     uint32_t n_wide = 0;

@@ -149,6 +149,22 @@ __device__ __forceinline__ void primary_ray(const Camera &cam, uint32_t px, uint
 }
 
 // ---- bounce: raygen.rgen:14-39 ---------------------------------------------------------
+// createCoordinateSystem alone (raygen.rgen:14-21): depends on the normal only, so k_pack evaluates it once per
+// triangle with exactly these operations and k_shade reads it from its LDS tables (one square root, two true divides
+// and a cross product less per bounce)
+__device__ __forceinline__ void tangent_frame(const f3 n, f3 &T, f3 &B)
+{
+    const bool bx = fabsf(n.x) > fabsf(n.y);
+    const float p = bx ? n.x : n.y, q = n.z;
+    const float l = fsqrt(p * p + q * q);
+    const float ql = fdiv(q, l), pl = fdiv(p, l);
+    const float zl = l > 0.0f ? 0.0f : __builtin_nanf("");
+    T = { bx ? ql : zl, bx ? zl : -ql, bx ? -pl : pl };
+    B = { n.y * T.z - n.z * T.y, n.z * T.x - n.x * T.z, n.x * T.y - n.y * T.x };
+}
+// sampleHemisphere + the change of basis (raygen.rgen:23-39) for a given frame
+__device__ __forceinline__ f3 sample_direction_frame(float r1, float r2, const f3 n, const f3 T, const f3 B);
+
 __device__ __forceinline__ f3 sample_direction(float r1, float r2, const f3 n)
 {
     // createCoordinateSystem (strict >): Nt = normalize(n.z, 0, -n.x) or normalize(0, -n.z, n.y).  Both
@@ -162,6 +178,16 @@ __device__ __forceinline__ f3 sample_direction(float r1, float r2, const f3 n)
     const float zl = l > 0.0f ? 0.0f : __builtin_nanf("");
     const f3 T = { bx ? ql : zl, bx ? zl : -ql, bx ? -pl : pl };
     const f3 B = { n.y * T.z - n.z * T.y, n.z * T.x - n.x * T.z, n.x * T.y - n.y * T.x };
+    const float sq = fsqrt(1.0f - r1 * r1);  // uniform hemisphere, pdf 1/(2*pi)
+    const float phi = 6.2831854820251465f * r2;
+    float sn, cs;
+    sincos_2pi(phi, sn, cs);
+    const float dx = cs * sq, dy = sn * sq, dz = r1;
+    return { (T.x * dx + B.x * dy) + n.x * dz, (T.y * dx + B.y * dy) + n.y * dz,
+             (T.z * dx + B.z * dy) + n.z * dz };
+}
+__device__ __forceinline__ f3 sample_direction_frame(float r1, float r2, const f3 n, const f3 T, const f3 B)
+{
     const float sq = fsqrt(1.0f - r1 * r1);  // uniform hemisphere, pdf 1/(2*pi)
     const float phi = 6.2831854820251465f * r2;
     float sn, cs;

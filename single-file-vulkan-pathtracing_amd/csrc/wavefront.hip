@@ -610,23 +610,27 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                                               const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst,
                                               const float4 *__restrict__ shade64, const float4 *__restrict__ ke4,
                                               const float4 *__restrict__ lights, uint32_t n_lights, float light_area,
-                                              ShadowQueue sq, uint32_t *sq_count)
+                                              ShadowQueue sq, uint32_t *sq_count, const float4 *__restrict__ g_frame4)
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const float4 *tri4 = g_tri4;
     const float4 *shade4 = g_shade4;
+    const float4 *frame4 = g_frame4;
     if (LDS_TABLES) {  // small scenes: the per-triangle tables live in LDS, no dependent global gathers
         float4 *s_tri = reinterpret_cast<float4 *>(smem);
         float4 *s_shade = s_tri + 3 * (size_t)n_tris;
+        float4 *s_frame = s_shade + 3 * (size_t)n_tris;
         for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
             s_tri[i] = g_tri4[i];
             s_shade[i] = g_shade4[i];
         }
+        for (uint32_t i = threadIdx.x; i < 2 * n_tris; i += TB) s_frame[i] = g_frame4[i];
         __syncthreads();
         tri4 = s_tri;
         shade4 = s_shade;
+        frame4 = s_frame;
     }
     const uint32_t n = *count_in;
     constexpr uint32_t CHUNK = TB * SH_ITEMS;
@@ -721,7 +725,12 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                     }
                     const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
                     const float r2 = ptm::rnd(seed);
-                    dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
+                    if (LDS_TABLES && !inst6) {  // the triangle's tangent frame was evaluated once, by k_pack, with the same operations
+                        const float4 f0 = frame4[2 * pos + 0], f1 = frame4[2 * pos + 1];
+                        dir = ptm::sample_direction_frame(r1, r2, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
+                    } else {
+                        dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
+                    }
                     const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
                     // raygen.rgen:79-80: weight *= brdf * dot / pdf, pdf = 1/(2*pi) as a true divide
                     float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
@@ -1493,7 +1502,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     // measured on MI355X: 4 paths per thread (one queue-tail atomic per 1024 paths) and 8 blocks per CU;
     // 1 path/thread is 40 % slower, 2 equal, grid size flat between 4 and 16 blocks per CU
     const int shade_grid = ctx->num_cus * 8;
-    const size_t shade_smem = sizeof(float4) * 6 * (size_t)s->n_tris;
+    const size_t shade_smem = sizeof(float4) * 8 * (size_t)s->n_tris;  // tri4 + shade4 + the tangent frames
     const bool shade_lds = shade_smem <= 16 * 1024 && !pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
     // Several pipelines on separate streams: the slot lanes of a batch are split into parts that run their
     // rounds independently, so the VALU-bound extend of one overlaps the HBM-bound shade of another
@@ -1632,7 +1641,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
                           &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst,                    \
                           pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4, s->d_lights, s->n_lights,   \
-                          s->light_area, sq, sq_count)
+                          s->light_area, sq, sq_count, s->d_frame4)
                     if (nee) {
                         if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, true); }
                         else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, true); }
