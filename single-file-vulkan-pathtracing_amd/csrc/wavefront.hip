@@ -614,6 +614,14 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
+#ifndef PT_SHADE_DENSE_REGEN
+#define PT_SHADE_DENSE_REGEN 1
+#endif
+    // (small scenes only: with the tables in HBM the kernel waits for its gathers, and the extra LDS round trip cost C5 1 %)
+    constexpr bool DENSE_REGEN = LDS_TABLES && PT_SHADE_DENSE_REGEN != 0;
+    // per wave: one 16-B cell per ended path -- first its job {slot, next sample}, then, written by the lane that took the
+    // job, the result {dir.xyz, seed} (dir.x = 2: the slot has no further sample)
+    __shared__ float4 s_regen[DENSE_REGEN ? 4 : 1][DENSE_REGEN ? 64 * SH_ITEMS : 1];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const float4 *tri4 = g_tri4;
     const float4 *shade4 = g_shade4;
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
         uint32_t o_slot[SH_ITEMS], o_ctr[SH_ITEMS];
         float4 o_state[SH_ITEMS], o_rayA[SH_ITEMS];
         float2 o_rayB[SH_ITEMS];
+        bool regen[SH_ITEMS];            // DENSE_REGEN: the path ended, the slot's next sample has to be started
         bool s_alive[SH_ITEMS];          // NEE: a shadow ray for this item
         float4 s_rayA[SH_ITEMS], s_contrib[SH_ITEMS];
         float2 s_rayB[SH_ITEMS];
@@ -646,6 +655,7 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
         for (int it = 0; it < SH_ITEMS; it++) {
             const uint32_t q = base + it * TB + threadIdx.x;
             alive[it] = false;
+            regen[it] = false;
             if (NEE) { s_alive[it] = false; o_slot[it] = 0u; }
             if (q >= n) continue;
             const uint2 id = in.id[q];
@@ -742,14 +752,18 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
             }
             if (terminated) {
                 sample++;
-                uint32_t f, g, px, py;
-                slot_pixel(rc, tiles, slot, f, g, px, py);
-                if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {  // next sample of this slot: raygen.rgen:45-60
-                    seed = ptm::make_seed(px, py, sample, rc.frame_base + (int32_t)f, rc.spp);
-                    ptm::primary_ray(rc.cam, px, py, seed, org, dir);
-                    wr = wg = wb = 1.0f;
-                    depth = 0;
-                    alive[it] = true;
+                if (DENSE_REGEN) {
+                    regen[it] = true;  // the next sample's primary ray is built after the item loop, by densely packed lanes
+                } else {
+                    uint32_t f, g, px, py;
+                    slot_pixel(rc, tiles, slot, f, g, px, py);
+                    if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {  // next sample of this slot: raygen.rgen:45-60
+                        seed = ptm::make_seed(px, py, sample, rc.frame_base + (int32_t)f, rc.spp);
+                        ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                        wr = wg = wb = 1.0f;
+                        depth = 0;
+                        alive[it] = true;
+                    }
                 }
             } else {
                 alive[it] = true;
@@ -759,6 +773,53 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
             o_state[it] = make_float4(__uint_as_float(seed), wr, wg, wb);
             o_rayA[it] = make_float4(org.x, org.y, org.z, dir.x);
             o_rayB[it] = make_float2(dir.y, dir.z);
+        }
+        if (DENSE_REGEN) {
+            // Regeneration (raygen.rgen:45-60 for the slot's next sample: pixel of the slot, seed, jitter, camera ray -- five
+            // true divides and a square root) used to sit in the per-item branch above, which a wave enters whenever ANY of
+            // its lanes ended a path, i.e. always, at ~30 % lane occupancy.  Here the ended paths of all SH_ITEMS items of a
+            // wave are handed, through a wave-private piece of LDS, to consecutive lanes: one pass (two when more than 64
+            // ended) at 60 % occupancy instead of SH_ITEMS passes at 30 %.  No block barrier: a wave's LDS operations
+            // execute in order.  Same operations per path, same bits.
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            float4 *cell = s_regen[wave];
+            uint32_t rank[SH_ITEMS], total = 0;
+#pragma unroll
+            for (int it = 0; it < SH_ITEMS; it++) {
+                const unsigned long long m = __ballot(regen[it]);
+                rank[it] = total + (uint32_t)__popcll(m & lt);
+                total += (uint32_t)__popcll(m);
+                if (regen[it]) cell[rank[it]] = make_float4(__uint_as_float(o_slot[it]), __uint_as_float(o_ctr[it] & 0xFFFFu), 0.f, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = (uint32_t)lane; j < total; j += 64u) {
+                const float4 jc = cell[j];
+                const uint2 job = make_uint2(__float_as_uint(jc.x), __float_as_uint(jc.y));
+                uint32_t f, g, px, py;
+                slot_pixel(rc, tiles, job.x, f, g, px, py);
+                float4 r = make_float4(2.0f, 0.f, 0.f, 0.f);
+                if (job.y < min(rc.spp, (g + 1u) * rc.group_size)) {
+                    uint32_t seed = ptm::make_seed(px, py, job.y, rc.frame_base + (int32_t)f, rc.spp);
+                    ptm::f3 org, dir;
+                    ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                    r = make_float4(dir.x, dir.y, dir.z, __uint_as_float(seed));
+                }
+                cell[j] = r;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < SH_ITEMS; it++) {
+                const float4 r = regen[it] ? cell[rank[it]] : make_float4(2.0f, 0.f, 0.f, 0.f);
+                if (r.x != 2.0f) {
+                    alive[it] = true;
+                    o_ctr[it] = o_ctr[it] & 0xFFFFu;  // depth 0
+                    o_state[it] = make_float4(r.w, 1.0f, 1.0f, 1.0f);  // raygen.rgen:59
+                    o_rayA[it] = make_float4(rc.cam.ox, rc.cam.oy, rc.cam.oz, r.x);
+                    o_rayB[it] = make_float2(r.y, r.z);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the area is reused by the next chunk
         }
         uint32_t dst[SH_ITEMS];
         if (NEE) {  // the shadow queue, compacted like the path queue (its entries outlive this path's regeneration: own slot copy)
