@@ -1,0 +1,334 @@
+// bvh4_sah_device.hip -- the "prefer fast trace" BVH4 of small scenes, built ON THE DEVICE.
+//
+// Same tree as the host builder of bvh4_sah.hip (which stays as the cross-check: the tests compare the two bit for
+// bit): primitives = triangles or fan pairs, binary surface-area sweep over every split position of all three centroid
+// orders, cost area(L) n(L) + area(R) n(R) in binary64, first minimum in (cost, axis, position) order, median split below
+// depth 24; then the BVH4 by opening the internal child of largest area, rows in the same format and order.
+//
+// One workgroup builds it (scenes of <= 2048 triangles; the Cornell box has 18 primitives).  No sorting: for a node
+// of m primitives each of the 3m candidates (axis a, primitive j) is "everything whose (centroid_a, id) key is <= j's
+// goes left" -- exactly the split positions of the sorted sweep -- and a thread evaluates it by one pass over the
+// node's primitives that grows the two boxes and counts the left side; that count minus one IS j's position in the sorted
+// order along a, so the winning axis' positions re-order the node's primitives for its children for free.  O(m^2) per
+// node, ~5 ms for 2048 triangles, tens of microseconds for the Cornell box.
+#include "pt_internal.h"
+#include "pt_math.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int TBD = 256;
+constexpr int SAH_MAX_DEPTH = 24;  // as bvh4_sah.hip
+
+struct SahNode {
+    int left, right;          // -1: leaf
+    uint32_t first, count;    // range of `ids` (primitives)
+    double lo[3], hi[3];
+};
+
+__device__ __forceinline__ double box_area_d(const double *lo, const double *hi)
+{
+    const double x = fmax(hi[0] - lo[0], 0.0), y = fmax(hi[1] - lo[1], 0.0), z = fmax(hi[2] - lo[2], 0.0);
+    return 2.0 * (x * y + y * z + z * x);
+}
+
+struct Best { double cost; int axis; uint32_t k; };
+__device__ __forceinline__ bool better(const Best &a, const Best &b)  // a before b in (cost, axis, position) order
+{
+    return a.cost < b.cost || (a.cost == b.cost && (a.axis < b.axis || (a.axis == b.axis && a.k < b.k)));
+}
+
+// prim boxes (binary64) from the triangle boxes; a primitive is one triangle or two consecutive ones
+__global__ void k_sah_prims(const float *__restrict__ tlo, const float *__restrict__ thi, const uint32_t *__restrict__ prim_first,
+                            const uint8_t *__restrict__ prim_tris, uint32_t np, double *__restrict__ plo, double *__restrict__ phi,
+                            uint32_t *__restrict__ ids)
+{
+    const uint32_t p = blockIdx.x * TBD + threadIdx.x;
+    if (p >= np) return;
+    const uint32_t t = prim_first[p];
+    for (int k = 0; k < 3; k++) {
+        double lo = tlo[3 * (size_t)t + k], hi = thi[3 * (size_t)t + k];
+        if (prim_tris[p] == 2) { lo = fmin(lo, (double)tlo[3 * (size_t)(t + 1) + k]); hi = fmax(hi, (double)thi[3 * (size_t)(t + 1) + k]); }
+        plo[3 * (size_t)p + k] = lo;
+        phi[3 * (size_t)p + k] = hi;
+    }
+    ids[p] = p;
+}
+
+// the binary tree: ONE block; nodes are processed depth first from an explicit stack
+__global__ __launch_bounds__(TBD) void k_sah_tree(uint32_t np, uint32_t leaf_max, const double *__restrict__ plo,
+                                                  const double *__restrict__ phi, uint32_t *__restrict__ ids,
+                                                  uint32_t *__restrict__ ids_tmp, uint32_t *__restrict__ cand_pos /* [3][np] */,
+                                                  SahNode *__restrict__ nodes, uint32_t *__restrict__ n_nodes_out,
+                                                  uint2 *__restrict__ todo /* {node, depth} */)
+{
+    extern __shared__ __attribute__((aligned(16))) char sah_smem[];  // the node's primitives: ids[np], boxes[6 np] (floats)
+    uint32_t *s_id = reinterpret_cast<uint32_t *>(sah_smem);
+    float *s_box = reinterpret_cast<float *>(sah_smem) + np;
+    __shared__ Best s_best[TBD / 64];
+    __shared__ double s_lo[TBD / 64][3], s_hi[TBD / 64][3];
+    __shared__ uint32_t s_n_nodes, s_sp;
+    __shared__ int s_axis;
+    __shared__ uint32_t s_k;
+    __shared__ int s_split;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        nodes[0].first = 0; nodes[0].count = np; nodes[0].left = nodes[0].right = -1;
+        s_n_nodes = 1; s_sp = 1;
+        todo[0] = make_uint2(0u, 0u);
+    }
+    __syncthreads();
+    const double INF = __builtin_inf();
+    while (s_sp > 0) {
+        __syncthreads();
+        const uint2 job = todo[s_sp - 1];
+        __syncthreads();
+        if (tid == 0) s_sp--;
+        const uint32_t me = job.x, depth = job.y;
+        const uint32_t first = nodes[me].first, m = nodes[me].count;
+        // node box
+        double lo[3] = { INF, INF, INF }, hi[3] = { -INF, -INF, -INF };
+        for (uint32_t i = tid; i < m; i += TBD) {
+            const uint32_t p = ids[first + i];
+            for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], plo[3 * (size_t)p + k]); hi[k] = fmax(hi[k], phi[3 * (size_t)p + k]); }
+        }
+        for (int o = 32; o > 0; o >>= 1)
+            for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], o, 64)); }
+        if ((tid & 63) == 0)
+            for (int k = 0; k < 3; k++) { s_lo[tid >> 6][k] = lo[k]; s_hi[tid >> 6][k] = hi[k]; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int t = 1; t < TBD / 64; t++)
+                for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], s_lo[t][k]); hi[k] = fmax(hi[k], s_hi[t][k]); }
+            for (int k = 0; k < 3; k++) { nodes[me].lo[k] = lo[k]; nodes[me].hi[k] = hi[k]; }
+        }
+        __syncthreads();
+        if (m <= 1) continue;  // leaf (uniform: m comes from global memory written before the barrier)
+        // the node's primitives go to LDS (boxes as the floats they were made from: the conversion to binary64 is exact),
+        // where the inner loop below reads them as broadcasts
+        for (uint32_t i = tid; i < m; i += TBD) {
+            const uint32_t p = ids[first + i];
+            s_id[i] = p;
+            for (int k = 0; k < 3; k++) { s_box[6 * i + k] = (float)plo[3 * (size_t)p + k]; s_box[6 * i + 3 + k] = (float)phi[3 * (size_t)p + k]; }
+        }
+        __syncthreads();
+        // every candidate (axis, primitive j): left = keys <= j's key
+        Best best = { INF, 0, 0u };
+        for (uint32_t c = tid; c < 3u * m; c += TBD) {
+            const int ax = (int)(c / m);
+            const uint32_t jj = c - (uint32_t)ax * m;
+            const uint32_t j = s_id[jj];
+            const double cj = (double)s_box[6 * jj + ax] + (double)s_box[6 * jj + 3 + ax];
+            float llo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, lhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+            float rlo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, rhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+            uint32_t nl = 0;
+            for (uint32_t i = 0; i < m; i++) {
+                const uint32_t p = s_id[i];
+                const double cp = (double)s_box[6 * i + ax] + (double)s_box[6 * i + 3 + ax];
+                const bool left = cp < cj || (cp == cj && p <= j);
+                if (left) {
+                    nl++;
+                    for (int k = 0; k < 3; k++) { llo[k] = fminf(llo[k], s_box[6 * i + k]); lhi[k] = fmaxf(lhi[k], s_box[6 * i + 3 + k]); }
+                } else {
+                    for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], s_box[6 * i + k]); rhi[k] = fmaxf(rhi[k], s_box[6 * i + 3 + k]); }
+                }
+            }
+            cand_pos[(size_t)ax * np + jj] = nl - 1u;  // j's position in the sorted order along ax
+            if (nl < m) {
+                const double dl[3] = { llo[0], llo[1], llo[2] }, dh[3] = { lhi[0], lhi[1], lhi[2] };
+                const double el[3] = { rlo[0], rlo[1], rlo[2] }, eh[3] = { rhi[0], rhi[1], rhi[2] };
+                const Best b = { box_area_d(dl, dh) * (double)nl + box_area_d(el, eh) * (double)(m - nl), ax, nl - 1u };
+                if (better(b, best)) best = b;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const Best other = { __shfl_xor(best.cost, o, 64), __shfl_xor(best.axis, o, 64), __shfl_xor(best.k, o, 64) };
+            if (better(other, best)) best = other;
+        }
+        if ((tid & 63) == 0) s_best[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            for (int t = 1; t < TBD / 64; t++)
+                if (better(s_best[t], best)) best = s_best[t];
+            const double a_node = box_area_d(nodes[me].lo, nodes[me].hi);
+            // a node of <= leaf_max primitives stays a leaf when splitting does not pay (node step : primitive = 1 : 0.6)
+            const bool leaf = m <= leaf_max && 0.6 * (double)m * a_node <= 1.0 * a_node + 0.6 * best.cost;
+            s_split = leaf ? 0 : 1;
+            s_axis = best.axis;
+            s_k = depth >= (uint32_t)SAH_MAX_DEPTH ? m / 2u - 1u : best.k;
+        }
+        __syncthreads();
+        if (!s_split) continue;
+        const int ax = s_axis;
+        for (uint32_t i = tid; i < m; i += TBD) ids[first + cand_pos[(size_t)ax * np + i]] = s_id[i];
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t l = s_n_nodes, r = s_n_nodes + 1u;
+            s_n_nodes += 2u;
+            nodes[me].left = (int)l; nodes[me].right = (int)r;
+            nodes[l].first = first; nodes[l].count = s_k + 1u; nodes[l].left = nodes[l].right = -1;
+            nodes[r].first = first + s_k + 1u; nodes[r].count = m - s_k - 1u; nodes[r].left = nodes[r].right = -1;
+            todo[s_sp++] = make_uint2(r, depth + 1u);  // left first
+            todo[s_sp++] = make_uint2(l, depth + 1u);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_nodes_out = s_n_nodes;
+}
+
+// per binary node, in parallel: the padded float box of its triangles (what a BVH4 slot holds) and its area
+__global__ __launch_bounds__(TBD) void k_sah_node_boxes(const SahNode *__restrict__ nodes, const uint32_t *__restrict__ n_nodes,
+                                                        const uint32_t *__restrict__ ids, const uint32_t *__restrict__ prim_first,
+                                                        const uint8_t *__restrict__ prim_tris, const float *__restrict__ tlo,
+                                                        const float *__restrict__ thi, float pad, float *__restrict__ nbox /* [6] */,
+                                                        double *__restrict__ narea, uint32_t *__restrict__ ntris)
+{
+    const uint32_t i = blockIdx.x * TBD + threadIdx.x;
+    if (i >= *n_nodes) return;
+    const SahNode &k = nodes[i];
+    const float inf = __builtin_inff();
+    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+    uint32_t n_tri = 0;
+    for (uint32_t t = 0; t < k.count; t++) {
+        const uint32_t prim = ids[k.first + t];
+        for (uint32_t h = 0; h < prim_tris[prim]; h++, n_tri++) {
+            const uint32_t tri = prim_first[prim] + h;
+            for (int c = 0; c < 3; c++) {
+                lo[c] = fminf(lo[c], tlo[3 * (size_t)tri + c] - pad);  // float, like k_refit
+                hi[c] = fmaxf(hi[c], thi[3 * (size_t)tri + c] + pad);
+            }
+        }
+    }
+    for (int c = 0; c < 3; c++) { nbox[6 * (size_t)i + c] = lo[c]; nbox[6 * (size_t)i + 3 + c] = hi[c]; }
+    narea[i] = box_area_d(k.lo, k.hi);
+    ntris[i] = n_tri;
+}
+
+// BVH4 rows + leaf order from the binary tree: one thread, the loop of pt_sah_build_bvh4 (bvh4_sah.hip)
+__global__ void k_sah_emit(const SahNode *__restrict__ nodes, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ prim_first,
+                           const uint8_t *__restrict__ prim_tris, const float *__restrict__ nbox, const double *__restrict__ narea,
+                           const uint32_t *__restrict__ ntris, uint32_t *__restrict__ rows, uint32_t *__restrict__ order, uint32_t *__restrict__ counts /* {n_rows, n_order} */,
+                           uint2 *__restrict__ todo /* {binary node, row} */)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float inf = __builtin_inff();
+    uint32_t n_rows = 0, n_order = 0, sp = 0;
+    auto new_row = [&]() -> uint32_t {
+        const uint32_t r = n_rows++;
+        float *f = reinterpret_cast<float *>(rows + 32 * (size_t)r);
+        for (int k = 0; k < 24; k++) f[k] = inf;  // empty slot: lo = hi = +inf
+        for (int k = 24; k < 28; k++) rows[32 * (size_t)r + k] = 0xFFFFFFFFu;
+        for (int k = 28; k < 32; k++) rows[32 * (size_t)r + k] = 0u;
+        return r;
+    };
+    todo[sp++] = make_uint2(0u, new_row());
+    while (sp > 0) {
+        const uint2 it = todo[--sp];
+        int kids[4];
+        int m = 0;
+        const SahNode &root = nodes[it.x];
+        if (root.left < 0) kids[m++] = (int)it.x;  // the whole scene is one leaf
+        else { kids[m++] = root.left; kids[m++] = root.right; }
+        while (m < 4) {
+            int pick = -1;
+            double pa = -1.0;
+            for (int j = 0; j < m; j++) {
+                if (nodes[kids[j]].left < 0) continue;
+                const double a = narea[kids[j]];
+                if (a > pa) { pa = a; pick = j; }
+            }
+            if (pick < 0) break;
+            const SahNode &k = nodes[kids[pick]];
+            for (int j = m; j > pick + 1; j--) kids[j] = kids[j - 1];
+            kids[pick] = k.left; kids[pick + 1] = k.right;
+            m++;
+        }
+        for (int j = 0; j < m; j++) {
+            const SahNode &k = nodes[kids[j]];
+            const float *nb = nbox + 6 * (size_t)kids[j];
+            const float lo[3] = { nb[0], nb[1], nb[2] }, hi[3] = { nb[3], nb[4], nb[5] };
+            const uint32_t n_tri = ntris[kids[j]];
+            uint32_t word;
+            if (k.left < 0) {
+                word = PT_LEAF | ((n_tri - 1u) << 28) | n_order;
+                for (uint32_t t = 0; t < k.count; t++) {
+                    const uint32_t prim = ids[k.first + t];
+                    for (uint32_t h = 0; h < prim_tris[prim]; h++) order[n_order++] = prim_first[prim] + h;
+                }
+            } else {
+                word = new_row();
+                todo[sp++] = make_uint2((uint32_t)kids[j], word);
+            }
+            float *f = reinterpret_cast<float *>(rows + 32 * (size_t)it.y);
+            for (int c = 0; c < 3; c++) { f[4 * c + j] = lo[c]; f[12 + 4 * c + j] = hi[c]; }
+            rows[32 * (size_t)it.y + 24 + j] = word;
+        }
+    }
+    counts[0] = n_rows;
+    counts[1] = n_order;
+}
+
+template <typename T>
+struct Buf {
+    T *p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)); }
+};
+
+}  // namespace
+
+// tlo / thi: HOST arrays of the unpadded triangle boxes (3 floats each), as pt_sah_build_bvh4 takes them.  The rows
+// (32 dwords per BVH4 node) and the leaf order are produced on the device and returned to the host vectors as well (the
+// caller keeps the device copies it uploads from them; a scene of <= 2048 triangles is a few hundred kilobytes).
+pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
+                                   uint32_t leaf_max, std::vector<uint32_t> &rows, std::vector<uint32_t> &order)
+{
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> prim_first;
+    std::vector<uint8_t> prim_tris;
+    for (uint32_t t = 0; t < n;) {
+        const uint32_t cnt = (pair_with_next && t + 1 < n && pair_with_next[t]) ? 2u : 1u;
+        prim_first.push_back(t);
+        prim_tris.push_back((uint8_t)cnt);
+        t += cnt;
+    }
+    const uint32_t np = (uint32_t)prim_first.size();
+    Buf<float> d_tlo, d_thi;
+    Buf<uint32_t> d_first, d_ids, d_tmp, d_pos, d_nn, d_rows, d_order, d_counts;
+    Buf<uint8_t> d_tris;
+    Buf<double> d_plo, d_phi;
+    Buf<SahNode> d_nodes;
+    Buf<uint2> d_todo;
+    PT_HIP(ctx, d_tlo.alloc(3 * (size_t)n)); PT_HIP(ctx, d_thi.alloc(3 * (size_t)n));
+    PT_HIP(ctx, d_first.alloc(np)); PT_HIP(ctx, d_tris.alloc(np)); PT_HIP(ctx, d_ids.alloc(np)); PT_HIP(ctx, d_tmp.alloc(np));
+    PT_HIP(ctx, d_pos.alloc(3 * (size_t)np)); PT_HIP(ctx, d_nn.alloc(1)); PT_HIP(ctx, d_plo.alloc(3 * (size_t)np)); PT_HIP(ctx, d_phi.alloc(3 * (size_t)np));
+    PT_HIP(ctx, d_nodes.alloc(2 * (size_t)np + 1)); PT_HIP(ctx, d_todo.alloc(2 * (size_t)np + 8));
+    PT_HIP(ctx, d_rows.alloc(32 * (size_t)(2 * np + 1))); PT_HIP(ctx, d_order.alloc(n)); PT_HIP(ctx, d_counts.alloc(2));
+    PT_HIP(ctx, hipMemcpyAsync(d_tlo.p, tlo, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_thi.p, thi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_first.p, prim_first.data(), sizeof(uint32_t) * np, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_tris.p, prim_tris.data(), np, hipMemcpyHostToDevice, st));
+    k_sah_prims<<<(np + TBD - 1) / TBD, TBD, 0, st>>>(d_tlo.p, d_thi.p, d_first.p, d_tris.p, np, d_plo.p, d_phi.p, d_ids.p);
+    const size_t tree_smem = sizeof(uint32_t) * 7 * (size_t)np;  // <= 56 KB for 2048 primitives
+    if (tree_smem > 48 * 1024)
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sah_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_smem));
+    k_sah_tree<<<1, TBD, tree_smem, st>>>(np, leaf_max > 0 ? leaf_max : 1u, d_plo.p, d_phi.p, d_ids.p, d_tmp.p, d_pos.p, d_nodes.p, d_nn.p, d_todo.p);
+    Buf<float> d_nbox;
+    Buf<double> d_narea;
+    Buf<uint32_t> d_ntris;
+    PT_HIP(ctx, d_nbox.alloc(6 * (2 * (size_t)np + 1))); PT_HIP(ctx, d_narea.alloc(2 * (size_t)np + 1)); PT_HIP(ctx, d_ntris.alloc(2 * (size_t)np + 1));
+    k_sah_node_boxes<<<(2 * np + 1 + TBD - 1) / TBD, TBD, 0, st>>>(d_nodes.p, d_nn.p, d_ids.p, d_first.p, d_tris.p, d_tlo.p, d_thi.p, pad, d_nbox.p,
+                                                                   d_narea.p, d_ntris.p);
+    k_sah_emit<<<1, 1, 0, st>>>(d_nodes.p, d_ids.p, d_first.p, d_tris.p, d_nbox.p, d_narea.p, d_ntris.p, d_rows.p, d_order.p, d_counts.p, d_todo.p);
+    uint32_t counts[2] = { 0, 0 };
+    PT_HIP(ctx, hipMemcpyAsync(counts, d_counts.p, sizeof(counts), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    if (counts[1] != n || counts[0] == 0 || counts[0] > 2 * np + 1) { ctx->err = "internal: device SAH build lost triangles"; return PT_ERR_HIP; }
+    rows.resize(32 * (size_t)counts[0]);
+    order.resize(n);
+    PT_HIP(ctx, hipMemcpy(rows.data(), d_rows.p, sizeof(uint32_t) * rows.size(), hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(order.data(), d_order.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    return PT_OK;
+}

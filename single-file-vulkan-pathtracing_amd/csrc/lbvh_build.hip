@@ -1058,8 +1058,16 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
         // rule, up to PT_SAH_LEAF_MAX independent triangles per leaf where splitting does not pay)
         const char *pe = getenv("PT_TUNE_PAIR_LEAVES");
         const bool pairs = !(pe && atoi(pe) == 0);
-        pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad, pairs ? 1u : PT_SAH_LEAF_MAX,
-                          rows, order);
+        // built on the device (bvh4_sah_device.hip); PT_TUNE_SAH_HOST=1 runs the host builder of bvh4_sah.hip, which gives
+        // the same rows and order bit for bit (tests compare them)
+        if (getenv("PT_TUNE_SAH_HOST") && atoi(getenv("PT_TUNE_SAH_HOST")) == 1) {
+            pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad, pairs ? 1u : PT_SAH_LEAF_MAX,
+                              rows, order);
+        } else {
+            const pt_status rc8 = pt_sah_build_bvh4_device(ctx, s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad,
+                                                           pairs ? 1u : PT_SAH_LEAF_MAX, rows, order);
+            if (rc8 != PT_OK) return rc8;
+        }
         s->sah_pair_leaves = pairs;
         if (order.size() != n || rows.empty()) { ctx->err = "internal: SAH build lost triangles"; return PT_ERR_HIP; }
         s->n_wide_sah = (uint32_t)(rows.size() / 32);

@@ -161,6 +161,9 @@ constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
 void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
                        uint32_t leaf_max_prims, std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
 uint32_t pt_wide_stack_need(const std::vector<uint32_t> &rows32);
+// bvh4_sah_device.hip: the same builder on the device (one workgroup), same rows and order bit for bit
+pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
+                                   uint32_t leaf_max_prims, std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
 void ptb_free_instances(pt_scene *s);
 // wavefront.hip
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);

@@ -1493,3 +1493,33 @@ def test_nee_converges_to_the_reference_estimators_mean(pt, gpu_ctx, cornell_gpu
     rel = lambda x, y: np.abs(x - y) / np.maximum(y, 0.05)
     assert rel(tiles(b), tiles(ref)).mean() <= 0.03
     assert rel(tiles(a1), tiles(a2)).mean() <= 0.03       # (the scale: the reference estimator against itself)
+
+
+@pytest.mark.parametrize("n,seed,pairs", [(0, 0, "1"), (0, 0, "0"), (7, 3, "1"), (300, 4, "1"), (300, 4, "0"), (2048, 5, "1")])
+def test_device_sah_builder_equals_the_host_builder(pt, gpu_ctx, cornell_arrays, n, seed, pairs):
+    """The surface-area BVH4 of small scenes is built on the device by one workgroup (bvh4_sah_device.hip: every split
+    candidate evaluated by a pass over the node's primitives, no sorting); the host builder of round 1 stays as the
+    cross-check behind PT_TUNE_SAH_HOST=1.  Same rows, same leaf order, bit for bit -- Cornell box (n = 0), soups with quads
+    mixed in, the <= 4-triangle leaf rule (PT_TUNE_PAIR_LEAVES=0), and the 2048-triangle limit."""
+    if n == 0:
+        v, i, f = cornell_arrays
+    else:
+        v, i, f = _soup(n, seed, spread=0.3)
+        tri = v.reshape(-1, 3, 3).copy()
+        for k in range(0, n - 1, 5):                 # every fifth triangle gets a fan partner (v0, v2, v3)
+            tri[k + 1, 0], tri[k + 1, 1] = tri[k, 0], tri[k, 2]
+        v = tri.reshape(-1)
+    out = {}
+    for host in ("1", "0"):
+        os.environ["PT_TUNE_SAH_HOST"], os.environ["PT_TUNE_PAIR_LEAVES"] = host, pairs
+        try:
+            sc = pt.Scene(gpu_ctx, v, i, f)
+            assert sc.info().bvh4_builder == 1
+            out[host] = (sc.read_bvh4().copy(), sc.info().build_ms)
+            rays = np.concatenate([np.random.default_rng(1).uniform(-1.2, 1.2, (5000, 3)), np.random.default_rng(2).normal(size=(5000, 3))], 1).astype(np.float32)
+            out[host] += (sc.trace(rays).tobytes(),)
+            sc.close()
+        finally:
+            os.environ.pop("PT_TUNE_SAH_HOST", None); os.environ.pop("PT_TUNE_PAIR_LEAVES", None)
+    assert out["0"][0].shape == out["1"][0].shape and out["0"][0].tobytes() == out["1"][0].tobytes()
+    assert out["0"][2] == out["1"][2]
