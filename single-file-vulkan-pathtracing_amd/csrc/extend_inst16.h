@@ -1,0 +1,282 @@
+// extend_inst16.h -- two-level closest hit (BASELINE config C4), round-2 kernel.
+//
+// Same contract and same hit records as k_extend_inst (wavefront.hip), which stays as the general fallback; this one is
+// for scenes whose TLAS and BLAS fit 15-bit child codes (< 32768 instances, BLAS <= 2047 triangles staged in LDS) and
+// tmin > 0.  What differs:
+//   * BOTH levels are 64-B nodes with fp16 planes (TLAS: normalised to the box of all instances, built top-down with
+//     contiguous children, read from L2 with four 16-B loads instead of seven; BLAS: the scene's fp16 BVH4, staged in LDS
+//     with its child words re-coded to 16 bits), so one slab routine serves both and the ray is re-normalised at every
+//     instance entry / exit;
+//   * a stack entry is ONE dword: bf16-truncated entry distance | 16-bit child code; keys are formed before the sort, so
+//     the network is min/max on integers (extend_kernel.h explains the trick), and the LDS stack is half the size;
+//   * BLAS leaves that are fan pairs are tested with shared vertex work (PAIRS, as k_extend_lds7p).
+// Codes: TLAS / BLAS inner node = index; TLAS leaf = 0x8000 | instance position (one instance per leaf); BLAS leaf =
+// 0x8000 | (count - 1) << 11 | first; 0x7FFF = the EXIT marker under an instance's entries; 0xFFFF = empty / done.
+#pragma once
+#include "extend_kernel.h"
+
+namespace {
+
+constexpr uint32_t I16_EXIT = 0x7FFFu, I16_DONE = 0xFFFFu, I16_LEAF = 0x8000u;
+constexpr uint32_t I16_NODE_DW = 20;  // dwords per BLAS node in LDS (16 used): 80-B stride spreads the banks
+
+// whole 16-B loads in each branch, then a register barrier: left alone the compiler turns the near / far plane selects
+// into address selects and reads the node with thirteen FLAT loads that serve both address spaces
+#define PT_REG_BARRIER16(A, B, C, D)                                                                                   \
+    asm volatile("" : "+v"(A.x), "+v"(A.y), "+v"(A.z), "+v"(A.w), "+v"(B.x), "+v"(B.y), "+v"(B.z), "+v"(B.w), "+v"(C.x), \
+                      "+v"(C.y), "+v"(C.z), "+v"(C.w), "+v"(D.x), "+v"(D.y), "+v"(D.z), "+v"(D.w));
+template <bool COUNT, bool PAIRS>
+__global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ tlas16, NormBox nbt, const uint4 *__restrict__ g_blas16,
+                                                      NormBox nbb, const float4 *__restrict__ g_tri4, uint32_t n_blas_wide,
+                                                      uint32_t n_tris, const float4 *__restrict__ inst6,
+                                                      const uint32_t *__restrict__ inst_id, const float4 *__restrict__ rayA,
+                                                      const float2 *__restrict__ rayB, float4 *__restrict__ hit,
+                                                      uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
+                                                      uint32_t *count_zero, unsigned long long *stats, uint32_t *__restrict__ spill,
+                                                      uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int raw_hit,
+                                                      int lds_stack, int enter_min)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem);  // [lds_stack][TB]
+    uint32_t *s_blas = s_stack + (size_t)lds_stack * TB;      // [n_blas_wide][I16_NODE_DW]
+    float4 *s_tri = reinterpret_cast<float4 *>(s_blas + (size_t)I16_NODE_DW * n_blas_wide);
+    for (uint32_t i = threadIdx.x; i < 4 * n_blas_wide; i += TB) {
+        uint4 v = g_blas16[i];
+        if ((i & 3u) == 3u) {  // the four child words -> 16-bit codes
+            auto code = [](uint32_t w) {
+                if (w == SENTINEL) return I16_DONE;
+                return (w & PT_LEAF) ? (I16_LEAF | (((w >> 28) & 3u) << 11) | (w & 0x7FFu)) : (w & 0x7FFFu);
+            };
+            v = make_uint4(code(v.x), code(v.y), code(v.z), code(v.w));
+        }
+        *reinterpret_cast<uint4 *>(s_blas + (size_t)(i >> 2) * I16_NODE_DW + 4 * (i & 3u)) = v;
+    }
+    for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {  // three axis-permuted copies (ptm::tri_test_perm)
+        const float4 v = g_tri4[i];
+        s_tri[i] = make_float4(v.y, v.z, v.x, v.w);
+        s_tri[3 * n_tris + i] = make_float4(v.z, v.x, v.y, v.w);
+        s_tri[6 * n_tris + i] = v;
+    }
+    __syncthreads();
+    const uint32_t n = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (count_zero) *count_zero = 0u;
+        if (stats) atomicAdd(stats, (unsigned long long)n);
+    }
+    lds_u32 *my_stack = (lds_u32 *)s_stack + threadIdx.x;
+    uint32_t *my_spill = spill + (size_t)blockIdx.x * TB + threadIdx.x;
+    const float INF = __builtin_inff();
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    bool have = false, exhausted = false, in_blas = false;
+    uint32_t q = 0;
+    ptm::f3 org_w{}, dir_w{};
+    ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};  // the level being walked, in that level's normalised coordinates
+    uint32_t mx = 0, my = 0, mz = 0;  // all ones where the level's direction component is negative
+    uint32_t tri_base = 0;
+    ptm::RayPre pre{};
+    float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
+    uint32_t best_pos = PT_MISS, best_prim = PT_MISS, best_ipos = PT_MISS, best_iid = PT_MISS;
+    uint32_t cur = I16_DONE, cur_ipos = 0, cur_iid = 0;
+    int sp = 0;
+    unsigned long long c_nodes = 0, c_tris = 0;
+    const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
+    const uint32_t wave_stride = gridDim.x * TB;
+    uint32_t cursor = 0;
+
+    auto level_setup = [&](const ptm::f3 o, const ptm::f3 d, const NormBox &nb) {  // slab constants of a level for ray (o, d)
+        const ptm::f3 on_ = { (o.x - nb.cx) * nb.rsx, (o.y - nb.cy) * nb.rsy, (o.z - nb.cz) * nb.rsz };
+        inv = { ptm::safe_inv(d.x) * nb.sx, ptm::safe_inv(d.y) * nb.sy, ptm::safe_inv(d.z) * nb.sz };
+        slab_setup(on_, inv, invf, on, of);
+        mx = inv.x < 0.f ? 0xFFFFFFFFu : 0u; my = inv.y < 0.f ? 0xFFFFFFFFu : 0u; mz = inv.z < 0.f ? 0xFFFFFFFFu : 0u;
+    };
+    auto push = [&](uint32_t e) {
+        if (sp < lds_stack) my_stack[sp * TB] = e;
+        else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
+        sp++;
+    };
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            sp--;
+            uint32_t e;
+            if (sp < lds_stack) e = my_stack[sp * TB];
+            else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
+            if ((e & 0xFFFFu) == I16_EXIT) {  // the instance is done: back to the world-space ray and the TLAS
+                level_setup(org_w, dir_w, nbt);
+                in_blas = false;
+                continue;
+            }
+            if (__uint_as_float(e & 0xFFFF0000u) <= best_t) return e & 0xFFFFu;
+        }
+        return I16_DONE;
+    };
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= refill_min_idle) {
+            if (!have) {
+                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
+                const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
+                if (qq < n) {
+                    q = qq;
+                    const float4 ra = rayA[q];
+                    const float2 rb = rayB[q];
+                    org_w = { ra.x, ra.y, ra.z };
+                    dir_w = { ra.w, rb.x, rb.y };
+                    level_setup(org_w, dir_w, nbt);
+                    in_blas = false;
+                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
+                    cur = 0u;  // TLAS root
+                    sp = 0;
+                    have = true;
+                }
+            }
+            cursor += (uint32_t)n_idle;
+            exhausted = (cursor >> 6) * wave_stride + wave_base >= n;
+        }
+        if (__ballot(have) == 0ull) break;
+
+        // ---- node phase, either level: one routine, the node comes from L2 (TLAS) or LDS (BLAS)
+        while (have && !(cur & I16_LEAF)) {
+            uint4 q0, q1, q2, cw;
+            if (in_blas) {
+                // (LDS-typed pointer: with generic ones the compiler folds the two branches into FLAT loads)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
+                lds_cu4 *nd = (lds_cu4 *)reinterpret_cast<const u32x4 *>(s_blas + (size_t)cur * I16_NODE_DW);
+                const u32x4 r0 = nd[0], r1 = nd[1], r2 = nd[2], r3 = nd[3];
+                q0 = make_uint4(r0.x, r0.y, r0.z, r0.w); q1 = make_uint4(r1.x, r1.y, r1.z, r1.w);
+                q2 = make_uint4(r2.x, r2.y, r2.z, r2.w); cw = make_uint4(r3.x, r3.y, r3.z, r3.w);
+                PT_REG_BARRIER16(q0, q1, q2, cw)
+            } else {
+                const uint4 *nd = tlas16 + 4 * (size_t)cur;
+                q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; cw = nd[3];
+                PT_REG_BARRIER16(q0, q1, q2, cw)
+            }
+            if (COUNT) c_nodes++;
+            // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw (two children per dword)
+            // near / far rows by bit-field insert with per-lane masks (mx = all ones where the direction component is negative):
+            // twelve v_cndmask_b32 on VCC in a row issue at ~23 cycles each on this chip and made this
+            // kernel stall on issue 3.7x as often as the fp32 one; v_bfi_b32 has no such hazard
+            auto sel = [](uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); };  // m ? a : b, bitwise
+            const uint2 hnx = { sel(mx, q1.z, q0.x), sel(mx, q1.w, q0.y) }, hfx = { sel(mx, q0.x, q1.z), sel(mx, q0.y, q1.w) };
+            const uint2 hny = { sel(my, q2.x, q0.z), sel(my, q2.y, q0.w) }, hfy = { sel(my, q0.z, q2.x), sel(my, q0.w, q2.y) };
+            const uint2 hnz = { sel(mz, q2.z, q1.x), sel(mz, q2.w, q1.y) }, hfz = { sel(mz, q1.x, q2.z), sel(mz, q1.y, q2.w) };
+            float t0, t1, t2, t3;
+            PT_SLAB4H(t0, x, 0)
+            PT_SLAB4H(t1, x, 1)
+            PT_SLAB4H(t2, y, 0)
+            PT_SLAB4H(t3, y, 1)
+            uint32_t k0 = (__float_as_uint(t0) & 0xFFFF0000u) | cw.x, k1 = (__float_as_uint(t1) & 0xFFFF0000u) | cw.y,
+                     k2 = (__float_as_uint(t2) & 0xFFFF0000u) | cw.z, k3 = (__float_as_uint(t3) & 0xFFFF0000u) | cw.w;
+#define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
+            PT_KSWAP(k0, k1)
+            PT_KSWAP(k2, k3)
+            PT_KSWAP(k0, k2)
+            PT_KSWAP(k1, k3)
+            PT_KSWAP(k1, k2)
+#undef PT_KSWAP
+            constexpr uint32_t KINF = 0x7F800000u;
+            if (k3 < KINF) push(k3);  // farthest first
+            if (k2 < KINF) push(k2);
+            if (k1 < KINF) push(k1);
+            cur = k0 < KINF ? (k0 & 0xFFFFu) : pop();
+        }
+        // ---- leaf phase: a BLAS leaf (triangles) or a TLAS leaf (enter the instance)
+        // entering costs ~130 VALU: lanes that want to wait until ENTER_MIN of them do, or no lane has triangle work
+        const int ENTER_MIN = enter_min;
+        const int n_enter = __popcll(__ballot(have && cur != I16_DONE && !in_blas));
+        const bool others = __ballot(have && cur != I16_DONE && in_blas) != 0ull;
+        const bool do_enter = n_enter >= ENTER_MIN || !others;
+        if (have) {
+            if (cur != I16_DONE && in_blas) {
+                const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
+                if (COUNT) c_tris += cnt;
+                auto accept = [&](float t, float V, float W, float det, uint32_t pos, uint32_t prim) {
+                    // closest t; equal t -> lowest (gl_InstanceID, gl_PrimitiveID)
+                    if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
+                        best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                        best_ipos = cur_ipos; best_iid = cur_iid;
+                    }
+                };
+                if (PAIRS) {
+                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
+                    const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
+                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
+                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
+                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
+                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
+                    const float pAC = Ax * Cy, qAC = Ay * Cx;
+                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
+                        if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+                        const float det = (U + V) + W;
+                        if (det == 0.0f) return;
+                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
+                        const float t = ptm::fdiv(T, det);
+                        if (!(t > tmin && t < tmax)) return;
+                        accept(t, V, W, det, pos, prim);
+                    };
+                    finish(Cx * By - Cy * Bx, pAC - qAC, Bx * Ay - By * Ax, Az_, Bz_, Cz_, first, __float_as_uint(a.w));
+                    if (cnt == 2u) {
+                        const float4 d = s_tri[ti + 5];
+                        const float Dz_ = d.z - orgp.z;
+                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
+                        finish(Dx * Cy - Dy * Cx, Ax * Dy - Ay * Dx, qAC - pAC, Az_, Cz_, Dz_, first + 1u, __float_as_uint(d.w));
+                    }
+                } else {
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const uint32_t pos = first + k;
+                        const size_t ti = (size_t)tri_base + 3 * (size_t)pos;
+                        const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
+                        float t, V, W, det;
+                        if (ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det))
+                            accept(t, V, W, det, pos, __float_as_uint(a.w));
+                    }
+                }
+                cur = pop();
+            } else if (cur != I16_DONE && do_enter) {
+                // TLAS leaf: one instance.  The ray goes to object space un-normalised (t is the same parameter)
+                const uint32_t first = cur & 0x7FFFu;
+                cur_ipos = first;
+                cur_iid = inst_id[first];
+                const float4 r0 = inst6[6 * (size_t)first + 3], r1 = inst6[6 * (size_t)first + 4], r2 = inst6[6 * (size_t)first + 5];
+                const ptm::f3 oo = { ((r0.x * org_w.x + r0.y * org_w.y) + r0.z * org_w.z) + r0.w,
+                                     ((r1.x * org_w.x + r1.y * org_w.y) + r1.z * org_w.z) + r1.w,
+                                     ((r2.x * org_w.x + r2.y * org_w.y) + r2.z * org_w.z) + r2.w };
+                const ptm::f3 od = { (r0.x * dir_w.x + r0.y * dir_w.y) + r0.z * dir_w.z,
+                                     (r1.x * dir_w.x + r1.y * dir_w.y) + r1.z * dir_w.z,
+                                     (r2.x * dir_w.x + r2.y * dir_w.y) + r2.z * dir_w.z };
+                level_setup(oo, od, nbb);
+                pre = ptm::ray_setup(oo, od);
+                tri_base = (uint32_t)pre.kz * 3u * n_tris;
+                orgp = { ptm::sel3(pre.kz, oo.y, oo.z, oo.x), ptm::sel3(pre.kz, oo.z, oo.x, oo.y), ptm::sel3(pre.kz, oo.x, oo.y, oo.z) };
+                push(I16_EXIT);
+                in_blas = true;
+                cur = 0u;  // BLAS root
+            }
+            if (cur == I16_DONE) {
+                const bool miss = best_pos == PT_MISS;
+                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                                 : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
+                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                hit_inst[q] = best_ipos;
+                have = false;
+            }
+        }
+    }
+    if (COUNT) {
+        for (int o = 32; o > 0; o >>= 1) {
+            c_nodes += __shfl_xor(c_nodes, o, 64);
+            c_tris += __shfl_xor(c_tris, o, 64);
+        }
+        if (lane == 0 && stats) {
+            atomicAdd(stats + 2, c_nodes);
+            atomicAdd(stats + 3, c_tris);
+        }
+    }
+}
+
+}  // namespace

@@ -109,6 +109,16 @@ struct NormBox { float cx, cy, cz, sx, sy, sz, rsx, rsy, rsz; };
         const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                              \
         T = tn <= tf ? tn : INF;                                                                    \
     }
+// m ? a : b for an all-ones / all-zeros mask, as one v_bfi_b32: a run of v_cndmask_b32 on VCC issues at ~23 cycles each on
+// gfx950, which made the two-level fp16 kernel stall on issue 3.7 times as often as its predecessor
+#ifndef PT_HBM_SELECT_BFI
+#define PT_HBM_SELECT_BFI 1
+#endif
+#if PT_HBM_SELECT_BFI
+#define PT_BFI(M, A, B) (((M) & (A)) | (~(M) & (B)))
+#else
+#define PT_BFI(M, A, B) ((M) ? (A) : (B))
+#endif
 #ifndef PT_EXTEND_WAVES
 #define PT_EXTEND_WAVES 7  // min waves per SIMD asked of the compiler for the no-spill LDS variant: 72 VGPRs instead of 76, no spills (8: 13 spilled, -13 %)
 #endif
@@ -325,10 +335,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 if (is_node) {
                     if (COUNT) c_nodes++;
                     PT_COUNT_WAVE(c_node_steps);
-                    const bool ngx = ax != 0u, ngy = ay != 0u, ngz = az != 0u;  // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw
-                    const uint2 hnx = { ngx ? q1.z : q0.x, ngx ? q1.w : q0.y }, hfx = { ngx ? q0.x : q1.z, ngx ? q0.y : q1.w };
-                    const uint2 hny = { ngy ? q2.x : q0.z, ngy ? q2.y : q0.w }, hfy = { ngy ? q0.z : q2.x, ngy ? q0.w : q2.y };
-                    const uint2 hnz = { ngz ? q2.z : q1.x, ngz ? q2.w : q1.y }, hfz = { ngz ? q1.x : q2.z, ngz ? q1.y : q2.w };
+                    // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw; near / far by bit-field insert (PT_BFI below)
+                    const uint32_t mx = ax ? 0xFFFFFFFFu : 0u, my = ay ? 0xFFFFFFFFu : 0u, mz = az ? 0xFFFFFFFFu : 0u;
+                    const uint2 hnx = { PT_BFI(mx, q1.z, q0.x), PT_BFI(mx, q1.w, q0.y) }, hfx = { PT_BFI(mx, q0.x, q1.z), PT_BFI(mx, q0.y, q1.w) };
+                    const uint2 hny = { PT_BFI(my, q2.x, q0.z), PT_BFI(my, q2.y, q0.w) }, hfy = { PT_BFI(my, q0.z, q2.x), PT_BFI(my, q0.w, q2.y) };
+                    const uint2 hnz = { PT_BFI(mz, q2.z, q1.x), PT_BFI(mz, q2.w, q1.y) }, hfz = { PT_BFI(mz, q1.x, q2.z), PT_BFI(mz, q1.y, q2.w) };
                     float t0, t1, t2, t3;
                     uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z, w3 = cw.w;
                     PT_SLAB4H(t0, x, 0)
@@ -427,10 +438,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 const uint4 q0 = *reinterpret_cast<const uint4 *>(nb_), q1 = *reinterpret_cast<const uint4 *>(nb_ + 16),
                             q2 = *reinterpret_cast<const uint4 *>(nb_ + 32);
                 const uint4 cw = *reinterpret_cast<const uint4 *>(nb_ + 48);
-                const bool ngx = ax != 0u, ngy = ay != 0u, ngz = az != 0u;  // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw
-                const uint2 hnx = { ngx ? q1.z : q0.x, ngx ? q1.w : q0.y }, hfx = { ngx ? q0.x : q1.z, ngx ? q0.y : q1.w };
-                const uint2 hny = { ngy ? q2.x : q0.z, ngy ? q2.y : q0.w }, hfy = { ngy ? q0.z : q2.x, ngy ? q0.w : q2.y };
-                const uint2 hnz = { ngz ? q2.z : q1.x, ngz ? q2.w : q1.y }, hfz = { ngz ? q1.x : q2.z, ngz ? q1.y : q2.w };
+                // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw; near / far by bit-field insert (PT_BFI)
+                const uint32_t mx = ax ? 0xFFFFFFFFu : 0u, my = ay ? 0xFFFFFFFFu : 0u, mz = az ? 0xFFFFFFFFu : 0u;
+                const uint2 hnx = { PT_BFI(mx, q1.z, q0.x), PT_BFI(mx, q1.w, q0.y) }, hfx = { PT_BFI(mx, q0.x, q1.z), PT_BFI(mx, q0.y, q1.w) };
+                const uint2 hny = { PT_BFI(my, q2.x, q0.z), PT_BFI(my, q2.y, q0.w) }, hfy = { PT_BFI(my, q0.z, q2.x), PT_BFI(my, q0.w, q2.y) };
+                const uint2 hnz = { PT_BFI(mz, q2.z, q1.x), PT_BFI(mz, q2.w, q1.y) }, hfz = { PT_BFI(mz, q1.x, q2.z), PT_BFI(mz, q1.y, q2.w) };
                 w0 = cw.x; w1 = cw.y; w2 = cw.z; w3 = cw.w;
                 PT_SLAB4H(t0, x, 0)
                 PT_SLAB4H(t1, x, 1)

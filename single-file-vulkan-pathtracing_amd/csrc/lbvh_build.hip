@@ -600,8 +600,9 @@ __global__ __launch_bounds__(TB) void k_w4_emit(uint32_t count, uint32_t level_b
                                                 const uint32_t *__restrict__ kids, const uint32_t *__restrict__ int_off,
                                                 const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi, float cx,
                                                 float cy, float cz, float rsx, float rsy, float rsz, uint4 *__restrict__ wide16,
-                                                uint32_t *__restrict__ next_front)
+                                                uint32_t *__restrict__ next_front, int compact16)
 {
+    // compact16 (the TLAS of k_extend_inst16): child words as 16-bit codes -- node index, 0x8000 | leaf position, 0xFFFF empty
     const uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= count) return;
     const float c[3] = { cx, cy, cz }, rs[3] = { rsx, rsy, rsz };
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(TB) void k_w4_emit(uint32_t count, uint32_t level_b
         const uint32_t r = kids[8 * (size_t)j + k];
         if (r == PT_MISS) {
             for (int ax = 0; ax < 3; ax++) hl[ax][k] = hh[ax][k] = 0x7C00u;
-            word[k] = PT_MISS;
+            word[k] = compact16 ? 0xFFFFu : PT_MISS;
             continue;
         }
         const bool leaf = (r & PT_LEAF) != 0u;
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(TB) void k_w4_emit(uint32_t count, uint32_t level_b
             hh[ax][k] = __half_as_ushort(__float2half_ru((h[ax] - c[ax]) * rs[ax] + 3.814697265625e-06f));
         }
         if (leaf) {
-            word[k] = r;  // PT_LEAF | sorted position, count 1
+            word[k] = compact16 ? (0x8000u | (r & 0x7FFFu)) : r;  // PT_LEAF | sorted position, count 1
         } else {
             word[k] = next_base + int_off[j] + ni;
             next_front[int_off[j] + ni] = r;
@@ -712,9 +713,12 @@ __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, c
     }
 }
 
+// top_down: bit 0 = also the BVH8 (+ its triangle order), bit 1 = also the top-down BVH4 in the 64-B format, bit 2 = that BVH4
+// with 16-bit child codes (k_w4_emit compact16: the TLAS of k_extend_inst16; needs n < 32768)
 static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, uint32_t leaf_max, BvhOut &out,
-                          bool want8 = false)
+                          int top_down = 0)
 {
+    const bool want8 = (top_down & 1) != 0, want4t = (top_down & 2) != 0;
     hipStream_t st = ctx->stream;
     const uint32_t gt = (n + TB - 1) / TB;
     DevBuf<uint32_t> d_scene, d_vals[2], d_hist, d_pint, d_pleaf, d_flags, d_height, d_wflag, d_widx, d_sums;
@@ -807,7 +811,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
     }
     PT_HIP(ctx, hipGetLastError());
     norm_box(out.bmin, out.bmax, out.norm_c, out.norm_s, out.norm_rs);
-    if (want8 && n > 1) {
+    if ((want8 || want4t) && n > 1) {
         // BVH8, level by level from the root (see k_w8_expand).  Worst case every wide node has two children: n - 1 nodes.
         const uint32_t n_int = n - 1;
         DevBuf<uint32_t> d_front[2], d_start[2], d_kids, d_ni, d_nl;
@@ -818,12 +822,13 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         PT_HIP(ctx, d_kids.alloc(8 * (size_t)n_int));
         PT_HIP(ctx, d_ni.alloc(n_int));
         PT_HIP(ctx, d_nl.alloc(n_int));
+        uint32_t count = 1, level_base = 0, tri_run = 0, levels = 0;
+        int cf = 0;
+        if (want8) {
         PT_HIP(ctx, hipMalloc((void **)&out.d_wide8, 128 * (size_t)n_int));
         PT_HIP(ctx, hipMalloc((void **)&out.d_order8, sizeof(uint32_t) * (size_t)n));
         PT_HIP(ctx, hipMemsetAsync(d_front[0].p, 0, sizeof(uint32_t), st));  // level 0: the binary root, whose range starts at 0
         PT_HIP(ctx, hipMemsetAsync(d_start[0].p, 0, sizeof(uint32_t), st));
-        uint32_t count = 1, level_base = 0, tri_run = 0, levels = 0;
-        int cf = 0;
         while (count > 0) {
             const uint32_t g = (count + TB - 1) / TB;
             k_w8_expand<8><<<g, TB, 0, st>>>(count, d_front[cf].p, (int)n, d_topo.p, d_blo.p, d_bhi.p, d_kids.p, d_ni.p, d_nl.p);
@@ -850,6 +855,8 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         if (tri_run != n) { ctx->err = "internal: BVH8 build lost triangles"; return PT_ERR_HIP; }
         out.n_wide8 = level_base;
         out.levels8 = levels;
+        }
+        if (want4t) {
         // ... and the four-wide tree in the 64-B format, same passes
         PT_HIP(ctx, hipMalloc((void **)&out.d_wide16t, 64 * (size_t)n_int));
         PT_HIP(ctx, hipMemsetAsync(d_front[0].p, 0, sizeof(uint32_t), st));
@@ -865,7 +872,8 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
             const uint32_t next_count = tot + last, next_base = level_base + count;
             if ((uint64_t)next_base + next_count > n_int) { ctx->err = "internal: BVH4 (top-down) build overran its bounds"; return PT_ERR_HIP; }
             k_w4_emit<<<g, TB, 0, st>>>(count, level_base, next_base, (int)n, d_kids.p, d_ni.p, d_blo.p, d_bhi.p, out.norm_c[0], out.norm_c[1],
-                                        out.norm_c[2], out.norm_rs[0], out.norm_rs[1], out.norm_rs[2], out.d_wide16t, d_front[cf ^ 1].p);
+                                        out.norm_c[2], out.norm_rs[0], out.norm_rs[1], out.norm_rs[2], out.d_wide16t, d_front[cf ^ 1].p,
+                                        (top_down & 4) ? 1 : 0);
             level_base = next_base;
             count = next_count;
             cf ^= 1;
@@ -873,6 +881,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         }
         out.n_wide16t = level_base;
         out.levels4t = levels;
+        }
         PT_HIP(ctx, hipStreamSynchronize(st));
         PT_HIP(ctx, hipGetLastError());
     }
@@ -955,7 +964,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p);
     BvhOut o;
-    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o, true);
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o, 3);
     s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
     s->d_wide8 = o.d_wide8; s->n_wide8 = o.n_wide8; s->levels8 = o.levels8;
     s->d_wide16t = o.d_wide16t; s->n_wide16t = o.n_wide16t; s->levels4t = o.levels4t;
@@ -1170,8 +1179,8 @@ static void invert_3x4(const float m[12], float inv[12])
 
 void ptb_free_instances(pt_scene *s)
 {
-    (void)hipFree(s->d_inst6); (void)hipFree(s->d_tlas_wide); (void)hipFree(s->d_tlas_prim_of);
-    s->d_inst6 = nullptr; s->d_tlas_wide = nullptr; s->d_tlas_prim_of = nullptr;
+    (void)hipFree(s->d_inst6); (void)hipFree(s->d_tlas_wide); (void)hipFree(s->d_tlas_prim_of); (void)hipFree(s->d_tlas16);
+    s->d_inst6 = nullptr; s->d_tlas_wide = nullptr; s->d_tlas_prim_of = nullptr; s->d_tlas16 = nullptr; s->n_tlas16 = 0;
     s->n_inst = 0; s->n_tlas_wide = 0; s->tlas_height = 0;
 }
 
@@ -1204,11 +1213,14 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     const uint32_t g = (n + TB - 1) / TB;
     k_inst_boxes<<<g, TB, 0, st>>>(s->d_wide, d_in.p, n, d_tlo.p, d_thi.p);
     BvhOut o;
-    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_TLAS_LEAF_MAX, o);
+    // (n < 32768: also the top-down 64-B TLAS with 16-bit child codes that k_extend_inst16 walks)
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_TLAS_LEAF_MAX, o, (n > 1 && n < 32768u && PT_TLAS_LEAF_MAX == 1u) ? 6 : 0);
     (void)hipFree(o.d_keys);
     (void)hipFree(o.d_nodes);
     s->d_tlas_wide = o.d_wide;
     s->d_tlas_prim_of = o.d_prim_of;
+    s->d_tlas16 = o.d_wide16t; s->n_tlas16 = o.n_wide16t; s->tlas16_levels = o.levels4t;
+    for (int k = 0; k < 3; k++) { s->tlas_norm_c[k] = o.norm_c[k]; s->tlas_norm_s[k] = o.norm_s[k]; s->tlas_norm_rs[k] = o.norm_rs[k]; }
     if (rc != PT_OK) { ptb_free_instances(s); return rc; }
     PT_HIP(ctx, hipMalloc((void **)&s->d_inst6, sizeof(float4) * 6 * (size_t)n));
     k_inst_sort<<<g, TB, 0, st>>>(d_in.p, s->d_tlas_prim_of, n, s->d_inst6);

@@ -100,6 +100,10 @@ struct pt_scene {
     float4 *d_inst6 = nullptr;
     float4 *d_tlas_wide = nullptr;        // BVH4 over the instances' world boxes
     uint32_t *d_tlas_prim_of = nullptr;   // sorted position -> instance id (gl_InstanceID)
+    // the TLAS k_extend_inst16 walks: 64-B fp16 nodes (normalised to the TLAS box), built top-down, 16-bit child codes
+    uint4 *d_tlas16 = nullptr;
+    uint32_t n_tlas16 = 0, tlas16_levels = 0;
+    float tlas_norm_c[3]{}, tlas_norm_s[3]{1.f, 1.f, 1.f}, tlas_norm_rs[3]{1.f, 1.f, 1.f};
 };
 
 struct pt_film {

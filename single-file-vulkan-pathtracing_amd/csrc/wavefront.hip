@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "extend_kernel.h"  // TB, SENTINEL, NormBox, k_extend<>, k_extend_lds7, the slab / stack helpers
+#include "extend_inst16.h"  // k_extend_inst16: the two-level kernel over 64-B fp16 nodes with one-dword stack entries
 
 // extend_hbm.hip: k_extend<false, *, true>, compiled with the max-ILP scheduler
 const void *ptw_extend_hbm_fn(bool count);
@@ -954,6 +955,8 @@ struct ExtendPlan {
     bool pairs = false;         // ... and every leaf of the BVH4 is one triangle or one fan pair: the PAIRS kernel
     bool bvh8 = false;          // PT_EXTEND_HBM8: the BVH8 and ITS triangle order (s->d_tri4_8, d_shade64_8, d_ke4_8)
     bool topdown4 = false;      // HBM variant over the top-down BVH4 with contiguous children (s->d_wide16t)
+    bool inst16 = false;        // two-level scenes: k_extend_inst16 (64-B fp16 nodes on both levels, one-dword stack entries)
+    size_t smem_inst_fallback = 0; int grid_inst_fallback = 0;  // k_extend_inst's launch shape (tmin <= 0 takes it)
     size_t smem_wide_entries = 0;  // LDS bytes of the same plan run by the 8-byte-entry kernel (negative tmin)
 };
 
@@ -978,13 +981,35 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
                          // 48: 9.26, 56: 9.2, 64: 9.38 Grays/s
         if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
         pl.grid = ctx->num_cus * per_cu_i;
+        pl.smem_inst_fallback = pl.smem; pl.grid_inst_fallback = pl.grid;
+        // the round-2 kernel when both levels fit its 15-bit child codes and the BLAS fits LDS
+        const size_t smem16_scene = sizeof(uint32_t) * I16_NODE_DW * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;
+        int lds16 = 16;
+        if (const char *e = getenv("PT_TUNE_LDS_STACK")) lds16 = std::max(1, std::min(atoi(e), 32));
+        pl.inst16 = s->d_tlas16 && s->d_wide16 && s->n_inst < 32768u && s->n_tlas16 < 32767u && s->n_wide < 32767u && s->n_tris <= 2047u &&
+                    smem16_scene <= 24 * 1024 && !(getenv("PT_TUNE_INST16") && atoi(getenv("PT_TUNE_INST16")) == 0);
+        if (pl.inst16) {
+            pl.lds_stack = lds16;
+            pl.smem = (size_t)lds16 * TB * sizeof(uint32_t) + smem16_scene;
+            const void *fn16 = s->pair_leaves ? reinterpret_cast<const void *>(k_extend_inst16<false, true>)
+                                              : reinterpret_cast<const void *>(k_extend_inst16<false, false>);
+            int per16 = 0;
+            PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per16, fn16, TB, pl.smem));
+            // four blocks per CU and refill at 48 idle lanes measured best on the 10 000-instance grid (C4: 4/48 10.73,
+            // 5/48 10.33, 4/40 10.66, 4/56 10.35, 4/64 9.74 Grays/s; the fp32 kernel at its best, 4/64: 9.33)
+            per16 = std::min(per16, 4);
+            if (const char *e = getenv("PT_TUNE_INST16_BLOCKS")) per16 = std::max(1, std::min(atoi(e), 8));
+            pl.grid = ctx->num_cus * std::max(1, std::min(per16, 8));
+            pl.refill = 48;
+            if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+        }
         // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk: the exact bound of the
         // BVH4 that is TRAVERSED when the builder gave one (the surface-area BVH4 of a small scene can be deeper
         // than the balanced LBVH whose height s->height is), else 3 per level of the collapsed LBVH
         const uint32_t blas_bound = s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u);
-        const uint32_t bound_i = 3u * (s->tlas_height / 2u + 1u) + 4u + blas_bound + 2u;
-        pl.spill_levels = bound_i > (uint32_t)LDS_STACK ? bound_i - (uint32_t)LDS_STACK : 0u;
-        const size_t need_i = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
+        const uint32_t bound_i = 3u * (std::max(s->tlas_height / 2u + 1u, s->tlas16_levels)) + 4u + blas_bound + 2u;
+        pl.spill_levels = bound_i > (uint32_t)LDS_STACK ? bound_i - (uint32_t)LDS_STACK : 0u;  // (sized for the 8-entry fallback kernel)
+        const size_t need_i = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)std::max(pl.grid, pl.grid_inst_fallback) * TB * sizeof(uint2);
         if (need_i > ctx->spill_bytes) {
             (void)hipFree(ctx->d_spill);
             ctx->d_spill = nullptr;
@@ -1100,11 +1125,32 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     // two overlapping pipelines an event recorded between kernels would also count queueing time
     // each concurrently running extend kernel owns its own [spill_levels][grid*TB] region
     const size_t spill_off = (size_t)pipe * std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB;
-    if (s->n_inst) {
-        uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
+    if (s->n_inst && pl.inst16 && tmin > 0.f) {
+        // own region of the spill buffer, counted in dwords (the buffer is sized in 8-byte entries for the larger grid)
+        uint32_t *sp32 = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s->ctx->d_spill) + (size_t)pipe * std::max(pl.spill_levels, 1u) * (size_t)std::max(pl.grid, pl.grid_inst_fallback) * TB);
         const uint32_t str = (uint32_t)pl.grid * TB;
+        const NormBox nbt = { s->tlas_norm_c[0], s->tlas_norm_c[1], s->tlas_norm_c[2], s->tlas_norm_s[0], s->tlas_norm_s[1], s->tlas_norm_s[2],
+                              s->tlas_norm_rs[0], s->tlas_norm_rs[1], s->tlas_norm_rs[2] };
+        const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
+        int enter_min = 16;  // lanes that wait to enter an instance together (8: , 16, 24 measured alike within 1 %)
+        if (const char *e = getenv("PT_TUNE_ENTER_MIN")) enter_min = std::max(1, std::min(atoi(e), 64));
+#define PT_LAUNCH_INST16(C, P)                                                                                              \
+    hipExtLaunchKernelGGL((k_extend_inst16<C, P>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
+                          reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6,     \
+                          s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp32, str, pl.refill, tmin, \
+                          tmax, raw, pl.lds_stack, enter_min)
+        if (s->pair_leaves) { if (count) PT_LAUNCH_INST16(true, true); else PT_LAUNCH_INST16(false, true); }
+        else { if (count) PT_LAUNCH_INST16(true, false); else PT_LAUNCH_INST16(false, false); }
+#undef PT_LAUNCH_INST16
+        return;
+    }
+    if (s->n_inst) {
+        const int grid_i = pl.inst16 ? pl.grid_inst_fallback : pl.grid;
+        const size_t smem_i = pl.inst16 ? pl.smem_inst_fallback : pl.smem;
+        uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill) + (size_t)pipe * std::max(pl.spill_levels, 1u) * (size_t)std::max(pl.grid, pl.grid_inst_fallback) * TB;
+        const uint32_t str = (uint32_t)grid_i * TB;
 #define PT_LAUNCH_INST(C, L)                                                                                             \
-    hipExtLaunchKernelGGL((k_extend_inst<C, L>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas_wide, \
+    hipExtLaunchKernelGGL((k_extend_inst<C, L>), dim3(grid_i), dim3(TB), (uint32_t)smem_i, st, ev0, ev1, 0u, s->d_tlas_wide, \
                           s->d_wide, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6, s->d_tlas_prim_of, rayA, rayB, hit,           \
                           hit_inst, count_in, count_zero, stats, sp, str, pl.refill, tmin, tmax, raw)
         if (pl.lds_scene) {
