@@ -102,7 +102,7 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
 
 def extend_kernel_name(pt, st, info, config):
     if config == "c4":
-        return "k_extend_inst"
+        return "k_extend_inst" if os.environ.get("PT_TUNE_INST16") == "0" else "k_extend_inst16"
     lds = "k_extend<lds>"
     if info.n_wide_nodes <= 8191 and info.n_tris <= 2047:     # the compact no-spill instantiations (plan_extend)
         lds = "k_extend_lds7" if os.environ.get("PT_TUNE_PAIR_KERNEL") == "0" or os.environ.get("PT_TUNE_PAIR_LEAVES") == "0" else "k_extend_lds7p"
@@ -153,7 +153,7 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
     # kernel reads fp32 nodes, 128 B); one triangle = 36 B of positions.  Counted only when the scene exceeds the
     # 32 MiB of L2; smaller scenes are LDS / L2 resident and HBM sees the queue I/O only.
     bvh8 = st.extend_variant == 4       # one 128-B line per node visit (8 fp16 child boxes + child / triangle bases and masks)
-    node_bytes = 128.0 if (config == "c4" or bvh8) else 64.0
+    node_bytes = 128.0 if ((config == "c4" and os.environ.get("PT_TUNE_INST16") == "0") or bvh8) else 64.0
     if bvh8:
         scene_bytes = info.device_bytes8
     gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0

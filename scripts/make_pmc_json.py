@@ -19,7 +19,7 @@ for line in open(os.path.join(root, "stats.log")):
 # dominant extend kernel of the timed region = the k_extend* kernel with most total time (the counting
 # instantiation only runs the one extra untimed frame)
 import re
-counting = re.compile(r"k_extend<\w+, true|k_extend_inst<true")   # the instrumented instantiations (PT_FLAG_COUNT_VISITS frame)
+counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations (PT_FLAG_COUNT_VISITS frame)
 name = max((k for k in s["kernels"] if k.startswith("k_extend") and not counting.match(k)), key=lambda k: s["kernels"][k]["total_ns"])
 e, kt = s["pmc"][name], s["kernels"][name]
 pl = lambda c: e[c + "_per_launch"]

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
     ptm::f3 org_w{}, dir_w{};
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};  // the level being walked, in that level's normalised coordinates
     uint32_t mx = 0, my = 0, mz = 0;  // all ones where the level's direction component is negative
+    ptm::f3 w_inv{}, w_invf{}, w_on{}, w_of{};  // the TLAS level's constants, kept across instance visits
+    uint32_t w_mx = 0, w_my = 0, w_mz = 0;
     uint32_t tri_base = 0;
     ptm::RayPre pre{};
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
@@ -102,8 +104,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
             uint32_t e;
             if (sp < lds_stack) e = my_stack[sp * TB];
             else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if ((e & 0xFFFFu) == I16_EXIT) {  // the instance is done: back to the world-space ray and the TLAS
-                level_setup(org_w, dir_w, nbt);
+            if ((e & 0xFFFFu) == I16_EXIT) {  // the instance is done: back to the world-space ray and the TLAS, whose slab
+                inv = w_inv; invf = w_invf; on = w_on; of = w_of;  // constants wait in registers (four blocks per CU leave 128)
+                mx = w_mx; my = w_my; mz = w_mz;
                 in_blas = false;
                 continue;
             }
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     org_w = { ra.x, ra.y, ra.z };
                     dir_w = { ra.w, rb.x, rb.y };
                     level_setup(org_w, dir_w, nbt);
+                    w_inv = inv; w_invf = invf; w_on = on; w_of = of; w_mx = mx; w_my = my; w_mz = mz;
                     in_blas = false;
                     best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
