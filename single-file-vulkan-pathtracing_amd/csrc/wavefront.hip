@@ -1092,6 +1092,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     int per_cu = 0;
     PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TB, pl.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
+    if (const char *e = getenv("PT_TUNE_EXTEND_BLOCKS")) per_cu = std::max(1, std::min(atoi(e), per_cu));
     pl.refill = pl.lds_scene ? REFILL_MIN_IDLE : 32;  // big scenes (vote-scheduled steps): 32 idle lanes measured best on C5 (16: -2.5 %, 48: -3 %)
     if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
     pl.grid = ctx->num_cus * per_cu;
@@ -1625,6 +1626,10 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
         int cur;
         bool done;
     };
+    // two pipelines overlap one's traversal with the other's shading.  A third: C2 +2 % on one box and -1 % on another
+    // (interleaved repetitions), C4 -3 %, C5 -3 %, C5x -5 %; a fourth loses everywhere.  Capping the persistent extend
+    // grid below the register-file limit (PT_TUNE_EXTEND_BLOCKS) so that k_shade of the other pipeline can be co-resident
+    // changes nothing measurable (C2, 7 -> 5 blocks per CU: within +-1 %).
     int n_pipes = (uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1;
     if (const char *e = getenv("PT_TUNE_PIPES")) n_pipes = atoi(e);
     n_pipes = std::max(1, std::min(n_pipes, std::min<int>(PT_MAX_PIPES, (int)(lanes * groups))));
