@@ -602,6 +602,14 @@ __global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad,
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 7
 #endif
+// PT_SHADE_PRELOAD=1 requests every queue record of a chunk before the first is used (one memory round trip per chunk
+// instead of one per item).  Alone on the chip (one pipeline) k_shade gets 13 % faster with it at 5 waves (91 VGPRs, no
+// spills: 104 -> 90 ms per 16 C2 frames); next to the other pipeline's traversal kernel, which is how it runs, nothing
+// changes (three interleaved repetitions, profiles/r02_shade_preload.txt) -- the frame is bound by the VALU work of both
+// kernels, not by k_shade's latency -- so the simpler code stays the default.
+#ifndef PT_SHADE_PRELOAD
+#define PT_SHADE_PRELOAD 0
+#endif
 template <int SH_ITEMS, bool LDS_TABLES, bool NEE = false>
 __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
@@ -652,6 +660,20 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
         bool s_alive[SH_ITEMS];          // NEE: a shadow ray for this item
         float4 s_rayA[SH_ITEMS], s_contrib[SH_ITEMS];
         float2 s_rayB[SH_ITEMS];
+#if PT_SHADE_PRELOAD
+        // every queue record of the chunk is requested before the first one is used: the per-item bodies below store and
+        // add to the radiance arrays, which the compiler must assume alias the queue, so without this each item's three
+        // loads wait behind the previous item's stores -- one memory round trip per item instead of one per chunk
+        uint2 in_id[SH_ITEMS];
+        float4 in_st[SH_ITEMS], in_hit[SH_ITEMS];
+#pragma unroll
+        for (int it = 0; it < SH_ITEMS; it++) {
+            const uint32_t q = min(base + it * TB + threadIdx.x, n - 1u);
+            in_id[it] = in.id[q];
+            in_st[it] = in.state[q];
+            in_hit[it] = hit[q];
+        }
+#endif
 #pragma unroll
         for (int it = 0; it < SH_ITEMS; it++) {
             const uint32_t q = base + it * TB + threadIdx.x;
@@ -659,10 +681,16 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
             regen[it] = false;
             if (NEE) { s_alive[it] = false; o_slot[it] = 0u; }
             if (q >= n) continue;
+#if PT_SHADE_PRELOAD
+            const uint2 id = in_id[it];
+            const float4 st = in_st[it];
+            const float4 h = in_hit[it];
+#else
             const uint2 id = in.id[q];
-            const uint32_t slot = id.x, ctr = id.y;
             const float4 st = in.state[q];
             const float4 h = hit[q];
+#endif
+            const uint32_t slot = id.x, ctr = id.y;
             uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
             uint32_t seed = __float_as_uint(st.x);
             float wr = st.y, wg = st.z, wb = st.w;
