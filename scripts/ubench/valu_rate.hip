@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
         if (OP == 39) { REP8(asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %1, vcc\n v_addc_co_u32 %4, vcc, %4, %1, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
         if (OP == 40) { REP8(asm volatile("v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %4, %0, vcc\n v_cndmask_b32 %4, %0, %2, vcc" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "vcc");) }
         if (OP == 41) { REP8(asm volatile("v_cndmask_b32 %0, %2, %3, s[10:11]\n v_cndmask_b32 %2, %3, %4, s[10:11]\n v_cndmask_b32 %3, %4, %0, s[10:11]\n v_cndmask_b32 %4, %0, %2, s[10:11]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : : "s10","s11");) }
+        if (OP == 42) { REP8(asm volatile("v_fma_f32 %0, %5, %1, %6\n v_fma_f32 %2, %6, %1, %5\n v_fma_f32 %3, %5, %1, %6\n v_fma_f32 %4, %6, %1, %5" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(r6), "v"(r7));) }
+        if (OP == 43) { REP8(asm volatile("v_pk_fma_f32 %0, %5, %1, %6 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %2, %6, %1, %5 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %5, %1, %6 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %4, %6, %1, %5 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "+v"(p0), "+v"(pa), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(p3), "v"(p2));) }
+        if (OP == 44) { REP8(asm volatile("v_max3_f32 %0, %5, %1, %6\n v_min3_f32 %2, %6, %1, %5\n v_max3_f32 %3, %5, %1, %6\n v_min3_f32 %4, %6, %1, %5" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(r6), "v"(r7));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + a;
 }
@@ -78,6 +81,7 @@ int main()
     run<30>("cmp vcc + cndmask vcc", d); run<31>("cmp sgpr + cndmask sgpr", d); run<32>("cndmask e64 vcc", d); run<33>("cmp vcc, 3x cndmask vcc", d);
     run<34>("cswap: cmp vcc + 4 cndmask e32 (x5/iter)", d); run<35>("cswap: cmp sgpr + 4 cndmask e64 (x5/iter)", d);
   run<36>("P1 cnd32vcc,add,cnd32vcc,add", d); run<37>("P2 cnd32vcc,cnd64sgpr alternating", d); run<38>("P3 cnd32vcc,s_nop alternating (2 valu/grp)", d); run<39>("P4 4x v_addc_co (vcc carry in/out)", d); run<40>("P5 4x cnd e32 vcc, distinct srcs", d); run<41>("P6 4x cnd e64 sgpr, distinct srcs", d);
+  run<42>("v_fma_f32 3 distinct srcs", d); run<43>("v_pk_fma_f32 3 srcs, op_sel broadcast", d); run<44>("v_max3/min3 3 distinct srcs", d);
     printf("(the two cswap lines issue 5 instructions per group, not 4: multiply their figure by 4/5... i.e. cycles per GROUP = figure x 4)\n");
     return 0;
 }

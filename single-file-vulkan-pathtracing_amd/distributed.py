@@ -14,6 +14,8 @@ collective, so progressive rendering can continue and present again.  `Presenter
 under `torch.distributed`: the launcher's process group only carries the 128-byte RCCL unique id
 to the ranks (and, in the CPU emulation of the tests, the packed tiles over gloo).
 """
+import os
+
 import numpy as np
 
 TILE = 8
@@ -99,25 +101,72 @@ class Presenter:
         self.image = torch.zeros_like(film_tensor) if rank == 0 else None
         self.comm = None
         self.ranks_seen = None
+        self.fallback = None
         if emulate:
             self.counts = [pt.film_tile_count(film, r, world) for r in range(world)]
             self.packed = torch.zeros((max(self.counts[rank], 1), 64, 3), dtype=torch.float32, device=dev)
             self.ranks_seen = dist.get_world_size()
         else:
-            box = [pt.Comm.unique_id() if rank == 0 else None]
+            # the library's communicator; if ANY rank cannot create it (no librccl to dlopen, ncclCommInitRank refused)
+            # every rank falls back to the same gather through torch.distributed's RCCL process group, so that a
+            # multi-GPU run still presents its image -- and says so in the bench line (`describe`)
+            err = None
+            try:
+                if os.environ.get("PT_PRESENT_FORCE_TORCH"):   # tests: take the fallback
+                    raise RuntimeError("PT_PRESENT_FORCE_TORCH")
+                box = [pt.Comm.unique_id() if rank == 0 else None]
+            except Exception as e:          # rank 0 could not even make the id: the others must not wait for a peer
+                box, err = [None], e
             dist.broadcast_object_list(box, src=0)
-            self.comm = pt.Comm(ctx, box[0], world, rank)
-            self.ranks_seen = self.comm.ranks()
+            if box[0] is not None:
+                try:
+                    self.comm = pt.Comm(ctx, box[0], world, rank)
+                    self.ranks_seen = self.comm.ranks()
+                except Exception as e:
+                    err = e
+            else:
+                err = err or RuntimeError("rank 0 has no RCCL unique id")
+            bad = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                if self.comm:
+                    self.comm.close()
+                    self.comm = None
+                self.fallback = repr(err) if err is not None else "another rank failed to create the communicator"
+                self.counts = [pt.film_tile_count(film, r, world) for r in range(world)]
+                self.packed = torch.zeros((max(self.counts[rank], 1), 64, 3), dtype=torch.float32, device=dev)
+                self.ranks_seen = dist.get_world_size()
 
     def describe(self):
-        return ("packed tiles gathered over gloo (emulation)" if self.emulate else
-                "one RCCL gather of the packed tiles to rank 0 (pt_film_present: ncclSend/ncclRecv, own communicator)")
+        if self.emulate:
+            return "packed tiles gathered over gloo (emulation)"
+        if self.fallback:
+            return ("one RCCL gather of the packed tiles to rank 0 through torch.distributed send/recv (the library's own "
+                    "communicator could not be created: %s)" % self.fallback)
+        return "one RCCL gather of the packed tiles to rank 0 (pt_film_present: ncclSend/ncclRecv, own communicator)"
 
     def present(self):
         pt, torch, dist = self.pt, self.torch, self.dist
-        if not self.emulate:
+        if self.comm:
             self.comm.present(self.film, self.image.data_ptr() if self.rank == 0 else 0, root=0)
             return self.image
+        if not self.emulate:   # fallback: same pack / unpack kernels, device buffers through the process group (RCCL)
+            pt.film_pack_tiles(self.film, self.rank, self.world, self.packed.data_ptr())
+            torch.cuda.synchronize()
+            if self.rank == 0:
+                bufs = [self.packed] + [torch.zeros((max(self.counts[r], 1), 64, 3), dtype=torch.float32, device=self.packed.device)
+                                        for r in range(1, self.world)]
+                ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, self.world) if self.counts[r]]
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()
+                torch.cuda.synchronize()
+                for r in range(self.world):
+                    pt.film_unpack_tiles(self.film, r, self.world, bufs[r].data_ptr(), self.image.data_ptr())
+                return self.image
+            if self.counts[self.rank]:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.packed, 0)]):
+                    w.wait()
+            return None
         pt.film_pack_tiles(self.film, self.rank, self.world, self.packed.data_ptr())
         host = self.packed.cpu()
         if self.rank == 0:

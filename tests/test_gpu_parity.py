@@ -1523,3 +1523,39 @@ def test_device_sah_builder_equals_the_host_builder(pt, gpu_ctx, cornell_arrays,
             os.environ.pop("PT_TUNE_SAH_HOST", None); os.environ.pop("PT_TUNE_PAIR_LEAVES", None)
     assert out["0"][0].shape == out["1"][0].shape and out["0"][0].tobytes() == out["1"][0].tobytes()
     assert out["0"][2] == out["1"][2]
+
+
+def test_presenter_falls_back_to_the_process_group_when_the_library_communicator_fails(tmp_path):
+    """bench.py's Presenter: when the library's own RCCL communicator cannot be created on any rank, all ranks gather the
+    packed tiles through torch.distributed's RCCL process group instead (same pack / unpack kernels) and say so.  One rank
+    is all a 1-GPU box can run: the forced fallback presents an image equal to the film, bit for bit."""
+    import subprocess
+    import sys
+    import textwrap
+    repo = os.path.dirname(HERE)
+    script = tmp_path / "fallback.py"
+    script.write_text(textwrap.dedent(f"""
+        import importlib, os, sys
+        sys.path.insert(0, {repo!r})
+        import torch, torch.distributed as dist
+        os.environ["PT_PRESENT_FORCE_TORCH"] = "1"
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+        pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
+        ptd = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+        ctx = pt.Context(0)
+        arrays = pt.load_obj(os.path.join({repo!r}, "assets", "CornellBox-Original.obj"))
+        scene = pt.Scene(ctx, *arrays)
+        w, h = 250, 131
+        t = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+        film = pt.Film(ctx, w, h)
+        pt.render(scene, film, pt.default_params(width=w, height=h, spp_per_frame=4, max_depth=8, frame=0, frame_count=2))
+        p = ptd.Presenter(pt, ctx, film, t, 0, 1, "cuda:0", False)
+        assert p.comm is None and "torch.distributed" in p.describe() and p.ranks_seen == 1, p.describe()
+        img = p.present()
+        assert img.cpu().numpy().tobytes() == film.read_f32().tobytes()
+        p.close(); film.close(); scene.close(); ctx.close()
+        dist.destroy_process_group()
+        print("FALLBACK_OK")
+    """))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
