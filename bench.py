@@ -455,6 +455,9 @@ def main():
             bytes_extend = out["roofline"]["algorithmic_bytes_per_ray"]
             pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
             out["roofline"]["pipeline_algorithmic_GBps"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2)
+            # SURVEY 8d's canonical whole-pipeline figure: (extend + 104 shade + 96 per path / mean length) B per ray over the
+            # device time of the timed region, of the HBM peak
+            out["roofline"]["pipeline_frac"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and not args.no_extra_legs and args.config == "c2":
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()

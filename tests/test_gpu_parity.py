@@ -1559,3 +1559,45 @@ def test_presenter_falls_back_to_the_process_group_when_the_library_communicator
     """))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("config", ["c2", "c4", "c5"])
+def test_full_size_frames_equal_the_oracle_known_answers(pt, gpu_ctx, config):
+    """BASELINE's configurations at their FULL size (1920x1080; C2 / C4: 32 spp, depth 8; C5: the 1 M-triangle soup, 16 spp,
+    depth 16): frame 0 on the GPU has exactly the oracle's ray count and its film is the oracle's bit for bit (SHA-256 of
+    6.2 M floats, tests/golden/fullsize_hashes.json, written by tests/golden/make_fullsize_hashes.py from an oracle run).
+    The same frame through other shapes of the pipeline (one slot lane and one sample group, eight sample groups, the
+    kernels that read the scene from HBM, rays sorted per round) is the same film: size-independent invariances at the
+    size the benchmark runs."""
+    import hashlib
+    import json
+    path = os.path.join(HERE, "golden", "fullsize_hashes.json")
+    gold = json.load(open(path)).get(config)
+    if gold is None:
+        pytest.skip(f"no known answer for {config} in {path}")
+    repo = os.path.dirname(HERE)
+    if config == "c5":
+        arrays = pt.make_soup(1000000, 1)
+    else:
+        arrays = pt.load_obj(os.path.join(repo, "assets", "CornellBox-Original.obj"))
+    scene = pt.Scene(gpu_ctx, *arrays)
+    if config == "c4":
+        scene.set_instances(pt.cornell_grid_instances())
+    w, h = gold["width"], gold["height"]
+    film = pt.Film(gpu_ctx, w, h)
+    base = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"], frame=0, frame_count=1)
+    variants = [dict(), dict(frames_in_flight=1, sample_groups=1), dict(frames_in_flight=1, sample_groups=8)]
+    if config == "c2":
+        variants += [dict(extend=pt.EXTEND_HBM), dict(extend=pt.EXTEND_HBM8)]
+    if config == "c5":
+        variants += [dict(flags=pt.FLAG_SORT_RAYS), dict(extend=pt.EXTEND_HBM8)]
+    for kw in variants:
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(scene, film, pt.default_params(**base, **kw))
+        assert gpu_ctx.stats().rays == gold["rays"], (config, kw)
+        got = film.read_f32()
+        assert got.shape == (h, w, 3)
+        assert hashlib.sha256(got.astype("<f4").tobytes()).hexdigest() == gold["film_sha256"], (config, kw, float(got.astype(np.float64).sum()), gold["film_sum_f64"])
+    film.close()
+    scene.close()
