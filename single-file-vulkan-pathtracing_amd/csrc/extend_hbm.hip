@@ -26,31 +26,43 @@ static bool unified_step()
     return on;
 }
 
+// PT_TUNE_REC64=0 keeps the 48-B tri4 records in the leaf step (extend_kernel.h, REC64): the A/B switch of the 64-B records.
+static bool rec64()
+{
+    static const bool on = !(getenv("PT_TUNE_REC64") && atoi(getenv("PT_TUNE_REC64")) == 0);
+    return on;
+}
+
 const void *ptw_extend_hbm_fn(bool count)
 {
     if (unified_step())
         return count ? reinterpret_cast<const void *>(k_extend<false, true, true, false, true>)
                      : reinterpret_cast<const void *>(k_extend<false, false, true, false, true>);
+    if (rec64())
+        return count ? reinterpret_cast<const void *>(k_extend<false, true, true, false, false, true>)
+                     : reinterpret_cast<const void *>(k_extend<false, false, true, false, false, true>);
     return count ? reinterpret_cast<const void *>(k_extend<false, true, true>)
                  : reinterpret_cast<const void *>(k_extend<false, false, true>);
 }
 
 void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                            const float4 *wide, const uint2 *wide16, const float *norm_c, const float *norm_s,
-                           const float *norm_rs, const float4 *tri4, uint32_t n_wide, uint32_t n_tris, const float4 *rayA,
-                           const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
+                           const float *norm_rs, const float4 *tri4, const float4 *rec64_tab, uint32_t n_wide, uint32_t n_tris,
+                           const float4 *rayA, const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
                            unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
                            float tmax, int lds_stack, int raw_hit, const uint32_t *perm, const float *ray_tmax)
 {
     const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
-#define PT_LAUNCH_HBM(C, U)                                                                                                  \
-    hipExtLaunchKernelGGL((k_extend<false, C, true, false, U>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, wide, wide16, \
+#define PT_LAUNCH_HBM(C, U, R)                                                                                               \
+    hipExtLaunchKernelGGL((k_extend<false, C, true, false, U, R>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, wide, wide16, \
                           nb, tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill, tmin, \
-                          tmax, lds_stack, raw_hit, perm, ray_tmax)
+                          tmax, lds_stack, raw_hit, perm, ray_tmax, rec64_tab)
     if (unified_step()) {
-        if (count) PT_LAUNCH_HBM(true, true); else PT_LAUNCH_HBM(false, true);
+        if (count) PT_LAUNCH_HBM(true, true, false); else PT_LAUNCH_HBM(false, true, false);
+    } else if (rec64() && rec64_tab) {
+        if (count) PT_LAUNCH_HBM(true, false, true); else PT_LAUNCH_HBM(false, false, true);
     } else {
-        if (count) PT_LAUNCH_HBM(true, false); else PT_LAUNCH_HBM(false, false);
+        if (count) PT_LAUNCH_HBM(true, false, false); else PT_LAUNCH_HBM(false, false, false);
     }
 #undef PT_LAUNCH_HBM
 }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                                                       uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
                                                       uint32_t *count_zero, unsigned long long *stats, uint32_t *__restrict__ spill,
                                                       uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int raw_hit,
-                                                      int lds_stack, int enter_min)
+                                                      int lds_stack, int enter_min, int node_yield)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem);  // [lds_stack][TB]
@@ -144,7 +144,11 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         if (__ballot(have) == 0ull) break;
 
         // ---- node phase, either level: one routine, the node comes from L2 (TLAS) or LDS (BLAS)
-        while (have && !(cur & I16_LEAF)) {
+        // (node_yield > 0: once fewer than 1/node_yield of the wave's rays are still descending, the rest -- waiting with a
+        // leaf -- goes first and the stragglers resume in the next outer iteration, as in the Cornell kernel)
+        const int n_have = __popcll(__ballot(have));
+        bool do_node = have && !(cur & I16_LEAF);
+        while (do_node) {
             uint4 q0, q1, q2, cw;
             if (in_blas) {
                 // (LDS-typed pointer: with generic ones the compiler folds the two branches into FLAT loads)
@@ -188,15 +192,18 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
             if (k2 < KINF) push(k2);
             if (k1 < KINF) push(k1);
             cur = k0 < KINF ? (k0 & 0xFFFFu) : pop();
+            do_node = !(cur & I16_LEAF);
+            if (node_yield > 0 && __popcll(__ballot(do_node)) * node_yield < n_have) break;
         }
         // ---- leaf phase: a BLAS leaf (triangles) or a TLAS leaf (enter the instance)
         // entering costs ~130 VALU: lanes that want to wait until ENTER_MIN of them do, or no lane has triangle work
         const int ENTER_MIN = enter_min;
-        const int n_enter = __popcll(__ballot(have && cur != I16_DONE && !in_blas));
-        const bool others = __ballot(have && cur != I16_DONE && in_blas) != 0ull;
+        const bool at_leaf = have && (cur & I16_LEAF) && cur != I16_DONE;  // (a lane that yielded above still holds a node)
+        const int n_enter = __popcll(__ballot(at_leaf && !in_blas));
+        const bool others = __ballot(have && cur != I16_DONE && (in_blas || !(cur & I16_LEAF))) != 0ull;
         const bool do_enter = n_enter >= ENTER_MIN || !others;
         if (have) {
-            if (cur != I16_DONE && in_blas) {
+            if (at_leaf && in_blas) {
                 const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
                 if (COUNT) c_tris += cnt;
                 auto accept = [&](float t, float V, float W, float det, uint32_t pos, uint32_t prim) {
@@ -214,22 +221,38 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
                     const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
                     const float pAC = Ax * Cy, qAC = Ay * Cx;
+                    // edge test of one half: inside (no strictly negative AND strictly positive edge function) and not edge-on
+                    auto inside = [](float U, float V, float W) {
+                        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
+                    };
                     auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
-                        if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
                         const float det = (U + V) + W;
-                        if (det == 0.0f) return;
                         const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
                         const float t = ptm::fdiv(T, det);
                         if (!(t > tmin && t < tmax)) return;
                         accept(t, V, W, det, pos, prim);
                     };
-                    finish(Cx * By - Cy * Bx, pAC - qAC, Bx * Ay - By * Ax, Az_, Bz_, Cz_, first, __float_as_uint(a.w));
+                    const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
+                    const bool inA = inside(UA, VA, WA);
+                    float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
+                    uint32_t primB = 0u;
+                    bool inB = false;
                     if (cnt == 2u) {
                         const float4 d = s_tri[ti + 5];
-                        const float Dz_ = d.z - orgp.z;
+                        Dz_ = d.z - orgp.z;
                         const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
-                        finish(Dx * Cy - Dy * Cx, Ax * Dy - Ay * Dx, qAC - pAC, Az_, Cz_, Dz_, first + 1u, __float_as_uint(d.w));
+                        UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
+                        primB = __float_as_uint(d.w);
+                        inB = inside(UB, VB, WB);
                     }
+                    // one divide block for the lanes inside either half (k_extend_lds7p explains); a lane inside both takes the
+                    // first half here and the second in a block of its own, in primitive order
+                    if (inA || inB) {
+                        const bool sb = !inA;
+                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first,
+                               sb ? primB : __float_as_uint(a.w));
+                    }
+                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u, primB);
                 } else {
                     for (uint32_t k = 0; k < cnt; k++) {
                         const uint32_t pos = first + k;
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     }
                 }
                 cur = pop();
-            } else if (cur != I16_DONE && do_enter) {
+            } else if (at_leaf && do_enter) {
                 // TLAS leaf: one instance.  The ray goes to object space un-normalised (t is the same parameter)
                 const uint32_t first = cur & 0x7FFFu;
                 cur_ipos = first;

@@ -132,7 +132,7 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // at ~88 atomics/us on this chip, which short Cornell traversals (3.6 nodes/ray) exceed 3x over.
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
-template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false>
+template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false, bool REC64 = false>
 __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
                                                NormBox nb, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
@@ -141,7 +141,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                                                unsigned long long *stats, uint2 *__restrict__ spill,
                                                uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
                                                int lds_stack, int raw_hit, const uint32_t *__restrict__ perm,
-                                               const float *__restrict__ ray_tmax)
+                                               const float *__restrict__ ray_tmax, const float4 *__restrict__ g_rec64 = nullptr)
 {
     // ray_tmax (shadow rays of the NEE pipeline): a per-ray upper bound instead of `tmax`, and ANY hit below it ends
     // the walk (the record then only says hit or miss)
@@ -173,6 +173,13 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     // node arithmetic runs for the lanes that fetched a node and the triangle test for those that fetched a triangle:
     // half the waits per ray and every ray advances in every iteration.
     static_assert(!UNIFIED || (!LDS_SCENE && SPILL), "the unified step is the HBM kernel's");
+    // REC64 (scenes walked out of L2 / MALL / HBM, vote-scheduled step): the three vertices come from the 64-B per-triangle
+    // record k_shade gathers anyway ({v0, n.x} {v1, n.y} {v2, n.z} {brdf, emits}, `g_rec64` = pt_scene::d_shade64) instead
+    // of the 48-B record of tri4.  Beyond L2 the chip charges a divergent access per distinct 128-B line
+    // (scripts/ubench/gather_rate.hip): two of every eight 48-B records straddle a line, a 64-B record never does, the
+    // shading pass of the same round finds the line of the winning triangle already fetched, and tri4 drops out of the
+    // working set (its primitive ids are read only when two hits have exactly the same t).
+    static_assert(!REC64 || (!LDS_SCENE && SPILL && !UNIFIED), "64-B triangle records are the vote-scheduled HBM kernel's");
     constexpr uint32_t LEAF_BIT = COMPACT ? 0x2000u : PT_LEAF;
     constexpr uint32_t DONE = COMPACT ? 0x3FFFu : SENTINEL;
 
@@ -421,7 +428,8 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             float t0, t1, t2, t3;
             uint32_t w0, w1, w2, w3;
             if (LDS_SCENE) {
-                const float4 *nd = wide + LDS_NODE_F4 * (size_t)cur;
+                // (a 24-bit multiply-add forms the node's LDS address: the child codes are below 2^14)
+                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wide) + __umul24(cur, 16u * LDS_NODE_F4));
                 PT_NODE_LOAD(nd)
                 w0 = __float_as_uint(cw.x); w1 = __float_as_uint(cw.y); w2 = __float_as_uint(cw.z); w3 = __float_as_uint(cw.w);
                 PT_SLAB4(t0, x)
@@ -567,8 +575,9 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 for (uint32_t k = 0; k < cnt; k++) {
                     if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) c_tri_steps++;
                     const uint32_t pos = first + k;
-                    const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : 3 * (size_t)pos;
-                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
+                    const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : (REC64 ? 4 : 3) * (size_t)pos;
+                    const float4 *tp = REC64 ? g_rec64 : tri4;
+                    const float4 a = tp[ti + 0], b = tp[ti + 1], c = tp[ti + 2];
                     float t, V, W, det;
                     bool divided = false;
                     const bool th = LDS_SCENE
@@ -576,11 +585,22 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                         : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr);
                     if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
                     if (th) {
-                        const uint32_t prim = __float_as_uint(a.w);
                         // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
+                        if constexpr (REC64) {  // .w of a 64-B record is the normal: the ids of the two rivals come from tri4, on ties only
+                            bool closer = t < best_t;
+                            if (!closer && t == best_t)
+                                closer = best_pos == PT_MISS ||
+                                         __float_as_uint(g_tri4[3 * (size_t)pos].w) < __float_as_uint(g_tri4[3 * (size_t)best_pos].w);
+                            if (closer) {
+                                best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos;
+                                if (ray_tmax) sp = 0;
+                            }
+                        } else {
+                        const uint32_t prim = __float_as_uint(a.w);
                         if (t < best_t || (t == best_t && prim < best_prim)) {
                             best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
                             if (ray_tmax) sp = 0;
+                        }
                         }
                     }
                 }
@@ -631,14 +651,14 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         const float2 *__restrict__ rayB, float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,           \
         uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill, uint32_t spill_stride,          \
         int refill_min_idle, float tmin, float tmax, int lds_stack, int raw_hit, const uint32_t *__restrict__ perm,       \
-        const float *__restrict__ ray_tmax
+        const float *__restrict__ ray_tmax, const float4 *__restrict__ g_rec64
 #define PT_EXTEND_ARGS                                                                                               \
     g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
-        refill_min_idle, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax
-template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false>
+        refill_min_idle, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax, g_rec64
+template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false, bool REC64 = false>
 __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 {
-    extend_body<LDS_SCENE, COUNT, SPILL, PAIRS, UNIFIED>(PT_EXTEND_ARGS);
+    extend_body<LDS_SCENE, COUNT, SPILL, PAIRS, UNIFIED, REC64>(PT_EXTEND_ARGS);
 }
 // The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
 // asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations

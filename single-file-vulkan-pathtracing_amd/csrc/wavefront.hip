@@ -35,8 +35,8 @@
 const void *ptw_extend_hbm_fn(bool count);
 void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                            const float4 *wide, const uint2 *wide16, const float *norm_c, const float *norm_s,
-                           const float *norm_rs, const float4 *tri4, uint32_t n_wide, uint32_t n_tris, const float4 *rayA,
-                           const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
+                           const float *norm_rs, const float4 *tri4, const float4 *rec64_tab, uint32_t n_wide, uint32_t n_tris,
+                           const float4 *rayA, const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
                            unsigned long long *stats, uint2 *spill, uint32_t spill_stride, int refill, float tmin,
                            float tmax, int lds_stack, int raw_hit, const uint32_t *perm, const float *ray_tmax);
 
@@ -1163,11 +1163,13 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
         int enter_min = 16;  // lanes that wait to enter an instance together (8: , 16, 24 measured alike within 1 %)
         if (const char *e = getenv("PT_TUNE_ENTER_MIN")) enter_min = std::max(1, std::min(atoi(e), 64));
+        int node_yield = 0;  // > 0: the node loop yields to the waiting leaves below 1/node_yield descending lanes
+        if (const char *e = getenv("PT_TUNE_NODE_YIELD")) node_yield = std::max(0, std::min(atoi(e), 64));
 #define PT_LAUNCH_INST16(C, P)                                                                                              \
     hipExtLaunchKernelGGL((k_extend_inst16<C, P>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
                           reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6,     \
                           s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp32, str, pl.refill, tmin, \
-                          tmax, raw, pl.lds_stack, enter_min)
+                          tmax, raw, pl.lds_stack, enter_min, node_yield)
         if (s->pair_leaves) { if (count) PT_LAUNCH_INST16(true, true); else PT_LAUNCH_INST16(false, true); }
         else { if (count) PT_LAUNCH_INST16(true, false); else PT_LAUNCH_INST16(false, false); }
 #undef PT_LAUNCH_INST16
@@ -1213,27 +1215,27 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     hipExtLaunchKernelGGL((k_extend<L, C, S>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, \
                           s->d_wide16, nbox,                                                                          \
                           s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, \
-                          pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax)
+                          pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax, nullptr)
     if (no_spill && pl.pairs) {
         if (count)
             hipExtLaunchKernelGGL((k_extend<true, true, false, true>), dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide,
                                   s->d_wide16, nbox, s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill,
-                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax);
+                                  stride, pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax, nullptr);
         else
             hipExtLaunchKernelGGL(ray_tmax ? k_extend_lds7p_sh : k_extend_lds7p, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
                                   s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
-                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax);
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax, nullptr);
     } else if (no_spill) {
         if (count) PT_LAUNCH_EXTEND(true, true, false);
         else
             hipExtLaunchKernelGGL(ray_tmax ? k_extend_lds7_sh : k_extend_lds7, dim3(pl.grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, s->d_wide, s->d_wide16, nbox,
                                   s->d_tri4, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
-                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax);
+                                  pl.refill, tmin, tmax, pl.lds_stack, raw, nullptr, ray_tmax, nullptr);
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
         ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
-                              s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
+                              s->d_shade64, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
                               tmax, pl.lds_stack, raw, perm, ray_tmax);
     }
 #undef PT_LAUNCH_EXTEND
