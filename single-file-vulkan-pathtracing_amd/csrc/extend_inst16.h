@@ -34,12 +34,16 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                                                       uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
                                                       uint32_t *count_zero, unsigned long long *stats, uint32_t *__restrict__ spill,
                                                       uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int raw_hit,
-                                                      int lds_stack, int enter_min, int node_yield)
+                                                      int lds_stack, int enter_min, int node_yield, uint32_t n_tlas_lds)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem);  // [lds_stack][TB]
-    uint32_t *s_blas = s_stack + (size_t)lds_stack * TB;      // [n_blas_wide][I16_NODE_DW]
-    float4 *s_tri = reinterpret_cast<float4 *>(s_blas + (size_t)I16_NODE_DW * n_blas_wide);
+    uint32_t *s_blas = s_stack + (size_t)lds_stack * TB;      // [n_blas_wide + n_tlas_lds][I16_NODE_DW]
+    // the first n_tlas_lds TLAS nodes -- its top levels: the builder numbers the nodes level by level -- sit behind the BLAS
+    // nodes, so a visit to one of them is the same LDS read as a BLAS node instead of four loads from L2
+    float4 *s_tri = reinterpret_cast<float4 *>(s_blas + (size_t)I16_NODE_DW * (n_blas_wide + n_tlas_lds));
+    for (uint32_t i = threadIdx.x; i < 4 * n_tlas_lds; i += TB)
+        *reinterpret_cast<uint4 *>(s_blas + (size_t)(n_blas_wide + (i >> 2)) * I16_NODE_DW + 4 * (i & 3u)) = tlas16[i];
     for (uint32_t i = threadIdx.x; i < 4 * n_blas_wide; i += TB) {
         uint4 v = g_blas16[i];
         if ((i & 3u) == 3u) {  // the four child words -> 16-bit codes
@@ -150,11 +154,12 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         bool do_node = have && !(cur & I16_LEAF);
         while (do_node) {
             uint4 q0, q1, q2, cw;
-            if (in_blas) {
+            if (in_blas || cur < n_tlas_lds) {
                 // (LDS-typed pointer: with generic ones the compiler folds the two branches into FLAT loads)
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
-                lds_cu4 *nd = (lds_cu4 *)reinterpret_cast<const u32x4 *>(s_blas + (size_t)cur * I16_NODE_DW);
+                const uint32_t li = in_blas ? cur : cur + n_blas_wide;
+                lds_cu4 *nd = (lds_cu4 *)reinterpret_cast<const u32x4 *>(s_blas + (size_t)li * I16_NODE_DW);
                 const u32x4 r0 = nd[0], r1 = nd[1], r2 = nd[2], r3 = nd[3];
                 q0 = make_uint4(r0.x, r0.y, r0.z, r0.w); q1 = make_uint4(r1.x, r1.y, r1.z, r1.w);
                 q2 = make_uint4(r2.x, r2.y, r2.z, r2.w); cw = make_uint4(r3.x, r3.y, r3.z, r3.w);

@@ -983,6 +983,7 @@ struct ExtendPlan {
     bool pairs = false;         // ... and every leaf of the BVH4 is one triangle or one fan pair: the PAIRS kernel
     bool bvh8 = false;          // PT_EXTEND_HBM8: the BVH8 and ITS triangle order (s->d_tri4_8, d_shade64_8, d_ke4_8)
     bool topdown4 = false;      // HBM variant over the top-down BVH4 with contiguous children (s->d_wide16t)
+    uint32_t n_tlas_lds = 0;    // k_extend_inst16: TLAS nodes staged in LDS (its top levels)
     bool inst16 = false;        // two-level scenes: k_extend_inst16 (64-B fp16 nodes on both levels, one-dword stack entries)
     size_t smem_inst_fallback = 0; int grid_inst_fallback = 0;  // k_extend_inst's launch shape (tmin <= 0 takes it)
     size_t smem_wide_entries = 0;  // LDS bytes of the same plan run by the 8-byte-entry kernel (negative tmin)
@@ -1018,9 +1019,19 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
                     smem16_scene <= 24 * 1024 && !(getenv("PT_TUNE_INST16") && atoi(getenv("PT_TUNE_INST16")) == 0);
         if (pl.inst16) {
             pl.lds_stack = lds16;
-            pl.smem = (size_t)lds16 * TB * sizeof(uint32_t) + smem16_scene;
+            // top levels of the TLAS staged in LDS next to the BLAS.  8 KB (102 nodes: the top four levels) measured best on
+            // C4: 0 / 4 / 8 / 16 / 24 KB -> 11.95 / 12.16 / 12.31 / 10.7 / 11.1 Grays/s (profiles/r02i_ab_c4_tlas_lds.log) --
+            // from 16 KB on the four resident blocks leave the other pipeline's k_shade no LDS to run beside them
+            size_t tlas_lds_bytes = 8 * 1024;
+            if (const char *e = getenv("PT_TUNE_TLAS_LDS_KB")) tlas_lds_bytes = (size_t)std::max(0, std::min(atoi(e), 96)) * 1024;
+            pl.n_tlas_lds = (uint32_t)std::min<size_t>(s->n_tlas16, tlas_lds_bytes / (sizeof(uint32_t) * I16_NODE_DW));
+            pl.smem = (size_t)lds16 * TB * sizeof(uint32_t) + smem16_scene + sizeof(uint32_t) * I16_NODE_DW * (size_t)pl.n_tlas_lds;
             const void *fn16 = s->pair_leaves ? reinterpret_cast<const void *>(k_extend_inst16<false, true>)
                                               : reinterpret_cast<const void *>(k_extend_inst16<false, false>);
+            if (pl.smem > 48 * 1024)
+                for (const void *f : { reinterpret_cast<const void *>(k_extend_inst16<false, true>), reinterpret_cast<const void *>(k_extend_inst16<false, false>),
+                                       reinterpret_cast<const void *>(k_extend_inst16<true, true>), reinterpret_cast<const void *>(k_extend_inst16<true, false>) })
+                    PT_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
             int per16 = 0;
             PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per16, fn16, TB, pl.smem));
             // four blocks per CU and refill at 48 idle lanes measured best on the 10 000-instance grid (C4: 4/48 10.73,
@@ -1163,13 +1174,15 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
         int enter_min = 16;  // lanes that wait to enter an instance together (8: , 16, 24 measured alike within 1 %)
         if (const char *e = getenv("PT_TUNE_ENTER_MIN")) enter_min = std::max(1, std::min(atoi(e), 64));
-        int node_yield = 0;  // > 0: the node loop yields to the waiting leaves below 1/node_yield descending lanes
+        // the node loop yields to the lanes waiting with a leaf once fewer than 1/6 of the wave's rays still descend
+        // (C4 11.7 -> 12.2 Grays/s; 2, 3, 4, 8 measured within 1 % of it, 0 = never: profiles/r02i_ab_c4_node_yield.log)
+        int node_yield = 6;
         if (const char *e = getenv("PT_TUNE_NODE_YIELD")) node_yield = std::max(0, std::min(atoi(e), 64));
 #define PT_LAUNCH_INST16(C, P)                                                                                              \
     hipExtLaunchKernelGGL((k_extend_inst16<C, P>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
                           reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6,     \
                           s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp32, str, pl.refill, tmin, \
-                          tmax, raw, pl.lds_stack, enter_min, node_yield)
+                          tmax, raw, pl.lds_stack, enter_min, node_yield, pl.n_tlas_lds)
         if (s->pair_leaves) { if (count) PT_LAUNCH_INST16(true, true); else PT_LAUNCH_INST16(false, true); }
         else { if (count) PT_LAUNCH_INST16(true, false); else PT_LAUNCH_INST16(false, false); }
 #undef PT_LAUNCH_INST16
