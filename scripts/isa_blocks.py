@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """VALU instructions per basic block of one kernel of the shipped HIP library, for the live VALU model of bench.py.
 
-    python scripts/isa_blocks.py [--kernel k_extend_lds7] [--src wavefront.hip] [--write]
+    python scripts/isa_blocks.py [--kernel k_extend_lds7] [--src wavefront.hip] [--extra flags]
 
 Compiles the translation unit to gfx950 assembly with the flags of csrc/Makefile (`hipcc -S --cuda-device-only`), cuts
 the kernel at its labels and prints, per block: loop depth (LLVM's loop comments), VALU / SALU / LDS / VMEM instruction
 counts and the anchors that identify what the block is (7 x ds_read_b128 = a BVH4 node staged in LDS, ds_read_b96 = a
 triangle, global_load = the refill, v_div_fixup = an IEEE divide, ds_write_b32 = a stack push, global_store = the hit
-record).  `--write` classifies the blocks by these anchors into the seven block kinds the instrumented kernel counts
-at wave level (pt_stats.wave_*, node_steps, tri_steps) and writes profiles/isa_valu_model.json, which bench.py
-multiplies with the live counts.  The classification is checked against a PMC run (SQ_INSTS_VALU) in
-profiles/r02_valu_model_check.json.
+record).  By these anchors the blocks are classified (by hand: profiles/isa_valu_model.json names the labels it summed)
+into the seven block kinds the instrumented kernel counts at wave level (pt_stats.wave_*, node_steps, tri_steps);
+bench.py multiplies that table with the live counts.  The classification is checked against a PMC run
+(SQ_INSTS_VALU) in profiles/r02_valu_model_check.json.
 """
 import argparse
 import json
