@@ -623,6 +623,15 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
+    // Under two pipelines the shade launches run back to back -- their durations add up to the wall clock -- while the VALU-bound
+    // traversal kernel of the other pipeline fits in between with slack: the shade waves are the critical chain and get issue
+    // priority over the traversal waves they share a SIMD with.  Same-box A/B, six rounds: C2 23.59 -> 24.26 Grays/s (+2.9 %,
+    // shade 153 -> 138 ms, extend 130 -> 138 ms per 16 frames), C4 +4.6 %; priority 1: none, 2: +1.7 %.  With the tables in HBM
+    // (C5 +0.6 %, C5x -0.7 %) the kernel waits for its gathers and keeps the default (profiles/r02i_ab_shade_prio.log).
+#ifndef PT_SHADE_PRIO
+#define PT_SHADE_PRIO 3
+#endif
+    if (LDS_TABLES && PT_SHADE_PRIO > 0) __builtin_amdgcn_s_setprio(PT_SHADE_PRIO);
 #ifndef PT_SHADE_DENSE_REGEN
 #define PT_SHADE_DENSE_REGEN 1
 #endif
