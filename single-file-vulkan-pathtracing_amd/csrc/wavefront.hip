@@ -1661,6 +1661,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
 
     // measured on MI355X: 4 paths per thread (one queue-tail atomic per 1024 paths) and 8 blocks per CU;
     // 1 path/thread is 40 % slower, 2 equal, grid size flat between 4 and 16 blocks per CU
+    const bool stagger = !(getenv("PT_TUNE_STAGGER") && atoi(getenv("PT_TUNE_STAGGER")) == 0);
     const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 8 * (size_t)s->n_tris;  // tri4 + shade4 + the tangent frames
     const bool shade_lds = shade_smem <= 16 * 1024 && !pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
@@ -1790,8 +1791,21 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                                              ctx->num_cus, static_cast<char *>(w.d_sort) + per_pipe * (size_t)k);
                         ctx->stats.launches_other += 1 + 5 * (uint32_t)((3 * sort_bits + 3 + 7) / 8);
                     }
+                    // The pipelines start half a round apart: pipeline k > 0 begins its first traversal launch when pipeline
+                    // k-1's first one has finished.  Started together they can lock in phase -- traversal beside traversal, shade
+                    // beside shade, nothing overlaps what it should -- and whether they do depended on the box: same-box A/B,
+                    // five rounds each, 22.45 -> 23.99 Grays/s on a box whose runs were all slow (21.95 ... 23.28) and no
+                    // change on one whose runs were all fast (24.1 vs 23.9); C4 unchanged (PT_TUNE_STAGGER=0: off;
+                    // profiles/r02i_ab_stagger.log).  Only where the two kernels are of similar length (tables in LDS) and more
+                    // than one frame is in flight: the waiting pipeline costs C5 1 % (its traversal launches are four times its
+                    // shade launches: nothing to interleave) and a single frame 0.1 ms of latency.  A strict token (one
+                    // traversal launch at a time) is 20 % slower: the tail of one traversal launch is where the next one's
+                    // blocks start.
+                    const bool stag = stagger && shade_lds && rc.lanes_active > 1 && round == 0;
+                    if (stag && k > 0) PT_HIP(ctx, hipStreamWaitEvent(pp.st, ctx->ev_fork, 0));
                     launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
                                   ctx->d_stats, p->tmin, p->tmax, count_visits, true, pp.st, k, x0, x1, perm);
+                    if (stag && k + 1 < pipes_now) PT_HIP(ctx, hipEventRecord(ctx->ev_fork, pp.st));
                     ShadowQueue sq{};
                     uint32_t *sq_count = nullptr;
                     if (nee) {
