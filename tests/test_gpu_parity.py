@@ -508,6 +508,36 @@ def test_c4_grid_of_10000_instances(pt, orc, gpu_ctx, cornell_arrays):
     film.close(); gs.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [dict(PT_TUNE_NODE_YIELD="0"), dict(PT_TUNE_NODE_YIELD="2"), dict(PT_TUNE_TLAS_LDS_KB="0"),
+                                   dict(PT_TUNE_TLAS_LDS_KB="24", PT_TUNE_NODE_YIELD="8"), dict(PT_TUNE_INST16="0")])
+def test_two_level_kernel_scheduling_knobs_keep_the_bits(pt, orc, gpu_ctx, cornell_arrays, knobs):
+    """The scheduling of the compact two-level kernel (when the node loop yields to waiting leaves, how many TLAS nodes are
+    staged in LDS; INST16=0: the round-1 kernel) must not show in the results: the 10 000-instance grid -- a partly LDS-resident
+    TLAS -- and a 7-instance set -- an entirely LDS-resident one -- render and trace to the oracle's bits under every setting."""
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        for inst in (pt.cornell_grid_instances(), _random_instances(7, 3)):
+            gs, osc = pt.Scene(gpu_ctx, *cornell_arrays), orc.Scene(*cornell_arrays)
+            gs.set_instances(inst)
+            osc.set_instances(inst)
+            kw = dict(width=192, height=108, spp_per_frame=2, max_depth=8)
+            film = pt.Film(gpu_ctx, 192, 108)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=1, **kw))
+            ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
+            assert gpu_ctx.stats().rays == orays, knobs
+            assert film.read_f32().tobytes() == ofilm.tobytes(), knobs
+            film.close(); gs.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_pt_main_host_driver_writes_the_same_image(pt, gpu_ctx, cornell_gpu, tmp_path):
     """The C++20 host driver (reference main() without Vulkan/GLFW) against the Python path."""
     import json
