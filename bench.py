@@ -2,9 +2,11 @@
 """bench.py -- the headline benchmark: Mrays/s (and ms/frame) of the radiance loop on the Cornell
 box at 1920x1080, 8 bounces (BASELINE.json metric), on N GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks,
+                                                            one process per GPU, rendezvous on 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --config c3                   (BASELINE config C3: 1024 spp = 32 steps, 8 GPUs, RCCL gather)
 
 A *step* is one frame = one reference launch (traceRaysKHR(W,H,1), main.cpp:659): 32 samples per
 pixel, <= 8 rays each, blended into the film (raygen.rgen:41-91).  K steps = 32*K spp; K=2 is
@@ -15,6 +17,10 @@ plus, for N>1, the one RCCL collective that assembles the presented image on ran
 N>1 shards the 8x8 pixel tiles of the SAME image over the ranks (config C3's decomposition), so
 the total work per step is fixed: "scaling": "strong".
 
+The timed region -- EXACTLY K steps between barrier + synchronize -- is repeated (--reps, default 5, and until the
+repetitions add up to >= 1 s of GPU time): `value` / `ms_per_step` are the MEDIAN repetition, `value_min` / `value_max`
+/ `values` the spread (a single 0.15 s sample moved by +-3 % from run to run on one box).
+
 Beside the headline the default single-GPU run appends, OUTSIDE the timed region, the legs VERDICT r01 asked for:
   * `c2_exact`            K = 2 (= 64 spp, exactly BASELINE config C2) in one call;
   * `latency_ms_1frame`   the reference's own dispatch shape: one blocking pt_render per frame (main.cpp:647-685);
@@ -23,12 +29,17 @@ Beside the headline the default single-GPU run appends, OUTSIDE the timed region
                           scene does not fit LDS/L2: algorithmic bytes per ray x rays per launch / average launch
                           time / 8 TB/s, every factor measured in this run (`--config c5` runs it as the headline,
                           `--config c5x` an 8M-triangle soup that does not fit the 256 MiB Infinity Cache either);
+  * `roofline_c4`         the two-level kernel on the 10 000-instance grid (BASELINE config C4, 8 frames) and
+    `roofline_c5x`        the 8M-triangle soup (2 frames): same shape as `roofline_c5`, incl. the VALU wave-instructions per
+                          64 rays and the active lanes per instruction from the live block counters;
   * `cpu_baseline`        the oracle on all host cores and on one, with the CPU model.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,12 +56,15 @@ BYTES_EXTEND = 40.0    # read ray 28 (index-free dense queue: 24 + 4 slot id pas
 BYTES_SHADE = 104.0
 BYTES_PER_PATH = 96.0
 
-# VALU instructions of the blocks of k_extend_lds7 (the Cornell instantiation of extend_body), counted in the ISA of
-# the shipped library by scripts/isa_blocks.py (re-run it after any change to extend_kernel.h; the table names the
-# git revision it was read at).  A launch's VALU wave-instructions = sum over blocks of (wave executions counted
-# live by the instrumented instantiation of the same template, PT_FLAG_COUNT_VISITS) x (instructions of the block).
-ISA_VALU_MODEL = json.load(open(os.path.join(REPO, "profiles", "isa_valu_model.json"))) \
-    if os.path.exists(os.path.join(REPO, "profiles", "isa_valu_model.json")) else None
+# VALU instructions of the blocks of the traversal kernels, counted in the ISA of the shipped library by
+# scripts/isa_blocks.py (re-run it after any change to the kernel headers; the table names the revision it was read at).
+# A launch's VALU wave-instructions = sum over blocks of (wave executions counted live by the instrumented instantiation
+# of the same template, PT_FLAG_COUNT_VISITS) x (instructions of the block); the lanes inside those executions, also
+# counted live, weighted the same way give the active lanes per VALU instruction.
+_MODEL = os.path.join(REPO, "profiles", "isa_valu_model.json")
+ISA_VALU_MODEL = json.load(open(_MODEL)) if os.path.exists(_MODEL) else None
+# which PMC record (scripts/make_pmc_json.py) carries the HBM-side traffic of a config's traversal kernel
+PMC_RECORD = "r03_pmc_extend_{config}.json"
 
 
 def cpu_model():
@@ -92,20 +106,24 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
         t0 = time.perf_counter()
         _, r1 = orc.render_rect(osc, p1, (width - cw) // 2, (height - ch) // 2, cw, ch, mode=1, nthreads=1)
         d1 = time.perf_counter() - t0
-    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
-            "cpu_model": cpu_model(), "single_thread_mrays": round(r1 / d1 / 1e6, 4),
+    all_mrays, one_mrays = rays / dt / 1e6, r1 / d1 / 1e6
+    base = {"value": round(all_mrays, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
+            "cpu_model": cpu_model(), "single_thread_mrays": round(one_mrays, 4),
+            # all threads against `cores` x the single thread (hardware threads, not physical cores: SMT siblings count,
+            # and the single thread runs at boost clock on the cheaper central crop -- an upper bound on perfect scaling)
+            "scaling_efficiency": round(all_mrays / (cores * one_mrays), 4),
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
-                      f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O2 -ffp-contract=off, {cores} threads; "
-                      f"single thread: central {cw}x{ch} crop, {spp1} spp, {r1} rays in {d1:.2f} s"}
+                      f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O3 -march=native -ffp-contract=off, {cores} threads "
+                      f"pulling 16x16 tiles from one counter; single thread: central {cw}x{ch} crop, {spp1} spp, {r1} rays in {d1:.2f} s"}
     return base, cnt.nodes_visited / max(rays, 1), cnt.tris_tested / max(rays, 1)
 
 
 def extend_kernel_name(pt, st, info, config):
-    if config == "c4":
-        return "k_extend_inst" if os.environ.get("PT_TUNE_INST16") == "0" else "k_extend_inst16"
+    if info.n_instances:
+        return "k_extend_inst16"
     lds = "k_extend<lds>"
     if info.n_wide_nodes <= 8191 and info.n_tris <= 2047:     # the compact no-spill instantiations (plan_extend)
-        lds = "k_extend_lds7" if os.environ.get("PT_TUNE_PAIR_KERNEL") == "0" or os.environ.get("PT_TUNE_PAIR_LEAVES") == "0" else "k_extend_lds7p"
+        lds = "k_extend_lds7p"
     return {1: "k_extend_flat", 2: lds, 3: "k_extend<hbm>", 4: "k_extend8"}.get(st.extend_variant, "?")
 
 
@@ -114,8 +132,7 @@ def count_visits(pt, ctx, scene, W, H, common, frames=1, frame0=False):
     (the wave-level block counts depend on how full the queues are, so the shape has to be the timed one: counted on a
     single frame the Cornell kernel shows 1075 VALU instructions per 64 rays, on the 16 of the timed run 930, which is what
     SQ_INSTS_VALU measures there); then, with `frame0` (the run that also times the CPU oracle), frame 0 alone through the
-    shipped kernels for the film / ray-count comparison -- left out of the profiled command so that rocprofv3's average
-    launch duration of the traversal kernel covers the timed launches only."""
+    shipped kernels for the film / ray-count comparison."""
     scratch = pt.Film(ctx, W, H)
     ctx.reset_stats()
     pt.render(scene, scratch, pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_COUNT_VISITS, **common))
@@ -132,34 +149,34 @@ def count_visits(pt, ctx, scene, W, H, common, frames=1, frame0=False):
 
 
 def valu_model(cst, kernel):
-    """VALU wave-instructions per 64 rays of the single-level traversal kernel from live wave-level block counts."""
+    """VALU wave-instructions per 64 rays of a traversal kernel, and the active lanes per VALU instruction, from live
+    wave-level block counts x the blocks' instruction counts in the shipped ISA."""
     m = (ISA_VALU_MODEL or {}).get(kernel)
     if not m or not cst.wave_iterations:
         return None
-    b = m["valu_per_block"]
-    total = (cst.wave_iterations * b["outer_iteration"] + cst.wave_refills * b["refill"] + cst.node_steps * b["node_step"] +
-             cst.wave_pops * b["pop_iteration"] + cst.tri_steps * b["triangle_step"] + cst.wave_hit_blocks * b["hit_block"] +
-             cst.wave_finishes * b["finish"])
-    return {"wave_instr": total, "per_64_rays": total / max(cst.rays, 1) * 64.0, "revision": m.get("revision"),
-            "blocks": {"outer_iterations": cst.wave_iterations, "refills": cst.wave_refills, "node_steps": cst.node_steps,
-                       "pop_iterations": cst.wave_pops, "triangle_steps": cst.tri_steps, "hit_blocks": cst.wave_hit_blocks,
-                       "finishes": cst.wave_finishes}}
+    total = lanes = 0.0
+    counts = {}
+    for name, b in m["blocks"].items():
+        waves = getattr(cst, b["waves"])
+        ln = 64.0 * waves if b["lanes"] is None else float(getattr(cst, b["lanes"]))
+        total += waves * b["valu"]
+        lanes += ln * b["valu"]
+        counts[name] = {"waves": waves, "lanes_per_wave": round(ln / waves, 1) if waves else None, "valu": b["valu"]}
+    return {"wave_instr": total, "per_64_rays": total / max(cst.rays, 1) * 64.0, "lanes_per_instr": lanes / max(total, 1.0),
+            "revision": m.get("revision"), "blocks": counts}
 
 
-def roofline_block(pt, st, cst, info, config, mean_len, note):
+def roofline_block(pt, st, cst, info, config, note):
     """`roofline` for the dominant kernel (the closest-hit traversal) of a leg: every number from this run."""
     nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
     tris_per_ray = cst.tris_tested / max(cst.rays, 1)
     node_occ = cst.nodes_visited / (64.0 * cst.node_steps) if cst.node_steps else None
-    tri_occ = cst.tris_tested / (64.0 * cst.tri_steps) if cst.tri_steps else None
+    leaf_occ = cst.leaf_lanes / (64.0 * cst.tri_steps) if cst.tri_steps else None
     scene_bytes = info.device_bytes
-    # one BVH4 node visit of the HBM variant = 64 B (4 fp16 child boxes 48 B + 4 child words 16 B; the two-level
-    # kernel reads fp32 nodes, 128 B); one triangle = 36 B of positions.  Counted only when the scene exceeds the
-    # 32 MiB of L2 (SURVEY 8d); smaller scenes are LDS / L2 resident and HBM sees the queue I/O only.
-    bvh8 = st.extend_variant == 4       # one 128-B line per node visit (8 fp16 child boxes + child / triangle bases and masks)
-    node_bytes = 128.0 if ((config == "c4" and os.environ.get("PT_TUNE_INST16") == "0") or bvh8) else 64.0
-    if bvh8:
-        scene_bytes = info.device_bytes8
+    # one BVH4 node visit of the HBM variant = 64 B (4 fp16 child boxes 48 B + 4 child words 16 B); one triangle = 36 B of
+    # positions.  Counted only when the scene exceeds the 32 MiB of L2 (SURVEY 8d); smaller scenes are LDS / L2 resident
+    # and HBM sees the queue I/O only.
+    node_bytes = 64.0
     gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
     bytes_extend = BYTES_EXTEND + gather
     gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
@@ -175,22 +192,23 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
         "gather": {"bvh_nodes_per_ray": round(nodes_per_ray, 2), "node_bytes": node_bytes, "tris_per_ray": round(tris_per_ray, 2),
                    "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
                    "source": "device counters of the instrumented extend kernel (PT_FLAG_COUNT_VISITS), the timed frames once more, untimed"},
+        # lanes of a wave64 inside one node step / one leaf step (a leaf = one triangle, or a fan pair tested together)
         "active_lanes": {"node_steps": round(64 * node_occ, 1) if node_occ else None,
-                         "triangle_steps": round(64 * tri_occ, 1) if tri_occ else None},
+                         "leaf_steps": round(64 * leaf_occ, 1) if leaf_occ else None},
         "extend_ms": round(st.ms_extend, 3), "shade_ms": round(st.ms_shade, 3),
         "note": note,
     }
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure is the
-    # bytes per ray of this round's committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs; 2 x FETCH +
-    # WRITE per the gfx950 correction of MI355X_MICROARCH.md) x this run's rays per launch
-    prof = os.path.join(REPO, "profiles", f"r02_pmc_extend_{config}.json")
+    # bytes per ray of this round's committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, corrected as
+    # calibrated on known byte counts: profiles/r03_fetch_size_calibration.json) x this run's rays per launch
+    prof = os.path.join(REPO, "profiles", PMC_RECORD.format(config=config))
     if os.path.exists(prof):
         try:
             pmc = json.load(open(prof))
             r["traffic"] = round(pmc["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
             r["pmc_profile"] = {k: (round(pmc[k], 3) if isinstance(pmc[k], float) else pmc[k]) for k in
-                                ("hbm_bytes_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays", "valu_active_lanes_per_instr",
-                                 "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "rocprof_avg_launch_us") if k in pmc}
+                                ("hbm_bytes_per_ray", "hbm_read_requests_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays",
+                                 "valu_active_lanes_per_instr", "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "rocprof_avg_launch_us") if k in pmc}
             r["pmc_profile"]["source"] = os.path.relpath(prof, REPO)
         except Exception:
             pass
@@ -198,8 +216,9 @@ def roofline_block(pt, st, cst, info, config, mean_len, note):
     if vm:
         rays_per_s = st.rays / (st.ms_extend * 1e-3)   # the kernel's own rate (its launches overlap the other pipeline's shade)
         r["valu_wave_instr_per_64_rays"] = round(vm["per_64_rays"], 1)
+        r["valu_active_lanes_per_instr"] = round(vm["lanes_per_instr"], 1)
         r["valu_frac"] = round(vm["per_64_rays"] / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4)
-        r["valu_model"] = {"peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "isa_revision": vm["revision"], "wave_block_counts": vm["blocks"],
+        r["valu_model"] = {"peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "isa_revision": vm["revision"], "blocks": vm["blocks"],
                            "source": "live wave-level block counts (PT_FLAG_COUNT_VISITS) x VALU instructions per block of the shipped ISA "
                                      "(profiles/isa_valu_model.json, scripts/isa_blocks.py)"}
     return r
@@ -210,7 +229,7 @@ def build_scene(pt, ctx, config, soup_tris, rank, bvh_quality):
     if config in ("c5", "c5x"):
         t0 = time.perf_counter()
         if config == "c5":
-            obj = f"/tmp/pt_soup_{soup_tris}_rank{rank}.obj"     # generated, not committed (139 MB of text)
+            obj = f"/tmp/pt_soup_{soup_tris}_rank{rank}_{os.getpid()}.obj"     # generated, not committed (139 MB of text)
             pt.write_soup_obj(obj, soup_tris, 1)
             t1 = time.perf_counter()
             arrays = pt.load_obj(obj)
@@ -238,23 +257,26 @@ def build_scene(pt, ctx, config, soup_tris, rank, bvh_quality):
 
 NOTES = {
     "c2": "Cornell (<8 KB scene+BVH) never leaves LDS: extend is VALU-issue bound (valu_frac), HBM sees only queue I/O; "
-          "the HBM fraction is physically meaningful on configs C5 / C5x only (roofline_c5)",
+          "the HBM fraction is physically meaningful on configs C5 / C5x only (roofline_c5, roofline_c5x)",
     "c4": "TLAS (10k instances) + BLAS fit in L2: traversal is VALU/latency bound, HBM sees queue I/O only",
-    "c5": "scene + BVH4 = 160 MB > L2 (32 MiB) but < Infinity Cache (256 MiB): every node/triangle fetch is a 64/48-B gather "
+    "c5": "scene + BVH4 = 160 MB > L2 (32 MiB) but < Infinity Cache (256 MiB): every node/triangle fetch is a 64-B gather "
           "through L1/L2/MALL; FETCH_SIZE counts MALL hits too",
     "c5x": "8M-triangle soup: the traversal working set (BVH4 64-B nodes + triangles) exceeds the 256 MiB Infinity Cache, "
            "gathers reach HBM",
 }
+NOTES["c3"] = NOTES["c2"]
+LEG_SHAPE = {"c4": dict(spp=32, depth=8, tris=0), "c5": dict(spp=16, depth=16, tris=1000000), "c5x": dict(spp=16, depth=16, tris=8000000)}
 
 
-def c5_leg(pt, ctx, W, H, config, soup_tris, frames, rank):
-    """The traversal kernel on the soup: `frames` warm-up frames, then the same `frames` frames timed with per-launch
-    events (identical launches, so rocprofv3's average over the whole process equals this leg's), then one
-    instrumented frame for the visit counts."""
-    scene, arrays, name, ingest, _ = build_scene(pt, ctx, config, soup_tris, rank, "fast_trace")
+def extra_leg(pt, ctx, W, H, config, frames, rank):
+    """The traversal kernel of another BASELINE config (C4 / C5 / C5x) in the default line: `frames` warm-up frames, then the
+    same `frames` frames timed with per-launch events (identical launches, so rocprofv3's average over the whole process
+    equals this leg's), then the same frames through the instrumented kernel for the visit and block counts."""
+    sh = LEG_SHAPE[config]
+    scene, arrays, name, ingest, tlas_ms = build_scene(pt, ctx, config, sh["tris"], rank, "fast_trace")
     info = scene.info()
     film = pt.Film(ctx, W, H)
-    common = dict(width=W, height=H, spp_per_frame=16, max_depth=16)
+    common = dict(width=W, height=H, spp_per_frame=sh["spp"], max_depth=sh["depth"])
     timed = pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_PROFILE, **common)
     pt.render_prepare(scene, film, timed)
     shape = ctx.stats()
@@ -268,29 +290,73 @@ def c5_leg(pt, ctx, W, H, config, soup_tris, frames, rank):
     dt = time.perf_counter() - t0
     st = ctx.stats()
     cst, _, _ = count_visits(pt, ctx, scene, W, H, common, frames)
-    r = roofline_block(pt, st, cst, info, config, st.rays / max(st.paths, 1), NOTES[config])
-    out = {"workload": f"{config.upper()}: {name} {W}x{H}, 16 spp/frame x {frames} frames, 16 bounces",
-           "mrays_per_s": round(st.rays / dt / 1e6, 2), "ms_per_frame": round(dt * 1e3 / frames, 3),
-           "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups,
-           "bvh": {"triangles": info.n_tris, "bvh4_nodes": info.n_wide_nodes, "bvh8_nodes": info.n_wide8_nodes, "bvh8_levels": info.wide8_levels,
-                   "height": info.bvh_height, "build_ms": round(info.build_ms, 3), "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant)},
-           "ingest": ingest}
+    r = roofline_block(pt, st, cst, info, config, NOTES[config])
+    out = {"workload": f"{config.upper()}: {name} {W}x{H}, {sh['spp']} spp/frame x {frames} frames, {sh['depth']} bounces",
+           "mrays_per_s": round(st.rays / dt / 1e6, 2), "ms_per_frame": round(dt * 1e3 / frames, 3), "rays": st.rays,
+           "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "workspace_bytes": st.workspace_bytes,
+           "bvh": {"triangles": info.n_tris, "bvh4_nodes": info.n_wide_nodes, "height": info.bvh_height, "build_ms": round(info.build_ms, 3),
+                   "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant)}}
+    if ingest:
+        out["ingest"] = ingest
+    if config == "c4":
+        out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
     out.update(r)
     film.close()
     scene.close()
     return out
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, exactly as
+    torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, rendezvous
+    on 127.0.0.1), wait for them, and fail as a whole -- stopping the others by their PIDs -- if any rank fails (a rank that
+    dies before a collective would otherwise leave its peers waiting in it).  Rank 0 prints the JSON line."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PT_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:
+                    procs[o].terminate()
+                deadline = time.time() + 10.0
+                for o in list(live):
+                    try:
+                        procs[o].wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        procs[o].kill()
+                        procs[o].wait()
+                live.clear()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=None, help="frames per timed region (default 16; --config c3: 32 = 1024 spp)")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region (median reported); more are run until they add up to >= 1 s")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--config", choices=["c2", "c4", "c5", "c5x"], default="c2",
-                    help="c2 = Cornell box (the headline), c4 = Cornell x 10 000 instances (two-level BVH), "
-                         "c5 = 1M-triangle soup, 16 spp/frame, depth 16; c5x = the same recipe with 8M triangles (> Infinity Cache)")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c5x"], default="c2",
+                    help="c2 = Cornell box (the headline); c3 = the same, 1024 spp = 32 steps (BASELINE config C3: run it with --gpus 8); "
+                         "c4 = Cornell x 10 000 instances (two-level BVH); c5 = 1M-triangle soup, 16 spp/frame, depth 16; "
+                         "c5x = the same recipe with 8M triangles (> Infinity Cache)")
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--soup-tris", type=int, default=None)
@@ -303,12 +369,17 @@ def main():
                     help="per-round device sort of the extend queue by (origin cell, octant); auto = scenes beyond the Infinity Cache")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c5 legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c4 / _c5 / _c5x legs")
     ap.add_argument("--c5-frames", type=int, default=4, help="frames of the roofline_c5 leg")
+    ap.add_argument("--c4-frames", type=int, default=8, help="frames of the roofline_c4 leg")
+    ap.add_argument("--c5x-frames", type=int, default=2, help="frames of the roofline_c5x leg")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0,
                     help="seconds of oracle time for cpu_baseline (it renders as many spp of frame 0 as fit; when that is the "
                          "whole frame, film and ray count are compared with the GPU's)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))    # no launcher: bench.py is its own
 
     import torch
     import torch.distributed as dist
@@ -316,10 +387,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world                                      # the launcher's world size is authoritative
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
     # PT_BENCH_EMULATE=1 (dev check of the N > 1 code path on a 1-GPU box): every rank uses GPU 0 and the
@@ -327,6 +395,9 @@ def main():
     emulate = os.environ.get("PT_BENCH_EMULATE") == "1" and world > 1
     if emulate:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this node has {torch.cuda.device_count()} "
+                 f"(--gpus {world}; PT_BENCH_EMULATE=1 runs all ranks on GPU 0 over gloo, for development only)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if emulate else dev     # where the collectives' tensors live
@@ -341,6 +412,9 @@ def main():
     ptd = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
 
     W, H = args.width, args.height
+    scene_config = "c2" if args.config == "c3" else args.config
+    if args.steps is None:
+        args.steps = 32 if args.config == "c3" else 16
     if args.config in ("c5", "c5x"):
         args.spp = args.spp or 16
         args.depth = args.depth or 16
@@ -350,7 +424,7 @@ def main():
         args.depth = args.depth or 8
     stream = torch.cuda.current_stream(dev)
     ctx = pt.Context(local_rank, stream=stream.cuda_stream)
-    scene, arrays, scene_name, ingest, tlas_ms = build_scene(pt, ctx, args.config, args.soup_tris, rank, args.bvh_quality)
+    scene, arrays, scene_name, ingest, tlas_ms = build_scene(pt, ctx, scene_config, args.soup_tris, rank, args.bvh_quality)
     info = scene.info()
     film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # this rank's accumulation film (torch owns the memory)
     film = pt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
@@ -378,21 +452,36 @@ def main():
         pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, flags=sort_flag, **common))
     if presenter:      # communicator set-up (the first collective of a process) is not a step: always outside the timed region
         presenter.present()
-    film.clear()
-    ctx.reset_stats()
 
-    barrier()
-    t0 = time.perf_counter()
-    pt.render(scene, film, timed)
-    presented = presenter.present() if presenter else film_t   # the one collective per presented image (none for N=1)
-    barrier()
-    dt = time.perf_counter() - t0
-
-    st = ctx.stats()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # ---- the timed region: EXACTLY `steps` frames (+ the one collective that presents the image for N > 1) between
+    # barrier + synchronize, repeated; the film is cleared and the counters reset between repetitions, outside of it
+    reps = []       # (seconds, present seconds, stats) per repetition; seconds = MAX over ranks
+    presented = film_t
+    while True:
+        film.clear()
+        ctx.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        pt.render(scene, film, timed)          # blocking: returns when the device is done (main.cpp:683 waitIdle)
+        t1 = time.perf_counter()
+        if presenter:
+            presented = presenter.present()    # the one collective per presented image (none for N = 1)
+            torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        barrier()
+        dt = time.perf_counter() - t0
+        tp = t2 - t1
+        if world > 1:
+            tm = torch.tensor([dt, tp], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt, tp = float(tm[0].item()), float(tm[1].item())
+        reps.append((dt, tp, ctx.stats()))
+        # (every rank sees the same reduced times, so all ranks stop together)
+        if len(reps) >= max(1, args.reps) and (sum(r[0] for r in reps) >= 1.0 or len(reps) >= 25):
+            break
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    med = order[len(order) // 2]            # the median repetition: its time, its counters, its per-kernel events
+    dt, present_s, st = reps[med]
     rays_total, paths_total = ptd.sum_counters([st.rays, st.paths], cdev)
     rays_minmax = None
     if world > 1:
@@ -404,8 +493,10 @@ def main():
 
     if rank == 0:
         mean_len = rays_total / max(paths_total, 1)
+        values = [round(rays_total / r[0] / 1e6, 2) for r in reps]    # every repetition traces the same rays
         out = {
             "metric": {"c2": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces (ms/frame in ms_per_step)",
+                       "c3": "Mrays/s, Cornell Box 1920x1080 @ 8 bounces, 1024 spp progressive (ms/frame in ms_per_step)",
                        "c4": "Mrays/s, Cornell Box x 10k instances (two-level BVH) 1920x1080 @ 8 bounces (BASELINE config C4)",
                        "c5": "Mrays/s, 1M-triangle soup 1920x1080 @ 16 bounces (BASELINE config C5)",
                        "c5x": "Mrays/s, 8M-triangle soup (> Infinity Cache) 1920x1080 @ 16 bounces"}[args.config],
@@ -418,7 +509,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("CornellBox-Original.obj (the reference's own scene, 36 triangles)" if args.config in ("c2", "c4") else
+            "data": ("CornellBox-Original.obj (the reference's own scene, 36 triangles)" if scene_config in ("c2", "c4") else
                      "synthetic triangle soup (generator pth_write_soup_obj / pth_make_soup, seed 1)"
                      + (", written as OBJ+MTL and parsed by the host loader" if args.config == "c5" else ""))
                     + "; rays are generated on device",
@@ -427,17 +518,22 @@ def main():
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
                        "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "sort_rays": args.sort_rays},
+            # the timed region repeated: value / ms_per_step are the median repetition
+            "reps": len(reps), "value_min": min(values), "value_max": max(values), "values": values,
+            "timed_seconds_total": round(sum(r[0] for r in reps), 4),
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
+            "workspace_bytes": st.workspace_bytes,
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
-                    "build_ms": round(info.build_ms, 3), "bvh4_nodes": info.n_wide_nodes, "bvh8_nodes": info.n_wide8_nodes,
-                    "bvh4_builder": ["collapsed LBVH", "surface-area sweep (<= 2048 triangles, ePreferFastTrace)"][info.bvh4_builder],
+                    "build_ms": round(info.build_ms, 3), "bvh4_nodes": info.n_wide_nodes,
+                    "bvh4_builder": ["collapsed LBVH", "surface-area sweep (ePreferFastTrace)"][min(info.bvh4_builder, 1)],
                     "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant, str(st.extend_variant))},
         }
-        if rays_minmax:
+        if world > 1:
             out["rays_per_rank_min_max"] = rays_minmax
-        if presenter:
             out["rccl_ranks"] = presenter.ranks_seen
+            out["present_ms"] = round(present_s * 1e3, 4)     # the collective + pack / unpack, max over ranks, median repetition
+            out["launcher"] = "bench.py's own (one process per GPU)" if os.environ.get("PT_BENCH_SPAWNED") else "external (torch.distributed.run)"
         # sum of the presented image (N = 1: the film; N > 1: what the gather assembled on rank 0), order-insensitive in float64
         out["presented_checksum"] = float(presented.double().sum().item())
         if ingest:
@@ -445,20 +541,20 @@ def main():
         if args.config == "c4":
             out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
         # traversal work per ray, counted by an instrumented build of the same kernel on the same
-        # BVH4 (untimed extra frame): feeds the scene-gather term of the algorithmic bytes and the VALU model
+        # BVH4 (untimed extra frames): feeds the scene-gather term of the algorithmic bytes and the VALU model
         frame0_rays_gpu = frame0_film_gpu = None
         cst = None
         if st.extend_variant != pt.EXTEND_FLAT:
             cst, frame0_film_gpu, frame0_rays_gpu = count_visits(pt, ctx, scene, W, H, common, args.steps, frame0=not args.no_cpu_baseline and world == 1)   # (rank 0's shard when N > 1)
         if flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
-            out["roofline"] = roofline_block(pt, st, cst, info, args.config, mean_len, NOTES[args.config])
+            out["roofline"] = roofline_block(pt, st, cst, info, scene_config, NOTES[args.config])
             bytes_extend = out["roofline"]["algorithmic_bytes_per_ray"]
             pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
             out["roofline"]["pipeline_algorithmic_GBps"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2)
             # SURVEY 8d's canonical whole-pipeline figure: (extend + 104 shade + 96 per path / mean length) B per ray over the
             # device time of the timed region, of the HBM peak
             out["roofline"]["pipeline_frac"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        if world == 1 and not args.no_extra_legs and args.config == "c2":
+        if world == 1 and not args.no_extra_legs and args.config in ("c2", "c3"):
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()
             film.clear()
@@ -492,12 +588,14 @@ def main():
                                      "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 2), "frames": len(lat),
                                      "sample_groups": s1.sample_groups,
                                      "shape": "K = 1: one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle, main.cpp:656-683)"}
-            # ---- the traversal kernel where HBM-side bandwidth is the bound: config C5 -------------------------
-            film.clear()
-            try:
-                out["roofline_c5"] = c5_leg(pt, ctx, W, H, "c5", 1000000, args.c5_frames, rank)
-            except Exception as e:      # never lose the headline to the extra leg
-                out["roofline_c5"] = {"error": repr(e)}
+            # ---- the other BASELINE configs' traversal kernels: C4 (two-level), C5 (where HBM-side bandwidth is the
+            # bound), C5x (beyond the Infinity Cache) -- never lose the headline to an extra leg
+            for leg, frames in (("c4", args.c4_frames), ("c5", args.c5_frames), ("c5x", args.c5x_frames)):
+                film.clear()
+                try:
+                    out["roofline_" + leg] = extra_leg(pt, ctx, W, H, leg, frames, rank) if frames > 0 else None
+                except Exception as e:
+                    out["roofline_" + leg] = {"error": repr(e)}
         base = None
         if not args.no_cpu_baseline and world == 1:
             base, _, _ = cpu_baseline(arrays, scene_name, W, H, args.spp, args.depth, budget_s=args.cpu_budget_s,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_API_VERSION 2
+#define PT_API_VERSION 3
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -255,6 +255,16 @@ typedef struct pt_stats {
      * the block that writes a hit record, one iteration of the outer loop.  With the per-block instruction counts
      * of the shipped ISA (bench.py) these give the VALU instructions a launch issues without a PMC run.     */
     uint64_t wave_refills, wave_pops, wave_hit_blocks, wave_finishes, wave_iterations;
+    /* (API version 3) PT_FLAG_COUNT_VISITS: LANES inside those wave-level steps -- leaf_lanes: lanes that ran a leaf step (one
+     * triangle, or a fan pair tested together: tris_tested counts two for those, so tris_tested / tri_steps can exceed 64
+     * and is not a lane count); pop_lanes / hit_lanes: lanes in the pop iterations / divide blocks; the two-level kernel's
+     * instance-entry block: enter_steps wave executions with enter_lanes lanes.  lanes / (64 * steps) is the occupancy
+     * of a block; weighted by the blocks' instruction counts it gives the active lanes per VALU instruction.        */
+    uint64_t leaf_lanes, pop_lanes, hit_lanes, enter_steps, enter_lanes;
+    /* device bytes the last pt_render / pt_render_prepare holds for its wavefront workspace: the film's queues, hit
+     * records, radiance accumulators or term logs, sort scratch and shadow queue, plus the context's traversal-stack
+     * spill area (the scene and the film images themselves are not included: pt_scene_info.device_bytes, W*H*16)   */
+    uint64_t workspace_bytes;
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

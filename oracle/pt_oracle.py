@@ -37,11 +37,29 @@ class Counters(C.Structure):
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("inst", "<u4")])
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force=False):
+    """gcc -O3 -march=native -ffp-contract=off: the binary is specific to the host CPU, so it is rebuilt when the CPU
+    model differs from the one recorded next to it (the in-tree .so travels from the build container to the GPU box)."""
     so = os.path.join(_HERE, "libpt_oracle.so")
+    stamp = os.path.join(_HERE, ".cpu_stamp")
     src = [os.path.join(_HERE, f) for f in ("pt_oracle.c", "pt_oracle.h", "Makefile")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    model = _cpu_model()
+    built_on = open(stamp).read().strip() if os.path.exists(stamp) else None
+    stale = not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale or built_on != model:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if (force or built_on != model) else []))
+        with open(stamp, "w") as fh:
+            fh.write(model + "\n")
     return so
 
 

@@ -74,7 +74,9 @@ class Stats(C.Structure):
                 ("node_steps", C.c_uint64), ("tri_steps", C.c_uint64),
                 ("redone_batches", C.c_uint32), ("reserved_", C.c_uint32),
                 ("wave_refills", C.c_uint64), ("wave_pops", C.c_uint64), ("wave_hit_blocks", C.c_uint64),
-                ("wave_finishes", C.c_uint64), ("wave_iterations", C.c_uint64)]
+                ("wave_finishes", C.c_uint64), ("wave_iterations", C.c_uint64),
+                ("leaf_lanes", C.c_uint64), ("pop_lanes", C.c_uint64), ("hit_lanes", C.c_uint64),
+                ("enter_steps", C.c_uint64), ("enter_lanes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
 
 
 class HostScene(C.Structure):

@@ -87,6 +87,11 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
     uint32_t cur = I16_DONE, cur_ipos = 0, cur_iid = 0;
     int sp = 0;
     unsigned long long c_nodes = 0, c_tris = 0;
+    // PT_FLAG_COUNT_VISITS: wave executions of the kernel's blocks and the lanes inside them (pt_stats, include/pt_api.h)
+    unsigned long long c_node_steps = 0, c_tri_steps = 0, c_leaf_lanes = 0, c_enter_steps = 0, c_enter_lanes = 0, c_iters = 0,
+                       c_refills = 0, c_finishes = 0, c_pops = 0, c_pop_lanes = 0, c_hit_blocks = 0, c_hit_lanes = 0;
+#define PT_COUNT_WAVE(C) \
+    if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) (C)++
     const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
     const uint32_t wave_stride = gridDim.x * TB;
     uint32_t cursor = 0;
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
     };
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
+            PT_COUNT_WAVE(c_pops);
+            if (COUNT) c_pop_lanes++;
             sp--;
             uint32_t e;
             if (sp < lds_stack) e = my_stack[sp * TB];
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
     };
 
     for (;;) {
+        PT_COUNT_WAVE(c_iters);
         const unsigned long long idle = __ballot(!have);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= refill_min_idle) {
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
+                    PT_COUNT_WAVE(c_refills);
                     q = qq;
                     const float4 ra = rayA[q];
                     const float2 rb = rayB[q];
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 PT_REG_BARRIER16(q0, q1, q2, cw)
             }
             if (COUNT) c_nodes++;
+            PT_COUNT_WAVE(c_node_steps);
             // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw (two children per dword)
             // near / far rows by bit-field insert with per-lane masks (mx = all ones where the direction component is negative):
             // twelve v_cndmask_b32 on VCC in a row issue at ~23 cycles each on this chip and made this
@@ -210,7 +220,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         if (have) {
             if (at_leaf && in_blas) {
                 const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
-                if (COUNT) c_tris += cnt;
+                if (COUNT) { c_tris += cnt; c_leaf_lanes += PAIRS ? 1u : cnt; }
+                if (PAIRS) { PT_COUNT_WAVE(c_tri_steps); }
                 auto accept = [&](float t, float V, float W, float det, uint32_t pos, uint32_t prim) {
                     // closest t; equal t -> lowest (gl_InstanceID, gl_PrimitiveID)
                     if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
@@ -232,6 +243,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     };
                     auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
                         const float det = (U + V) + W;
+                        PT_COUNT_WAVE(c_hit_blocks);
+                        if (COUNT) c_hit_lanes++;
                         const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
                         const float t = ptm::fdiv(T, det);
                         if (!(t > tmin && t < tmax)) return;
@@ -260,18 +273,23 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u, primB);
                 } else {
                     for (uint32_t k = 0; k < cnt; k++) {
+                        PT_COUNT_WAVE(c_tri_steps);
                         const uint32_t pos = first + k;
                         const size_t ti = (size_t)tri_base + 3 * (size_t)pos;
                         const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
                         float t, V, W, det;
-                        if (ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det))
+                        bool divided = false;
+                        if (ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr))
                             accept(t, V, W, det, pos, __float_as_uint(a.w));
+                        if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
                     }
                 }
                 cur = pop();
             } else if (at_leaf && do_enter) {
                 // TLAS leaf: one instance.  The ray goes to object space un-normalised (t is the same parameter)
                 const uint32_t first = cur & 0x7FFFu;
+                PT_COUNT_WAVE(c_enter_steps);
+                if (COUNT) c_enter_lanes++;
                 cur_ipos = first;
                 cur_iid = inst_id[first];
                 const float4 r0 = inst6[6 * (size_t)first + 3], r1 = inst6[6 * (size_t)first + 4], r2 = inst6[6 * (size_t)first + 5];
@@ -290,6 +308,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 cur = 0u;  // BLAS root
             }
             if (cur == I16_DONE) {
+                PT_COUNT_WAVE(c_finishes);
                 const bool miss = best_pos == PT_MISS;
                 hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
                                  : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
@@ -303,12 +322,24 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         for (int o = 32; o > 0; o >>= 1) {
             c_nodes += __shfl_xor(c_nodes, o, 64);
             c_tris += __shfl_xor(c_tris, o, 64);
+            c_node_steps += __shfl_xor(c_node_steps, o, 64); c_tri_steps += __shfl_xor(c_tri_steps, o, 64);
+            c_leaf_lanes += __shfl_xor(c_leaf_lanes, o, 64); c_enter_steps += __shfl_xor(c_enter_steps, o, 64);
+            c_enter_lanes += __shfl_xor(c_enter_lanes, o, 64); c_iters += __shfl_xor(c_iters, o, 64);
+            c_refills += __shfl_xor(c_refills, o, 64); c_finishes += __shfl_xor(c_finishes, o, 64);
+            c_pops += __shfl_xor(c_pops, o, 64); c_pop_lanes += __shfl_xor(c_pop_lanes, o, 64);
+            c_hit_blocks += __shfl_xor(c_hit_blocks, o, 64); c_hit_lanes += __shfl_xor(c_hit_lanes, o, 64);
         }
         if (lane == 0 && stats) {
             atomicAdd(stats + 2, c_nodes);
             atomicAdd(stats + 3, c_tris);
+            atomicAdd(stats + 4, c_node_steps); atomicAdd(stats + 5, c_tri_steps);
+            atomicAdd(stats + 8, c_refills); atomicAdd(stats + 9, c_pops); atomicAdd(stats + 10, c_hit_blocks);
+            atomicAdd(stats + 11, c_finishes); atomicAdd(stats + 12, c_iters);
+            atomicAdd(stats + 13, c_leaf_lanes); atomicAdd(stats + 14, c_pop_lanes); atomicAdd(stats + 15, c_hit_lanes);
+            atomicAdd(stats + 16, c_enter_steps); atomicAdd(stats + 17, c_enter_lanes);
         }
     }
+#undef PT_COUNT_WAVE
 }
 
 }  // namespace

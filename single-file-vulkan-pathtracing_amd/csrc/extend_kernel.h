@@ -242,6 +242,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     int sp = 0;
     unsigned long long c_nodes = 0, c_tris = 0, c_node_steps = 0, c_tri_steps = 0;
     unsigned long long c_refills = 0, c_pops = 0, c_hit_blocks = 0, c_finishes = 0, c_iters = 0;  // wave executions of the other blocks
+    unsigned long long c_leaf_lanes = 0, c_pop_lanes = 0, c_hit_lanes = 0;  // lanes inside the leaf steps / pop iterations / divide blocks
     // one lane per wave counts a block the wave executes (exec mask of the moment)
 #define PT_COUNT_WAVE(C) \
     if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) (C)++
@@ -261,6 +262,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         if (COMPACT) {
             while (sp > 0) {
                 PT_COUNT_WAVE(c_pops);
+                if (COUNT) c_pop_lanes++;
                 sp--;
                 const uint32_t e = my_stack32[sp * TB];
                 if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
@@ -269,6 +271,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         }
         while (sp > 0) {
             PT_COUNT_WAVE(c_pops);
+            if (COUNT) c_pop_lanes++;
             sp--;
             unsigned long long e;
             if (!SPILL || sp < lds_stack) e = my_stack[sp * TB];
@@ -373,7 +376,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     if (!need_pop) cur = w0;
                 } else {
                     const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-                    if (COUNT) c_tris += cnt;
+                    if (COUNT) { c_tris += cnt; c_leaf_lanes++; }
                     PT_COUNT_WAVE(c_tri_steps);
                     auto consider = [&](const float4 a, const float4 b, const float4 c, uint32_t pos) {
                         float t, V, W, det;
@@ -386,7 +389,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                                 if (ray_tmax) sp = 0;
                             }
                         }
-                        if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
+                        if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
                     };
                     auto as_f4 = [](const uint4 u) { return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); };
                     consider(as_f4(q0), as_f4(q1), as_f4(q2), first);
@@ -513,7 +516,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 if (cur != DONE && (cur & LEAF_BIT)) {
                     const uint32_t first = cur & 0x7FFu;
                     const bool two = ((cur >> 11) & 3u) != 0u;  // count - 1: a fan pair at positions first, first + 1
-                    if (COUNT) c_tris += two ? 2u : 1u;
+                    if (COUNT) { c_tris += two ? 2u : 1u; c_leaf_lanes++; }
                     PT_COUNT_WAVE(c_tri_steps);
                     const size_t ti = (size_t)tri_base + 3 * (size_t)first;
                     const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
@@ -531,6 +534,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
                         const float det = (U + V) + W;
                         PT_COUNT_WAVE(c_hit_blocks);
+                        if (COUNT) c_hit_lanes++;
                         const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
                         const float t = ptm::fdiv(T, det);
                         if (!(t > tmin && t < tmax)) return;
@@ -574,6 +578,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 if (COUNT) c_tris += cnt;
                 for (uint32_t k = 0; k < cnt; k++) {
                     if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) c_tri_steps++;
+                    if (COUNT) c_leaf_lanes++;
                     const uint32_t pos = first + k;
                     const size_t ti = LDS_SCENE ? (size_t)tri_base + 3 * (size_t)pos : (REC64 ? 4 : 3) * (size_t)pos;
                     const float4 *tp = REC64 ? g_rec64 : tri4;
@@ -583,7 +588,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     const bool th = LDS_SCENE
                         ? ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr)
                         : ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr);
-                    if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
+                    if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
                     if (th) {
                         // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
                         if constexpr (REC64) {  // .w of a 64-B record is the normal: the ids of the two rivals come from tri4, on ties only
@@ -630,6 +635,9 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             c_hit_blocks += __shfl_xor(c_hit_blocks, o, 64);
             c_finishes += __shfl_xor(c_finishes, o, 64);
             c_iters += __shfl_xor(c_iters, o, 64);
+            c_leaf_lanes += __shfl_xor(c_leaf_lanes, o, 64);
+            c_pop_lanes += __shfl_xor(c_pop_lanes, o, 64);
+            c_hit_lanes += __shfl_xor(c_hit_lanes, o, 64);
         }
         if (lane == 0 && stats) {
             atomicAdd(stats + 2, c_nodes);
@@ -641,6 +649,9 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             atomicAdd(stats + 10, c_hit_blocks);
             atomicAdd(stats + 11, c_finishes);
             atomicAdd(stats + 12, c_iters);
+            atomicAdd(stats + 13, c_leaf_lanes);
+            atomicAdd(stats + 14, c_pop_lanes);
+            atomicAdd(stats + 15, c_hit_lanes);
         }
     }
 }

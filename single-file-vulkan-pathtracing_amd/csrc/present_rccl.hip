@@ -130,8 +130,8 @@ struct pt_comm {
     pt_ctx *ctx = nullptr;
     void *nccl = nullptr;
     uint32_t world = 1, rank = 0;
-    // per film geometry: tile lists of every rank, the packed send buffer and the root's receive buffer
-    uint32_t w = 0, h = 0;
+    // per (film geometry, root): tile lists of every rank, the packed send buffer and the root's receive buffer
+    uint32_t w = 0, h = 0, root = 0;
     std::vector<TileList> tiles;   // [world]
     float *d_send = nullptr;
     float *d_recv = nullptr;       // root: concatenation of all ranks' packed tiles
@@ -254,7 +254,7 @@ pt_status pt_film_present(pt_film *f, pt_comm *c, uint32_t root, float *d_image)
     }
     PT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    if (c->w != f->w || c->h != f->h) {  // first presentation of this geometry: tile lists and staging buffers
+    if (c->w != f->w || c->h != f->h || c->root != root) {  // first presentation of this (geometry, root): tile lists and staging buffers
         comm_free_geometry(c);
         c->tiles.resize(c->world);
         c->recv_off.assign(c->world + 1, 0);
@@ -270,7 +270,7 @@ pt_status pt_film_present(pt_film *f, pt_comm *c, uint32_t root, float *d_image)
         }
         PT_HIP(ctx, hipMalloc((void **)&c->d_send, sizeof(float) * std::max<size_t>((size_t)c->tiles[c->rank].n * TILE_FLOATS, 1)));
         if (c->rank == root) PT_HIP(ctx, hipMalloc((void **)&c->d_recv, sizeof(float) * std::max<size_t>(c->recv_off[c->world], 1)));
-        c->w = f->w; c->h = f->h;
+        c->w = f->w; c->h = f->h; c->root = root;
     }
     const TileList &mine = c->tiles[c->rank];
     const uint32_t n_mine = mine.n * TILE_FLOATS;

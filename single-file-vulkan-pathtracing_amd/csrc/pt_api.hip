@@ -345,6 +345,8 @@ pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
     ctx->stats.tri_steps = h[5];
     ctx->stats.wave_refills = h[8]; ctx->stats.wave_pops = h[9]; ctx->stats.wave_hit_blocks = h[10];
     ctx->stats.wave_finishes = h[11]; ctx->stats.wave_iterations = h[12];
+    ctx->stats.leaf_lanes = h[13]; ctx->stats.pop_lanes = h[14]; ctx->stats.hit_lanes = h[15];
+    ctx->stats.enter_steps = h[16]; ctx->stats.enter_lanes = h[17];
     *out = ctx->stats;
     return PT_OK;
 }

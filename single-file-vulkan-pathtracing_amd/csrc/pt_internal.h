@@ -19,7 +19,7 @@
 //            as halves (2 dwords each), child[4]                                                      64 B
 //   wide   : BVH4 collapsed from it, 8 x float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
 //            hi.z[4] child[4] spare; leaf child = LEAF | (count-1)<<28 | first sorted position     128 B
-constexpr int PT_N_STATS = 16;  // u64 slots of pt_ctx::d_stats
+constexpr int PT_N_STATS = 24;  // u64 slots of pt_ctx::d_stats
 constexpr int PT_MAX_PIPES = 4;  // concurrent wavefront pipelines (streams) per pt_render
 
 struct pt_ctx {
@@ -28,7 +28,7 @@ struct pt_ctx {
     bool own_stream = false;
     int num_cus = 256;
     std::string err;
-    // statistics block in device memory (u64 x 8): [0] rays, [1] unused, [2] BVH4 nodes visited, [3] triangles tested, [4] wave steps of the node code, [5] of the triangle code, [6] term-log overflow flag, [7] term pool fill, [8..12] wave executions of refill / pop iteration / hit block / finish / outer iteration
+    // statistics block in device memory (u64 x 8): [0] rays, [1] unused, [2] BVH4 nodes visited, [3] triangles tested, [4] wave steps of the node code, [5] of the triangle code, [6] term-log overflow flag, [7] term pool fill, [8..12] wave executions of refill / pop iteration / hit block / finish / outer iteration, [13] lanes in leaf steps, [14] lanes in pop iterations, [15] lanes in divide blocks, [16] wave executions of the instance entry, [17] lanes in them
     unsigned long long *d_stats = nullptr;
     pt_stats stats{};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;

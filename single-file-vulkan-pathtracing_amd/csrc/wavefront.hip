@@ -1550,6 +1550,13 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
 
 }  // namespace
 
+// what pt_stats.workspace_bytes reports: everything the film's wavefront workspace holds + the context's stack-spill area
+static uint64_t workspace_bytes(const pt_film *f)
+{
+    const pt_film::Work &w = f->work;
+    return (uint64_t)w.bytes + (uint64_t)w.cap_sq * (16 + 8 + 16 + 4 + 4 + 16) + (uint64_t)f->ctx->spill_bytes;
+}
+
 void ptw_free_work(pt_film *f)
 {
     pt_film::Work &w = f->work;
@@ -1587,6 +1594,7 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     s->ctx->stats.frames_in_flight = sh.lanes;
     s->ctx->stats.sample_groups = sh.groups;
     if (rc_ != PT_OK) return rc_;
+    s->ctx->stats.workspace_bytes = workspace_bytes(f);
     // the other one-time objects of a render: pipeline streams, fork / join events and, with PT_FLAG_PROFILE, the
     // pooled (start, stop) events of every extend / shade launch of one batch (4 per round and pipeline)
     pt_ctx *ctx = s->ctx;
@@ -1904,6 +1912,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
         }
     }
     if (!nested) {
+        ctx->stats.workspace_bytes = workspace_bytes(f);
         // samples started = valid local pixels x spp x frames
         uint64_t valid = 0;
         const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;

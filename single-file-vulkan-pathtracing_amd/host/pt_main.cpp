@@ -12,6 +12,8 @@
 // (pt_film_present); the image written is the presented one.
 // Prints one JSON line with ray count, ms/frame and Mrays/s.
 #include <algorithm>
+#include <atomic>
+#include <barrier>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +40,21 @@ struct Options {
     std::vector<int> devices;    // --devices a,b,...: HIP ordinals of the ranks (default 0..N-1)
 };
 
+// --ranks N: the ranks agree on success before every collective (ncclCommInitRank, the gather inside pt_film_present): a rank
+// that failed on its own -- bad ordinal, out of memory, a failed render -- would otherwise leave its peers waiting inside the
+// collective for ever.  Every rank arrives at the barrier whether it failed or not; after it, all of them see the flag.
+struct Agreement {
+    std::barrier<> sync;
+    std::atomic<bool> failed{ false };
+    explicit Agreement(uint32_t n) : sync((std::ptrdiff_t)n) {}
+    bool all_ok(bool mine_ok)
+    {
+        if (!mine_ok) failed.store(true);
+        sync.arrive_and_wait();
+        return !failed.load();
+    }
+};
+
 struct RankResult {
     pt_stats st{};
     pt_scene_info info{};
@@ -49,7 +66,7 @@ struct RankResult {
 // What one rank does: the reference's main() from the scene upload on (main.cpp:492-685), for its share of the
 // tiles; then the one collective per presented image.  Rank 0 returns the image in `image` (device -> host).
 void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_unique_id *id, RankResult &res,
-              std::vector<float> *image_f32, std::vector<uint8_t> *image_bgra8)
+              std::vector<float> *image_f32, std::vector<uint8_t> *image_bgra8, Agreement *agree)
 {
     pt_ctx *ctx = nullptr;
     pt_scene *scene = nullptr;
@@ -60,15 +77,22 @@ void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_uni
         res.error = std::string(what) + ": " + (ctx ? pt_last_error(ctx) : pt_last_error(nullptr));
     };
     const int device = o.ranks > 1 ? o.devices[rank] : o.device;
+    // peers_ok(ok): single rank -> ok; else every rank's verdict (a rank that already failed keeps arriving at the barriers)
+    auto peers_ok = [&](bool ok) { return agree ? agree->all_ok(ok) : ok; };
+    const char *peer_msg = "stopped: another rank failed";
     do {
-        if (pt_ctx_create(device, nullptr, &ctx) != PT_OK) { fail("pt_ctx_create"); break; }
-        if (pt_scene_create(ctx, hs.vertices, hs.n_verts, hs.indices, hs.n_tris, hs.faces, &scene) != PT_OK) { fail("pt_scene_create"); break; }
-        pt_scene_get_info(scene, &res.info);
-        if (pt_film_create(ctx, o.width, o.height, &film) != PT_OK) { fail("pt_film_create"); break; }
+        bool ok = true;
+        if (pt_ctx_create(device, nullptr, &ctx) != PT_OK) { fail("pt_ctx_create"); ok = false; }
+        else if (pt_scene_create(ctx, hs.vertices, hs.n_verts, hs.indices, hs.n_tris, hs.faces, &scene) != PT_OK) { fail("pt_scene_create"); ok = false; }
+        else if (pt_film_create(ctx, o.width, o.height, &film) != PT_OK) { fail("pt_film_create"); ok = false; }
+        if (ok) pt_scene_get_info(scene, &res.info);
+        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; if (agree) { agree->all_ok(false); agree->all_ok(false); } break; }
         if (o.ranks > 1) {
-            if (pt_comm_create(ctx, id, o.ranks, rank, &comm) != PT_OK) { fail("pt_comm_create"); break; }
-            pt_comm_ranks(comm, &res.rccl_ranks);
+            // collective: all ranks are here.  RCCL refuses two ranks on one device (--devices 0,0) on every rank alike
+            if (pt_comm_create(ctx, id, o.ranks, rank, &comm) != PT_OK) { fail("pt_comm_create"); ok = false; }
+            else pt_comm_ranks(comm, &res.rccl_ranks);
         }
+        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; if (agree) agree->all_ok(false); break; }
         pt_params p;
         pt_params_default(&p);
         p.width = o.width; p.height = o.height; p.spp_per_frame = o.spp; p.max_depth = o.depth;
@@ -78,13 +102,14 @@ void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_uni
         // independent until the blend, so they are handed over in one call and batched on the device
         p.frame = 0; p.frame_count = o.frames;
         const auto t0 = std::chrono::steady_clock::now();
-        if (pt_render(scene, film, &p) != PT_OK) { fail("pt_render"); break; }
+        if (pt_render(scene, film, &p) != PT_OK) { fail("pt_render"); ok = false; }
         const auto t1 = std::chrono::steady_clock::now();
         res.render_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        pt_get_stats(ctx, &res.st);
+        if (ok) pt_get_stats(ctx, &res.st);
+        // the presented image lives in its own device buffer on rank 0 (main.cpp:661-667 copies the storage image)
+        if (ok && o.ranks > 1 && rank == 0 && pt_device_alloc(ctx, sizeof(float) * 3 * (size_t)o.width * o.height, (void **)&d_image) != PT_OK) { fail("pt_device_alloc"); ok = false; }
+        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; break; }
         if (o.ranks > 1) {
-            // the presented image lives in its own device buffer on rank 0 (main.cpp:661-667 copies the storage image)
-            if (rank == 0 && pt_device_alloc(ctx, sizeof(float) * 3 * (size_t)o.width * o.height, (void **)&d_image) != PT_OK) { fail("pt_device_alloc"); break; }
             if (pt_film_present(film, comm, 0, d_image) != PT_OK) { fail("pt_film_present"); break; }
             res.present_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
             if (rank == 0 && image_f32) {
@@ -157,19 +182,21 @@ int main(int argc, char **argv)
     const bool want_f32 = !o.pfm.empty() || (o.ranks > 1 && !o.ppm.empty());
     const auto t2 = std::chrono::steady_clock::now();
     if (o.ranks == 1) {
-        run_rank(o, hs, 0, nullptr, res[0], want_f32 ? &image_f32 : nullptr, !o.ppm.empty() ? &image_bgra8 : nullptr);
+        run_rank(o, hs, 0, nullptr, res[0], want_f32 ? &image_f32 : nullptr, !o.ppm.empty() ? &image_bgra8 : nullptr, nullptr);
     } else {
         // one host thread per GPU (north star: host code stays C++; the reference has one device, main.cpp:105)
         pt_unique_id id{};
         if (pt_comm_unique_id(&id) != PT_OK) die("RCCL is not available (pt_comm_unique_id)");
         std::vector<std::thread> th;
+        Agreement agree(o.ranks);
         for (uint32_t r = 0; r < o.ranks; r++)
-            th.emplace_back([&, r] { run_rank(o, hs, r, &id, res[r], r == 0 && want_f32 ? &image_f32 : nullptr, nullptr); });
+            th.emplace_back([&, r] { run_rank(o, hs, r, &id, res[r], r == 0 && want_f32 ? &image_f32 : nullptr, nullptr, &agree); });
         for (auto &t : th) t.join();
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
-    for (uint32_t r = 0; r < o.ranks; r++)
-        if (!res[r].error.empty()) die("rank " + std::to_string(r) + ": " + res[r].error);
+    for (int pass = 0; pass < 2; pass++)   // the rank that failed first, not the peers that stopped because of it
+        for (uint32_t r = 0; r < o.ranks; r++)
+            if (!res[r].error.empty() && (pass == 1 || res[r].error.rfind("stopped:", 0) != 0)) die("rank " + std::to_string(r) + ": " + res[r].error);
 
     if (!o.ppm.empty()) {
         if (o.ranks > 1) {  // display transform of the presented float image: clamp + unorm8 (one frame's worth of main.cpp:481-484)
