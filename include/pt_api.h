@@ -44,6 +44,36 @@ typedef struct pt_film pt_film;   /* replaces the storage Image (main.cpp:481-48
  *         keeps ownership of a stream it passes in.                                        */
 pt_status pt_ctx_create(int device, void *stream, pt_ctx **out);
 void pt_ctx_destroy(pt_ctx *ctx);
+/* Tuning knobs of a context: launch shapes and kernel choices that change SPEED, never results (every combination is
+ * covered by the bit-exact parity tests).  -1 = the built-in choice, which is what was measured best on MI355X
+ * (DESIGN.md section 6 has the numbers).  pt_ctx_create fills the defaults and then applies the environment variable
+ * PT_TUNE once ("name=value,name=value", names as below) -- the library reads no other tuning from the environment,
+ * and nothing at all inside pt_render.  Set before pt_scene_create (pair_leaves is read when a scene's BVH4 is built). */
+typedef struct pt_tuning {
+    int32_t refill;         /* idle lanes of a wave before it takes new rays (1..64)                                   */
+    int32_t lds_stack;      /* traversal-stack entries per lane kept in LDS (kernels with a spill path)                */
+    int32_t extend_blocks;  /* cap on persistent extend blocks per CU                                                  */
+    int32_t pipes;          /* concurrent wavefront pipelines (streams) per pt_render, 1..4                            */
+    int32_t stagger;        /* 0: the pipelines start together instead of half a round apart                          */
+    int32_t sort_bits;      /* ray sorting: Morton bits per axis of the origin cell (1..9)                             */
+    int32_t pair_leaves;    /* 0: small scenes get leaves of <= 4 independent triangles instead of one primitive each  */
+    int32_t pair_kernel;    /* 0: the per-triangle leaf loop over a pair-leaf tree instead of the pair test            */
+    int32_t topdown4;       /* 0: the HBM kernel walks the collapsed LBVH instead of the top-down BVH4                 */
+    int32_t rec64;          /* 0: the HBM kernel reads leaves from the 48-B tri4 records instead of the 64-B ones      */
+    int32_t inst16;         /* 0: instanced scenes always take the general two-level kernel (32-bit child words)       */
+    int32_t inst16_blocks;  /* compact two-level kernel: persistent blocks per CU                                      */
+    int32_t enter_min;      /* ... lanes that wait to enter an instance together (1..64)                               */
+    int32_t node_yield;     /* ... the node loop yields below 1/N descending lanes (0 = never)                         */
+    int32_t tlas_lds_kb;    /* ... KB of TLAS top levels staged in LDS                                                 */
+    int32_t term_ocap;      /* tests: cap on the per-slot overflow term log (entries)                                  */
+    int32_t term_spill;     /* tests: cap on the shared term pool (entries)                                            */
+    int32_t mem_budget_mb;  /* upper bound on a film's wavefront workspace (also env PT_MEM_BUDGET_MB); 0 = none       */
+    int32_t hbm8;           /* 1: AUTO walks big scenes through the 8-wide compressed nodes (PT_EXTEND_HBM8)           */
+    int32_t rebin;          /* block-level re-binning of the LDS kernels: 0 off, 1 on                                  */
+    int32_t reserved[12];
+} pt_tuning;
+pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
+pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);
 /* Last error text of this context (ctx may be NULL: text of the last failed pt_ctx_create). */
 const char *pt_last_error(const pt_ctx *ctx);
 /* Blocks until everything queued on the context's stream is done (queue.waitIdle, main.cpp:683). */

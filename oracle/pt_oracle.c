@@ -738,13 +738,19 @@ static void render_pixel(job *jb, uint32_t px, uint32_t py)
             orc_shade_hit(s, &h, pos, n, brdf, emi);
             if (!p->nee || depth == 0)
                 for (int k = 0; k < 3; k++) color[k] = color[k] + weight[k] * emi[k]; /* :76 */
-            if (p->nee && s->n_lights && !s->n_inst) {
+            /* (not at the path's last hit: its direct light stands for the emission the NEXT ray would find, and there is no
+             * next ray -- the reference sums emission over the hits of rays 0 .. max_depth-1, raygen.rgen:62-83) */
+            if (p->nee && s->n_lights && !s->n_inst && depth + 1u < p->max_depth) {
                 /* next-event estimation (not in the reference): one point on one emitter, chosen by area; the
                  * contribution weight * brdf * Ke * cos_s |cos_l| / d^2 * total_area if the shadow ray is free */
                 const float rl = orc_rand(&seed), ru = orc_rand(&seed), rv = orc_rand(&seed);
                 const float pick = rl * s->light_area;
-                uint32_t li = 0;
-                while (li + 1 < s->n_lights && !(s->lights[16 * (size_t)li + 15] > pick)) li++;
+                /* first emitter whose running area exceeds pick (the last one if none does): binary search of the cdf */
+                uint32_t li = 0, hi_ = s->n_lights - 1u;
+                while (li < hi_) {
+                    const uint32_t mid = (li + hi_) >> 1;
+                    if (s->lights[16 * (size_t)mid + 15] > pick) hi_ = mid; else li = mid + 1u;
+                }
                 const float *L = s->lights + 16 * (size_t)li;
                 const float su = sqrtf(ru);
                 const float b0 = 1.0f - su, b1 = su * (1.0f - rv), b2 = su * rv;

@@ -79,6 +79,16 @@ class Stats(C.Structure):
                 ("enter_steps", C.c_uint64), ("enter_lanes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
 
 
+TUNING_NAMES = ["refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves", "pair_kernel", "topdown4",
+                "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield", "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb",
+                "hbm8", "rebin"]
+
+
+class Tuning(C.Structure):
+    """include/pt_api.h pt_tuning: speed knobs of a context, -1 = the built-in choice; never changes a result."""
+    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 12)]
+
+
 class HostScene(C.Structure):
     _fields_ = [("vertices", C.POINTER(C.c_float)), ("n_verts", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
                 ("n_tris", C.c_uint32), ("faces", C.POINTER(C.c_float))]
@@ -95,7 +105,7 @@ API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "p
                "pt_get_stats", "pt_reset_stats",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_ranks", "pt_comm_destroy", "pt_film_present",
                "pt_film_tile_count", "pt_film_pack_tiles", "pt_film_unpack_tiles",
-               "pt_device_alloc", "pt_device_free", "pt_device_read"]
+               "pt_device_alloc", "pt_device_free", "pt_device_read", "pt_ctx_get_tuning", "pt_ctx_set_tuning"]
 HOST_SYMBOLS = ["pth_load_obj", "pth_load_obj_ex", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj", "pth_make_soup"]
 
 _amd = None
@@ -124,6 +134,8 @@ def lib_amd():
         L.pt_last_error.argtypes = [vp]
         L.pt_last_error.restype = C.c_char_p
         L.pt_sync.argtypes = [vp]
+        L.pt_ctx_get_tuning.argtypes = [vp, C.POINTER(Tuning)]
+        L.pt_ctx_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.pt_scene_create.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(vp)]
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None
@@ -279,6 +291,24 @@ class Context:
 
     def sync(self):
         self._check(lib_amd().pt_sync(self.h))
+
+    def tuning(self):
+        t = Tuning()
+        self._check(lib_amd().pt_ctx_get_tuning(self.h, C.byref(t)))
+        return t
+
+    def set_tuning(self, **kw):
+        """Change speed knobs (names: TUNING_NAMES; -1 = built-in choice) -> the previous values of the ones changed, so a
+        caller can put them back: ctx.set_tuning(**ctx.set_tuning(node_yield=0))."""
+        t = self.tuning()
+        old = {}
+        for k, v in kw.items():
+            if k not in TUNING_NAMES:
+                raise AttributeError(k)
+            old[k] = getattr(t, k)
+            setattr(t, k, int(v))
+        self._check(lib_amd().pt_ctx_set_tuning(self.h, C.byref(t)))
+        return old
 
     def stats(self):
         s = Stats()

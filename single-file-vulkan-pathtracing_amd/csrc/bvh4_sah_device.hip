@@ -1,7 +1,7 @@
 // bvh4_sah_device.hip -- the "prefer fast trace" BVH4 of small scenes, built ON THE DEVICE.
 //
-// Same tree as the host builder of bvh4_sah.hip (which stays as the cross-check: the tests compare the two bit for
-// bit): primitives = triangles or fan pairs, binary surface-area sweep over every split position of all three centroid
+// (Round 1 built the same tree on the host; that builder is gone -- tests/test_gpu_parity.py checks this one's trees
+// structurally and through the hit records.)  Primitives = triangles or fan pairs, binary surface-area sweep over every split position of all three centroid
 // orders, cost area(L) n(L) + area(R) n(R) in binary64, first minimum in (cost, axis, position) order, median split below
 // depth 24; then the BVH4 by opening the internal child of largest area, rows in the same format and order.
 //
@@ -14,12 +14,13 @@
 #include "pt_internal.h"
 #include "pt_math.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace {
 
 constexpr int TBD = 256;
-constexpr int SAH_MAX_DEPTH = 24;  // as bvh4_sah.hip
+constexpr int SAH_MAX_DEPTH = 24;
 
 struct SahNode {
     int left, right;          // -1: leaf
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(TBD) void k_sah_node_boxes(const SahNode *__restric
     ntris[i] = n_tri;
 }
 
-// BVH4 rows + leaf order from the binary tree: one thread, the loop of pt_sah_build_bvh4 (bvh4_sah.hip)
+// BVH4 rows + leaf order from the binary tree: one thread opens, per wide node, the internal child of largest area
 __global__ void k_sah_emit(const SahNode *__restrict__ nodes, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ prim_first,
                            const uint8_t *__restrict__ prim_tris, const float *__restrict__ nbox, const double *__restrict__ narea,
                            const uint32_t *__restrict__ ntris, uint32_t *__restrict__ rows, uint32_t *__restrict__ order, uint32_t *__restrict__ counts /* {n_rows, n_order} */,
@@ -331,4 +332,39 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
     PT_HIP(ctx, hipMemcpy(rows.data(), d_rows.p, sizeof(uint32_t) * rows.size(), hipMemcpyDeviceToHost));
     PT_HIP(ctx, hipMemcpy(order.data(), d_order.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+// Most entries a depth-first walk of a BVH4 (rows of 32 dwords, child words at 24..27) can have pending: what the LDS-only
+// traversal kernels size their stacks by (plan_extend in wavefront.hip).
+uint32_t pt_wide_stack_need(const std::vector<uint32_t> &w)
+{
+    // a node with k children pushes at most k-1 of them before descending:
+    // need(node) = k-1 + max over internal children (iterative, children always have larger indices or not -- use DFS)
+    struct F { uint32_t node; uint32_t depth; };
+    const size_t n = w.size() / 32;
+    std::vector<uint32_t> need(n, 0);
+    std::vector<int> state(n, 0);
+    std::vector<uint32_t> stack{ 0u };
+    while (!stack.empty()) {
+        const uint32_t nd = stack.back();
+        if (nd >= n || stack.size() > 4096) return 1u << 20;  // malformed: forces the spilling variant
+        if (state[nd] == 0) {
+            state[nd] = 1;
+            for (int c = 0; c < 4; c++) {
+                const uint32_t word = w[32 * (size_t)nd + 24 + c];
+                if (word != 0xFFFFFFFFu && !(word & PT_LEAF)) stack.push_back(word);
+            }
+        } else {
+            stack.pop_back();
+            uint32_t k = 0, deepest = 0;
+            for (int c = 0; c < 4; c++) {
+                const uint32_t word = w[32 * (size_t)nd + 24 + c];
+                if (word == 0xFFFFFFFFu) continue;
+                k++;
+                if (!(word & PT_LEAF) && word < n) deepest = std::max(deepest, need[word]);
+            }
+            need[nd] = (k ? k - 1 : 0) + deepest;
+        }
+    }
+    return need[0];
 }

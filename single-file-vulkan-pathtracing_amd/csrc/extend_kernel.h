@@ -132,7 +132,7 @@ constexpr int REFILL_MIN_IDLE = 16;  // default number of idle lanes before the 
 // at ~88 atomics/us on this chip, which short Cornell traversals (3.6 nodes/ray) exceed 3x over.
 // Incoherent rays otherwise leave a wave64 at 15-20 % lane utilisation (measured: 6x more VALU
 // instructions per wave than per average lane).
-template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false, bool REC64 = false>
+template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool REC64 = false>
 __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, const uint2 *__restrict__ g_wide16,
                                                NormBox nb, const float4 *__restrict__ g_tri4,
                                                uint32_t n_wide, uint32_t n_tris, const float4 *__restrict__ rayA,
@@ -160,26 +160,19 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
     // Half the stack bytes in LDS: 15 KB instead of 25 KB per block for the Cornell box, which lifts the LDS cap
     // on resident blocks from 6 to 10 per CU.  The host only picks it for tmin >= 0.
     // PAIRS (a COMPACT variant): every leaf holds ONE primitive -- a triangle, or the two halves (v0,v1,v2),(v0,v2,v3)
-    // of a quad at consecutive positions (bvh4_sah.hip, pair_with_next).  The leaf step is then one straight piece of
+    // of a quad at consecutive positions (bvh4_sah_device.hip, pair_with_next).  The leaf step is then one straight piece of
     // code for all lanes that hold a leaf (no per-lane triangle count to loop over: that loop ran at 31 % lane
     // occupancy on the Cornell box), and the second half re-uses the first one's sheared v0, v2 and the products of
     // their shared edge function: 44 instead of 60 VALU for the two edge tests, bit for bit the per-triangle results.
     constexpr bool COMPACT = LDS_SCENE && !SPILL;
     static_assert(!PAIRS || COMPACT, "pair leaves are implemented for the compact LDS kernel");
-    // UNIFIED (scenes walked out of L2 / MALL / HBM): this kernel waits for memory, and with vote-scheduled steps a wave
-    // pays one memory latency per NODE step and another per LEAF step, each with the lanes that want the other kind
-    // idle.  A 64-B node is four 16-B loads and a 48-B triangle three, so instead every lane that holds ANYTHING
-    // fetches "what cur points to" with the same three or four load instructions, the wave waits once, and then the
-    // node arithmetic runs for the lanes that fetched a node and the triangle test for those that fetched a triangle:
-    // half the waits per ray and every ray advances in every iteration.
-    static_assert(!UNIFIED || (!LDS_SCENE && SPILL), "the unified step is the HBM kernel's");
     // REC64 (scenes walked out of L2 / MALL / HBM, vote-scheduled step): the three vertices come from the 64-B per-triangle
     // record k_shade gathers anyway ({v0, n.x} {v1, n.y} {v2, n.z} {brdf, emits}, `g_rec64` = pt_scene::d_shade64) instead
     // of the 48-B record of tri4.  Beyond L2 the chip charges a divergent access per distinct 128-B line
     // (scripts/ubench/gather_rate.hip): two of every eight 48-B records straddle a line, a 64-B record never does, the
     // shading pass of the same round finds the line of the winning triangle already fetched, and tri4 drops out of the
     // working set (its primitive ids are read only when two hits have exactly the same t).
-    static_assert(!REC64 || (!LDS_SCENE && SPILL && !UNIFIED), "64-B triangle records are the vote-scheduled HBM kernel's");
+    static_assert(!REC64 || (!LDS_SCENE && SPILL), "64-B triangle records are the vote-scheduled HBM kernel's");
     constexpr uint32_t LEAF_BIT = COMPACT ? 0x2000u : PT_LEAF;
     constexpr uint32_t DONE = COMPACT ? 0x3FFFu : SENTINEL;
 
@@ -327,90 +320,6 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         }
         if (__ballot(have) == 0ull) break;
 
-        if constexpr (UNIFIED) {
-            const bool is_node = have && !(cur & LEAF_BIT);
-            const bool is_leaf = have && (cur & LEAF_BIT) && cur != DONE;
-            if (is_node || is_leaf) {
-                const uint32_t first = cur & 0x0FFFFFFFu;
-                const char *p_ = is_node ? reinterpret_cast<const char *>(g_wide16) + 64 * (size_t)cur
-                                         : reinterpret_cast<const char *>(g_tri4) + 48 * (size_t)first;
-                // all four loads for every lane (a triangle lane's fourth reads the 16 bytes behind its 48: the next
-                // record, or the pad at the end of tri4) and a register barrier behind them: left alone the compiler
-                // sinks the loads into the two branches below, and the wave waits for memory twice again
-                uint4 q0 = *reinterpret_cast<const uint4 *>(p_), q1 = *reinterpret_cast<const uint4 *>(p_ + 16),
-                      q2 = *reinterpret_cast<const uint4 *>(p_ + 32), cw = *reinterpret_cast<const uint4 *>(p_ + 48);
-                asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                                  "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(cw.x), "+v"(cw.y), "+v"(cw.z), "+v"(cw.w));
-                bool need_pop;
-                if (is_node) {
-                    if (COUNT) c_nodes++;
-                    PT_COUNT_WAVE(c_node_steps);
-                    // lo planes: q0.xy q0.zw q1.xy, hi planes: q1.zw q2.xy q2.zw; near / far by bit-field insert (PT_BFI below)
-                    const uint32_t mx = ax ? 0xFFFFFFFFu : 0u, my = ay ? 0xFFFFFFFFu : 0u, mz = az ? 0xFFFFFFFFu : 0u;
-                    const uint2 hnx = { PT_BFI(mx, q1.z, q0.x), PT_BFI(mx, q1.w, q0.y) }, hfx = { PT_BFI(mx, q0.x, q1.z), PT_BFI(mx, q0.y, q1.w) };
-                    const uint2 hny = { PT_BFI(my, q2.x, q0.z), PT_BFI(my, q2.y, q0.w) }, hfy = { PT_BFI(my, q0.z, q2.x), PT_BFI(my, q0.w, q2.y) };
-                    const uint2 hnz = { PT_BFI(mz, q2.z, q1.x), PT_BFI(mz, q2.w, q1.y) }, hfz = { PT_BFI(mz, q1.x, q2.z), PT_BFI(mz, q1.y, q2.w) };
-                    float t0, t1, t2, t3;
-                    uint32_t w0 = cw.x, w1 = cw.y, w2 = cw.z, w3 = cw.w;
-                    PT_SLAB4H(t0, x, 0)
-                    PT_SLAB4H(t1, x, 1)
-                    PT_SLAB4H(t2, y, 0)
-                    PT_SLAB4H(t3, y, 1)
-#define PT_CSWAP(TA, WA, TB_, WB)                            \
-    {                                                        \
-        const bool sw = TB_ < TA;                            \
-        const float ta = sw ? TB_ : TA, tb = sw ? TA : TB_;  \
-        const uint32_t wa = sw ? WB : WA, wb = sw ? WA : WB; \
-        TA = ta; TB_ = tb; WA = wa; WB = wb;                 \
-    }
-                    PT_CSWAP(t0, w0, t1, w1)
-                    PT_CSWAP(t2, w2, t3, w3)
-                    PT_CSWAP(t0, w0, t2, w2)
-                    PT_CSWAP(t1, w1, t3, w3)
-                    PT_CSWAP(t1, w1, t2, w2)
-#undef PT_CSWAP
-                    if (t3 < INF) push(w3, t3);  // farthest first, so the nearest pending pops first
-                    if (t2 < INF) push(w2, t2);
-                    if (t1 < INF) push(w1, t1);
-                    need_pop = !(t0 < INF);
-                    if (!need_pop) cur = w0;
-                } else {
-                    const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-                    if (COUNT) { c_tris += cnt; c_leaf_lanes++; }
-                    PT_COUNT_WAVE(c_tri_steps);
-                    auto consider = [&](const float4 a, const float4 b, const float4 c, uint32_t pos) {
-                        float t, V, W, det;
-                        bool divided = false;
-                        if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr)) {
-                            const uint32_t prim = __float_as_uint(a.w);
-                            // closest t; equal t -> lowest gl_PrimitiveID
-                            if (t < best_t || (t == best_t && prim < best_prim)) {
-                                best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
-                                if (ray_tmax) sp = 0;
-                            }
-                        }
-                        if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
-                    };
-                    auto as_f4 = [](const uint4 u) { return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); };
-                    consider(as_f4(q0), as_f4(q1), as_f4(q2), first);
-                    for (uint32_t k = 1; k < cnt; k++) {  // leaves of more than one triangle: only small scenes forced onto this kernel
-                        const size_t ti = 3 * (size_t)(first + k);
-                        consider(g_tri4[ti + 0], g_tri4[ti + 1], g_tri4[ti + 2], first + k);
-                    }
-                    need_pop = true;
-                }
-                if (need_pop) cur = pop();
-            }
-            if (have && cur == DONE) {  // traversal finished: emit the hit record, the lane becomes idle
-                PT_COUNT_WAVE(c_finishes);
-                const bool miss = best_pos == PT_MISS;
-                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
-                                 : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
-                have = false;
-            }
-            continue;
-        }
         // ---- node phase: every lane descends until it holds a leaf (or runs out of nodes)
         // VOTE: one step per outer iteration, of the kind (node / leaf) that more lanes are waiting for
         bool do_leaf = true;
@@ -666,10 +575,10 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
 #define PT_EXTEND_ARGS                                                                                               \
     g_wide, g_wide16, nb, g_tri4, n_wide, n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, \
         refill_min_idle, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax, g_rec64
-template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool UNIFIED = false, bool REC64 = false>
+template <bool LDS_SCENE, bool COUNT, bool SPILL, bool PAIRS = false, bool REC64 = false>
 __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 {
-    extend_body<LDS_SCENE, COUNT, SPILL, PAIRS, UNIFIED, REC64>(PT_EXTEND_ARGS);
+    extend_body<LDS_SCENE, COUNT, SPILL, PAIRS, REC64>(PT_EXTEND_ARGS);
 }
 // The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
 // asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations

@@ -951,7 +951,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, d_tlo.alloc(n));
     PT_HIP(ctx, d_thi.alloc(n));
     s->n_tris = n;
-    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * (3 * (size_t)n + 1)));  // + 16 B: the unified fetch of k_extend reads 64 B at a 48-B record
+    PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * 3 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade64, sizeof(float4) * 4 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_ke4, sizeof(float4) * (size_t)n));
@@ -1063,20 +1063,12 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
         for (int k = 0; k < 3; k++) scale = fmaxf(scale, fmaxf(fabsf(s->bmin[k]), fabsf(s->bmax[k])));
         const float pad = scale * 3.814697265625e-06f;
         std::vector<uint32_t> rows, order;
-        // one primitive per leaf, a primitive being a triangle or a quad's two halves (PT_TUNE_PAIR_LEAVES=0: the former
-        // rule, up to PT_SAH_LEAF_MAX independent triangles per leaf where splitting does not pay)
-        const char *pe = getenv("PT_TUNE_PAIR_LEAVES");
-        const bool pairs = !(pe && atoi(pe) == 0);
-        // built on the device (bvh4_sah_device.hip); PT_TUNE_SAH_HOST=1 runs the host builder of bvh4_sah.hip, which gives
-        // the same rows and order bit for bit (tests compare them)
-        if (getenv("PT_TUNE_SAH_HOST") && atoi(getenv("PT_TUNE_SAH_HOST")) == 1) {
-            pt_sah_build_bvh4(s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad, pairs ? 1u : PT_SAH_LEAF_MAX,
-                              rows, order);
-        } else {
-            const pt_status rc8 = pt_sah_build_bvh4_device(ctx, s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad,
-                                                           pairs ? 1u : PT_SAH_LEAF_MAX, rows, order);
-            if (rc8 != PT_OK) return rc8;
-        }
+        // one primitive per leaf, a primitive being a triangle or a quad's two halves (pt_tuning.pair_leaves = 0: the former
+        // rule, up to PT_SAH_LEAF_MAX independent triangles per leaf where splitting does not pay); built on the device
+        const bool pairs = ctx->tune.pair_leaves != 0;
+        const pt_status rc8 = pt_sah_build_bvh4_device(ctx, s->h_tlo.data(), s->h_thi.data(), n, pairs ? s->h_pair.data() : nullptr, pad,
+                                                       pairs ? 1u : PT_SAH_LEAF_MAX, rows, order);
+        if (rc8 != PT_OK) return rc8;
         s->sah_pair_leaves = pairs;
         if (order.size() != n || rows.empty()) { ctx->err = "internal: SAH build lost triangles"; return PT_ERR_HIP; }
         s->n_wide_sah = (uint32_t)(rows.size() / 32);

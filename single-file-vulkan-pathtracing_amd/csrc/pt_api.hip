@@ -27,7 +27,61 @@ static pt_status guarded(pt_ctx *ctx, F &&body)
     }
 }
 
+// ---- tuning (include/pt_api.h pt_tuning): the names PT_TUNE and the Python mirror use, in field order
+static const char *const k_tune_names[] = { "refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves",
+                                            "pair_kernel", "topdown4", "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield",
+                                            "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb", "hbm8", "rebin" };
+constexpr int k_tune_count = (int)(sizeof(k_tune_names) / sizeof(k_tune_names[0]));
+static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 12), "pt_tuning: names and fields out of step");
+
+static void tuning_defaults(pt_tuning *t)
+{
+    int32_t *f = reinterpret_cast<int32_t *>(t);
+    for (size_t i = 0; i < sizeof(pt_tuning) / sizeof(int32_t); i++) f[i] = -1;
+}
+
+// "name=value,name=value" (also ';' or blanks between pairs); unknown names and malformed pairs are reported, not ignored
+static bool tuning_parse(const char *text, pt_tuning *t, std::string &err)
+{
+    int32_t *f = reinterpret_cast<int32_t *>(t);
+    std::string s(text ? text : "");
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && (s[i] == ',' || s[i] == ';' || s[i] == ' ')) i++;
+        if (i >= s.size()) break;
+        size_t e = i;
+        while (e < s.size() && s[e] != ',' && s[e] != ';' && s[e] != ' ') e++;
+        const std::string pair = s.substr(i, e - i);
+        i = e;
+        const size_t eq = pair.find('=');
+        int idx = -1;
+        if (eq != std::string::npos)
+            for (int k = 0; k < k_tune_count; k++)
+                if (pair.compare(0, eq, k_tune_names[k]) == 0) idx = k;
+        char *end = nullptr;
+        const long v = eq != std::string::npos ? std::strtol(pair.c_str() + eq + 1, &end, 10) : 0;
+        if (idx < 0 || !end || *end != 0 || end == pair.c_str() + eq + 1) { err = "PT_TUNE: cannot use '" + pair + "'"; return false; }
+        f[idx] = (int32_t)v;
+    }
+    return true;
+}
+
 extern "C" {
+
+pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out)
+{
+    if (!ctx || !out) return PT_ERR_INVALID_ARG;
+    *out = ctx->tune;
+    return PT_OK;
+}
+
+pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in)
+{
+    if (!ctx || !in) return PT_ERR_INVALID_ARG;
+    ctx->tune = *in;
+    if (in->mem_budget_mb >= 0) ctx->mem_budget = (size_t)in->mem_budget_mb << 20;
+    return PT_OK;
+}
 
 pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
 {
@@ -56,7 +110,14 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *mb = getenv("PT_MEM_BUDGET_MB")) ctx->mem_budget = (size_t)std::max(0ll, atoll(mb)) << 20;
+    // the only two environment variables the library reads, both here and only here
+    tuning_defaults(&ctx->tune);
+    const char *const env[2] = { "PT_TUNE", "PT_MEM_BUDGET_MB" };
+    const char *val[2];
+    for (int k = 0; k < 2; k++) val[k] = getenv(env[k]);
+    if (val[0] && !tuning_parse(val[0], &ctx->tune, g_create_err)) { pt_ctx_destroy(ctx); return PT_ERR_INVALID_ARG; }
+    if (val[1]) ctx->tune.mem_budget_mb = (int32_t)std::max(0ll, std::min(atoll(val[1]), 1ll << 30));
+    if (ctx->tune.mem_budget_mb > 0) ctx->mem_budget = (size_t)ctx->tune.mem_budget_mb << 20;
     if (stream) {
         ctx->stream = reinterpret_cast<hipStream_t>(stream);
     } else {

@@ -41,7 +41,10 @@ struct pt_ctx {
     // environment variable PT_MEM_BUDGET_MB at pt_ctx_create: for processes that share the GPU with another
     // allocator (torch), and for the out-of-memory tests.
     size_t mem_budget = 0;
+    pt_tuning tune;            // include/pt_api.h: defaults (-1) + PT_TUNE, filled once by pt_ctx_create
 };
+// a tuning field with its built-in choice and its valid range
+inline int pt_tuned(int32_t v, int dflt, int lo, int hi) { return v < 0 ? dflt : (v < lo ? lo : (v > hi ? hi : v)); }
 
 struct pt_scene {
     pt_ctx *ctx = nullptr;
@@ -59,7 +62,7 @@ struct pt_scene {
     uint32_t stack_need = 0xFFFFFFFFu;    // exact bound of pending traversal-stack entries (small scenes), else unknown
     // BVH quality (main.cpp:419 asks the driver for ePreferFastTrace).  d_wide / n_wide / stack_need above and
     // the order of tri4/shade4 describe the BVH4 that is TRAVERSED: the collapsed LBVH (builder 0) or, for
-    // scenes of <= PT_SAH_MAX_TRIS triangles, a surface-area sweep built on the host (builder 1, bvh4_sah.hip).
+    // scenes of <= PT_SAH_MAX_TRIS triangles, a surface-area sweep built on the device (builder 1, bvh4_sah_device.hip).
     // d_wide aliases one of the two owned arrays below.
     uint32_t bvh4_builder = 0;
     // 64-B copy of the traversed BVH4 for scenes that are walked in HBM/L2 (lbvh_build.hip make_wide16):
@@ -160,12 +163,9 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
 pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality);
 void ptb_free_scene_buffers(pt_scene *s);
 constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
-// bvh4_sah.hip: host surface-area sweep -> BVH4 rows (32 dwords each) + leaf order
+// bvh4_sah_device.hip: surface-area sweep on the device (one workgroup) -> BVH4 rows (32 dwords each) + leaf order
 // pair_with_next (nullable): [n] flags, triangle i and i+1 are the two halves (v0,v1,v2),(v0,v2,v3) of a quad and form ONE primitive
-void pt_sah_build_bvh4(const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
-                       uint32_t leaf_max_prims, std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
 uint32_t pt_wide_stack_need(const std::vector<uint32_t> &rows32);
-// bvh4_sah_device.hip: the same builder on the device (one workgroup), same rows and order bit for bit
 pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
                                    uint32_t leaf_max_prims, std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
 void ptb_free_instances(pt_scene *s);

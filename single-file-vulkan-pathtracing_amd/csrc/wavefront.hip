@@ -32,8 +32,8 @@
 #include "extend_inst16.h"  // k_extend_inst16: the two-level kernel over 64-B fp16 nodes with one-dword stack entries
 
 // extend_hbm.hip: k_extend<false, *, true>, compiled with the max-ILP scheduler
-const void *ptw_extend_hbm_fn(bool count);
-void ptw_launch_extend_hbm(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+const void *ptw_extend_hbm_fn(bool count, bool rec64);
+void ptw_launch_extend_hbm(bool count, bool rec64, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                            const float4 *wide, const uint2 *wide16, const float *norm_c, const float *norm_s,
                            const float *norm_rs, const float4 *tri4, const float4 *rec64_tab, uint32_t n_wide, uint32_t n_tris,
                            const float4 *rayA, const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero,
@@ -558,8 +558,12 @@ __device__ __forceinline__ bool nee_sample(const float4 *__restrict__ lights, ui
 {
     const float rl = ptm::rnd(seed), ru = ptm::rnd(seed), rv = ptm::rnd(seed);
     const float pick = rl * light_area;
-    uint32_t li = 0;
-    while (li + 1u < n_lights && !(lights[5 * (size_t)li].w > pick)) li++;
+    // first emitter whose running area exceeds pick (the last one if none does): binary search of the cdf
+    uint32_t li = 0, hi_ = n_lights - 1u;
+    while (li < hi_) {
+        const uint32_t mid = (li + hi_) >> 1;
+        if (lights[5 * (size_t)mid].w > pick) hi_ = mid; else li = mid + 1u;
+    }
     const float4 A = lights[5 * (size_t)li + 0], B = lights[5 * (size_t)li + 1], C = lights[5 * (size_t)li + 2],
                  N = lights[5 * (size_t)li + 3], Ke = lights[5 * (size_t)li + 4];
     const float su = ptm::fsqrt(ru);
@@ -731,7 +735,9 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                 if ((!NEE || depth == 0u) && !(er == 0.f && eg == 0.f && eb == 0.f)) add_radiance(rc, rad, slot, er, eg, eb);
                 depth++;
                 terminated = depth >= rc.max_depth;  // raygen.rgen:62 loop bound
-                if (!terminated || (NEE && n_lights)) {
+                // (NEE samples no light at the path's last hit: that sample stands for the emission the next ray would find,
+                // and the reference's sum ends with the hit of ray max_depth - 1, raygen.rgen:62-83)
+                if (!terminated) {
                     if (LDS_TABLES) {
                         a = tri4[3 * pos + 0]; b = tri4[3 * pos + 1]; c = tri4[3 * pos + 2];
                     } else {
@@ -1017,22 +1023,20 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         pl.refill = 64;  // a wave takes new rays only when all its lanes are done: entering an instance (ray transform, three
                          // divides) and the TLAS root are too expensive to run for a few refilled lanes.  C4: 16: 8.2, 32: 8.85,
                          // 48: 9.26, 56: 9.2, 64: 9.38 Grays/s
-        if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+        pl.refill = pt_tuned(ctx->tune.refill, pl.refill, 1, 64);
         pl.grid = ctx->num_cus * per_cu_i;
         pl.smem_inst_fallback = pl.smem; pl.grid_inst_fallback = pl.grid;
         // the round-2 kernel when both levels fit its 15-bit child codes and the BLAS fits LDS
         const size_t smem16_scene = sizeof(uint32_t) * I16_NODE_DW * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;
-        int lds16 = 16;
-        if (const char *e = getenv("PT_TUNE_LDS_STACK")) lds16 = std::max(1, std::min(atoi(e), 32));
+        const int lds16 = pt_tuned(ctx->tune.lds_stack, 16, 1, 32);
         pl.inst16 = s->d_tlas16 && s->d_wide16 && s->n_inst < 32768u && s->n_tlas16 < 32767u && s->n_wide < 32767u && s->n_tris <= 2047u &&
-                    smem16_scene <= 24 * 1024 && !(getenv("PT_TUNE_INST16") && atoi(getenv("PT_TUNE_INST16")) == 0);
+                    smem16_scene <= 24 * 1024 && ctx->tune.inst16 != 0;
         if (pl.inst16) {
             pl.lds_stack = lds16;
             // top levels of the TLAS staged in LDS next to the BLAS.  8 KB (102 nodes: the top four levels) measured best on
             // C4: 0 / 4 / 8 / 16 / 24 KB -> 11.95 / 12.16 / 12.31 / 10.7 / 11.1 Grays/s (profiles/r02i_ab_c4_tlas_lds.log) --
             // from 16 KB on the four resident blocks leave the other pipeline's k_shade no LDS to run beside them
-            size_t tlas_lds_bytes = 8 * 1024;
-            if (const char *e = getenv("PT_TUNE_TLAS_LDS_KB")) tlas_lds_bytes = (size_t)std::max(0, std::min(atoi(e), 96)) * 1024;
+            const size_t tlas_lds_bytes = (size_t)pt_tuned(ctx->tune.tlas_lds_kb, 8, 0, 96) * 1024;
             pl.n_tlas_lds = (uint32_t)std::min<size_t>(s->n_tlas16, tlas_lds_bytes / (sizeof(uint32_t) * I16_NODE_DW));
             pl.smem = (size_t)lds16 * TB * sizeof(uint32_t) + smem16_scene + sizeof(uint32_t) * I16_NODE_DW * (size_t)pl.n_tlas_lds;
             const void *fn16 = s->pair_leaves ? reinterpret_cast<const void *>(k_extend_inst16<false, true>)
@@ -1045,11 +1049,9 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
             PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per16, fn16, TB, pl.smem));
             // four blocks per CU and refill at 48 idle lanes measured best on the 10 000-instance grid (C4: 4/48 10.73,
             // 5/48 10.33, 4/40 10.66, 4/56 10.35, 4/64 9.74 Grays/s; the fp32 kernel at its best, 4/64: 9.33)
-            per16 = std::min(per16, 4);
-            if (const char *e = getenv("PT_TUNE_INST16_BLOCKS")) per16 = std::max(1, std::min(atoi(e), 8));
+            per16 = pt_tuned(ctx->tune.inst16_blocks, std::min(per16, 4), 1, 8);
             pl.grid = ctx->num_cus * std::max(1, std::min(per16, 8));
-            pl.refill = 48;
-            if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+            pl.refill = pt_tuned(ctx->tune.refill, 48, 1, 64);
         }
         // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk: the exact bound of the
         // BVH4 that is TRAVERSED when the builder gave one (the surface-area BVH4 of a small scene can be deeper
@@ -1081,19 +1083,17 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     // BVH8 visits 26 % fewer nodes but fetches as many 128-B LINES (two 64-B BVH4 siblings share one), and lines are
     // what the memory system charges beyond L2 -- extend + shade kernel time 458 vs 395 ms per 4 frames of C5, equal on
     // C5x.  PT_EXTEND_HBM8 (or PT_TUNE_BVH8=1 under AUTO) selects it.
-    const bool auto8 = want == PT_EXTEND_AUTO && scene_bytes > 24 * 1024 && s->d_wide8 && getenv("PT_TUNE_BVH8") && atoi(getenv("PT_TUNE_BVH8")) == 1;
+    const bool auto8 = want == PT_EXTEND_AUTO && scene_bytes > 24 * 1024 && s->d_wide8 && ctx->tune.hbm8 == 1;
     if (want == PT_EXTEND_HBM8 || auto8) {
         pl.variant = PT_EXTEND_HBM8;
         pl.bvh8 = true;
         pl.lds_scene = false;
-        pl.lds_stack = 12;
-        if (const char *e = getenv("PT_TUNE_LDS_STACK")) pl.lds_stack = std::max(1, std::min(atoi(e), 32));
+        pl.lds_stack = pt_tuned(ctx->tune.lds_stack, 12, 1, 32);
         pl.smem = (size_t)pl.lds_stack * TB * sizeof(uint2);
         int per_cu8 = 0;
         PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, ptw_extend8_fn(false), TB, pl.smem));
         per_cu8 = std::max(1, std::min(per_cu8, 8));
-        pl.refill = 32;
-        if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+        pl.refill = pt_tuned(ctx->tune.refill, 32, 1, 64);
         pl.grid = ctx->num_cus * per_cu8;
         // one stack entry per visited node: at most one per level of the BVH8
         const uint32_t bound8 = s->levels8 + 1u;
@@ -1119,7 +1119,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     // (the no-spill kernel packs child words into 14 bits: <= 2047 triangles, <= 8191 nodes, leaves of <= 4)
     pl.spill = !(pl.lds_scene && s->stack_need <= 16u && s->n_tris <= 2047u && s->n_wide <= 8191u);
     if (!pl.spill) pl.lds_stack = (int)std::max(s->stack_need, 1u);
-    pl.pairs = !pl.spill && s->pair_leaves && !(getenv("PT_TUNE_PAIR_KERNEL") && atoi(getenv("PT_TUNE_PAIR_KERNEL")) == 0);
+    pl.pairs = !pl.spill && s->pair_leaves && ctx->tune.pair_kernel != 0;
     pl.smem_wide_entries = (size_t)pl.lds_stack * TB * sizeof(uint2) + (pl.lds_scene ? scene_bytes : 0);
     pl.smem = pl.spill ? pl.smem_wide_entries : (size_t)pl.lds_stack * TB * sizeof(uint32_t) + scene_bytes;
     if (!pl.spill && pl.smem_wide_entries > 48 * 1024) {
@@ -1129,23 +1129,26 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     const void *fn = pl.pairs ? reinterpret_cast<const void *>(k_extend_lds7p)
                      : !pl.spill ? reinterpret_cast<const void *>(k_extend_lds7)
                      : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, false, true>)
-                                    : ptw_extend_hbm_fn(false);
+                                    : ptw_extend_hbm_fn(false, ctx->tune.rec64 != 0);
     const void *fn_count = pl.pairs ? reinterpret_cast<const void *>(k_extend<true, true, false, true>)
                            : !pl.spill ? reinterpret_cast<const void *>(k_extend<true, true, false>)
                            : pl.lds_scene ? reinterpret_cast<const void *>(k_extend<true, true, true>)
-                                          : ptw_extend_hbm_fn(true);
+                                          : ptw_extend_hbm_fn(true, ctx->tune.rec64 != 0);
     if (pl.smem > 48 * 1024)
         PT_HIP(ctx, hipFuncSetAttribute(fn_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
     if (pl.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
+    if (pl.smem > 48 * 1024 && !pl.spill)  // the shadow-ray twins of the two compact kernels (NEE pipeline)
+        PT_HIP(ctx, hipFuncSetAttribute(pl.pairs ? reinterpret_cast<const void *>(k_extend_lds7p_sh) : reinterpret_cast<const void *>(k_extend_lds7_sh),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
     int per_cu = 0;
     PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TB, pl.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
-    if (const char *e = getenv("PT_TUNE_EXTEND_BLOCKS")) per_cu = std::max(1, std::min(atoi(e), per_cu));
-    pl.refill = pl.lds_scene ? REFILL_MIN_IDLE : 32;  // big scenes (vote-scheduled steps): 32 idle lanes measured best on C5 (16: -2.5 %, 48: -3 %)
-    if (const char *e = getenv("PT_TUNE_REFILL")) pl.refill = std::max(1, std::min(atoi(e), 64));
+    per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
+    // big scenes (vote-scheduled steps): 32 idle lanes measured best on C5 (16: -2.5 %, 48: -3 %)
+    pl.refill = pt_tuned(ctx->tune.refill, pl.lds_scene ? REFILL_MIN_IDLE : 32, 1, 64);
     pl.grid = ctx->num_cus * per_cu;
     // the HBM variant of a scene whose traversed BVH4 is the collapsed LBVH walks the top-down layout of it
-    pl.topdown4 = !pl.lds_scene && s->bvh4_builder == 0 && s->d_wide16t && !(getenv("PT_TUNE_TOPDOWN4") && atoi(getenv("PT_TUNE_TOPDOWN4")) == 0);
+    pl.topdown4 = !pl.lds_scene && s->bvh4_builder == 0 && s->d_wide16t && ctx->tune.topdown4 != 0;
     // stack bound: the exact one of the BVH4 that is traversed when its builder computed it (small scenes; the
     // surface-area BVH4 is not bounded by the LBVH's height), else a BVH4 node pushes <= 3 entries per level and the
     // collapsed LBVH's wide height is <= binary height/2 + 1
@@ -1181,12 +1184,10 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         const NormBox nbt = { s->tlas_norm_c[0], s->tlas_norm_c[1], s->tlas_norm_c[2], s->tlas_norm_s[0], s->tlas_norm_s[1], s->tlas_norm_s[2],
                               s->tlas_norm_rs[0], s->tlas_norm_rs[1], s->tlas_norm_rs[2] };
         const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
-        int enter_min = 16;  // lanes that wait to enter an instance together (8: , 16, 24 measured alike within 1 %)
-        if (const char *e = getenv("PT_TUNE_ENTER_MIN")) enter_min = std::max(1, std::min(atoi(e), 64));
+        const int enter_min = pt_tuned(s->ctx->tune.enter_min, 16, 1, 64);  // lanes that wait to enter an instance together (8, 16, 24 measured alike within 1 %)
         // the node loop yields to the lanes waiting with a leaf once fewer than 1/6 of the wave's rays still descend
         // (C4 11.7 -> 12.2 Grays/s; 2, 3, 4, 8 measured within 1 % of it, 0 = never: profiles/r02i_ab_c4_node_yield.log)
-        int node_yield = 6;
-        if (const char *e = getenv("PT_TUNE_NODE_YIELD")) node_yield = std::max(0, std::min(atoi(e), 64));
+        const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
 #define PT_LAUNCH_INST16(C, P)                                                                                              \
     hipExtLaunchKernelGGL((k_extend_inst16<C, P>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
                           reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6,     \
@@ -1256,7 +1257,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     } else if (pl.lds_scene) {
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
-        ptw_launch_extend_hbm(count, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
+        ptw_launch_extend_hbm(count, s->ctx->tune.rec64 != 0, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
                               s->d_shade64, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
                               tmax, pl.lds_stack, raw, perm, ray_tmax);
     }
@@ -1502,7 +1503,7 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, int shrink = 0)
         const uint64_t room = avail > planned(lanes, sh.groups) ? avail - planned(lanes, sh.groups) : 0;
         const uint64_t budget = std::min<uint64_t>(std::min<uint64_t>(16ull << 30, (have_log + free_b) / 4), room);
         uint64_t ocap = std::min<uint64_t>(worst - sh.term_pcap, budget / std::max<uint64_t>(n_slots * sizeof(float4), 1));
-        if (const char *e = getenv("PT_TUNE_TERM_OCAP")) ocap = std::min<uint64_t>(ocap, (uint64_t)std::max(0, atoi(e)));  // tests
+        if (f->ctx->tune.term_ocap >= 0) ocap = std::min<uint64_t>(ocap, (uint64_t)f->ctx->tune.term_ocap);  // tests
         sh.term_cap = sh.term_pcap + (uint32_t)ocap;
         sh.bounded = sh.term_cap < worst;
     }
@@ -1636,7 +1637,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     pt_film::Work &w = f->work;
     unsigned long long *const d_overflow = ctx->d_stats + 6, *const d_spill_count = ctx->d_stats + 7;
     uint32_t spill_cap = sh.bounded ? SPILL_POOL_ENTRIES : 0u;  // worst-case logs never reach the pool
-    if (const char *e = getenv("PT_TUNE_TERM_SPILL")) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)std::max(0, atoi(e)));  // tests
+    if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);  // tests
     Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
 
     RenderConst rc{};
@@ -1669,7 +1670,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
 
     // measured on MI355X: 4 paths per thread (one queue-tail atomic per 1024 paths) and 8 blocks per CU;
     // 1 path/thread is 40 % slower, 2 equal, grid size flat between 4 and 16 blocks per CU
-    const bool stagger = !(getenv("PT_TUNE_STAGGER") && atoi(getenv("PT_TUNE_STAGGER")) == 0);
+    const bool stagger = ctx->tune.stagger != 0;
     const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 8 * (size_t)s->n_tris;  // tri4 + shade4 + the tangent frames
     const bool shade_lds = shade_smem <= 16 * 1024 && !pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
@@ -1692,7 +1693,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     // grid below the register-file limit (PT_TUNE_EXTEND_BLOCKS) so that k_shade of the other pipeline can be co-resident
     // changes nothing measurable (C2, 7 -> 5 blocks per CU: within +-1 %).
     int n_pipes = (uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1;
-    if (const char *e = getenv("PT_TUNE_PIPES")) n_pipes = atoi(e);
+    n_pipes = pt_tuned(ctx->tune.pipes, n_pipes, 1, PT_MAX_PIPES);
     n_pipes = std::max(1, std::min(n_pipes, std::min<int>(PT_MAX_PIPES, (int)(lanes * groups))));
     for (int k = 1; k < n_pipes; k++)
         if (!ctx->pipe_stream[k]) {
@@ -1710,8 +1711,8 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
         if (p->flags & PT_FLAG_SORT_RAYS) sort_rays = true;
         if (p->flags & PT_FLAG_NO_SORT_RAYS) sort_rays = false;
     }
-    int sort_bits = 4;  // 4 bits per axis + octant = 15-bit keys = two 8-bit passes (C5x: 6 bits, three passes: +0 %, 4 bits: +3.5 %)
-    if (const char *e = getenv("PT_TUNE_SORT_BITS")) sort_bits = std::max(1, std::min(atoi(e), 9));
+    // 4 bits per axis + octant = 15-bit keys = two 8-bit passes (C5x: 6 bits, three passes: +0 %, 4 bits: +3.5 %)
+    const int sort_bits = pt_tuned(ctx->tune.sort_bits, 4, 1, 9);
     if (sort_rays) {
         // one scratch area per pipeline, sized for that pipeline's share of the slots (+ slack for the uneven split)
         const size_t per_pipe = ptw_ray_sort_bytes((size_t)w.n_slots / (size_t)n_pipes + (size_t)rc.slots_per_lane + 1);

@@ -86,13 +86,13 @@ void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_uni
         else if (pt_scene_create(ctx, hs.vertices, hs.n_verts, hs.indices, hs.n_tris, hs.faces, &scene) != PT_OK) { fail("pt_scene_create"); ok = false; }
         else if (pt_film_create(ctx, o.width, o.height, &film) != PT_OK) { fail("pt_film_create"); ok = false; }
         if (ok) pt_scene_get_info(scene, &res.info);
-        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; if (agree) { agree->all_ok(false); agree->all_ok(false); } break; }
+        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; break; }  // (the flag is sticky: every rank leaves here together)
         if (o.ranks > 1) {
             // collective: all ranks are here.  RCCL refuses two ranks on one device (--devices 0,0) on every rank alike
             if (pt_comm_create(ctx, id, o.ranks, rank, &comm) != PT_OK) { fail("pt_comm_create"); ok = false; }
             else pt_comm_ranks(comm, &res.rccl_ranks);
         }
-        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; if (agree) agree->all_ok(false); break; }
+        if (!peers_ok(ok)) { if (ok) res.error = peer_msg; break; }
         pt_params p;
         pt_params_default(&p);
         p.width = o.width; p.height = o.height; p.spp_per_frame = o.spp; p.max_depth = o.depth;

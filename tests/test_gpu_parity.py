@@ -509,14 +509,13 @@ def test_c4_grid_of_10000_instances(pt, orc, gpu_ctx, cornell_arrays):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [dict(PT_TUNE_NODE_YIELD="0"), dict(PT_TUNE_NODE_YIELD="2"), dict(PT_TUNE_TLAS_LDS_KB="0"),
-                                   dict(PT_TUNE_TLAS_LDS_KB="24", PT_TUNE_NODE_YIELD="8"), dict(PT_TUNE_INST16="0")])
+@pytest.mark.parametrize("knobs", [dict(node_yield=0), dict(node_yield=2), dict(tlas_lds_kb=0),
+                                   dict(tlas_lds_kb=24, node_yield=8), dict(inst16=0)])
 def test_two_level_kernel_scheduling_knobs_keep_the_bits(pt, orc, gpu_ctx, cornell_arrays, knobs):
     """The scheduling of the compact two-level kernel (when the node loop yields to waiting leaves, how many TLAS nodes are
-    staged in LDS; INST16=0: the round-1 kernel) must not show in the results: the 10 000-instance grid -- a partly LDS-resident
+    staged in LDS; inst16 = 0: the general two-level kernel) must not show in the results: the 10 000-instance grid -- a partly LDS-resident
     TLAS -- and a 7-instance set -- an entirely LDS-resident one -- render and trace to the oracle's bits under every setting."""
-    old = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
+    old = gpu_ctx.set_tuning(**knobs)      # include/pt_api.h pt_tuning (the library reads no tuning from the environment)
     try:
         for inst in (pt.cornell_grid_instances(), _random_instances(7, 3)):
             gs, osc = pt.Scene(gpu_ctx, *cornell_arrays), orc.Scene(*cornell_arrays)
@@ -531,11 +530,7 @@ def test_two_level_kernel_scheduling_knobs_keep_the_bits(pt, orc, gpu_ctx, corne
             assert film.read_f32().tobytes() == ofilm.tobytes(), knobs
             film.close(); gs.close()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        gpu_ctx.set_tuning(**old)
 
 
 def test_pt_main_host_driver_writes_the_same_image(pt, gpu_ctx, cornell_gpu, tmp_path):
@@ -857,6 +852,99 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
         assert k in j2
 
 
+def _bench(args, env=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the form the driver's N = 1 command has -- must
+    start its own two ranks instead of exiting.  On one GPU under PT_BENCH_EMULATE (gloo carries the packed tiles between
+    the same kernels): the same rays and the same presented image as N = 1, and the multi-rank fields of the line."""
+    args = ["--steps", "2", "--warmup", "1", "--reps", "2", "--width", "320", "--height", "184", "--no-cpu-baseline", "--no-extra-legs"]
+    one, j1 = _bench(args)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = {"PT_BENCH_EMULATE": "1"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        assert k not in os.environ, "this test must run without a launcher's environment"
+    two, j2 = _bench(["--gpus", "2"] + args, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    assert j2["n_gpus"] == 2 and j2["steps"] == 2 and j2["reps"] >= 2
+    assert j2["launcher"].startswith("bench.py's own")
+    assert j2["rays"] == j1["rays"] and j2["paths"] == j1["paths"]
+    assert abs(j2["presented_checksum"] - j1["presented_checksum"]) <= 1e-9 * abs(j1["presented_checksum"])
+    lo, hi = j2["rays_per_rank_min_max"]
+    assert lo + hi == j2["rays"] and hi - lo < 0.02 * hi
+    assert j2["rccl_ranks"] == 2 and j2["present_ms"] > 0.0
+    assert j2["value_min"] <= j2["value"] <= j2["value_max"] and len(j2["values"]) == j2["reps"]
+    assert j2["workspace_bytes"] > 0
+
+
+def test_bench_gpus2_without_a_second_gpu_fails_cleanly():
+    """The real (RCCL) N = 2 path on a box with one GPU: rank 1 has no device, says so, and bench.py's own launcher stops
+    rank 0 too -- a non-zero status within seconds, never a hang inside a collective.  (With two GPUs it simply runs.)"""
+    import time
+    t0 = time.time()
+    r, j = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--reps", "1", "--width", "256", "--height", "128",
+                   "--no-cpu-baseline", "--no-extra-legs"], timeout=300)
+    if _two_gpus():
+        assert r.returncode == 0 and j["n_gpus"] == 2 and j["rccl_ranks"] == 2, r.stderr[-2000:]
+    else:
+        assert r.returncode != 0 and j is None
+        assert "needs GPU 1" in r.stderr and "stopping the other ranks" in r.stderr
+        assert time.time() - t0 < 120
+
+
+def test_bench_config_c3_shape():
+    """--config c3 = the Cornell box with 32 steps (1024 spp) unless --steps says otherwise; a small film keeps it short."""
+    r, j = _bench(["--config", "c3", "--width", "160", "--height", "96", "--reps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra-legs"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["steps"] == 32 and "1024 spp" in j["metric"] and j["config"]["workload"].startswith("C3:")
+    assert j["paths"] == 160 * 96 * 32 * 32
+
+
+def test_pt_main_two_ranks_on_one_device_is_a_clean_error():
+    """`pt_main --ranks 2 --devices 0,0`: RCCL refuses two ranks on one device.  The host threads agree on success before
+    every collective (host/pt_main.cpp Agreement), so the process reports the error and exits -- it must not hang."""
+    import subprocess
+    repo = os.path.dirname(HERE)
+    exe = os.path.join(repo, "single-file-vulkan-pathtracing_amd", "pt_main")
+    r = subprocess.run([exe, "--obj", os.path.join(repo, "assets", "CornellBox-Original.obj"), "--width", "128", "--height", "64",
+                        "--spp", "2", "--ranks", "2", "--devices", "0,0"], capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0, r.stdout
+    assert "pt_main: rank" in r.stderr and ("pt_comm_create" in r.stderr or "RCCL" in r.stderr), r.stderr
+    # ... and a rank with an ordinal that does not exist stops its peer before ncclCommInitRank
+    r = subprocess.run([exe, "--obj", os.path.join(repo, "assets", "CornellBox-Original.obj"), "--width", "128", "--height", "64",
+                        "--spp", "2", "--ranks", "2", "--devices", "0,99"], capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0 and "rank 1: pt_ctx_create" in r.stderr, r.stderr
+
+
+def test_present_with_another_root_rebuilds_the_geometry(pt, gpu_ctx, cornell_gpu):
+    """pt_film_present cached its tile lists and buffers per film size only; a later call with another root
+    found no receive buffer.  World 1 has one possible root, so this checks the cache key through two film sizes and
+    repeated presents; the root is part of the key now (csrc/present_rccl.hip)."""
+    try:
+        uid = pt.Comm.unique_id()
+    except pt.PtError:
+        pytest.skip("RCCL not installed")
+    comm = pt.Comm(gpu_ctx, uid, 1, 0)
+    for (w, h) in ((96, 40), (64, 64), (96, 40)):
+        film = pt.Film(gpu_ctx, w, h)
+        pt.render(cornell_gpu, film, pt.default_params(width=w, height=h, spp_per_frame=2, max_depth=4))
+        img = pt.DeviceBuffer(gpu_ctx, w * h * 12)
+        comm.present(film, img.ptr, root=0)
+        assert img.read(np.float32, (h, w, 3)).tobytes() == film.read_f32().tobytes()
+        img.close()
+        film.close()
+    comm.close()
+
+
 def test_term_log_overflow_path_bit_exact(pt, orc, gpu_ctx, cornell_arrays):
     """Every surface emits, so every ray adds a radiance term: with sample groups the slots' logs run far past
     the dense primary part (group_size + 2 entries) into the overflow log.  Still the oracle's bits."""
@@ -1026,7 +1114,7 @@ def test_full_term_log_spills_to_the_pool_or_the_batch_is_redone_exactly(pt, orc
                                                                          cornell_oracle, ocap, pool):
     """The overflow part of the sample-group term log is sized to a memory budget, not to the worst case.  Terms beyond
     it go to a pool shared by all slots (per-slot chains, replayed in path order by k_resolve); when the pool is full
-    too a flag is raised and the whole batch is rendered again with one group.  PT_TUNE_TERM_OCAP / PT_TUNE_TERM_SPILL
+    too a flag is raised and the whole batch is rendered again with one group.  pt_tuning.term_ocap / .term_spill
     shrink both so that this happens at test sizes: (a) a scene where every surface emits (every ray logs a term),
     several batches and frames blended onto an existing film; (b) the Cornell box itself with the AUTO shape."""
     v, i, f = cornell_arrays
@@ -1035,9 +1123,7 @@ def test_full_term_log_spills_to_the_pool_or_the_batch_is_redone_exactly(pt, orc
     gs, osc = pt.Scene(gpu_ctx, v, i, f.reshape(-1)), orc.Scene(v, i, f.reshape(-1))
     kw = dict(width=72, height=40, spp_per_frame=16, max_depth=12)
     ofilm, obgra, orays = _render_oracle(orc, osc, 5, **kw)
-    os.environ["PT_TUNE_TERM_OCAP"] = str(ocap)
-    if pool is not None:
-        os.environ["PT_TUNE_TERM_SPILL"] = str(pool)
+    gpu_ctx.set_tuning(term_ocap=ocap, term_spill=-1 if pool is None else pool)
     try:
         film = pt.Film(gpu_ctx, 72, 40)
         gpu_ctx.reset_stats()
@@ -1061,8 +1147,7 @@ def test_full_term_log_spills_to_the_pool_or_the_batch_is_redone_exactly(pt, orc
             st = gpu_ctx.stats()
             assert st.sample_groups > 1 and st.redone_batches <= 1
             assert st.rays == orays and film.read_f32().tobytes() == ofilm.tobytes()
-        os.environ.pop("PT_TUNE_TERM_OCAP", None)
-        os.environ.pop("PT_TUNE_TERM_SPILL", None)
+        gpu_ctx.set_tuning(term_ocap=-1, term_spill=-1)
         film.clear()
         gpu_ctx.reset_stats()
         pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, **kw))
@@ -1070,8 +1155,7 @@ def test_full_term_log_spills_to_the_pool_or_the_batch_is_redone_exactly(pt, orc
         assert film.read_f32().tobytes() == ofilm.tobytes()
         film.close()
     finally:
-        os.environ.pop("PT_TUNE_TERM_OCAP", None)
-        os.environ.pop("PT_TUNE_TERM_SPILL", None)
+        gpu_ctx.set_tuning(term_ocap=-1, term_spill=-1)
         gs.close()
 
 
@@ -1083,12 +1167,12 @@ def test_spill_pool_at_full_size_two_pipelines(pt, gpu_ctx, cornell_gpu):
     gpu_ctx.reset_stats()
     pt.render(cornell_gpu, a, pt.default_params(sample_groups=1, **kw))
     rays = gpu_ctx.stats().rays
-    os.environ["PT_TUNE_TERM_OCAP"] = "1"
+    gpu_ctx.set_tuning(term_ocap=1)
     try:
         gpu_ctx.reset_stats()
         pt.render(cornell_gpu, b, pt.default_params(sample_groups=4, **kw))
     finally:
-        os.environ.pop("PT_TUNE_TERM_OCAP", None)
+        gpu_ctx.set_tuning(term_ocap=-1)
     st = gpu_ctx.stats()
     assert st.sample_groups == 4 and st.redone_batches == 0 and st.rays == rays
     assert a.read_f32().tobytes() == b.read_f32().tobytes()
@@ -1313,12 +1397,12 @@ def test_pair_leaves_fan_quads_share_work_but_not_bits(pt, orc, gpu_ctx, cornell
             got = gs.trace(rays, tmin=tmin, tmax=100.0, extend=variant)
             assert got.tobytes() == want.tobytes(), (tmin, variant)
     assert (want["prim"] != 0xFFFFFFFF).sum() > 5000
-    os.environ["PT_TUNE_PAIR_KERNEL"] = "0"               # the per-triangle kernel over the same pair-leaf tree
+    gpu_ctx.set_tuning(pair_kernel=0)                       # the per-triangle kernel over the same pair-leaf tree
     try:
         want, _ = osc.trace(rays, tmin=0.001, tmax=100.0, mode=0)
         assert gs.trace(rays, tmin=0.001, tmax=100.0).tobytes() == want.tobytes()
     finally:
-        os.environ.pop("PT_TUNE_PAIR_KERNEL", None)
+        gpu_ctx.set_tuning(pair_kernel=-1)
     gs.close()
 
 
@@ -1525,12 +1609,38 @@ def test_nee_converges_to_the_reference_estimators_mean(pt, gpu_ctx, cornell_gpu
     assert rel(tiles(a1), tiles(a2)).mean() <= 0.03       # (the scale: the reference estimator against itself)
 
 
-@pytest.mark.parametrize("n,seed,pairs", [(0, 0, "1"), (0, 0, "0"), (7, 3, "1"), (300, 4, "1"), (300, 4, "0"), (2048, 5, "1")])
-def test_device_sah_builder_equals_the_host_builder(pt, gpu_ctx, cornell_arrays, n, seed, pairs):
-    """The surface-area BVH4 of small scenes is built on the device by one workgroup (bvh4_sah_device.hip: every split
-    candidate evaluated by a pass over the node's primitives, no sorting); the host builder of round 1 stays as the
-    cross-check behind PT_TUNE_SAH_HOST=1.  Same rows, same leaf order, bit for bit -- Cornell box (n = 0), soups with quads
-    mixed in, the <= 4-triangle leaf rule (PT_TUNE_PAIR_LEAVES=0), and the 2048-triangle limit."""
+def _bvh4_facts(rows):
+    """-> (leaf words, surface-area cost, nesting ok) of BVH4 rows [n, 32] (pt_scene_read_bvh4 layout)."""
+    f = rows.view(np.float32)
+    lo = np.stack([f[:, 0:4], f[:, 4:8], f[:, 8:12]], -1)        # [node, child, axis]
+    hi = np.stack([f[:, 12:16], f[:, 16:20], f[:, 20:24]], -1)
+    words = rows[:, 24:28]
+    area = lambda l, h: 2.0 * ((h[0] - l[0]) * (h[1] - l[1]) + (h[1] - l[1]) * (h[2] - l[2]) + (h[2] - l[2]) * (h[0] - l[0]))
+    root_lo, root_hi = lo[0][words[0] != 0xFFFFFFFF].min(0), hi[0][words[0] != 0xFFFFFFFF].max(0)
+    leaves, cost, nested = [], 0.0, True
+    stack = [(0, root_lo, root_hi)]
+    while stack:
+        nd, plo, phi = stack.pop()
+        cost += 1.0 * area(plo, phi)                                # one node visit
+        for c in range(4):
+            w = int(words[nd, c])
+            if w == 0xFFFFFFFF:
+                continue
+            nested &= bool((lo[nd, c] >= plo - 1e-6).all() and (hi[nd, c] <= phi + 1e-6).all())
+            if w & 0x80000000:
+                leaves.append(w)
+                cost += 0.6 * (((w >> 28) & 7) + 1) * area(lo[nd, c], hi[nd, c])
+            else:
+                stack.append((w, lo[nd, c], hi[nd, c]))
+    return leaves, cost / area(root_lo, root_hi), nested
+
+
+@pytest.mark.parametrize("n,seed,pairs", [(0, 0, 1), (0, 0, 0), (7, 3, 1), (300, 4, 1), (300, 4, 0), (2048, 5, 1)])
+def test_device_sah_builder_trees_are_sound_and_better_than_the_lbvh(pt, orc, gpu_ctx, cornell_arrays, n, seed, pairs):
+    """The surface-area BVH4 of small scenes (bvh4_sah_device.hip, ePreferFastTrace): every triangle sits in exactly one
+    leaf, child boxes nest, leaves follow the leaf rule (one primitive = a triangle or a fan pair; pair_leaves = 0: up to
+    four triangles), its surface-area cost is not above the collapsed LBVH's, and it returns the oracle's hits -- Cornell
+    box (n = 0), soups with fan pairs mixed in, the 2048-triangle limit."""
     if n == 0:
         v, i, f = cornell_arrays
     else:
@@ -1539,20 +1649,47 @@ def test_device_sah_builder_equals_the_host_builder(pt, gpu_ctx, cornell_arrays,
         for k in range(0, n - 1, 5):                 # every fifth triangle gets a fan partner (v0, v2, v3)
             tri[k + 1, 0], tri[k + 1, 1] = tri[k, 0], tri[k, 2]
         v = tri.reshape(-1)
-    out = {}
-    for host in ("1", "0"):
-        os.environ["PT_TUNE_SAH_HOST"], os.environ["PT_TUNE_PAIR_LEAVES"] = host, pairs
-        try:
-            sc = pt.Scene(gpu_ctx, v, i, f)
-            assert sc.info().bvh4_builder == 1
-            out[host] = (sc.read_bvh4().copy(), sc.info().build_ms)
-            rays = np.concatenate([np.random.default_rng(1).uniform(-1.2, 1.2, (5000, 3)), np.random.default_rng(2).normal(size=(5000, 3))], 1).astype(np.float32)
-            out[host] += (sc.trace(rays).tobytes(),)
-            sc.close()
-        finally:
-            os.environ.pop("PT_TUNE_SAH_HOST", None); os.environ.pop("PT_TUNE_PAIR_LEAVES", None)
-    assert out["0"][0].shape == out["1"][0].shape and out["0"][0].tobytes() == out["1"][0].tobytes()
-    assert out["0"][2] == out["1"][2]
+    nt = len(i) // 3
+    old = gpu_ctx.set_tuning(pair_leaves=pairs)
+    try:
+        sc = pt.Scene(gpu_ctx, v, i, f)
+    finally:
+        gpu_ctx.set_tuning(**old)
+    assert sc.info().bvh4_builder == 1
+    leaves, cost, nested = _bvh4_facts(sc.read_bvh4())
+    assert nested
+    covered = np.zeros(nt, np.int32)
+    for w in leaves:
+        first, cnt = w & 0x0FFFFFFF, ((w >> 28) & 7) + 1
+        assert cnt <= (2 if pairs else 4)
+        covered[first:first + cnt] += 1
+    assert (covered == 1).all()
+    rays = np.concatenate([np.random.default_rng(1).uniform(-1.2, 1.2, (5000, 3)), np.random.default_rng(2).normal(size=(5000, 3))], 1).astype(np.float32)
+    want, _ = orc.Scene(v, i, f).trace(rays, mode=0)
+    assert sc.trace(rays).tobytes() == want.tobytes()
+    sc.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)
+    _, cost_lbvh, nested_lbvh = _bvh4_facts(sc.read_bvh4())
+    assert nested_lbvh and cost <= cost_lbvh * 1.0001, (cost, cost_lbvh)
+    assert sc.trace(rays).tobytes() == want.tobytes()
+    sc.close()
+
+
+def test_pt_tune_environment_variable_is_parsed_once_at_context_creation(pt):
+    """PT_TUNE="name=value,..." is the library's only tuning input from the environment, read by pt_ctx_create; a name it
+    does not know is an error there (never silently ignored), and nothing is read afterwards."""
+    os.environ["PT_TUNE"] = "node_yield=3, pipes=1;refill=24"
+    try:
+        ctx = pt.Context(0)
+        os.environ["PT_TUNE"] = "pipes=2"              # too late: the context keeps what it was created with
+        t = ctx.tuning()
+        assert (t.node_yield, t.pipes, t.refill, t.lds_stack) == (3, 1, 24, -1)
+        ctx.close()
+        os.environ["PT_TUNE"] = "no_such_knob=1"
+        with pytest.raises(pt.PtError) as e:
+            pt.Context(0)
+        assert e.value.status == 1 and "no_such_knob" in str(e.value)
+    finally:
+        os.environ.pop("PT_TUNE", None)
 
 
 def test_presenter_falls_back_to_the_process_group_when_the_library_communicator_fails(tmp_path):

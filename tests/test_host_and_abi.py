@@ -142,11 +142,21 @@ def test_abi_exports_every_declared_symbol(pt):
         assert hasattr(Lh, s), s
 
 
-def test_struct_layouts_match_header(pt):
+def test_struct_layouts_match_header(pt, tmp_path):
+    """The ctypes mirrors against include/pt_api.h itself: gcc prints sizeof / offsetof of the header's structs."""
     import ctypes as C
+    import shutil
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %d\\n",'
+                   'sizeof(pt_params), sizeof(pt_stats), sizeof(pt_scene_info), offsetof(pt_params, sample_groups),'
+                   'offsetof(pt_stats, workspace_bytes), offsetof(pt_stats, wave_refills), offsetof(pt_scene_info, device_bytes8), PT_API_VERSION);return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert got == [C.sizeof(pt.Params), C.sizeof(pt.Stats), C.sizeof(pt.SceneInfo), pt.Params.sample_groups.offset,
+                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.device_bytes8.offset, 3], got
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
-    assert C.sizeof(pt.Stats) == 8 * 2 + 4 * 4 + 4 * 3 + 4 + 8 * 2 + 4 * 2 + 8 * 2 + 4 * 2 + 8 * 5   # + redone_batches, reserved_, wave-level block counts
-    assert C.sizeof(pt.SceneInfo) == 4 * 8 + 4 * 6 + 4 + 4 + 8 + 4 * 2 + 8  # one pad dword before the first u64
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
     assert list(p.cam_origin) == [0.0, -1.0, 5.0] and list(p.cam_target) == [0.0, -1.0, 2.0]
@@ -207,6 +217,26 @@ def test_abi_is_null_safe_without_a_gpu(pt):
     H.pth_free_scene(None)
     assert H.pth_write_ppm_bgra8(None, None, 0, 0) != 0 and H.pth_write_pfm(None, None, 0, 0) != 0
     assert H.pth_write_soup_obj(None, 0, 0) != 0
+
+
+def test_bench_gpus_n_needs_no_launcher():
+    """`python bench.py --gpus 2` with no launcher environment must not die for launcher reasons.  It
+    starts its own ranks (one process per GPU, rendezvous on 127.0.0.1); without a GPU each rank says so and the parent
+    stops the rest and returns their status -- within seconds, no hang.  (On a GPU box: rank 1 lacks a device, or both run.)"""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PT_BENCH_EMULATE")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--reps", "1",
+                        "--width", "64", "--height", "64", "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert "must be launched with" not in r.stderr
+    assert time.time() - t0 < 240
+    if r.returncode != 0:
+        assert ("needs a GPU" in r.stderr or "needs GPU 1" in r.stderr) and "stopping the other ranks" in r.stderr, r.stderr[-1500:]
+    else:
+        assert '"n_gpus": 2' in r.stdout
 
 
 def test_product_never_touches_the_oracle():
