@@ -77,6 +77,31 @@ def cpu_model():
     return "unknown"
 
 
+def effective_cores():
+    """-> (threads this process can really run at once, how that was found).  A container may see every hardware thread
+    of the host (os.cpu_count() = 256 on the GPU boxes) and still be capped by a cgroup CPU quota (cpu.max = 16 CPUs there):
+    beyond the quota more threads only get throttled (scripts/probe_cpu_scaling.py: linear to 16 threads, erratic above)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = f"{n} schedulable hardware threads"
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:                                                                  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        how = f"cgroup CPU quota of {quota:g} CPUs on a host with {n} hardware threads"
+        n = max(1, int(quota + 0.999))
+    return n, how
+
+
 def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, instances=None):
     """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
     bounded sample of the same workload: the same image, all cores, as many samples per pixel as fit
@@ -85,7 +110,7 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
     osc = orc.Scene(*arrays)
     if instances is not None:
         osc.set_instances(instances)      # two-level scene (config C4): the oracle walks its own TLAS
-    cores = os.cpu_count() or 1
+    cores, cores_how = effective_cores()
     t0 = time.perf_counter()
     osc.render_frame(orc.default_params(width=width, height=height, spp_per_frame=1, max_depth=depth), mode=1, nthreads=cores)
     t1 = time.perf_counter() - t0
@@ -108,9 +133,9 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
         d1 = time.perf_counter() - t0
     all_mrays, one_mrays = rays / dt / 1e6, r1 / d1 / 1e6
     base = {"value": round(all_mrays, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
-            "cpu_model": cpu_model(), "single_thread_mrays": round(one_mrays, 4),
-            # all threads against `cores` x the single thread (hardware threads, not physical cores: SMT siblings count,
-            # and the single thread runs at boost clock on the cheaper central crop -- an upper bound on perfect scaling)
+            "cpu_model": cpu_model(), "cores_available": cores_how, "single_thread_mrays": round(one_mrays, 4),
+            # all threads against `cores` x the single thread (the single thread runs the central crop, which has no
+            # cheap border pixels: an upper bound on perfect scaling)
             "scaling_efficiency": round(all_mrays / (cores * one_mrays), 4),
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
                       f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O3 -march=native -ffp-contract=off, {cores} threads "
@@ -526,7 +551,7 @@ def main():
             "workspace_bytes": st.workspace_bytes,
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
                     "build_ms": round(info.build_ms, 3), "bvh4_nodes": info.n_wide_nodes,
-                    "bvh4_builder": ["collapsed LBVH", "surface-area sweep (ePreferFastTrace)"][min(info.bvh4_builder, 1)],
+                    "bvh4_builder": ["collapsed LBVH", "surface-area sweep, one primitive per leaf (ePreferFastTrace)", "PLOC rebuild of the binary tree (ePreferFastTrace)"][min(info.bvh4_builder, 2)],
                     "extend_variant": pt.EXTEND_NAMES.get(st.extend_variant, str(st.extend_variant))},
         }
         if world > 1:

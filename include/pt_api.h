@@ -70,7 +70,8 @@ typedef struct pt_tuning {
     int32_t mem_budget_mb;  /* upper bound on a film's wavefront workspace (also env PT_MEM_BUDGET_MB); 0 = none       */
     int32_t hbm8;           /* 1: AUTO walks big scenes through the 8-wide compressed nodes (PT_EXTEND_HBM8)           */
     int32_t rebin;          /* block-level re-binning of the LDS kernels: 0 off, 1 on                                  */
-    int32_t reserved[12];
+    int32_t ploc_radius;    /* PLOC rebuild of big scenes' binary tree: neighbours searched on either side (1..32, 8)  */
+    int32_t reserved[11];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);
@@ -108,22 +109,28 @@ typedef struct pt_scene_info {
     uint32_t n_instances;     /* 0 = single-level scene                                           */
     uint32_t n_tlas_nodes;    /* BVH4 nodes of the TLAS                                           */
     uint32_t leaf_max;        /* triangles per BVH4 leaf of the collapse rule (bvh4 read-back)    */
-    uint32_t bvh4_builder;    /* which BVH4 is traversed: 0 collapsed LBVH, 1 surface-area sweep   */
+    uint32_t bvh4_builder;    /* which BVH4 is traversed: 0 collapsed LBVH, 1 surface-area sweep (small scenes), 2 PLOC tree */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
     uint64_t device_bytes;    /* resident scene + BVH bytes of the BVH4 path                    */
     uint32_t n_wide8_nodes;   /* BVH8 nodes (128 B each) of the PT_EXTEND_HBM8 path, levels of that tree */
     uint32_t wide8_levels;
     uint64_t device_bytes8;   /* resident triangle tables + BVH8 bytes of that path             */
+    /* big scenes (> 2048 triangles): sum of the surface areas of the binary tree's internal nodes over the root's, for
+     * the Morton-median LBVH and for its PLOC rebuild (0: not built -- FAST_BUILD, or small scene).  FAST_TRACE keeps
+     * the tree with the smaller sum (bvh4_builder says which).                                                      */
+    float    tree_area_lbvh, tree_area_ploc;
 } pt_scene_info;
 pt_status pt_scene_get_info(const pt_scene *scene, pt_scene_info *info);
 
 /* Build quality, the counterpart of vk::BuildAccelerationStructureFlagBitsKHR (main.cpp:419 passes
  * ePreferFastTrace, which is the default here too).  FAST_TRACE: scenes of <= 2048 triangles get their
- * BVH4 from a surface-area sweep (host, microseconds) instead of the collapsed device LBVH -- about
- * 1/6 less traversal work on the Cornell box; larger scenes keep the LBVH either way.  FAST_BUILD: always
- * the collapsed LBVH.  Hit records and images do not depend on the choice (closest t, lowest
- * primitive id).  Call before pt_scene_set_instances.                                          */
+ * BVH4 from an exhaustive surface-area sweep (one workgroup on the device) -- about 1/6 less traversal work
+ * on the Cornell box; larger scenes get the LBVH's binary tree rebuilt bottom-up by parallel locally-ordered
+ * clustering (PLOC, radius 8) before the wide nodes are collapsed from it -- what makes a finely tessellated
+ * object in a large room cheap to walk.  FAST_BUILD: always the collapsed LBVH (Morton median splits).  Hit
+ * records and images do not depend on the choice (closest t, lowest primitive id).  Changing the quality of
+ * a big scene rebuilds its tree.  Call before pt_scene_set_instances.                                       */
 typedef enum pt_bvh_quality { PT_BVH_PREFER_FAST_TRACE = 0, PT_BVH_PREFER_FAST_BUILD = 1 } pt_bvh_quality;
 pt_status pt_scene_set_bvh_quality(pt_scene *scene, uint32_t quality);
 

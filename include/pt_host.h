@@ -55,6 +55,13 @@ int pth_write_soup_obj(const char *obj_path, uint32_t n_tris, uint32_t seed);
  * larger than the Infinity Cache (bench.py --config c5x) without a gigabyte of OBJ text in between.      */
 int pth_make_soup(uint32_t n_tris, uint32_t seed, pth_scene *out);
 
+/* The "teapot in a stadium" stress scene (frozen recipe, host/image_io.cpp): a Cornell-sized room whose floor is a
+ * floor_side x floor_side grid of jittered quads, two-triangle walls, the Cornell light, two boxes and a sphere of
+ * sphere_seg x 2 sphere_seg quads -- primitive sizes over four orders of magnitude, what a Morton-median BVH handles
+ * badly and ePreferFastTrace (main.cpp:419) is for.  Arrays as pth_load_obj returns them (free with pth_free_scene).
+ * (384, 160) = 396 706 triangles: the tests' and the probe's scene; (640, 224) = 1.02 M.                            */
+int pth_make_stadium(uint32_t floor_side, uint32_t sphere_seg, pth_scene *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@
 // them; each kernel is launched REPS times and prints the bytes it asked for per launch:
 //   k_stream_read<MB>     coalesced 16 B / lane, every byte of the footprint once
 //   k_stream_write<MB>    coalesced 16 B / lane stores
+//   k_gather_line<MB>     both 64-B halves of a pseudo-random 128-B line: does the L2 fetch lines or halves?
 //   k_gather<MB, LOADS>   the BVH walk's pattern: every lane reads LOADS consecutive 16-B pieces of a pseudo-random
 //                         64-B record (LOADS = 1: 16 B of the record, 4: the whole record)
 // Footprints: 128 MB (beyond the 32 MiB of L2, inside the 256 MiB Infinity Cache) and 8192 MB (beyond both).
@@ -52,6 +53,22 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ buf, u
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// both 64-B halves of a pseudo-random 128-B line (16 B at offset 0 and 16 B at offset 64): one request per line if the
+// L2 fetches whole 128-B lines from the fabric, two if it fetches 64-B halves
+template <int MB>
+__global__ __launch_bounds__(256) void k_gather_line(const uint4 *__restrict__ buf, uint32_t mask, int iters, uint32_t *out)
+{
+    uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; i++) {
+        const uint4 *p = buf + 8 * (size_t)(idx & mask);
+        const uint4 a = p[0], b = p[4];
+        acc += a.x ^ b.y;
+        idx = idx * 747796405u + 2891336453u;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <typename F>
 static float timed(F launch)
 {
@@ -88,6 +105,8 @@ static void run_footprint(uint32_t *out)
     printf("CALIB kernel=k_gather<%d,1> launches=%d bytes_per_launch=%zu records_per_launch=%zu ms=%.4f\n", MB, REPS, records * 16, records, ms);
     ms = timed([&] { k_gather<MB, 4><<<gblocks, 256>>>(buf, mask, iters, out); });
     printf("CALIB kernel=k_gather<%d,4> launches=%d bytes_per_launch=%zu records_per_launch=%zu ms=%.4f\n", MB, REPS, records * 64, records, ms);
+    ms = timed([&] { k_gather_line<MB><<<gblocks, 256>>>(buf, mask >> 1, iters, out); });
+    printf("CALIB kernel=k_gather_line<%d> launches=%d bytes_per_launch=%zu records_per_launch=%zu ms=%.4f\n", MB, REPS, records * 128, records, ms);
     hipFree(buf);
 }
 

@@ -62,7 +62,7 @@ class SceneInfo(C.Structure):
                 ("leaf_max", C.c_uint32), ("bvh4_builder", C.c_uint32),
                 ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("build_ms", C.c_float),
                 ("device_bytes", C.c_uint64), ("n_wide8_nodes", C.c_uint32), ("wide8_levels", C.c_uint32),
-                ("device_bytes8", C.c_uint64)]
+                ("device_bytes8", C.c_uint64), ("tree_area_lbvh", C.c_float), ("tree_area_ploc", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -81,12 +81,12 @@ class Stats(C.Structure):
 
 TUNING_NAMES = ["refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves", "pair_kernel", "topdown4",
                 "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield", "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb",
-                "hbm8", "rebin"]
+                "hbm8", "rebin", "ploc_radius"]
 
 
 class Tuning(C.Structure):
     """include/pt_api.h pt_tuning: speed knobs of a context, -1 = the built-in choice; never changes a result."""
-    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 12)]
+    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 11)]
 
 
 class HostScene(C.Structure):
@@ -106,7 +106,8 @@ API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "p
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_ranks", "pt_comm_destroy", "pt_film_present",
                "pt_film_tile_count", "pt_film_pack_tiles", "pt_film_unpack_tiles",
                "pt_device_alloc", "pt_device_free", "pt_device_read", "pt_ctx_get_tuning", "pt_ctx_set_tuning"]
-HOST_SYMBOLS = ["pth_load_obj", "pth_load_obj_ex", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj", "pth_make_soup"]
+HOST_SYMBOLS = ["pth_load_obj", "pth_load_obj_ex", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj", "pth_make_soup",
+                "pth_make_stadium"]
 
 _amd = None
 _host = None
@@ -190,6 +191,7 @@ def lib_host():
         L.pth_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.pth_write_soup_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
         L.pth_make_soup.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(HostScene)]
+        L.pth_make_stadium.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(HostScene)]
         _host = L
     return _host
 
@@ -239,6 +241,20 @@ def make_soup(n_tris, seed=1):
     hs = HostScene()
     if lib_host().pth_make_soup(n_tris, seed, C.byref(hs)) != 0:
         raise RuntimeError("pth_make_soup failed")
+    try:
+        v = np.ctypeslib.as_array(hs.vertices, shape=(3 * hs.n_verts,)).copy()
+        i = np.ctypeslib.as_array(hs.indices, shape=(3 * hs.n_tris,)).copy()
+        f = np.ctypeslib.as_array(hs.faces, shape=(6 * hs.n_tris,)).copy()
+    finally:
+        lib_host().pth_free_scene(C.byref(hs))
+    return v, i, f
+
+
+def make_stadium(floor_side=384, sphere_seg=160):
+    """The "teapot in a stadium" stress scene (include/pt_host.h pth_make_stadium): -> (vertices, indices, faces)."""
+    hs = HostScene()
+    if lib_host().pth_make_stadium(floor_side, sphere_seg, C.byref(hs)) != 0:
+        raise RuntimeError("pth_make_stadium failed")
     try:
         v = np.ctypeslib.as_array(hs.vertices, shape=(3 * hs.n_verts,)).copy()
         i = np.ctypeslib.as_array(hs.indices, shape=(3 * hs.n_tris,)).copy()
@@ -378,6 +394,7 @@ class Scene:
 
     def read_bvh8(self):
         """-> (nodes [n_wide8, 32] u32, prim_of_pos8 [n_tris] u32) of the BVH8 (include/pt_api.h: pt_scene_read_bvh8)"""
+        self.ctx._check(lib_amd().pt_scene_read_bvh8(self.h, None, None))      # big scenes build their 8-wide nodes on first request
         i = self.info()
         nodes = np.zeros((i.n_wide8_nodes, 32), dtype=np.uint32)
         prim = np.zeros(i.n_tris, dtype=np.uint32)

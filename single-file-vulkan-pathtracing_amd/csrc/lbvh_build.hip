@@ -451,6 +451,205 @@ __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig
 }
 
 
+// ---- PLOC: the surface-area-class binary tree of big scenes (ePreferFastTrace, main.cpp:419) --------------------------
+// The LBVH above splits by Morton-code bits, i.e. at spatial medians: near-optimal for uniformly distributed, equally sized
+// triangles and poor for everything else (a finely tessellated object in a large room: the "teapot in a stadium").  For
+// scenes beyond the one-workgroup surface-area sweep (bvh4_sah_device.hip, <= PT_SAH_MAX_TRIS triangles) the binary tree is
+// therefore rebuilt BOTTOM-UP from the Morton order by parallel locally-ordered clustering (Meister & Bittner 2018): every
+// cluster looks at its PLOC_R neighbours on either side in the current cluster array, picks the one whose union with it
+// has the smallest surface area, and mutual choices merge -- all clusters at once, ~log n rounds, each one a nearest-
+// neighbour kernel, two scans and a merge kernel.  Small triangles cluster with small triangles before anything large
+// touches them, which is what the spatial median cannot do.  Output: the same arrays the LBVH stage produces (topo, range,
+// parents, boxes at [pos] / [n + node], root = node 0) over a NEW leaf order -- the depth-first order of the new tree, so
+// a subtree is again a contiguous range of positions -- and everything downstream (BVH4 collapse, top-down BVH4, 8-wide
+// nodes, triangle tables) runs unchanged.  Deterministic: ties go to the lowest index, node numbers come from scans.
+__device__ __forceinline__ float box_area(const float4 lo, const float4 hi)
+{
+    const float x = hi.x - lo.x, y = hi.y - lo.y, z = hi.z - lo.z;
+    return (x * y + y * z) + z * x;
+}
+
+constexpr int PLOC_R_MAX = 32;  // the search radius is a run-time choice (pt_tuning.ploc_radius, default 8) up to this
+
+__device__ __forceinline__ float union_area(const float4 alo, const float4 ahi, const float4 blo, const float4 bhi)
+{
+    const float x = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), y = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y),
+                z = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+    return (x * y + y * z) + z * x;
+}
+
+__global__ __launch_bounds__(TB) void k_ploc_init(uint32_t n, const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
+                                                  uint32_t *__restrict__ cl_ref, float4 *__restrict__ cl_lo, float4 *__restrict__ cl_hi)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    cl_ref[i] = PT_LEAF | i;
+    cl_lo[i] = box_lo[i];
+    cl_hi[i] = box_hi[i];
+}
+
+// nearest neighbour of every cluster within `radius` positions: the partner j minimising the PAIR key
+// (union area, parity of the pair's lower index, lower index, upper index).  The key is a function of the unordered pair,
+// so the pair that is minimal among all candidate pairs chooses each other and every round merges at least one; the parity
+// term is what keeps regular geometry moving: in a row of equal tiles every union area ties, "lowest index wins" would make
+// everybody point left (one merge per round), "even lower index first" pairs them all up at once.
+__global__ __launch_bounds__(TB) void k_ploc_nn(uint32_t m, int radius, const float4 *__restrict__ cl_lo, const float4 *__restrict__ cl_hi,
+                                                uint32_t *__restrict__ nn)
+{
+    __shared__ float4 s_lo[TB + 2 * PLOC_R_MAX], s_hi[TB + 2 * PLOC_R_MAX];
+    const int base = (int)(blockIdx.x * TB) - radius;
+    for (int t = threadIdx.x; t < TB + 2 * radius; t += TB) {
+        const int j = base + t;
+        if (j >= 0 && j < (int)m) { s_lo[t] = cl_lo[j]; s_hi[t] = cl_hi[j]; }
+    }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * TB + threadIdx.x);
+    if (i >= (int)m) return;
+    const float4 alo = s_lo[threadIdx.x + radius], ahi = s_hi[threadIdx.x + radius];
+    float best = INFINITY;
+    int bj = -1, bpar = 0;
+    for (int d = -radius; d <= radius; d++) {  // ascending j: among equal (area, parity) the lowest partner, i.e. the lowest pair
+        const int j = i + d;
+        if (d == 0 || j < 0 || j >= (int)m) continue;
+        const float a = union_area(alo, ahi, s_lo[threadIdx.x + radius + d], s_hi[threadIdx.x + radius + d]);
+        const int par = (j < i ? j : i) & 1;
+        if (bj < 0 || a < best || (a == best && par < bpar)) { best = a; bj = j; bpar = par; }
+    }
+    nn[i] = (uint32_t)bj;
+}
+
+// sum of the surface areas of the internal nodes' boxes, per block (the host adds the partial sums in order): what a
+// surface-area cost compares between two binary trees over the same leaves
+__global__ __launch_bounds__(TB) void k_tree_area(uint32_t n_int, uint32_t n, const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
+                                                  double *__restrict__ partial)
+{
+    __shared__ double s[TB];
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    double a = 0.0;
+    if (i < n_int) a = (double)box_area(box_lo[(size_t)n + i], box_hi[(size_t)n + i]);
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = TB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+// keep[i] = the cluster stays in the array (itself, or as the node it merges into); lower[i] = it is the lower half of a
+// merging pair and creates the node
+__global__ __launch_bounds__(TB) void k_ploc_mark(uint32_t m, const uint32_t *__restrict__ nn, uint32_t *__restrict__ keep,
+                                                  uint32_t *__restrict__ lower)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    const bool mutual = nn[j] == i;
+    keep[i] = (mutual && j < i) ? 0u : 1u;
+    lower[i] = (mutual && i < j) ? 1u : 0u;
+}
+
+// node ids are handed out downwards from id_hi (the ids still free are [0, id_hi)), so that the last merge is node 0
+__global__ __launch_bounds__(TB) void k_ploc_merge(uint32_t m, uint32_t n, uint32_t id_hi, const uint32_t *__restrict__ nn,
+                                                   const uint32_t *__restrict__ oidx, const uint32_t *__restrict__ mrank,
+                                                   const uint32_t *__restrict__ ref_in, const float4 *__restrict__ lo_in,
+                                                   const float4 *__restrict__ hi_in, uint32_t *__restrict__ ref_out,
+                                                   float4 *__restrict__ lo_out, float4 *__restrict__ hi_out, uint2 *__restrict__ topo,
+                                                   uint32_t *__restrict__ parent_int, uint32_t *__restrict__ parent_leaf,
+                                                   uint32_t *__restrict__ isz, float4 *__restrict__ box_lo, float4 *__restrict__ box_hi)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    const bool mutual = nn[j] == i;
+    if (mutual && j < i) return;  // the upper half: its partner writes the node
+    uint32_t ref = ref_in[i];
+    float4 lo = lo_in[i], hi = hi_in[i];
+    if (mutual) {
+        const uint32_t id = id_hi - 1u - mrank[i];
+        const uint32_t rj = ref_in[j];
+        const float4 jlo = lo_in[j], jhi = hi_in[j];
+        topo[id] = make_uint2(ref, rj);
+        const uint32_t sa = (ref & PT_LEAF) ? 1u : isz[ref], sb = (rj & PT_LEAF) ? 1u : isz[rj];
+        isz[id] = sa + sb;
+        if (ref & PT_LEAF) parent_leaf[ref & ~PT_LEAF] = id; else parent_int[ref] = id;
+        if (rj & PT_LEAF) parent_leaf[rj & ~PT_LEAF] = id; else parent_int[rj] = id;
+        lo = make_float4(fminf(lo.x, jlo.x), fminf(lo.y, jlo.y), fminf(lo.z, jlo.z), 0.f);
+        hi = make_float4(fmaxf(hi.x, jhi.x), fmaxf(hi.y, jhi.y), fmaxf(hi.z, jhi.z), 0.f);
+        box_lo[(size_t)n + id] = lo;
+        box_hi[(size_t)n + id] = hi;
+        ref = id;
+    }
+    const uint32_t o = oidx[i];
+    ref_out[o] = ref;
+    lo_out[o] = lo;
+    hi_out[o] = hi;
+}
+
+// position of a subtree's first leaf in the depth-first leaf order: the sizes of all left siblings on the way to the root
+__device__ __forceinline__ uint32_t ploc_first(uint32_t ref, uint32_t node, const uint2 *__restrict__ topo,
+                                               const uint32_t *__restrict__ parent_int, const uint32_t *__restrict__ isz, uint32_t &depth)
+{
+    uint32_t off = 0;
+    depth = 1;
+    for (;;) {
+        const uint2 ch = topo[node];
+        if (ch.y == ref) off += (ch.x & PT_LEAF) ? 1u : isz[ch.x];
+        if (node == 0u) break;
+        ref = node;
+        node = parent_int[node];
+        depth++;
+    }
+    return off;
+}
+
+__global__ __launch_bounds__(TB) void k_ploc_leaf_order(uint32_t n, const uint2 *__restrict__ topo, const uint32_t *__restrict__ parent_int,
+                                                        const uint32_t *__restrict__ parent_leaf, const uint32_t *__restrict__ isz,
+                                                        uint32_t *__restrict__ newpos, uint32_t *__restrict__ height)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    uint32_t depth;
+    newpos[i] = ploc_first(PT_LEAF | i, parent_leaf[i], topo, parent_int, isz, depth);
+    atomicMax(height, depth);
+}
+
+__global__ __launch_bounds__(TB) void k_ploc_ranges(uint32_t n_int, const uint2 *__restrict__ topo, const uint32_t *__restrict__ parent_int,
+                                                    const uint32_t *__restrict__ isz, uint2 *__restrict__ range)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n_int) return;
+    uint32_t depth, first = 0;
+    if (i != 0u) first = ploc_first(i, parent_int[i], topo, parent_int, isz, depth);
+    range[i] = make_uint2(first, first + isz[i] - 1u);
+}
+
+// leaves move to their new positions: boxes, parents, primitive ids
+__global__ __launch_bounds__(TB) void k_ploc_move_leaves(uint32_t n, const uint32_t *__restrict__ newpos, const float4 *__restrict__ lo_in,
+                                                         const float4 *__restrict__ hi_in, const uint32_t *__restrict__ pleaf_in,
+                                                         const uint32_t *__restrict__ prim_in, float4 *__restrict__ box_lo,
+                                                         float4 *__restrict__ box_hi, uint32_t *__restrict__ pleaf_out,
+                                                         uint32_t *__restrict__ prim_out)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = newpos[i];
+    box_lo[p] = lo_in[i];
+    box_hi[p] = hi_in[i];
+    pleaf_out[p] = pleaf_in[i];
+    prim_out[p] = prim_in[i];
+}
+
+__global__ __launch_bounds__(TB) void k_ploc_retarget(uint32_t n_int, const uint32_t *__restrict__ newpos, uint2 *__restrict__ topo)
+{
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n_int) return;
+    uint2 ch = topo[i];
+    if (ch.x & PT_LEAF) ch.x = PT_LEAF | newpos[ch.x & ~PT_LEAF];
+    if (ch.y & PT_LEAF) ch.y = PT_LEAF | newpos[ch.y & ~PT_LEAF];
+    topo[i] = ch;
+}
+
 // ---- BVH8 (scenes walked out of L2 / MALL / HBM) ------------------------------------------------------------------
 // Measured on MI355X (scripts/ubench/gather_rate.hip): beyond L2 a wave's divergent loads cost per distinct 128-B LINE
 // (~56 G lines/s for the chip), not per byte or per load instruction -- four 16-B loads of one line cost what one does.
@@ -468,11 +667,6 @@ __global__ __launch_bounds__(TB) void k_pack(const float4 *__restrict__ tri_orig
 // node and keeps opening the internal one of LARGEST SURFACE AREA until it has eight (the area-guided collapse that
 // stands in for ePreferFastTrace, main.cpp:419, on big scenes).  Scans give every level's nodes and triangles their
 // places, so the result is deterministic.
-__device__ __forceinline__ float box_area(const float4 lo, const float4 hi)
-{
-    const float x = hi.x - lo.x, y = hi.y - lo.y, z = hi.z - lo.z;
-    return (x * y + y * z) + z * x;
-}
 
 // one thread per wide node of this level: its up-to-W children as binary references in slot order (PT_MISS = empty)
 template <int W>
@@ -660,9 +854,10 @@ struct DevBuf {
 struct BvhOut {
     unsigned long long *d_keys = nullptr;  // sorted Morton keys           (caller owns)
     uint32_t *d_prim_of = nullptr;         // sorted position -> box id
+    uint32_t *d_prim_q = nullptr;          // PLOC: leaf position of the rebuilt tree -> box id (null: the LBVH is the tree)
     float4 *d_nodes = nullptr;             // binary nodes, 64 B
     float4 *d_wide = nullptr;              // BVH4 nodes, 128 B
-    uint32_t n_nodes = 0, n_wide = 0, height = 0;
+    uint32_t n_nodes = 0, n_wide = 0, height = 0, height_tree = 0;  // height: of the LBVH; height_tree: of the tree the collapses ran on
     uint32_t stack_need = 0;               // most entries a depth-first walk of the BVH4 can have pending
     float bmin[3]{}, bmax[3]{};
     // BVH8 (want8): 128-B nodes, the triangle order that goes with them (position -> sorted position), levels
@@ -672,6 +867,7 @@ struct BvhOut {
     uint4 *d_wide16t = nullptr;            // BVH4, 64-B nodes, built top-down with contiguous children (k_w4_emit)
     uint32_t n_wide16t = 0, levels4t = 0;
     float norm_c[3]{}, norm_s[3]{1.f, 1.f, 1.f}, norm_rs[3]{1.f, 1.f, 1.f};
+    double area_lbvh = 0.0, area_ploc = 0.0, area_tree = 0.0;  // sums of the internal nodes' surface areas: LBVH, PLOC rebuild (0: not built), the tree kept
 };
 
 // the normalisation of the fp16 node formats: x' = (x - c) * rs with c the centre and 1/rs the half extent of the scene box
@@ -713,10 +909,111 @@ __global__ __launch_bounds__(TB) void k_bounds(const float4 *__restrict__ tlo, c
     }
 }
 
+
+// Rebuilds the binary tree over the Morton-ordered leaves by PLOC (kernels above), in place of the LBVH's arrays.
+// In: leaf boxes box_lo/box_hi[0, n) and prim_of in Morton order.  Out: topo / range / parent_int / parent_leaf, boxes of
+// leaves [0, n) and internal nodes [n, 2n - 1) in the NEW leaf order, d_prim_q (new position -> primitive id), height.
+// Returns PT_ERR_UNSUPPORTED (and leaves the LBVH arrays untouched as far as the caller's later stages are concerned: they
+// are only overwritten at the very end) if the clustering stalls, which the caller answers by keeping the LBVH.
+// sum of the internal nodes' surface areas of a tree in the [pos] / [n + node] box layout (deterministic: partial sums added in order)
+static pt_status tree_area(pt_ctx *ctx, uint32_t n, const float4 *d_blo, const float4 *d_bhi, double *out)
+{
+    const uint32_t n_int = n - 1u, g = (n_int + TB - 1) / TB;
+    DevBuf<double> part;
+    PT_HIP(ctx, part.alloc(g));
+    k_tree_area<<<g, TB, 0, ctx->stream>>>(n_int, n, d_blo, d_bhi, part.p);
+    std::vector<double> h(g);
+    PT_HIP(ctx, hipMemcpyAsync(h.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double a = 0.0;
+    for (double x : h) a += x;
+    *out = a;
+    return PT_OK;
+}
+
+// area_lbvh: the LBVH's sum of internal surface areas; *area_ploc gets the rebuilt tree's.  The rebuilt tree is adopted
+// (PT_OK, arrays replaced) only if its sum is smaller -- ePreferFastTrace means the cheaper tree, whichever builder made
+// it; otherwise PT_ERR_UNSUPPORTED and the LBVH stands.
+static pt_status ploc_refine(pt_ctx *ctx, uint32_t n, int radius, double area_lbvh, double *area_ploc, uint2 *d_topo, uint2 *d_range,
+                             uint32_t *d_pint, uint32_t *d_pleaf, float4 *d_blo, float4 *d_bhi, const uint32_t *d_prim_of,
+                             uint32_t *d_prim_q, uint32_t *d_sums, uint32_t *h_height)
+{
+    hipStream_t st = ctx->stream;
+    DevBuf<uint32_t> ref[2], nn, keep, lower, isz, newpos, pint, pleaf, pleaf2, height;
+    DevBuf<float4> lo[2], hi[2], nblo, nbhi;
+    DevBuf<uint2> topo;
+    for (int k = 0; k < 2; k++) {
+        PT_HIP(ctx, ref[k].alloc(n));
+        PT_HIP(ctx, lo[k].alloc(n));
+        PT_HIP(ctx, hi[k].alloc(n));
+    }
+    PT_HIP(ctx, nn.alloc(n));
+    PT_HIP(ctx, keep.alloc(n));
+    PT_HIP(ctx, lower.alloc(n));
+    PT_HIP(ctx, isz.alloc(n));
+    PT_HIP(ctx, newpos.alloc(n));
+    PT_HIP(ctx, pint.alloc(n));
+    PT_HIP(ctx, pleaf.alloc(n));
+    PT_HIP(ctx, pleaf2.alloc(n));
+    PT_HIP(ctx, height.alloc(1));
+    PT_HIP(ctx, topo.alloc(n));
+    PT_HIP(ctx, nblo.alloc(2 * (size_t)n));
+    PT_HIP(ctx, nbhi.alloc(2 * (size_t)n));
+    k_ploc_init<<<(n + TB - 1) / TB, TB, 0, st>>>(n, d_blo, d_bhi, ref[0].p, lo[0].p, hi[0].p);
+    uint32_t m = n, id_hi = n - 1u;
+    int cur = 0;
+    for (int round = 0; m > 1u; round++) {
+        const uint32_t g = (m + TB - 1) / TB;
+        k_ploc_nn<<<g, TB, 0, st>>>(m, radius, lo[cur].p, hi[cur].p, nn.p);
+        k_ploc_mark<<<g, TB, 0, st>>>(m, nn.p, keep.p, lower.p);
+        uint32_t last[2] = { 0, 0 }, tot[2] = { 0, 0 };
+        PT_HIP(ctx, hipMemcpyAsync(&last[0], keep.p + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(&last[1], lower.p + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        exclusive_scan(keep.p, m, d_sums, st);
+        exclusive_scan(lower.p, m, d_sums, st);
+        PT_HIP(ctx, hipMemcpyAsync(&tot[0], keep.p + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(&tot[1], lower.p + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t m_new = tot[0] + last[0], merges = tot[1] + last[1];
+        if (merges == 0u || m_new + merges != m || merges > id_hi) { ctx->err = "internal: PLOC round made no progress"; return PT_ERR_HIP; }
+        // a scene whose clusters merge a handful at a time (pathological chains) would need ~n rounds: keep the LBVH
+        if (round >= 48 && merges * 64u < m) return PT_ERR_UNSUPPORTED;
+        k_ploc_merge<<<g, TB, 0, st>>>(m, n, id_hi, nn.p, keep.p, lower.p, ref[cur].p, lo[cur].p, hi[cur].p, ref[cur ^ 1].p, lo[cur ^ 1].p,
+                                       hi[cur ^ 1].p, topo.p, pint.p, pleaf.p, isz.p, nblo.p, nbhi.p);
+        id_hi -= merges;
+        m = m_new;
+        cur ^= 1;
+    }
+    if (id_hi != 0u) { ctx->err = "internal: PLOC did not use every node id"; return PT_ERR_HIP; }
+    {
+        const pt_status arc = tree_area(ctx, n, nblo.p, nbhi.p, area_ploc);   // (internal boxes do not depend on the leaf order)
+        if (arc != PT_OK) return arc;
+        if (!(*area_ploc < area_lbvh)) return PT_ERR_UNSUPPORTED;
+    }
+    const uint32_t n_int = n - 1u, gi = (n_int + TB - 1) / TB, gl = (n + TB - 1) / TB;
+    PT_HIP(ctx, hipMemsetAsync(height.p, 0, sizeof(uint32_t), st));
+    k_ploc_leaf_order<<<gl, TB, 0, st>>>(n, topo.p, pint.p, pleaf.p, isz.p, newpos.p, height.p);
+    k_ploc_ranges<<<gi, TB, 0, st>>>(n_int, topo.p, pint.p, isz.p, d_range);
+    k_ploc_move_leaves<<<gl, TB, 0, st>>>(n, newpos.p, d_blo, d_bhi, pleaf.p, d_prim_of, nblo.p, nbhi.p, pleaf2.p, d_prim_q);
+    k_ploc_retarget<<<gi, TB, 0, st>>>(n_int, newpos.p, topo.p);
+    // the new tree replaces the LBVH's working arrays
+    PT_HIP(ctx, hipMemcpyAsync(d_topo, topo.p, sizeof(uint2) * (size_t)n_int, hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_pint, pint.p, sizeof(uint32_t) * (size_t)n_int, hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_pleaf, pleaf2.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_blo, nblo.p, sizeof(float4) * (2 * (size_t)n - 1), hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d_bhi, nbhi.p, sizeof(float4) * (2 * (size_t)n - 1), hipMemcpyDeviceToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(h_height, height.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 // top_down: bit 0 = also the BVH8 (+ its triangle order), bit 1 = also the top-down BVH4 in the 64-B format, bit 2 = that BVH4
 // with 16-bit child codes (k_w4_emit compact16: the TLAS of k_extend_inst16; needs n < 32768)
+// ploc: the binary tree is rebuilt by PLOC before the collapses (out.d_prim_q = its leaf order; out.d_prim_of, d_keys and
+// d_nodes stay the LBVH's, for the parity read-back)
 static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi, uint32_t n, uint32_t leaf_max, BvhOut &out,
-                          int top_down = 0)
+                          int top_down = 0, bool ploc = false)
 {
     const bool want8 = (top_down & 1) != 0, want4t = (top_down & 2) != 0;
     hipStream_t st = ctx->stream;
@@ -774,6 +1071,22 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
     } else {
         k_single<<<1, 1, 0, st>>>(d_tlo, d_thi, d_scene.p, out.d_nodes, d_height.p);
     }
+    uint32_t ploc_height = 0;
+    if (n > 2) {
+        const pt_status arc = tree_area(ctx, n, d_blo.p, d_bhi.p, &out.area_lbvh);
+        if (arc != PT_OK) return arc;
+        out.area_tree = out.area_lbvh;
+    }
+    if (ploc && n > 2) {
+        PT_HIP(ctx, hipMalloc((void **)&out.d_prim_q, sizeof(uint32_t) * (size_t)n));
+        double area_ploc = 0.0;
+        const pt_status prc = ploc_refine(ctx, n, pt_tuned(ctx->tune.ploc_radius, 8, 1, PLOC_R_MAX), out.area_lbvh, &area_ploc, d_topo.p, d_range.p,
+                                          d_pint.p, d_pleaf.p, d_blo.p, d_bhi.p, out.d_prim_of, out.d_prim_q, d_sums.p, &ploc_height);
+        out.area_ploc = area_ploc;
+        if (prc == PT_ERR_UNSUPPORTED) { (void)hipFree(out.d_prim_q); out.d_prim_q = nullptr; }   // stalled, or no cheaper: the LBVH stands
+        else if (prc != PT_OK) return prc;
+        else out.area_tree = area_ploc;
+    }
     // BVH4 collapse: flag wide roots, number them (exclusive scan), emit 128-B nodes
     uint32_t n_wide = 1;
     if (n > 1) {
@@ -805,6 +1118,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
     PT_HIP(ctx, hipMemcpyAsync(ord, d_scene.p, sizeof(ord), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipMemcpyAsync(&out.height, d_height.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipStreamSynchronize(st));
+    out.height_tree = out.d_prim_q ? ploc_height : out.height;   // (out.height stays the LBVH's: the parity read-back)
     for (int k = 0; k < 3; k++) {
         out.bmin[k] = ord2f(ord[k]);
         out.bmax[k] = ord2f(ord[3 + k]);
@@ -934,6 +1248,93 @@ static pt_status make_wide16(pt_scene *s)
     return PT_OK;
 }
 
+// triangle boxes from the de-indexed triangles (the same float operations as k_gather)
+__global__ __launch_bounds__(TB) void k_tri_boxes(const float4 *__restrict__ tri_orig, uint32_t n, float4 *__restrict__ tlo,
+                                                  float4 *__restrict__ thi)
+{
+    const uint32_t t = blockIdx.x * TB + threadIdx.x;
+    if (t >= n) return;
+    const float4 a = tri_orig[3 * (size_t)t + 0], b = tri_orig[3 * (size_t)t + 1], c = tri_orig[3 * (size_t)t + 2];
+    tlo[t] = make_float4(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z), 0.f);
+    thi[t] = make_float4(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z), 0.f);
+}
+
+// Everything that hangs off the binary tree -- the tree itself (LBVH, or its PLOC rebuild for big scenes under
+// ePreferFastTrace), the BVH4 in both node formats, optionally the 8-wide nodes, the per-triangle tables in the traversed
+// leaf order -- built (or rebuilt: quality change, first request for the 8-wide nodes) from the kept triangles.
+static void free_tree_products(pt_scene *s)
+{
+    (void)hipFree(s->d_nodes); (void)hipFree(s->d_keys); (void)hipFree(s->d_prim_of); (void)hipFree(s->d_prim_of_sah);
+    (void)hipFree(s->d_wide_lbvh ? s->d_wide_lbvh : s->d_wide); (void)hipFree(s->d_wide_sah);
+    (void)hipFree(s->d_wide16); (void)hipFree(s->d_wide16t);
+    (void)hipFree(s->d_wide8); (void)hipFree(s->d_prim_of8); (void)hipFree(s->d_tri4_8); (void)hipFree(s->d_shade64_8); (void)hipFree(s->d_ke4_8);
+    s->d_nodes = nullptr; s->d_keys = nullptr; s->d_prim_of = s->d_prim_of_sah = nullptr;
+    s->d_wide = s->d_wide_lbvh = s->d_wide_sah = nullptr; s->d_wide16 = nullptr; s->d_wide16t = nullptr;
+    s->d_wide8 = nullptr; s->d_prim_of8 = nullptr; s->d_tri4_8 = s->d_shade64_8 = s->d_ke4_8 = nullptr;
+    s->n_wide8 = s->levels8 = 0; s->n_wide16t = s->levels4t = 0;
+}
+
+static pt_status build_tree_products(pt_scene *s, uint32_t quality, bool want8)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = s->n_tris, gt = (n + TB - 1) / TB;
+    free_tree_products(s);
+    DevBuf<float4> d_tlo, d_thi;
+    PT_HIP(ctx, d_tlo.alloc(n));
+    PT_HIP(ctx, d_thi.alloc(n));
+    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    k_tri_boxes<<<gt, TB, 0, st>>>(s->d_tri_orig, n, d_tlo.p, d_thi.p);
+    const bool ploc = quality == PT_BVH_PREFER_FAST_TRACE && n > PT_SAH_MAX_TRIS;
+    BvhOut o;
+    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o, 2 | (want8 ? 1 : 0), ploc);
+    s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
+    s->d_prim_of_sah = o.d_prim_q;
+    s->d_wide8 = o.d_wide8; s->n_wide8 = o.n_wide8; s->levels8 = o.levels8;
+    s->d_wide16t = o.d_wide16t; s->n_wide16t = o.n_wide16t; s->levels4t = o.levels4t;
+    DevBuf<uint32_t> d_order8;
+    d_order8.p = o.d_order8;
+    s->d_wide_lbvh = s->d_wide;
+    if (rc != PT_OK) return rc;
+    s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height; s->height_tree = o.height_tree; s->stack_need = o.stack_need;
+    s->n_wide_lbvh = s->n_wide; s->stack_need_lbvh = s->stack_need;
+    for (int k = 0; k < 3; k++) { s->bmin[k] = o.bmin[k]; s->bmax[k] = o.bmax[k]; }
+    s->bvh4_builder = o.d_prim_q ? 2u : 0u;
+    s->area_lbvh = o.area_lbvh; s->area_ploc = o.area_ploc;
+    s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;
+    const uint32_t *order = o.d_prim_q ? o.d_prim_q : s->d_prim_of;   // the traversed leaf order
+    k_pack<<<gt, TB, 0, st>>>(s->d_tri_orig, s->d_faces, order, n, s->d_tri4, s->d_shade4, s->d_shade64, s->d_ke4, s->d_frame4);
+    if (s->d_wide8) {  // the 8-wide tree's own triangle order: its per-triangle tables (the LDS-sized shade4 is never used with it)
+        PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of8, sizeof(uint32_t) * (size_t)n));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_tri4_8, sizeof(float4) * 3 * (size_t)n));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_shade64_8, sizeof(float4) * 4 * (size_t)n));
+        PT_HIP(ctx, hipMalloc((void **)&s->d_ke4_8, sizeof(float4) * (size_t)n));
+        DevBuf<float4> d_shade4_scratch;
+        PT_HIP(ctx, d_shade4_scratch.alloc(3 * (size_t)n));
+        k_compose<<<gt, TB, 0, st>>>(d_order8.p, order, n, s->d_prim_of8);
+        k_pack<<<gt, TB, 0, st>>>(s->d_tri_orig, s->d_faces, s->d_prim_of8, n, s->d_tri4_8, d_shade4_scratch.p, s->d_shade64_8, s->d_ke4_8);
+        PT_HIP(ctx, hipStreamSynchronize(st));
+    }
+    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
+    // resident bytes of the BVH4 path: triangle tables (tri4 48 + shade4 48 + shade64 64 + ke4 16 + frames 32 B each) + the
+    // 128-B and the two 64-B node arrays; of the 8-wide path: its tables + nodes
+    s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
+    s->device_bytes8 = s->d_wide8 ? (uint64_t)n * (48 + 64 + 16 + 4) + 128ull * s->n_wide8 : 0ull;
+    s->quality = quality;
+    return make_wide16(s);
+}
+
+// PT_EXTEND_HBM8 / pt_tuning.hbm8 on a scene that was built without the 8-wide nodes: build them now (wavefront.hip asks)
+pt_status ptb_ensure_wide8(pt_scene *s)
+{
+    if (s->d_wide8 || s->n_tris < 2 || s->n_inst) return PT_OK;
+    PT_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return build_tree_products(s, s->quality, true);
+}
+
 pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
                           uint32_t n_tris, const float *h_faces)
 {
@@ -941,16 +1342,18 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     hipStream_t st = ctx->stream;
     const uint32_t n = n_tris;
     const uint32_t gt = (n + TB - 1) / TB;
-    DevBuf<float> d_vert, d_faces;
+    DevBuf<float> d_vert;
     DevBuf<uint32_t> d_idx;
-    DevBuf<float4> d_tri_orig, d_tlo, d_thi;
+    DevBuf<float4> d_tlo, d_thi;
     PT_HIP(ctx, d_vert.alloc(3 * (size_t)n_verts));
     PT_HIP(ctx, d_idx.alloc(3 * (size_t)n));
-    PT_HIP(ctx, d_faces.alloc(6 * (size_t)n));
-    PT_HIP(ctx, d_tri_orig.alloc(3 * (size_t)n));
     PT_HIP(ctx, d_tlo.alloc(n));
     PT_HIP(ctx, d_thi.alloc(n));
     s->n_tris = n;
+    // the de-indexed triangles and the per-face materials stay resident (72 B per triangle): a change of the BVH quality,
+    // or the first request for the 8-wide nodes, re-packs the tables from them in another leaf order
+    PT_HIP(ctx, hipMalloc((void **)&s->d_tri_orig, sizeof(float4) * 3 * (size_t)n));
+    PT_HIP(ctx, hipMalloc((void **)&s->d_faces, sizeof(float) * 6 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_tri4, sizeof(float4) * 3 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade4, sizeof(float4) * 3 * (size_t)n));
     PT_HIP(ctx, hipMalloc((void **)&s->d_shade64, sizeof(float4) * 4 * (size_t)n));
@@ -958,37 +1361,14 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     PT_HIP(ctx, hipMalloc((void **)&s->d_frame4, sizeof(float4) * 2 * (size_t)n));
     PT_HIP(ctx, hipMemcpyAsync(d_vert.p, h_vertices, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d_idx.p, h_indices, sizeof(uint32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemcpyAsync(d_faces.p, h_faces, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(s->d_faces, h_faces, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipStreamSynchronize(st));  // pageable host sources are done with
-
-    PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
-    k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, d_tri_orig.p, d_tlo.p, d_thi.p);
-    BvhOut o;
-    pt_status rc = build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_BLAS_LEAF_MAX, o, 3);
-    s->d_keys = o.d_keys; s->d_prim_of = o.d_prim_of; s->d_nodes = o.d_nodes; s->d_wide = o.d_wide;  // freed by pt_scene_destroy
-    s->d_wide8 = o.d_wide8; s->n_wide8 = o.n_wide8; s->levels8 = o.levels8;
-    s->d_wide16t = o.d_wide16t; s->n_wide16t = o.n_wide16t; s->levels4t = o.levels4t;
-    DevBuf<uint32_t> d_order8;
-    d_order8.p = o.d_order8;
+    k_gather<<<gt, TB, 0, st>>>(d_vert.p, d_idx.p, n, s->d_tri_orig, d_tlo.p, d_thi.p);
+    // the tree of the default quality (ePreferFastTrace, main.cpp:419): PLOC for big scenes; small scenes get the LBVH
+    // here and the exact surface-area BVH4 below.  The 8-wide nodes only when the context asks AUTO to use them.
+    // (small scenes get the 8-wide nodes at once -- a few KB; big ones on first request: 260 B per triangle nobody else needs)
+    pt_status rc = build_tree_products(s, PT_BVH_PREFER_FAST_TRACE, ctx->tune.hbm8 == 1 || n <= PT_SAH_MAX_TRIS);
     if (rc != PT_OK) return rc;
-    s->n_nodes = o.n_nodes; s->n_wide = o.n_wide; s->height = o.height; s->stack_need = o.stack_need;
-    for (int k = 0; k < 3; k++) { s->bmin[k] = o.bmin[k]; s->bmax[k] = o.bmax[k]; }
-    k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of, n, s->d_tri4, s->d_shade4, s->d_shade64, s->d_ke4, s->d_frame4);
-    if (s->d_wide8) {  // the BVH8's own triangle order: its per-triangle tables (the LDS-sized shade4 is never used with it)
-        PT_HIP(ctx, hipMalloc((void **)&s->d_prim_of8, sizeof(uint32_t) * (size_t)n));
-        PT_HIP(ctx, hipMalloc((void **)&s->d_tri4_8, sizeof(float4) * (3 * (size_t)n + 1)));
-        PT_HIP(ctx, hipMalloc((void **)&s->d_shade64_8, sizeof(float4) * 4 * (size_t)n));
-        PT_HIP(ctx, hipMalloc((void **)&s->d_ke4_8, sizeof(float4) * (size_t)n));
-        DevBuf<float4> d_shade4_scratch;
-        PT_HIP(ctx, d_shade4_scratch.alloc(3 * (size_t)n));
-        k_compose<<<gt, TB, 0, st>>>(d_order8.p, s->d_prim_of, n, s->d_prim_of8);
-        k_pack<<<gt, TB, 0, st>>>(d_tri_orig.p, d_faces.p, s->d_prim_of8, n, s->d_tri4_8, d_shade4_scratch.p, s->d_shade64_8, s->d_ke4_8);
-        PT_HIP(ctx, hipStreamSynchronize(st));
-    }
-    PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
-    PT_HIP(ctx, hipStreamSynchronize(st));
-    PT_HIP(ctx, hipGetLastError());
-    PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
     {   // emitters for the NEE pipeline: normal as closesthit.rchit:43-48, area = |cross| / 2, cdf = running float sum of the
         // areas in primitive order (this file is compiled with -ffp-contract=off on the host side too)
         std::vector<float4> lights;
@@ -1015,11 +1395,6 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
             PT_HIP(ctx, hipMemcpy(s->d_lights, lights.data(), sizeof(float4) * lights.size(), hipMemcpyHostToDevice));
         }
     }
-    s->d_wide_lbvh = s->d_wide; s->n_wide_lbvh = s->n_wide; s->stack_need_lbvh = s->stack_need;
-    s->bvh4_builder = 0;
-    s->pair_leaves = PT_BLAS_LEAF_MAX == 1u;
-    s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
-    s->device_bytes8 = sizeof(float4) * 8 * (uint64_t)n + 128ull * s->n_wide8;  // tri4_8 + shade64_8 + ke4_8 + nodes
     if (n <= PT_SAH_MAX_TRIS) {
         // small scene: keep what a rebuild of the BVH4 in another leaf order needs, then apply the default
         // quality (ePreferFastTrace, main.cpp:419)
@@ -1040,12 +1415,17 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
             const bool same = std::memcmp(vtx(i, 0), vtx(i + 1, 0), 12) == 0 && std::memcmp(vtx(i, 2), vtx(i + 1, 1), 12) == 0;
             if (same) { s->h_pair[i] = 1; i++; }
         }
-        s->d_tri_orig = d_tri_orig.release();
-        s->d_faces = d_faces.release();
+        const float lbvh_ms = s->build_ms;
+        PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
         const pt_status q = ptb_set_bvh_quality(s, PT_BVH_PREFER_FAST_TRACE);
         if (q != PT_OK) return q;
+        PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        float sah_ms = 0.f;
+        PT_HIP(ctx, hipEventElapsedTime(&sah_ms, ctx->ev_a, ctx->ev_b));
+        s->build_ms = lbvh_ms + sah_ms;
     }
-    return s->d_wide16 ? PT_OK : make_wide16(s);
+    return PT_OK;
 }
 
 // Chooses the BVH4 that is traversed (pt_internal.h).  Re-packs the per-triangle tables in its leaf order.
@@ -1054,6 +1434,11 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
     pt_ctx *ctx = s->ctx;
     if (quality > PT_BVH_PREFER_FAST_BUILD) { ctx->err = "unknown BVH quality"; return PT_ERR_INVALID_ARG; }
     if (s->n_inst) { ctx->err = "set the BVH quality before the instances"; return PT_ERR_UNSUPPORTED; }
+    if (s->n_tris > PT_SAH_MAX_TRIS) {  // big scene: PLOC tree <-> LBVH, everything that hangs off the tree is rebuilt
+        if (quality == s->quality) return PT_OK;
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return build_tree_products(s, quality, s->d_wide8 != nullptr);
+    }
     const bool want_sah = quality == PT_BVH_PREFER_FAST_TRACE && s->n_tris <= PT_SAH_MAX_TRIS && s->d_tri_orig;
     if (want_sah == (s->bvh4_builder == 1u)) return PT_OK;
     hipStream_t st = ctx->stream;
@@ -1090,7 +1475,8 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
                                            s->d_shade4, s->d_shade64, s->d_ke4, s->d_frame4);
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
-    s->device_bytes = sizeof(float4) * 6 * (uint64_t)n + 128ull * s->n_wide;
+    s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
+    s->quality = quality;
     return make_wide16(s);
 }
 

@@ -30,9 +30,9 @@ static pt_status guarded(pt_ctx *ctx, F &&body)
 // ---- tuning (include/pt_api.h pt_tuning): the names PT_TUNE and the Python mirror use, in field order
 static const char *const k_tune_names[] = { "refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves",
                                             "pair_kernel", "topdown4", "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield",
-                                            "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb", "hbm8", "rebin" };
+                                            "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb", "hbm8", "rebin", "ploc_radius" };
 constexpr int k_tune_count = (int)(sizeof(k_tune_names) / sizeof(k_tune_names[0]));
-static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 12), "pt_tuning: names and fields out of step");
+static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 11), "pt_tuning: names and fields out of step");
 
 static void tuning_defaults(pt_tuning *t)
 {
@@ -212,11 +212,16 @@ pt_status pt_scene_get_info(const pt_scene *s, pt_scene_info *info)
     info->n_instances = s->n_inst;
     info->n_tlas_nodes = s->n_tlas_wide;
     info->leaf_max = PT_BLAS_LEAF_MAX;
-    info->n_wide8_nodes = s->n_wide8; info->wide8_levels = s->levels8; info->device_bytes8 = s->device_bytes8;
+    info->n_wide8_nodes = s->n_wide8; info->wide8_levels = s->levels8; info->device_bytes8 = s->device_bytes8;  // (0 until built: big scenes, first request)
     info->bvh4_builder = s->bvh4_builder;
     for (int k = 0; k < 3; k++) { info->bbox_min[k] = s->bmin[k]; info->bbox_max[k] = s->bmax[k]; }
     info->build_ms = s->build_ms;
     info->device_bytes = s->device_bytes;
+    // (normalised by the root's area = the scene box's: the same for both trees)
+    const double ex = (double)s->bmax[0] - s->bmin[0], ey = (double)s->bmax[1] - s->bmin[1], ez = (double)s->bmax[2] - s->bmin[2];
+    const double root = (ex * ey + ey * ez) + ez * ex;
+    info->tree_area_lbvh = root > 0.0 ? (float)(s->area_lbvh / root) : 0.f;
+    info->tree_area_ploc = root > 0.0 ? (float)(s->area_ploc / root) : 0.f;
     return PT_OK;
 }
 
@@ -244,7 +249,11 @@ pt_status pt_scene_read_bvh8(const pt_scene *s, uint32_t *nodes32, uint32_t *pri
 {
     if (!s) return PT_ERR_INVALID_ARG;
     pt_ctx *ctx = s->ctx;
-    if (!s->d_wide8) { ctx->err = "the scene has no BVH8 (a single triangle)"; return PT_ERR_UNSUPPORTED; }
+    if (!s->d_wide8) {   // big scenes build their 8-wide nodes on first request
+        const pt_status rc = guarded(ctx, [&] { return ptb_ensure_wide8(const_cast<pt_scene *>(s)); });
+        if (rc != PT_OK) return rc;
+    }
+    if (!s->d_wide8) { ctx->err = "the scene has no BVH8 (a single triangle, or instanced)"; return PT_ERR_UNSUPPORTED; }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (nodes32) PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide8, 128 * (size_t)s->n_wide8, hipMemcpyDeviceToHost));
     if (prim_of_pos8) PT_HIP(ctx, hipMemcpy(prim_of_pos8, s->d_prim_of8, sizeof(uint32_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));

@@ -48,7 +48,8 @@ inline int pt_tuned(int32_t v, int dflt, int lo, int hi) { return v < 0 ? dflt :
 
 struct pt_scene {
     pt_ctx *ctx = nullptr;
-    uint32_t n_tris = 0, n_nodes = 0, height = 0;
+    uint32_t n_tris = 0, n_nodes = 0, height = 0;   // height: of the binary LBVH (read-back)
+    uint32_t height_tree = 0;                       // height of the binary tree the traversed BVH4 was collapsed from (LBVH or PLOC)
     float bmin[3]{}, bmax[3]{};
     float build_ms = 0.f;
     float4 *d_tri4 = nullptr;
@@ -64,7 +65,9 @@ struct pt_scene {
     // the order of tri4/shade4 describe the BVH4 that is TRAVERSED: the collapsed LBVH (builder 0) or, for
     // scenes of <= PT_SAH_MAX_TRIS triangles, a surface-area sweep built on the device (builder 1, bvh4_sah_device.hip).
     // d_wide aliases one of the two owned arrays below.
-    uint32_t bvh4_builder = 0;
+    uint32_t bvh4_builder = 0;            // 0 collapsed LBVH, 1 surface-area sweep (small scenes), 2 PLOC rebuild of the binary tree (big scenes)
+    uint32_t quality = 0;                 // pt_bvh_quality the products were built for
+    double area_lbvh = 0.0, area_ploc = 0.0;  // big scenes: sum of the internal nodes' surface areas of the two binary trees (0 = not built)
     // 64-B copy of the traversed BVH4 for scenes that are walked in HBM/L2 (lbvh_build.hip make_wide16):
     // boxes as fp16 of coordinates normalised to the scene box, rounded outwards; halves the bytes per node
     uint2 *d_wide16 = nullptr;
@@ -162,6 +165,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
 pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
 pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality);
 void ptb_free_scene_buffers(pt_scene *s);
+pt_status ptb_ensure_wide8(pt_scene *s);  // builds the 8-wide nodes of a scene that was created without them
 constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
 // bvh4_sah_device.hip: surface-area sweep on the device (one workgroup) -> BVH4 rows (32 dwords each) + leaf order
 // pair_with_next (nullable): [n] flags, triangle i and i+1 are the two halves (v0,v1,v2),(v0,v2,v3) of a quad and form ONE primitive

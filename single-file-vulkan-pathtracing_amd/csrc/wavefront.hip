@@ -1008,7 +1008,11 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
     if (want > PT_EXTEND_HBM8) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
-    if (want == PT_EXTEND_HBM8 && (s->n_inst || !s->d_wide8)) { ctx->err = "no BVH8 for this scene (instanced, or a single triangle)"; return PT_ERR_UNSUPPORTED; }
+    if ((want == PT_EXTEND_HBM8 || (want == PT_EXTEND_AUTO && ctx->tune.hbm8 == 1)) && !s->n_inst && !s->d_wide8) {
+        const pt_status rc8 = ptb_ensure_wide8(s);   // built on first request (260 B per triangle nobody else needs)
+        if (rc8 != PT_OK) return rc8;
+    }
+    if (want == PT_EXTEND_HBM8 && (s->n_inst || !s->d_wide8)) { ctx->err = "no 8-wide nodes for this scene (instanced, or <= 2048 triangles)"; return PT_ERR_UNSUPPORTED; }
     if (s->n_inst) {  // two-level scenes: one kernel variant (BVH4s read through L1/L2)
         if (want == PT_EXTEND_FLAT || want == PT_EXTEND_LDS) { ctx->err = "instanced scenes only have the HBM extend variant"; return PT_ERR_UNSUPPORTED; }
         pl.variant = PT_EXTEND_HBM;
@@ -1056,7 +1060,7 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         // TLAS pushes <= 3 per level + 3 extra instances of a leaf, + EXIT, + the BLAS walk: the exact bound of the
         // BVH4 that is TRAVERSED when the builder gave one (the surface-area BVH4 of a small scene can be deeper
         // than the balanced LBVH whose height s->height is), else 3 per level of the collapsed LBVH
-        const uint32_t blas_bound = s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u);
+        const uint32_t blas_bound = s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height_tree / 2u + 1u);
         const uint32_t bound_i = 3u * (std::max(s->tlas_height / 2u + 1u, s->tlas16_levels)) + 4u + blas_bound + 2u;
         pl.spill_levels = bound_i > (uint32_t)LDS_STACK ? bound_i - (uint32_t)LDS_STACK : 0u;  // (sized for the 8-entry fallback kernel)
         const size_t need_i = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)std::max(pl.grid, pl.grid_inst_fallback) * TB * sizeof(uint2);
@@ -1148,12 +1152,12 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     pl.refill = pt_tuned(ctx->tune.refill, pl.lds_scene ? REFILL_MIN_IDLE : 32, 1, 64);
     pl.grid = ctx->num_cus * per_cu;
     // the HBM variant of a scene whose traversed BVH4 is the collapsed LBVH walks the top-down layout of it
-    pl.topdown4 = !pl.lds_scene && s->bvh4_builder == 0 && s->d_wide16t && ctx->tune.topdown4 != 0;
+    pl.topdown4 = !pl.lds_scene && s->bvh4_builder != 1 && s->d_wide16t && ctx->tune.topdown4 != 0;
     // stack bound: the exact one of the BVH4 that is traversed when its builder computed it (small scenes; the
     // surface-area BVH4 is not bounded by the LBVH's height), else a BVH4 node pushes <= 3 entries per level and the
     // collapsed LBVH's wide height is <= binary height/2 + 1
     const uint32_t bound = pl.topdown4 ? 3u * s->levels4t + 1u
-                           : s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height / 2u + 1u) + 1u;
+                           : s->stack_need != 0xFFFFFFFFu ? s->stack_need + 1u : 3u * (s->height_tree / 2u + 1u) + 1u;
     pl.spill_levels = bound > (uint32_t)pl.lds_stack ? bound - (uint32_t)pl.lds_stack : 0u;
     const size_t need = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
     if (need > ctx->spill_bytes) {

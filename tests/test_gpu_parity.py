@@ -189,18 +189,20 @@ def _leaf_cover(wide, n):
 def test_fast_trace_bvh4_is_a_valid_tree_and_changes_no_hit(pt, orc, gpu_ctx, cornell_arrays, n, seed):
     """pt_scene_set_bvh_quality: the surface-area BVH4 of small scenes (n = 0 here is the Cornell box) covers
     every triangle exactly once, is reachable from node 0, and returns the oracle's hits -- as does the
-    collapsed LBVH after switching back.  Above 2048 triangles both qualities are the LBVH."""
+    collapsed LBVH after switching back.  Above 2048 triangles FAST_TRACE is the cheaper of the LBVH and its PLOC rebuild."""
     v, i, f = cornell_arrays if n == 0 else _soup(n, seed, spread=0.3)
     nt = len(i) // 3
     gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
-    assert gs.info().bvh4_builder == (1 if nt <= 2048 else 0)
+    assert gs.info().bvh4_builder in ((1,) if nt <= 2048 else (0, 2))
     rng = np.random.default_rng(seed)
     rays = np.concatenate([rng.uniform(-1.2, 1.2, (30000, 3)), rng.normal(size=(30000, 3))], axis=1).astype(np.float32)
     want, _ = osc.trace(rays)
     for quality in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD, pt.BVH_PREFER_FAST_TRACE):
         gs.set_bvh_quality(quality)
         info = gs.info()
-        assert info.bvh4_builder == (1 if quality == pt.BVH_PREFER_FAST_TRACE and nt <= 2048 else 0)
+        assert info.bvh4_builder in ((0,) if quality == pt.BVH_PREFER_FAST_BUILD else ((1,) if nt <= 2048 else (0, 2)))
+        if nt > 2048 and quality == pt.BVH_PREFER_FAST_TRACE:      # the kept tree is the one with the smaller area sum
+            assert (info.bvh4_builder == 2) == (info.tree_area_ploc < info.tree_area_lbvh) and info.tree_area_ploc > 0
         wide = gs.read_bvh4()
         assert wide.shape[0] == info.n_wide_nodes
         assert (_leaf_cover(wide, nt) == 1).all()
@@ -1413,8 +1415,8 @@ def _half(u16):
 def _check_bvh8(pt, gs, v, n):
     """structure of the BVH8: contiguous children, every triangle in exactly one leaf slot, fp16 child boxes that contain
     their triangles (through every level)"""
-    info = gs.info()
     nodes, prim8 = gs.read_bvh8()
+    info = gs.info()
     assert nodes.shape[0] == info.n_wide8_nodes >= 1 and sorted(prim8.tolist()) == list(range(n))
     bmin, bmax = np.array(list(info.bbox_min), np.float64), np.array(list(info.bbox_max), np.float64)
     ext = (bmax - bmin).max()
@@ -1669,8 +1671,54 @@ def test_device_sah_builder_trees_are_sound_and_better_than_the_lbvh(pt, orc, gp
     assert sc.trace(rays).tobytes() == want.tobytes()
     sc.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)
     _, cost_lbvh, nested_lbvh = _bvh4_facts(sc.read_bvh4())
-    assert nested_lbvh and cost <= cost_lbvh * 1.0001, (cost, cost_lbvh)
+    assert nested_lbvh
+    if nt >= 36:      # (a handful of triangles: the collapsed LBVH's multi-triangle leaves can undercut one-primitive leaves)
+        assert cost <= cost_lbvh * 1.0001, (cost, cost_lbvh)
     assert sc.trace(rays).tobytes() == want.tobytes()
+    sc.close()
+
+
+def test_stadium_scene_ploc_tree_is_sound_and_cheaper_to_walk_than_the_lbvh(pt, orc, gpu_ctx):
+    """ePreferFastTrace (main.cpp:419) above 2048 triangles: the binary tree is rebuilt by PLOC before the wide nodes are
+    collapsed from it.  On the "teapot in a stadium" scene (primitive sizes over four orders of magnitude; here its
+    25 k-triangle version so that the oracle traces it in seconds): every triangle in exactly one leaf, nested boxes, the
+    oracle's hit records under both qualities and both extend kernels, the LBVH read-back untouched, a lower surface-area
+    cost and fewer node visits per ray than the Morton-median tree; and the switch back and forth rebuilds cleanly."""
+    v, i, f = pt.make_stadium(96, 40)
+    nt = len(i) // 3
+    sc, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    assert nt > 2048 and sc.info().bvh4_builder == 2
+    rng = np.random.default_rng(11)
+    org = np.tile(np.float32([0, -1, 5]), (30000, 1))                      # the camera's rays ...
+    tgt = np.stack([rng.uniform(-1, 1, 30000), rng.uniform(-2, 0, 30000), np.full(30000, 2.0)], 1)
+    rays = np.concatenate([np.concatenate([org, tgt - org], 1),          # ... and incoherent ones from inside the room
+                           np.concatenate([rng.uniform(-0.9, 0.9, (30000, 3)) * [1, 1, 1] + [0, -1, 0], rng.normal(size=(30000, 3))], 1)]).astype(np.float32)
+    want, _ = osc.trace(rays, mode=1)
+    assert (want["prim"] != pt.MISS).mean() > 0.6
+    keys, prim_of, nodes = sc.read_bvh()                                   # the LBVH read-back is the LBVH's, whatever is traversed
+    okeys, oprim = osc.bvh_keys()
+    assert keys.tobytes() == okeys.tobytes() and prim_of.tobytes() == oprim.tobytes() and nodes.tobytes() == osc.bvh_nodes().tobytes()
+    assert sc.info().bvh_height == osc.bvh_info().height
+    facts = {}
+    for quality, builder in ((pt.BVH_PREFER_FAST_TRACE, 2), (pt.BVH_PREFER_FAST_BUILD, 0), (pt.BVH_PREFER_FAST_TRACE, 2)):
+        sc.set_bvh_quality(quality)
+        assert sc.info().bvh4_builder == builder
+        leaves, cost, nested = _bvh4_facts(sc.read_bvh4())
+        covered = np.zeros(nt, np.int32)
+        for w in leaves:
+            covered[(w & 0x0FFFFFFF):(w & 0x0FFFFFFF) + ((w >> 28) & 7) + 1] += 1
+        assert nested and (covered == 1).all()
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_HBM):
+            assert sc.trace(rays, extend=variant).tobytes() == want.tobytes(), (quality, variant)
+        film = pt.Film(gpu_ctx, 160, 90)
+        gpu_ctx.reset_stats()
+        pt.render(sc, film, pt.default_params(width=160, height=90, spp_per_frame=4, max_depth=8, flags=pt.FLAG_COUNT_VISITS))
+        st = gpu_ctx.stats()
+        facts[builder] = (cost, st.nodes_visited / st.rays, st.rays, film.read_f32().tobytes())
+        film.close()
+    assert facts[2][2] == facts[0][2] and facts[2][3] == facts[0][3]       # same rays, same film, bit for bit
+    assert facts[2][0] < 0.8 * facts[0][0], facts                          # surface-area cost
+    assert facts[2][1] < 0.85 * facts[0][1], facts                         # BVH4 node visits per ray of a render
     sc.close()
 
 
