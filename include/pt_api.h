@@ -118,7 +118,7 @@ typedef struct pt_scene_info {
     uint64_t device_bytes8;   /* resident triangle tables + BVH8 bytes of that path             */
     /* big scenes (> 2048 triangles): sum of the surface areas of the binary tree's internal nodes over the root's, for
      * the Morton-median LBVH and for its PLOC rebuild (0: not built -- FAST_BUILD, or small scene).  FAST_TRACE keeps
-     * the tree with the smaller sum (bvh4_builder says which).                                                      */
+     * the rebuild when its sum is below 0.9 of the LBVH's (bvh4_builder says which tree is traversed).                                                      */
     float    tree_area_lbvh, tree_area_ploc;
 } pt_scene_info;
 pt_status pt_scene_get_info(const pt_scene *scene, pt_scene_info *info);

@@ -932,8 +932,8 @@ static pt_status tree_area(pt_ctx *ctx, uint32_t n, const float4 *d_blo, const f
 }
 
 // area_lbvh: the LBVH's sum of internal surface areas; *area_ploc gets the rebuilt tree's.  The rebuilt tree is adopted
-// (PT_OK, arrays replaced) only if its sum is smaller -- ePreferFastTrace means the cheaper tree, whichever builder made
-// it; otherwise PT_ERR_UNSUPPORTED and the LBVH stands.
+// (PT_OK, arrays replaced) only if its sum is below 0.9 of the LBVH's -- ePreferFastTrace means the cheaper tree, whichever
+// builder made it; otherwise PT_ERR_UNSUPPORTED and the LBVH stands.
 static pt_status ploc_refine(pt_ctx *ctx, uint32_t n, int radius, double area_lbvh, double *area_ploc, uint2 *d_topo, uint2 *d_range,
                              uint32_t *d_pint, uint32_t *d_pleaf, float4 *d_blo, float4 *d_bhi, const uint32_t *d_prim_of,
                              uint32_t *d_prim_q, uint32_t *d_sums, uint32_t *h_height)
@@ -976,8 +976,9 @@ static pt_status ploc_refine(pt_ctx *ctx, uint32_t n, int radius, double area_lb
         PT_HIP(ctx, hipStreamSynchronize(st));
         const uint32_t m_new = tot[0] + last[0], merges = tot[1] + last[1];
         if (merges == 0u || m_new + merges != m || merges > id_hi) { ctx->err = "internal: PLOC round made no progress"; return PT_ERR_HIP; }
-        // a scene whose clusters merge a handful at a time (pathological chains) would need ~n rounds: keep the LBVH
-        if (round >= 48 && merges * 64u < m) return PT_ERR_UNSUPPORTED;
+        // (typical: a fifth to two fifths of the clusters merge per round, 60-90 rounds for a million triangles.)  A scene
+        // whose clusters merge a handful at a time -- pathological chains -- would need ~n rounds: keep the LBVH
+        if ((round >= 64 && m > 1024u && merges * 256u < m) || round >= 2000) return PT_ERR_UNSUPPORTED;
         k_ploc_merge<<<g, TB, 0, st>>>(m, n, id_hi, nn.p, keep.p, lower.p, ref[cur].p, lo[cur].p, hi[cur].p, ref[cur ^ 1].p, lo[cur ^ 1].p,
                                        hi[cur ^ 1].p, topo.p, pint.p, pleaf.p, isz.p, nblo.p, nbhi.p);
         id_hi -= merges;
@@ -988,7 +989,10 @@ static pt_status ploc_refine(pt_ctx *ctx, uint32_t n, int radius, double area_lb
     {
         const pt_status arc = tree_area(ctx, n, nblo.p, nbhi.p, area_ploc);   // (internal boxes do not depend on the leaf order)
         if (arc != PT_OK) return arc;
-        if (!(*area_ploc < area_lbvh)) return PT_ERR_UNSUPPORTED;
+        // adopted only when clearly cheaper: on uniformly distributed, equally sized triangles (the soup of config C5) the
+        // two sums are within 1 % of each other and the LBVH's balanced tree collapses into the better BVH4 (measured:
+        // 36.2 against 38.9 node visits per ray, profiles/r03_probe_stress_scene.txt)
+        if (!(*area_ploc < 0.9 * area_lbvh)) return PT_ERR_UNSUPPORTED;
     }
     const uint32_t n_int = n - 1u, gi = (n_int + TB - 1) / TB, gl = (n + TB - 1) / TB;
     PT_HIP(ctx, hipMemsetAsync(height.p, 0, sizeof(uint32_t), st));
