@@ -143,9 +143,14 @@ pt_status pt_scene_read_bvh(const pt_scene *scene, uint64_t *keys, uint32_t *pri
  * hi.z[4] child[4] 0[4]}; child = 0xFFFFFFFF empty | node index | bit31: leaf,
  * (count-1)<<28 | first sorted position.                                                     */
 pt_status pt_scene_read_bvh4(const pt_scene *scene, uint32_t *nodes32);
-/* The BVH8 of big scenes: n_wide8_nodes x 32 dwords {lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8] as fp16 of
- * (x - c) / s with c, s the centre and half extent of the scene box, child_base, tri_base, imask | lmask << 8, 0, 0[4]}
- * and prim_of_pos8: n_tris entries, BVH8 triangle position -> gl_PrimitiveID.  Either pointer may be NULL.        */
+/* The 8-wide tree (PT_EXTEND_HBM8; big scenes build it on first request): n_wide8_nodes x 16 dwords = 64 B per node --
+ * dwords 0..11: the rows lo.x lo.y lo.z hi.x hi.y hi.z of the eight children's boxes, one BYTE per child (two dwords per
+ * row, child k in byte k & 3 of dword k >> 2); dword 12: origin.x | origin.y << 16; dword 13: origin.z | ex << 16 |
+ * ey << 21 | ez << 26; dword 14: child_base | imask << 24; dword 15: tri_base | lmask << 24.  A plane is
+ * origin16 * 2^-14 - 2 + byte * 2^-e in coordinates (x - c) / s normalised to the scene box (c, s: its centre and half
+ * extent); lower planes are rounded down and upper planes up; an empty slot is lo = 255, hi = 0.  Internal children are
+ * the nodes child_base + (rank of the slot in imask), leaf children the triangle positions tri_base + (rank in lmask).
+ * prim_of_pos8: n_tris entries, 8-wide triangle position -> gl_PrimitiveID.  Either pointer may be NULL.               */
 pt_status pt_scene_read_bvh8(const pt_scene *scene, uint32_t *nodes32, uint32_t *prim_of_pos8);
 
 /* ---- film: descriptor binding 1 (raygen.rgen:7, main.cpp:481-484) ---------------------- */
@@ -170,7 +175,7 @@ enum {
      * expectation): next-event estimation.  At every hit one point on one emitter (chosen by area) is sampled and a
      * SHADOW ray queued -- a third queue, compacted like the others and traced by the same extend kernels as an
      * any-hit query; the emission of a surface the path runs into counts for camera rays only.  Same random stream
-     * otherwise (three more numbers per hit).  Fully specified arithmetic like the reference path's (the tests' CPU checker restates it bit for bit).  Single-level scenes. */
+     * otherwise (three more numbers per hit).  Fully specified arithmetic like the reference path's (the tests' CPU checker restates it bit for bit).  Instanced scenes sample every instance's copy of the emitters (world space, one cdf). */
     PT_PIPELINE_WAVEFRONT_NEE = 1
 };
 enum {
@@ -190,7 +195,7 @@ enum {
     PT_EXTEND_FLAT = 1, /* <= 1024 triangles: one wide leaf scanned wave-uniformly (SGPR stream); never AUTO  */
     PT_EXTEND_LDS = 2,  /* BVH4 + triangles staged in LDS (scenes <= 24 KB by AUTO), lane refill             */
     PT_EXTEND_HBM = 3,  /* BVH4 + triangles read through L1/L2/MALL from HBM, LDS short stack + HBM spill    */
-    PT_EXTEND_HBM8 = 4  /* BVH8 (one 128-B line per node, one stack entry per node); never AUTO (measured slower)  */
+    PT_EXTEND_HBM8 = 4  /* 8-wide tree: 64-B nodes with byte planes, one stack entry per node (AUTO only with pt_tuning.hbm8) */
 };
 
 typedef struct pt_params {

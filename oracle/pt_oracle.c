@@ -324,12 +324,52 @@ static inline void xform_vector(const float m[12], const float v[3], float out[3
     for (int k = 0; k < 3; k++) out[k] = (m[4 * k] * v[0] + m[4 * k + 1] * v[1]) + m[4 * k + 2] * v[2];
 }
 
+/* Emitters for the NEE estimator (pt_api: PT_PIPELINE_WAVEFRONT_NEE): every triangle with Ke != 0, in primitive order --
+ * for an instanced scene once per instance, in gl_InstanceID order, with the vertices taken to world space by the
+ * instance's matrix (xform_point); normal = -cross / |cross| as closesthit.rchit:43-48 (of the world-space triangle: only
+ * |cos| of it is used); area = |cross| / 2; cdf = running float sum of the areas. */
+static void build_lights(orc_scene *s)
+{
+    free(s->lights); s->lights = NULL; s->n_lights = 0; s->light_area = 0.0f;
+    uint32_t per = 0;
+    for (uint32_t t = 0; t < s->n_tris; t++) {
+        const float *f = s->face + 6 * (size_t)t;
+        if (f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f) per++;
+    }
+    const uint32_t copies = s->n_inst ? s->n_inst : 1u;
+    if (!per) return;
+    s->n_lights = per * copies;
+    s->lights = malloc(sizeof(float) * 16 * (size_t)s->n_lights);
+    uint32_t k = 0;
+    float run = 0.0f;
+    for (uint32_t i = 0; i < copies; i++)
+        for (uint32_t t = 0; t < s->n_tris; t++) {
+            const float *f = s->face + 6 * (size_t)t;
+            if (!(f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f)) continue;
+            const float *tv = s->tri + 9 * (size_t)t;
+            float *L = s->lights + 16 * (size_t)k++;
+            float e1[3], e2[3];
+            if (s->n_inst) for (int c = 0; c < 3; c++) xform_point(s->inst[i].m, tv + 3 * c, L + 3 * c);
+            else for (int c = 0; c < 9; c++) L[c] = tv[c];
+            for (int c = 0; c < 3; c++) { e1[c] = L[3 + c] - L[c]; e2[c] = L[6 + c] - L[c]; }
+            float cx = e1[1] * e2[2] - e1[2] * e2[1];
+            float cy = e1[2] * e2[0] - e1[0] * e2[2];
+            float cz = e1[0] * e2[1] - e1[1] * e2[0];
+            float len = sqrtf((cx * cx + cy * cy) + cz * cz);
+            L[9] = -(cx / len); L[10] = -(cy / len); L[11] = -(cz / len);
+            L[12] = f[3]; L[13] = f[4]; L[14] = f[5];
+            run = run + 0.5f * len;
+            L[15] = run;
+        }
+    s->light_area = run;
+}
+
 int orc_scene_set_instances(orc_scene *s, const float *xforms3x4, uint32_t n)
 {
     if (!s || (n && !xforms3x4)) return 1;
     free(s->inst); s->inst = NULL; s->n_inst = 0;
     bvh_free(&s->tlas);
-    if (n == 0) return 0;
+    if (n == 0) { build_lights(s); return 0; }
     s->inst = malloc(sizeof(orc_instance) * (size_t)n);
     s->n_inst = n;
     float *blo = malloc(sizeof(float) * 3 * (size_t)n), *bhi = malloc(sizeof(float) * 3 * (size_t)n);
@@ -354,6 +394,7 @@ int orc_scene_set_instances(orc_scene *s, const float *xforms3x4, uint32_t n)
     }
     build_lbvh(&s->tlas, blo, bhi, n);
     free(blo); free(bhi);
+    build_lights(s);
     return 0;
 }
 
@@ -373,35 +414,7 @@ orc_scene *orc_scene_create(const float *vertices, uint32_t n_verts, const uint3
                 s->tri[9 * (size_t)t + 3 * c + k] = vertices[3 * (size_t)indices[3 * (size_t)t + c] + k];
     memcpy(s->face, faces, sizeof(float) * 6 * (size_t)n_tris);
     build_blas(s);
-    /* emitters for the NEE estimator (pt_api: PT_PIPELINE_WAVEFRONT_NEE): every triangle with Ke != 0, in primitive
-     * order; normal as closesthit.rchit:43-48; area = |cross| / 2; cdf = running float sum of the areas */
-    for (uint32_t t = 0; t < n_tris; t++) {
-        const float *f = s->face + 6 * (size_t)t;
-        if (f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f) s->n_lights++;
-    }
-    if (s->n_lights) {
-        s->lights = malloc(sizeof(float) * 16 * (size_t)s->n_lights);
-        uint32_t k = 0;
-        float run = 0.0f;
-        for (uint32_t t = 0; t < n_tris; t++) {
-            const float *f = s->face + 6 * (size_t)t;
-            if (!(f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f)) continue;
-            const float *tv = s->tri + 9 * (size_t)t;
-            float *L = s->lights + 16 * (size_t)k++;
-            float e1[3], e2[3];
-            for (int c = 0; c < 9; c++) L[c] = tv[c];
-            for (int c = 0; c < 3; c++) { e1[c] = tv[3 + c] - tv[c]; e2[c] = tv[6 + c] - tv[c]; }
-            float cx = e1[1] * e2[2] - e1[2] * e2[1];
-            float cy = e1[2] * e2[0] - e1[0] * e2[2];
-            float cz = e1[0] * e2[1] - e1[1] * e2[0];
-            float len = sqrtf((cx * cx + cy * cy) + cz * cz);
-            L[9] = -(cx / len); L[10] = -(cy / len); L[11] = -(cz / len);
-            L[12] = f[3]; L[13] = f[4]; L[14] = f[5];
-            run = run + 0.5f * len;
-            L[15] = run;
-        }
-        s->light_area = run;
-    }
+    build_lights(s);
     return s;
 }
 
@@ -740,7 +753,7 @@ static void render_pixel(job *jb, uint32_t px, uint32_t py)
                 for (int k = 0; k < 3; k++) color[k] = color[k] + weight[k] * emi[k]; /* :76 */
             /* (not at the path's last hit: its direct light stands for the emission the NEXT ray would find, and there is no
              * next ray -- the reference sums emission over the hits of rays 0 .. max_depth-1, raygen.rgen:62-83) */
-            if (p->nee && s->n_lights && !s->n_inst && depth + 1u < p->max_depth) {
+            if (p->nee && s->n_lights && depth + 1u < p->max_depth) {
                 /* next-event estimation (not in the reference): one point on one emitter, chosen by area; the
                  * contribution weight * brdf * Ke * cos_s |cos_l| / d^2 * total_area if the shadow ray is free */
                 const float rl = orc_rand(&seed), ru = orc_rand(&seed), rv = orc_rand(&seed);

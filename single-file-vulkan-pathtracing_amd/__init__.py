@@ -35,7 +35,7 @@ FLAG_NO_SORT_RAYS = 16
 EXTEND_AUTO, EXTEND_FLAT, EXTEND_LDS, EXTEND_HBM, EXTEND_HBM8 = 0, 1, 2, 3, 4
 BVH_PREFER_FAST_TRACE, BVH_PREFER_FAST_BUILD = 0, 1
 EXTEND_NAMES = {1: "flat (one wide leaf, SGPR triangle stream)", 2: "BVH4, scene staged in LDS", 3: "BVH4, scene in HBM/L2",
-                4: "BVH8 (128-B nodes, one stack entry per node), scene in HBM/L2"}
+                4: "8-wide tree (64-B nodes with byte planes, one stack entry per node), scene in HBM/L2"}
 MISS = 0xFFFFFFFF
 
 
@@ -393,10 +393,10 @@ class Scene:
         return nodes
 
     def read_bvh8(self):
-        """-> (nodes [n_wide8, 32] u32, prim_of_pos8 [n_tris] u32) of the BVH8 (include/pt_api.h: pt_scene_read_bvh8)"""
+        """-> (nodes [n_wide8, 16] u32, prim_of_pos8 [n_tris] u32) of the 8-wide tree (include/pt_api.h: pt_scene_read_bvh8)"""
         self.ctx._check(lib_amd().pt_scene_read_bvh8(self.h, None, None))      # big scenes build their 8-wide nodes on first request
         i = self.info()
-        nodes = np.zeros((i.n_wide8_nodes, 32), dtype=np.uint32)
+        nodes = np.zeros((i.n_wide8_nodes, 16), dtype=np.uint32)
         prim = np.zeros(i.n_tris, dtype=np.uint32)
         self.ctx._check(lib_amd().pt_scene_read_bvh8(self.h, nodes.ctypes.data, prim.ctypes.data))
         return nodes, prim

@@ -1,11 +1,15 @@
-// extend8_kernel.h -- closest hit over the BVH8 (scenes walked out of L2 / MALL / HBM; lbvh_build.hip k_w8_*).
+// extend8_kernel.h -- closest hit over the 8-wide tree (scenes walked out of L2 / MALL / HBM; lbvh_build.hip k_w8_*).
 //
 // Same contract as k_extend (extend_kernel.h): persistent threads, lane refill from a wave-private sequence of 64-ray
 // chunks, the canonical watertight triangle test, closest t with ties to the lowest primitive id -- the hit records are
 // bit-identical.  What differs is what a ray fetches and what it remembers:
-//   * a node is one 128-B line with EIGHT children (fp16 planes in the normalised scene box): beyond L2 this chip
-//     charges a divergent load per distinct line, not per byte (scripts/ubench/gather_rate.hip), and eight-wide
-//     nodes need a third fewer visits than four-wide ones;
+//   * a node is 64 B with EIGHT children: the planes are bytes on the node's own grid (16-bit origin per axis on the
+//     normalised scene box + q * 2^-e, lbvh_build.hip k_w8_emit), so two nodes share a 128-B line and the eight children of a
+//     node are four lines: beyond L2 this chip charges a divergent load per distinct line, not per byte
+//     (scripts/ubench/gather_rate.hip), and eight-wide nodes need a quarter fewer visits than four-wide ones.  (Round 2's
+//     128-B node with fp16 planes fetched as many lines as the four-wide tree and lost; it is gone.)  The price is the
+//     decode: per visit the node's origin and scales, the slab constants relative to that origin, 48 byte -> float
+//     conversions;
 //   * internal children are contiguous and a node's leaf triangles are contiguous, so what is pending of a node is
 //     {child_base, mask of the internal children still to visit}: ONE 8-byte stack entry per visited node (with the
 //     smallest entry distance of its hit children in the top 16 bits, so a popped group that lies behind the best hit
@@ -19,7 +23,7 @@
 namespace {
 
 template <bool COUNT>
-__device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4,
+__device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
                                              const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                              float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                              uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
@@ -43,12 +47,11 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
     const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
     const uint32_t wave_stride = gridDim.x * TB;
     uint32_t cursor = 0;
-    ptm::f3 inv{}, invf{}, on{}, of{};
+    ptm::f3 inv{}, orgn{};            // the ray in the normalised scene box: reciprocal direction and origin
     ptm::RayPre pre{};
-    uint32_t ax = 0, ay = 0, az = 0;  // 48 where the direction component is negative: byte offset of the near-plane row
     uint32_t oct = 0;                 // ray octant: bit k set where direction component k is negative
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
-    uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
+    uint32_t best_pos = PT_MISS;
     // node group: internal children of one node still to visit.  meta = priority-ordered hit mask (bit p = slot p ^ oct)
     // | imask << 8 | top 16 bits of the smallest entry distance of the node's hit children
     uint32_t ng_base = 0, ng_meta = 0;
@@ -56,7 +59,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
     uint32_t tg_base = 0, tg_hits = 0, tg_lmask = 0;
     int sp = 0;
     unsigned long long c_nodes = 0, c_tris = 0, c_node_steps = 0, c_tri_steps = 0, c_refills = 0, c_pops = 0, c_hit_blocks = 0,
-                       c_finishes = 0, c_iters = 0;
+                       c_finishes = 0, c_iters = 0, c_leaf_lanes = 0, c_pop_lanes = 0, c_hit_lanes = 0;
 #define PT_COUNT_WAVE(C) \
     if (COUNT && lane == __ffsll((long long)__ballot(1)) - 1) (C)++
 
@@ -78,15 +81,11 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup(org, dir);
                     inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
-                    const ptm::f3 orgn = { (org.x - nb.cx) * nb.rsx, (org.y - nb.cy) * nb.rsy, (org.z - nb.cz) * nb.rsz };
+                    orgn = { (org.x - nb.cx) * nb.rsx, (org.y - nb.cy) * nb.rsy, (org.z - nb.cz) * nb.rsz };
                     inv = { inv.x * nb.sx, inv.y * nb.sy, inv.z * nb.sz };
-                    slab_setup(orgn, inv, invf, on, of);
-                    ax = inv.x < 0.f ? 48u : 0u;
-                    ay = inv.y < 0.f ? 48u : 0u;
-                    az = inv.z < 0.f ? 48u : 0u;
                     oct = (inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u);
                     best_t = ray_tmax ? ray_tmax[q] : tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;  // (shadow rays: extend_kernel.h)
-                    best_pos = PT_MISS; best_prim = PT_MISS;
+                    best_pos = PT_MISS;
                     // the root as the only child (slot `oct`, so priority 0) of a virtual parent
                     ng_base = 0u;
                     ng_meta = 1u | ((1u << oct) << 8) | (__float_as_uint(tmin < 0.f ? -INF : 0.f) & 0xFFFF0000u);
@@ -118,31 +117,45 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                     else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
                     sp++;
                 }
-                const char *nb_ = reinterpret_cast<const char *>(nodes8) + 128 * (size_t)idx;
-                // near / far plane rows picked through the load address (row = 8 halves = 16 B; lo rows at 0/16/32, hi at 48/64/80)
-                const uint4 rnx = *reinterpret_cast<const uint4 *>(nb_ + ax), rfx = *reinterpret_cast<const uint4 *>(nb_ - ax + 48),
-                            rny = *reinterpret_cast<const uint4 *>(nb_ + ay + 16), rfy = *reinterpret_cast<const uint4 *>(nb_ - ay + 64),
-                            rnz = *reinterpret_cast<const uint4 *>(nb_ + az + 32), rfz = *reinterpret_cast<const uint4 *>(nb_ - az + 80);
-                const uint4 m6 = *reinterpret_cast<const uint4 *>(nb_ + 96);
-                // hit mask and the smallest entry distance, child by child (nothing per child stays live: 84 VGPRs, 6 waves)
+                const uint4 *nd = nodes8 + 4 * (size_t)idx;
+                const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], hd = nd[3];  // the whole node: four 16-B loads of one 64-B record
+                // the node's grid: origin = o16 * 2^-14 - 2 (exact), step = 2^-e; the slab constants are those of slab_setup
+                // (extend_kernel.h) for the ray origin RELATIVE to the node's (one exactly rounded subtraction), so a plane
+                // distance is again ONE fma, q * (step * inv) + (-(org - origin) * inv), with the same outward margins
+                const ptm::f3 orel = { orgn.x - (__builtin_fmaf((float)(hd.x & 0xFFFFu), 0x1p-14f, -2.0f)),
+                                       orgn.y - (__builtin_fmaf((float)(hd.x >> 16), 0x1p-14f, -2.0f)),
+                                       orgn.z - (__builtin_fmaf((float)(hd.y & 0xFFFFu), 0x1p-14f, -2.0f)) };
+                const ptm::f3 stp = { __uint_as_float((127u - ((hd.y >> 16) & 31u)) << 23), __uint_as_float((127u - ((hd.y >> 21) & 31u)) << 23),
+                                      __uint_as_float((127u - (hd.y >> 26)) << 23) };
+                ptm::f3 invf, on, of;
+                slab_setup(orel, inv, invf, on, of);
+                const ptm::f3 an = { stp.x * inv.x, stp.y * inv.y, stp.z * inv.z }, af = { stp.x * invf.x, stp.y * invf.y, stp.z * invf.z };
+                // near / far rows by the ray's octant (bit-field insert with all-ones / all-zeros masks, as k_extend<hbm>):
+                // rows lo.x = q0.xy, lo.y = q0.zw, lo.z = q1.xy, hi.x = q1.zw, hi.y = q2.xy, hi.z = q2.zw (4 children per dword)
+                const uint32_t mx = (oct & 1u) ? 0xFFFFFFFFu : 0u, my = (oct & 2u) ? 0xFFFFFFFFu : 0u, mz = (oct & 4u) ? 0xFFFFFFFFu : 0u;
+                const uint32_t rnx[2] = { PT_BFI(mx, q1.z, q0.x), PT_BFI(mx, q1.w, q0.y) }, rfx[2] = { PT_BFI(mx, q0.x, q1.z), PT_BFI(mx, q0.y, q1.w) };
+                const uint32_t rny[2] = { PT_BFI(my, q2.x, q0.z), PT_BFI(my, q2.y, q0.w) }, rfy[2] = { PT_BFI(my, q0.z, q2.x), PT_BFI(my, q0.w, q2.y) };
+                const uint32_t rnz[2] = { PT_BFI(mz, q2.z, q1.x), PT_BFI(mz, q2.w, q1.y) }, rfz[2] = { PT_BFI(mz, q1.x, q2.z), PT_BFI(mz, q1.y, q2.w) };
+                // hit mask and the smallest entry distance, child by child (nothing per child stays live)
                 uint32_t h = 0;
                 float gmin = INF;
-#define PT_SLAB8(K, REGC, HI)                                                                             \
-    {                                                                                                     \
-        float nxv, nyv, nzv, fxv, fyv, fzv;                                                               \
-        PT_MIXH(nxv, rnx.REGC, HI, inv.x, on.x); PT_MIXH(nyv, rny.REGC, HI, inv.y, on.y);                 \
-        PT_MIXH(nzv, rnz.REGC, HI, inv.z, on.z); PT_MIXH(fxv, rfx.REGC, HI, invf.x, of.x);                \
-        PT_MIXH(fyv, rfy.REGC, HI, invf.y, of.y); PT_MIXH(fzv, rfz.REGC, HI, invf.z, of.z);               \
-        const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                                    \
-        const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                                    \
-        const bool hk = tn <= tf;                                                                         \
-        h |= hk ? (1u << K) : 0u;                                                                         \
-        gmin = hk ? min_raw(tn, gmin) : gmin;                                                             \
+#define PT_BYTE(W, B) ((float)(((W) >> (8 * (B))) & 0xFFu))   /* v_cvt_f32_ubyteB */
+#define PT_SLAB8(K)                                                                                               \
+    {                                                                                                             \
+        const float nxv = __builtin_fmaf(PT_BYTE(rnx[(K) >> 2], (K) & 3), an.x, on.x), nyv = __builtin_fmaf(PT_BYTE(rny[(K) >> 2], (K) & 3), an.y, on.y), \
+                    nzv = __builtin_fmaf(PT_BYTE(rnz[(K) >> 2], (K) & 3), an.z, on.z), fxv = __builtin_fmaf(PT_BYTE(rfx[(K) >> 2], (K) & 3), af.x, of.x), \
+                    fyv = __builtin_fmaf(PT_BYTE(rfy[(K) >> 2], (K) & 3), af.y, of.y), fzv = __builtin_fmaf(PT_BYTE(rfz[(K) >> 2], (K) & 3), af.z, of.z); \
+        const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                                            \
+        const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                                            \
+        const bool hk = tn <= tf;                                                                                 \
+        h |= hk ? (1u << (K)) : 0u;                                                                               \
+        gmin = hk ? min_raw(tn, gmin) : gmin;                                                                     \
     }
-                PT_SLAB8(0, x, 0) PT_SLAB8(1, x, 1) PT_SLAB8(2, y, 0) PT_SLAB8(3, y, 1)
-                PT_SLAB8(4, z, 0) PT_SLAB8(5, z, 1) PT_SLAB8(6, w, 0) PT_SLAB8(7, w, 1)
+                PT_SLAB8(0) PT_SLAB8(1) PT_SLAB8(2) PT_SLAB8(3) PT_SLAB8(4) PT_SLAB8(5) PT_SLAB8(6) PT_SLAB8(7)
 #undef PT_SLAB8
-                const uint32_t nim = m6.z & 0xFFu, lm = (m6.z >> 8) & 0xFFu;
+#undef PT_BYTE
+                const uint32_t nim = hd.z >> 24, lm = hd.w >> 24;
+                h &= nim | lm;   // (empty slots are inverted intervals, never hit; the mask costs one instruction)
                 uint32_t hi_ = h & nim;
                 // slot mask -> priority mask: bit p = slot p ^ oct (swap neighbours / pairs / nibbles per octant bit)
                 if (oct & 1u) hi_ = ((hi_ & 0x55u) << 1) | ((hi_ & 0xAAu) >> 1);
@@ -152,36 +165,41 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 // away from zero)
                 const uint32_t gb = __float_as_uint(gmin);
                 const uint32_t g16 = (gb + ((uint32_t)((int32_t)gb >> 31) & 0xFFFFu)) & 0xFFFF0000u;
-                ng_base = m6.x;
+                ng_base = hd.z & 0x00FFFFFFu;
                 ng_meta = hi_ | (nim << 8) | g16;
-                tg_base = m6.y;
+                tg_base = hd.w & 0x00FFFFFFu;
                 tg_hits = h & lm;
                 tg_lmask = lm;
             }
         } else if (want_tri) {
-            if (COUNT) c_tris++;
+            if (COUNT) { c_tris++; c_leaf_lanes++; }
             PT_COUNT_WAVE(c_tri_steps);
             const uint32_t slot = (uint32_t)(__ffs((int)tg_hits) - 1);
             tg_hits &= tg_hits - 1u;
             const uint32_t pos = tg_base + (uint32_t)__popc(tg_lmask & ((1u << slot) - 1u));
-            const float4 a = tri4[3 * (size_t)pos + 0], b = tri4[3 * (size_t)pos + 1], c = tri4[3 * (size_t)pos + 2];
+            // the vertices come from the 64-B record k_shade gathers anyway (extend_kernel.h REC64: never straddles a line);
+            // its .w components are the normal, so the ids of two rivals at exactly the same t come from tri4
+            const float4 a = rec64[4 * (size_t)pos + 0], b = rec64[4 * (size_t)pos + 1], c = rec64[4 * (size_t)pos + 2];
             float t, V, W, det;
             bool divided = false;
             if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, COUNT ? &divided : nullptr)) {
-                const uint32_t prim = __float_as_uint(a.w);
                 // closest t; equal t -> lowest gl_PrimitiveID
-                if (t < best_t || (t == best_t && prim < best_prim)) {
-                    best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                bool closer = t < best_t;
+                if (!closer && t == best_t)
+                    closer = best_pos == PT_MISS || __float_as_uint(tri4[3 * (size_t)pos].w) < __float_as_uint(tri4[3 * (size_t)best_pos].w);
+                if (closer) {
+                    best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos;
                     if (ray_tmax) { sp = 0; tg_hits = 0u; ng_meta &= 0xFFFFFF00u; }  // any hit ends a shadow ray
                 }
             }
-            if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); }
+            if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
         }
         // ---- nothing left of the current node: the next pending group that can still hold the closest hit, or done
         if (have && tg_hits == 0u && (ng_meta & 0xFFu) == 0u) {
             bool got = false;
             while (sp > 0) {
                 PT_COUNT_WAVE(c_pops);
+                if (COUNT) c_pop_lanes++;
                 sp--;
                 unsigned long long e;
                 if (sp < lds_stack) e = my_stack[sp * TB];
@@ -216,6 +234,9 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
             c_hit_blocks += __shfl_xor(c_hit_blocks, o, 64);
             c_finishes += __shfl_xor(c_finishes, o, 64);
             c_iters += __shfl_xor(c_iters, o, 64);
+            c_leaf_lanes += __shfl_xor(c_leaf_lanes, o, 64);
+            c_pop_lanes += __shfl_xor(c_pop_lanes, o, 64);
+            c_hit_lanes += __shfl_xor(c_hit_lanes, o, 64);
         }
         if (lane == 0 && stats) {
             atomicAdd(stats + 2, c_nodes);
@@ -227,6 +248,9 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
             atomicAdd(stats + 10, c_hit_blocks);
             atomicAdd(stats + 11, c_finishes);
             atomicAdd(stats + 12, c_iters);
+            atomicAdd(stats + 13, c_leaf_lanes);
+            atomicAdd(stats + 14, c_pop_lanes);
+            atomicAdd(stats + 15, c_hit_lanes);
         }
     }
 }
@@ -235,14 +259,14 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
 #define PT_EXTEND8_WAVES 6
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(TB, PT_EXTEND8_WAVES) void k_extend8(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4,
+__global__ __launch_bounds__(TB, PT_EXTEND8_WAVES) void k_extend8(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
                                                 const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                                 float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                                 uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
                                                 uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
                                                 int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
-    extend8_body<COUNT>(nodes8, nb, tri4, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
+    extend8_body<COUNT>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
                         tmax, lds_stack, raw_hit, perm, ray_tmax);
 }
 

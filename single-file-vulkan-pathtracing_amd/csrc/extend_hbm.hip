@@ -51,16 +51,16 @@ const void *ptw_extend8_fn(bool count)
 }
 
 void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
-                        const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
+                        const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rec64, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                         uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
                         const uint32_t *perm, const float *ray_tmax)
 {
     const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
     if (count)
-        hipExtLaunchKernelGGL((k_extend8<true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rayA, rayB, hit,
+        hipExtLaunchKernelGGL((k_extend8<true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rec64, rayA, rayB, hit,
                               count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax);
     else
-        hipExtLaunchKernelGGL((k_extend8<false>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rayA, rayB, hit,
+        hipExtLaunchKernelGGL((k_extend8<false>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rec64, rayA, rayB, hit,
                               count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax);
 }

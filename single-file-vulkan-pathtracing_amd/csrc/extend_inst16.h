@@ -25,7 +25,8 @@ constexpr uint32_t I16_NODE_DW = 20;  // dwords per BLAS node in LDS (16 used): 
 #define PT_REG_BARRIER16(A, B, C, D)                                                                                   \
     asm volatile("" : "+v"(A.x), "+v"(A.y), "+v"(A.z), "+v"(A.w), "+v"(B.x), "+v"(B.y), "+v"(B.z), "+v"(B.w), "+v"(C.x), \
                       "+v"(C.y), "+v"(C.z), "+v"(C.w), "+v"(D.x), "+v"(D.y), "+v"(D.z), "+v"(D.w));
-template <bool COUNT, bool PAIRS>
+// SHADOW (the NEE pipeline's shadow rays): a per-ray upper bound `ray_tmax` instead of tmax, and ANY hit below it ends the walk
+template <bool COUNT, bool PAIRS, bool SHADOW = false>
 __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ tlas16, NormBox nbt, const uint4 *__restrict__ g_blas16,
                                                       NormBox nbb, const float4 *__restrict__ g_tri4, uint32_t n_blas_wide,
                                                       uint32_t n_tris, const float4 *__restrict__ inst6,
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                                                       uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
                                                       uint32_t *count_zero, unsigned long long *stats, uint32_t *__restrict__ spill,
                                                       uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int raw_hit,
-                                                      int lds_stack, int enter_min, int node_yield, uint32_t n_tlas_lds)
+                                                      int lds_stack, int enter_min, int node_yield, uint32_t n_tlas_lds,
+                                                      const float *__restrict__ ray_tmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem);  // [lds_stack][TB]
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     level_setup(org_w, dir_w, nbt);
                     w_inv = inv; w_invf = invf; w_on = on; w_of = of; w_mx = mx; w_my = my; w_mz = mz;
                     in_blas = false;
-                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_t = SHADOW ? ray_tmax[q] : tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
                     cur = 0u;  // TLAS root
                     sp = 0;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
                         best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
                         best_ipos = cur_ipos; best_iid = cur_iid;
+                        if (SHADOW) sp = 0;  // any hit will do: nothing pending any more (the pop below finds the stack empty)
                     }
                 };
                 if (PAIRS) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
                                  : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
                                                miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
-                hit_inst[q] = best_ipos;
+                if (!SHADOW) hit_inst[q] = best_ipos;
                 have = false;
             }
         }

@@ -742,7 +742,8 @@ __global__ __launch_bounds__(TB) void k_w8_emit(uint32_t count, uint32_t level_b
     const uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= count) return;
     const float c[3] = { cx, cy, cz }, rs[3] = { rsx, rsy, rsz };
-    uint32_t hl[3][8], hh[3][8];
+    float bl[3][8], bh[3][8];          // child boxes in normalised scene coordinates, rounded outwards (as k_wide_half)
+    bool present[8];
     uint32_t imask = 0, lmask = 0, ni = 0, nl = 0;
     const uint32_t child_base = next_base + int_off[j], tri_base = tri_start[j];
     uint32_t sub_start = tri_base;  // where the next internal child's range begins: behind this node's own leaves
@@ -750,23 +751,24 @@ __global__ __launch_bounds__(TB) void k_w8_emit(uint32_t count, uint32_t level_b
         const uint32_t r = kids[8 * (size_t)j + k];
         if (r != PT_MISS && (r & PT_LEAF)) sub_start++;
     }
+    float nlo[3] = { INFINITY, INFINITY, INFINITY }, nhi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (int k = 0; k < 8; k++) {
         const uint32_t r = kids[8 * (size_t)j + k];
-        if (r == PT_MISS) {
-            for (int ax = 0; ax < 3; ax++) hl[ax][k] = hh[ax][k] = 0x7C00u;  // +inf: no slab interval
-            continue;
-        }
+        present[k] = r != PT_MISS;
+        if (!present[k]) continue;
         const bool leaf = (r & PT_LEAF) != 0u;
         const size_t bi = leaf ? (size_t)(r & ~PT_LEAF) : (size_t)n + r;
         const float4 lo = box_lo[bi], hi = box_hi[bi];
         const float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
-        for (int ax = 0; ax < 3; ax++) {  // as k_wide_half: every fp16 box contains its fp32 box
-            hl[ax][k] = __half_as_ushort(__float2half_rd((l[ax] - c[ax]) * rs[ax] - 3.814697265625e-06f));
-            hh[ax][k] = __half_as_ushort(__float2half_ru((h[ax] - c[ax]) * rs[ax] + 3.814697265625e-06f));
+        for (int ax = 0; ax < 3; ax++) {
+            bl[ax][k] = (l[ax] - c[ax]) * rs[ax] - 3.814697265625e-06f;
+            bh[ax][k] = (h[ax] - c[ax]) * rs[ax] + 3.814697265625e-06f;
+            nlo[ax] = fminf(nlo[ax], bl[ax][k]);
+            nhi[ax] = fmaxf(nhi[ax], bh[ax][k]);
         }
         if (leaf) {
             lmask |= 1u << k;
-            order8[tri_base + nl] = r & ~PT_LEAF;  // BVH8 triangle position -> sorted (Morton) position
+            order8[tri_base + nl] = r & ~PT_LEAF;  // 8-wide triangle position -> position of the binary tree's leaf order
             nl++;
         } else {
             imask |= 1u << k;
@@ -777,13 +779,34 @@ __global__ __launch_bounds__(TB) void k_w8_emit(uint32_t count, uint32_t level_b
             ni++;
         }
     }
-    uint4 *o = wide8 + 8 * (size_t)(level_base + j);
+    // 64-B node: the six planes of the eight children as BYTES on the node's own grid -- origin (16 bits per axis on the
+    // 2^-14 grid of [-2, 2), at or below the node's lower corner) + q * 2^-e with a per-axis exponent (5 bits) just large enough
+    // for 255 steps to reach the node's upper corner; lower planes rounded down, upper planes up, so every decoded box contains
+    // the box it stands for.  Empty slots: lo = 255, hi = 0 (an inverted interval on every axis: no ray hits it; the
+    // traversal also masks them out).  Then child_base | imask << 24 and tri_base | lmask << 24.
+    uint32_t o16[3], ecode[3], ql[3][8], qh[3][8];
     for (int ax = 0; ax < 3; ax++) {
-        o[ax] = make_uint4(hl[ax][0] | (hl[ax][1] << 16), hl[ax][2] | (hl[ax][3] << 16), hl[ax][4] | (hl[ax][5] << 16), hl[ax][6] | (hl[ax][7] << 16));
-        o[3 + ax] = make_uint4(hh[ax][0] | (hh[ax][1] << 16), hh[ax][2] | (hh[ax][3] << 16), hh[ax][4] | (hh[ax][5] << 16), hh[ax][6] | (hh[ax][7] << 16));
+        const double og = floor(((double)nlo[ax] + 2.0) * 16384.0);
+        o16[ax] = (uint32_t)fmin(fmax(og, 0.0), 65535.0);
+        const double origin = (double)o16[ax] * (1.0 / 16384.0) - 2.0;
+        const double ext = (double)nhi[ax] - origin;
+        int e = -31;
+        while (e < 0 && 255.0 * ldexp(1.0, e) < ext) e++;
+        ecode[ax] = (uint32_t)(-e);
+        const double inv_step = ldexp(1.0, -e);
+        for (int k = 0; k < 8; k++) {
+            if (!present[k]) { ql[ax][k] = 255u; qh[ax][k] = 0u; continue; }
+            ql[ax][k] = (uint32_t)fmin(fmax(floor(((double)bl[ax][k] - origin) * inv_step), 0.0), 255.0);
+            qh[ax][k] = (uint32_t)fmin(fmax(ceil(((double)bh[ax][k] - origin) * inv_step), 0.0), 255.0);
+        }
     }
-    o[6] = make_uint4(child_base, tri_base, imask | (lmask << 8), 0u);
-    o[7] = make_uint4(0u, 0u, 0u, 0u);
+    auto pack4 = [](const uint32_t *q) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
+    uint4 *o = wide8 + 4 * (size_t)(level_base + j);
+    o[0] = make_uint4(pack4(ql[0]), pack4(ql[0] + 4), pack4(ql[1]), pack4(ql[1] + 4));
+    o[1] = make_uint4(pack4(ql[2]), pack4(ql[2] + 4), pack4(qh[0]), pack4(qh[0] + 4));
+    o[2] = make_uint4(pack4(qh[1]), pack4(qh[1] + 4), pack4(qh[2]), pack4(qh[2] + 4));
+    o[3] = make_uint4(o16[0] | (o16[1] << 16), o16[2] | (ecode[0] << 16) | (ecode[1] << 21) | (ecode[2] << 26), child_base | (imask << 24),
+                      tri_base | (lmask << 24));
 }
 
 // The same level-by-level build with FOUR children per node, in the 64-B format k_extend<hbm> walks (fp16 planes +
@@ -1143,7 +1166,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
         uint32_t count = 1, level_base = 0, tri_run = 0, levels = 0;
         int cf = 0;
         if (want8) {
-        PT_HIP(ctx, hipMalloc((void **)&out.d_wide8, 128 * (size_t)n_int));
+        PT_HIP(ctx, hipMalloc((void **)&out.d_wide8, 64 * (size_t)n_int));
         PT_HIP(ctx, hipMalloc((void **)&out.d_order8, sizeof(uint32_t) * (size_t)n));
         PT_HIP(ctx, hipMemsetAsync(d_front[0].p, 0, sizeof(uint32_t), st));  // level 0: the binary root, whose range starts at 0
         PT_HIP(ctx, hipMemsetAsync(d_start[0].p, 0, sizeof(uint32_t), st));
@@ -1161,6 +1184,7 @@ static pt_status build_bvh(pt_ctx *ctx, const float4 *d_tlo, const float4 *d_thi
             const uint32_t next_count = tot[0] + last[0], leaves = tot[1] + last[1];
             const uint32_t next_base = level_base + count;
             if ((uint64_t)next_base + next_count > n_int || (uint64_t)tri_run + leaves > n) { ctx->err = "internal: BVH8 build overran its bounds"; return PT_ERR_HIP; }
+            if ((uint64_t)next_base + next_count >= (1u << 24) || n >= (1u << 24)) { ctx->err = "the 8-wide nodes hold 24-bit child and triangle bases (scenes up to 16.7 M triangles)"; return PT_ERR_UNSUPPORTED; }
             k_w8_emit<<<g, TB, 0, st>>>(count, level_base, next_base, (int)n, d_kids.p, d_ni.p, d_start[cf].p, d_range.p, d_blo.p, d_bhi.p,
                                         out.norm_c[0], out.norm_c[1], out.norm_c[2], out.norm_rs[0], out.norm_rs[1], out.norm_rs[2],
                                         out.d_wide8, d_front[cf ^ 1].p, d_start[cf ^ 1].p, out.d_order8);
@@ -1326,7 +1350,7 @@ static pt_status build_tree_products(pt_scene *s, uint32_t quality, bool want8)
     // resident bytes of the BVH4 path: triangle tables (tri4 48 + shade4 48 + shade64 64 + ke4 16 + frames 32 B each) + the
     // 128-B and the two 64-B node arrays; of the 8-wide path: its tables + nodes
     s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
-    s->device_bytes8 = s->d_wide8 ? (uint64_t)n * (48 + 64 + 16 + 4) + 128ull * s->n_wide8 : 0ull;
+    s->device_bytes8 = s->d_wide8 ? (uint64_t)n * (48 + 64 + 16 + 4) + 64ull * s->n_wide8 : 0ull;
     s->quality = quality;
     return make_wide16(s);
 }
@@ -1371,7 +1395,8 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     // the tree of the default quality (ePreferFastTrace, main.cpp:419): PLOC for big scenes; small scenes get the LBVH
     // here and the exact surface-area BVH4 below.  The 8-wide nodes only when the context asks AUTO to use them.
     // (small scenes get the 8-wide nodes at once -- a few KB; big ones on first request: 260 B per triangle nobody else needs)
-    pt_status rc = build_tree_products(s, PT_BVH_PREFER_FAST_TRACE, ctx->tune.hbm8 == 1 || n <= PT_SAH_MAX_TRIS);
+    // ... and scenes whose traversal working set will exceed the 32 MiB of L2 (~96 B per triangle), which AUTO walks through them
+    pt_status rc = build_tree_products(s, PT_BVH_PREFER_FAST_TRACE, ctx->tune.hbm8 == 1 || n <= PT_SAH_MAX_TRIS || (ctx->tune.hbm8 != 0 && 96ull * n > (32ull << 20)));
     if (rc != PT_OK) return rc;
     {   // emitters for the NEE pipeline: normal as closesthit.rchit:43-48, area = |cross| / 2, cdf = running float sum of the
         // areas in primitive order (this file is compiled with -ffp-contract=off on the host side too)
@@ -1394,6 +1419,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
         }
         s->n_lights = (uint32_t)(lights.size() / 5);
         s->light_area = run;
+        s->h_lights = lights;
         if (s->n_lights) {
             PT_HIP(ctx, hipMalloc((void **)&s->d_lights, sizeof(float4) * lights.size()));
             PT_HIP(ctx, hipMemcpy(s->d_lights, lights.data(), sizeof(float4) * lights.size(), hipMemcpyHostToDevice));
@@ -1561,6 +1587,8 @@ static void invert_3x4(const float m[12], float inv[12])
 
 void ptb_free_instances(pt_scene *s)
 {
+    (void)hipFree(s->d_lights_inst);
+    s->d_lights_inst = nullptr; s->n_lights_inst = 0; s->light_area_inst = 0.f;
     (void)hipFree(s->d_inst6); (void)hipFree(s->d_tlas_wide); (void)hipFree(s->d_tlas_prim_of); (void)hipFree(s->d_tlas16);
     s->d_inst6 = nullptr; s->d_tlas_wide = nullptr; s->d_tlas_prim_of = nullptr; s->d_tlas16 = nullptr; s->n_tlas16 = 0;
     s->n_inst = 0; s->n_tlas_wide = 0; s->tlas_height = 0;
@@ -1605,6 +1633,37 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     for (int k = 0; k < 3; k++) { s->tlas_norm_c[k] = o.norm_c[k]; s->tlas_norm_s[k] = o.norm_s[k]; s->tlas_norm_rs[k] = o.norm_rs[k]; }
     if (rc != PT_OK) { ptb_free_instances(s); return rc; }
     PT_HIP(ctx, hipMalloc((void **)&s->d_inst6, sizeof(float4) * 6 * (size_t)n));
+    if (s->n_lights) {
+        // emitters of the NEE pipeline for an instanced scene: every instance's copy, in gl_InstanceID order, vertices taken to
+        // world space by the instance's matrix with the operation order of the shading transform; normal and area from the
+        // world-space triangle; one running cdf over all of them (the tests' CPU checker restates this loop)
+        std::vector<float4> wl;
+        wl.reserve(5 * (size_t)n * s->n_lights);
+        float run = 0.f;
+        for (uint32_t i = 0; i < n; i++) {
+            const float *m = xforms3x4 + 12 * (size_t)i;
+            for (uint32_t k = 0; k < s->n_lights; k++) {
+                float w[3][3];
+                for (int c = 0; c < 3; c++) {
+                    const float4 v = s->h_lights[5 * (size_t)k + c];
+                    for (int r = 0; r < 3; r++) w[c][r] = ((m[4 * r] * v.x + m[4 * r + 1] * v.y) + m[4 * r + 2] * v.z) + m[4 * r + 3];
+                }
+                const float e1[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, e2[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
+                const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                const float len = sqrtf((cx * cx + cy * cy) + cz * cz);
+                run = run + 0.5f * len;
+                wl.push_back(make_float4(w[0][0], w[0][1], w[0][2], run));
+                wl.push_back(make_float4(w[1][0], w[1][1], w[1][2], 0.f));
+                wl.push_back(make_float4(w[2][0], w[2][1], w[2][2], 0.f));
+                wl.push_back(make_float4(-(cx / len), -(cy / len), -(cz / len), 0.f));
+                wl.push_back(s->h_lights[5 * (size_t)k + 4]);
+            }
+        }
+        PT_HIP(ctx, hipMalloc((void **)&s->d_lights_inst, sizeof(float4) * wl.size()));
+        PT_HIP(ctx, hipMemcpy(s->d_lights_inst, wl.data(), sizeof(float4) * wl.size(), hipMemcpyHostToDevice));
+        s->n_lights_inst = (uint32_t)(wl.size() / 5);
+        s->light_area_inst = run;
+    }
     k_inst_sort<<<g, TB, 0, st>>>(d_in.p, s->d_tlas_prim_of, n, s->d_inst6);
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());

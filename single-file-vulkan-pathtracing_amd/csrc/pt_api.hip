@@ -255,7 +255,7 @@ pt_status pt_scene_read_bvh8(const pt_scene *s, uint32_t *nodes32, uint32_t *pri
     }
     if (!s->d_wide8) { ctx->err = "the scene has no BVH8 (a single triangle, or instanced)"; return PT_ERR_UNSUPPORTED; }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (nodes32) PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide8, 128 * (size_t)s->n_wide8, hipMemcpyDeviceToHost));
+    if (nodes32) PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide8, 64 * (size_t)s->n_wide8, hipMemcpyDeviceToHost));
     if (prim_of_pos8) PT_HIP(ctx, hipMemcpy(prim_of_pos8, s->d_prim_of8, sizeof(uint32_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
     return PT_OK;
 }

@@ -101,6 +101,11 @@ struct pt_scene {
     float4 *d_lights = nullptr;
     uint32_t n_lights = 0;
     float light_area = 0.f;
+    std::vector<float4> h_lights;   // host copy of d_lights: instancing makes its world-space copies from it
+    // instanced scenes: every instance's emitters in world space, gl_InstanceID-major, same 5-float4 layout and running cdf
+    float4 *d_lights_inst = nullptr;
+    uint32_t n_lights_inst = 0;
+    float light_area_inst = 0.f;
     // two-level scenes: instances in TLAS leaf order, 6 float4 each {object->world rows, world->object rows}
     uint32_t n_inst = 0, n_tlas_wide = 0, tlas_height = 0;
     float4 *d_inst6 = nullptr;

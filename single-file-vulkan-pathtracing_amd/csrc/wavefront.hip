@@ -43,7 +43,7 @@ void ptw_launch_extend_hbm(bool count, bool rec64, int grid, size_t smem, hipStr
 // extend_hbm.hip: k_extend8 (BVH8)
 const void *ptw_extend8_fn(bool count);
 void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
-                        const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rayA,
+                        const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rec64, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                         uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
                         const uint32_t *perm, const float *ray_tmax);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
 // (one identity instance, main.cpp:515-538); semantics in DESIGN.md section 3.
 constexpr uint32_t EXIT_MARK = 0x7FFFFFFFu;
 
-template <bool COUNT, bool LDS_BLAS>
+template <bool COUNT, bool LDS_BLAS, bool SHADOW = false>
 __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ tlas, const float4 *__restrict__ g_blas,
                                                     const float4 *__restrict__ g_tri4, uint32_t n_blas_wide,
                                                     uint32_t n_tris, const float4 *__restrict__ inst6,
@@ -261,8 +261,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                                                     uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
                                                     uint32_t *count_zero, unsigned long long *stats,
                                                     uint2 *__restrict__ spill, uint32_t spill_stride, int refill_min_idle,
-                                                    float tmin, float tmax, int raw_hit)
+                                                    float tmin, float tmax, int raw_hit, const float *__restrict__ ray_tmax)
 {
+    // SHADOW (the NEE pipeline's shadow rays): a per-ray upper bound instead of tmax, any hit below it ends the walk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *stack = reinterpret_cast<uint2 *>(smem);  // [LDS_STACK][TB]
     const float4 *blas = g_blas;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                     ay = inv.y < 0.f ? 48u : 0u;
                     az = inv.z < 0.f ? 48u : 0u;
                     in_blas = false;
-                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_t = SHADOW ? ray_tmax[q] : tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
                     best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
                     cur = 0u;  // TLAS root
                     cur_t = tmin;
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                             if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
                                 best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
                                 best_ipos = cur_ipos; best_iid = cur_iid;
+                                if (SHADOW) sp = 0;  // any hit will do
                             }
                         }
                     }
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst(const float4 *__restrict__ t
                 hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
                                  : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
                                                miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
-                hit_inst[q] = best_ipos;
+                if (!SHADOW) hit_inst[q] = best_ipos;
                 have = false;
             }
         }
@@ -1008,7 +1010,13 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
     if (want > PT_EXTEND_HBM8) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
-    if ((want == PT_EXTEND_HBM8 || (want == PT_EXTEND_AUTO && ctx->tune.hbm8 == 1)) && !s->n_inst && !s->d_wide8) {
+    // AUTO walks scenes beyond L2 through the 8-wide tree (64-B nodes with byte planes): fewer distinct lines per ray -- measured on
+    // MI355X, same box, three rounds: C5 2 465 -> 2 547 Mrays/s (+3.4 %), C5x 2 405 -> 2 546 (+5.9 %), 36.2 -> 27.7 and 29.5 -> 24.2
+    // node visits per ray (profiles/r03_ab_c5_c5x_hbm8_64B_nodes.log); pt_tuning.hbm8 = 0 keeps the BVH4, 1 takes the 8-wide tree
+    // for every scene that does not fit LDS
+    const uint64_t ws4 = 64ull * (s->n_wide16t ? s->n_wide16t : s->n_wide) + 64ull * s->n_tris;
+    const bool auto8_big = want == PT_EXTEND_AUTO && ctx->tune.hbm8 != 0 && ws4 > (32ull << 20) && s->n_tris > PT_SAH_MAX_TRIS;
+    if ((want == PT_EXTEND_HBM8 || (want == PT_EXTEND_AUTO && ctx->tune.hbm8 == 1) || auto8_big) && !s->n_inst && !s->d_wide8) {
         const pt_status rc8 = ptb_ensure_wide8(s);   // built on first request (260 B per triangle nobody else needs)
         if (rc8 != PT_OK) return rc8;
     }
@@ -1083,11 +1091,9 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         return PT_OK;
     }
     const size_t scene_bytes = 16 * LDS_NODE_F4 * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;  // 3 permuted triangle copies
-    // AUTO keeps the BVH4 (64-B nodes) for scenes that do not fit LDS: measured on MI355X (1M / 8M-triangle soups) the
-    // BVH8 visits 26 % fewer nodes but fetches as many 128-B LINES (two 64-B BVH4 siblings share one), and lines are
-    // what the memory system charges beyond L2 -- extend + shade kernel time 458 vs 395 ms per 4 frames of C5, equal on
-    // C5x.  PT_EXTEND_HBM8 (or PT_TUNE_BVH8=1 under AUTO) selects it.
-    const bool auto8 = want == PT_EXTEND_AUTO && scene_bytes > 24 * 1024 && s->d_wide8 && ctx->tune.hbm8 == 1;
+    // (round 2's 128-B eight-wide node with fp16 planes visited 26 % fewer nodes and fetched as many 128-B LINES -- two 64-B
+    // BVH4 siblings share one -- and lost: 458 vs 395 ms of kernel time per 4 frames of C5; the 64-B node above is its successor)
+    const bool auto8 = want == PT_EXTEND_AUTO && scene_bytes > 24 * 1024 && s->d_wide8 && (ctx->tune.hbm8 == 1 || auto8_big);
     if (want == PT_EXTEND_HBM8 || auto8) {
         pl.variant = PT_EXTEND_HBM8;
         pl.bvh8 = true;
@@ -1192,13 +1198,14 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         // the node loop yields to the lanes waiting with a leaf once fewer than 1/6 of the wave's rays still descend
         // (C4 11.7 -> 12.2 Grays/s; 2, 3, 4, 8 measured within 1 % of it, 0 = never: profiles/r02i_ab_c4_node_yield.log)
         const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
-#define PT_LAUNCH_INST16(C, P)                                                                                              \
-    hipExtLaunchKernelGGL((k_extend_inst16<C, P>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
+#define PT_LAUNCH_INST16(C, P, S)                                                                                           \
+    hipExtLaunchKernelGGL((k_extend_inst16<C, P, S>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
                           reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6,     \
                           s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp32, str, pl.refill, tmin, \
-                          tmax, raw, pl.lds_stack, enter_min, node_yield, pl.n_tlas_lds)
-        if (s->pair_leaves) { if (count) PT_LAUNCH_INST16(true, true); else PT_LAUNCH_INST16(false, true); }
-        else { if (count) PT_LAUNCH_INST16(true, false); else PT_LAUNCH_INST16(false, false); }
+                          tmax, raw, pl.lds_stack, enter_min, node_yield, pl.n_tlas_lds, ray_tmax)
+        if (ray_tmax) { if (s->pair_leaves) PT_LAUNCH_INST16(false, true, true); else PT_LAUNCH_INST16(false, false, true); }  // shadow rays (NEE)
+        else if (s->pair_leaves) { if (count) PT_LAUNCH_INST16(true, true, false); else PT_LAUNCH_INST16(false, true, false); }
+        else { if (count) PT_LAUNCH_INST16(true, false, false); else PT_LAUNCH_INST16(false, false, false); }
 #undef PT_LAUNCH_INST16
         return;
     }
@@ -1207,14 +1214,15 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         const size_t smem_i = pl.inst16 ? pl.smem_inst_fallback : pl.smem;
         uint2 *sp = reinterpret_cast<uint2 *>(s->ctx->d_spill) + (size_t)pipe * std::max(pl.spill_levels, 1u) * (size_t)std::max(pl.grid, pl.grid_inst_fallback) * TB;
         const uint32_t str = (uint32_t)grid_i * TB;
-#define PT_LAUNCH_INST(C, L)                                                                                             \
-    hipExtLaunchKernelGGL((k_extend_inst<C, L>), dim3(grid_i), dim3(TB), (uint32_t)smem_i, st, ev0, ev1, 0u, s->d_tlas_wide, \
+#define PT_LAUNCH_INST(C, L, S)                                                                                          \
+    hipExtLaunchKernelGGL((k_extend_inst<C, L, S>), dim3(grid_i), dim3(TB), (uint32_t)smem_i, st, ev0, ev1, 0u, s->d_tlas_wide, \
                           s->d_wide, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6, s->d_tlas_prim_of, rayA, rayB, hit,           \
-                          hit_inst, count_in, count_zero, stats, sp, str, pl.refill, tmin, tmax, raw)
-        if (pl.lds_scene) {
-            if (count) PT_LAUNCH_INST(true, true); else PT_LAUNCH_INST(false, true);
+                          hit_inst, count_in, count_zero, stats, sp, str, pl.refill, tmin, tmax, raw, ray_tmax)
+        if (ray_tmax) { if (pl.lds_scene) PT_LAUNCH_INST(false, true, true); else PT_LAUNCH_INST(false, false, true); }  // shadow rays (NEE)
+        else if (pl.lds_scene) {
+            if (count) PT_LAUNCH_INST(true, true, false); else PT_LAUNCH_INST(false, true, false);
         } else {
-            if (count) PT_LAUNCH_INST(true, false); else PT_LAUNCH_INST(false, false);
+            if (count) PT_LAUNCH_INST(true, false, false); else PT_LAUNCH_INST(false, false, false);
         }
 #undef PT_LAUNCH_INST
         return;
@@ -1227,7 +1235,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
     if (pl.bvh8) {
-        ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, rayA, rayB, hit,
+        ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, s->d_shade64_8, rayA, rayB, hit,
                            count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw, perm, ray_tmax);
         return;
     }
@@ -1546,7 +1554,6 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
     if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
     if (p->pipeline > PT_PIPELINE_WAVEFRONT_NEE) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT_NEE) {
-        if (s->n_inst) { ctx->err = "the NEE pipeline renders single-level scenes only"; return PT_ERR_UNSUPPORTED; }
         if (p->extend == PT_EXTEND_FLAT) { ctx->err = "the NEE pipeline has no flat extend variant (shadow rays need a per-ray tmax)"; return PT_ERR_UNSUPPORTED; }
         if (p->sample_groups > 1) { ctx->err = "the NEE pipeline runs one sample group per pixel"; return PT_ERR_UNSUPPORTED; }
     }
@@ -1709,7 +1716,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     // ray sorting (ray_sort.hip): the HBM kernels only; AUTO when the traversal working set does not fit the Infinity Cache
     bool sort_rays = false;
     if ((pl.variant == PT_EXTEND_HBM || pl.variant == PT_EXTEND_HBM8) && !s->n_inst) {
-        const uint64_t working_set = pl.bvh8 ? 128ull * s->n_wide8 + 48ull * s->n_tris
+        const uint64_t working_set = pl.bvh8 ? 64ull * s->n_wide8 + 64ull * s->n_tris
                                              : 64ull * (pl.topdown4 ? s->n_wide16t : s->n_wide) + 48ull * s->n_tris;
         sort_rays = working_set > (256ull << 20);
         if (p->flags & PT_FLAG_SORT_RAYS) sort_rays = true;
@@ -1732,6 +1739,10 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
         }
     }
     const bool nee = p->pipeline == PT_PIPELINE_WAVEFRONT_NEE;
+    // the emitters the NEE pipeline samples: the scene's, or -- instanced -- every instance's copy of them in world space
+    const float4 *const nee_lights = s->n_inst ? s->d_lights_inst : s->d_lights;
+    const uint32_t nee_n_lights = s->n_inst ? s->n_lights_inst : s->n_lights;
+    const float nee_light_area = s->n_inst ? s->light_area_inst : s->light_area;
     if (nee && (size_t)w.n_slots > w.cap_sq) {  // the shadow queue: at most one entry per live path and round
         (void)hipFree(w.d_sq_rayA); (void)hipFree(w.d_sq_rayB); (void)hipFree(w.d_sq_contrib); (void)hipFree(w.d_sq_slot);
         (void)hipFree(w.d_sq_tmax); (void)hipFree(w.d_sq_hit);
@@ -1831,12 +1842,12 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     hipExtLaunchKernelGGL((k_shade<N, L, E>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
                           &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst,                    \
-                          pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4, s->d_lights, s->n_lights,   \
-                          s->light_area, sq, sq_count, s->d_frame4)
+                          pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4, nee_lights, nee_n_lights,      \
+                          nee_light_area, sq, sq_count, s->d_frame4)
                     if (nee) {
                         if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, true); }
                         else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, true); }
-                        if (s->n_lights) {
+                        if (nee_n_lights) {
                             // the shadow rays of this round: any-hit queries with their own tmax, then the unoccluded terms
                             launch_extend(pl, s, sq.rayA, sq.rayB, w.d_sq_hit + pp.slot_begin, nullptr, sq_count, nullptr, ctx->d_stats,
                                           p->tmin, p->tmax, false, true, pp.st, k, nullptr, nullptr, nullptr, sq.tmax);

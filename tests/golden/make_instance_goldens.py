@@ -126,7 +126,7 @@ def main():
     t0 = time.time()
     w, h = 120, 68
     with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
-        res = pool.map(run_pixel, [(x, y, w, h, True) for y in range(h) for x in range(w)], chunksize=32)
+        res = pool.map(run_pixel, [(x, y, w, h, (x + y) % 3 == 0) for y in range(h) for x in range(w)], chunksize=32)   # every third pixel's queries are logged
     log = [e for r in res for e in r[2]]
     out = {"launch": np.array([w, h], np.int32), "instances": instances(),
            "texels": np.array([r[0] for r in res], np.float32).reshape(h, w, 4),

@@ -1413,8 +1413,8 @@ def _half(u16):
 
 
 def _check_bvh8(pt, gs, v, n):
-    """structure of the BVH8: contiguous children, every triangle in exactly one leaf slot, fp16 child boxes that contain
-    their triangles (through every level)"""
+    """structure of the 8-wide tree: contiguous children, every triangle in exactly one leaf slot, decoded byte-plane boxes
+    that contain their triangles (through every level)"""
     nodes, prim8 = gs.read_bvh8()
     info = gs.info()
     assert nodes.shape[0] == info.n_wide8_nodes >= 1 and sorted(prim8.tolist()) == list(range(n))
@@ -1422,11 +1422,15 @@ def _check_bvh8(pt, gs, v, n):
     ext = (bmax - bmin).max()
     c, s = 0.5 * (bmin + bmax), np.maximum(0.5 * (bmax - bmin), max(ext * 2.0 ** -10, 1e-30))
     tri = np.asarray(v, np.float64).reshape(-1, 3, 3)
-    halves = nodes[:, :24].copy().view(np.uint16).reshape(-1, 6, 8)          # [node][lo.x lo.y lo.z hi.x hi.y hi.z][slot]
-    lo = _half(halves[:, 0:3, :]) * s[None, :, None] + c[None, :, None]
-    hi = _half(halves[:, 3:6, :]) * s[None, :, None] + c[None, :, None]
-    child_base, tri_base, masks = nodes[:, 24], nodes[:, 25], nodes[:, 26]
-    imask, lmask = masks & 0xFF, (masks >> 8) & 0xFF
+    # 64-B nodes: byte planes on the node's grid (include/pt_api.h pt_scene_read_bvh8)
+    q = nodes[:, :12].copy().view(np.uint8).reshape(-1, 6, 8).astype(np.float64)   # [node][lo.x lo.y lo.z hi.x hi.y hi.z][slot]
+    o16 = np.stack([nodes[:, 12] & 0xFFFF, nodes[:, 12] >> 16, nodes[:, 13] & 0xFFFF], 1).astype(np.float64)
+    ecode = np.stack([(nodes[:, 13] >> 16) & 31, (nodes[:, 13] >> 21) & 31, nodes[:, 13] >> 26], 1).astype(np.float64)
+    origin, step = o16 * 2.0 ** -14 - 2.0, 2.0 ** -ecode
+    lo = (origin[:, :, None] + q[:, 0:3, :] * step[:, :, None]) * s[None, :, None] + c[None, :, None]
+    hi = (origin[:, :, None] + q[:, 3:6, :] * step[:, :, None]) * s[None, :, None] + c[None, :, None]
+    child_base, tri_base = nodes[:, 14] & 0xFFFFFF, nodes[:, 15] & 0xFFFFFF
+    imask, lmask = nodes[:, 14] >> 24, nodes[:, 15] >> 24
     assert ((imask & lmask) == 0).all()
     seen_node = np.zeros(len(nodes), np.int64)
     seen_tri = np.zeros(n, np.int64)
@@ -1452,7 +1456,7 @@ def _check_bvh8(pt, gs, v, n):
                 assert (lo[i, :, sl] <= t.min(0) + tol).all() and (hi[i, :, sl] >= t.max(0) - tol).all()
                 sub_lo[i] = np.minimum(sub_lo[i], t.min(0)); sub_hi[i] = np.maximum(sub_hi[i], t.max(0))
             else:
-                assert np.isinf(lo[i, :, sl]).all() and np.isinf(hi[i, :, sl]).all()   # empty slot: no slab interval
+                assert (q[i, 0:3, sl] == 255).all() and (q[i, 3:6, sl] == 0).all()     # empty slot: an inverted interval on every axis
     assert (seen_tri == 1).all() and seen_node[0] == 0 and (seen_node[1:] == 1).all()
     return info
 
@@ -1582,6 +1586,32 @@ def test_nee_pipeline_on_a_soup_with_many_emitters(pt, orc, gpu_ctx):
         assert film.read_f32().tobytes() == ofilm.tobytes(), extend
         film.close()
     gs.close()
+
+
+@pytest.mark.parametrize("knobs", [dict(), dict(inst16=0)])
+def test_nee_pipeline_on_instanced_scenes(pt, orc, gpu_ctx, cornell_arrays, knobs):
+    """NEE x instances: the emitters of an instanced scene are every instance's copy in world space (one
+    cdf over all of them), the shadow rays walk TLAS + BLAS as any-hit queries with a per-ray tmax -- through the compact
+    two-level kernel and the general one.  Film and the count of all rays equal the oracle's nee mode bit for bit: 7 random
+    instances (rotated, scaled) and a 12 x 12 corner of config C4's grid."""
+    grid = pt.cornell_grid_instances().reshape(100, 100, 3, 4)[:12, :12].reshape(-1, 3, 4)
+    old = gpu_ctx.set_tuning(**knobs)
+    try:
+        for inst, cam in ((_random_instances(7, 3), {}), (grid, dict(cam_origin=(-0.88, -1.9, 0.5), cam_target=(-0.88, -1.9, 0.0)))):
+            gs, osc = pt.Scene(gpu_ctx, *cornell_arrays), orc.Scene(*cornell_arrays)
+            gs.set_instances(inst)
+            osc.set_instances(inst)
+            kw = dict(width=80, height=56, spp_per_frame=4, max_depth=6, **cam)
+            ofilm, orays = _render_oracle_nee(orc, osc, 2, **kw)
+            film = pt.Film(gpu_ctx, 80, 56)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_WAVEFRONT_NEE, **kw))
+            assert gpu_ctx.stats().rays == orays, knobs
+            assert film.read_f32().tobytes() == ofilm.tobytes(), knobs
+            assert ofilm.mean() > 0.05
+            film.close(); gs.close()
+    finally:
+        gpu_ctx.set_tuning(**old)
 
 
 def test_nee_converges_to_the_reference_estimators_mean(pt, gpu_ctx, cornell_gpu):
