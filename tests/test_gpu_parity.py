@@ -641,9 +641,15 @@ def test_c5_full_size_soup_structure_and_hits(pt, orc, gpu_ctx, tmp_path):
     kw = dict(width=128, height=72, spp_per_frame=2, max_depth=16)
     pt.render(gs, film, pt.default_params(**kw))
     ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
-    assert gpu_ctx.stats().rays == orays and gpu_ctx.stats().extend_variant == pt.EXTEND_HBM
+    # 128 MB of nodes + records: beyond L2, so AUTO walks the 8-wide tree (wavefront.hip plan_extend)
+    assert gpu_ctx.stats().rays == orays and gpu_ctx.stats().extend_variant == pt.EXTEND_HBM8
     assert film.read_f32().tobytes() == ofilm.tobytes()
-    film.close(); gs.close()
+    gpu_ctx.reset_stats()
+    film2 = pt.Film(gpu_ctx, 128, 72)
+    pt.render(gs, film2, pt.default_params(extend=pt.EXTEND_HBM, **kw))  # and the BVH4 kernel on the same scene
+    assert gpu_ctx.stats().rays == orays and gpu_ctx.stats().extend_variant == pt.EXTEND_HBM
+    assert film2.read_f32().tobytes() == ofilm.tobytes()
+    film.close(); film2.close(); gs.close()
 
 
 def test_c2_full_size_32spp_crop_matches_golden(pt, orc, gpu_ctx, cornell_gpu):
