@@ -70,7 +70,8 @@ typedef struct pt_tuning {
     int32_t mem_budget_mb;  /* upper bound on a film's wavefront workspace (also env PT_MEM_BUDGET_MB); 0 = none       */
     int32_t hbm8;           /* 1: AUTO walks big scenes through the 8-wide compressed nodes (PT_EXTEND_HBM8)           */
     int32_t ploc_radius;    /* PLOC rebuild of big scenes' binary tree: neighbours searched on either side (1..32, 8)  */
-    int32_t reserved[12];
+    int32_t leaf_min;       /* compact two-level kernel: lanes that wait with a triangle leaf before the leaf step runs */
+    int32_t reserved[11];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                                                       uint32_t *__restrict__ hit_inst, const uint32_t *__restrict__ count_in,
                                                       uint32_t *count_zero, unsigned long long *stats, uint32_t *__restrict__ spill,
                                                       uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int raw_hit,
-                                                      int lds_stack, int enter_min, int node_yield, uint32_t n_tlas_lds,
+                                                      int lds_stack, int enter_min, int leaf_min, int node_yield, uint32_t n_tlas_lds,
                                                       const float *__restrict__ ray_tmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,13 +214,19 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         }
         // ---- leaf phase: a BLAS leaf (triangles) or a TLAS leaf (enter the instance)
         // entering costs ~130 VALU: lanes that want to wait until ENTER_MIN of them do, or no lane has triangle work
-        const int ENTER_MIN = enter_min;
+        const int ENTER_MIN = enter_min, LEAF_MIN = leaf_min;
         const bool at_leaf = have && (cur & I16_LEAF) && cur != I16_DONE;  // (a lane that yielded above still holds a node)
         const int n_enter = __popcll(__ballot(at_leaf && !in_blas));
-        const bool others = __ballot(have && cur != I16_DONE && (in_blas || !(cur & I16_LEAF))) != 0ull;
+        const int n_leaf = __popcll(__ballot(at_leaf && in_blas));
+        const bool descending = __ballot(have && !(cur & I16_LEAF)) != 0ull;
+        // triangle work, too, waits for LEAF_MIN lanes as long as something else moves (a lane still descending, or an entry that
+        // runs): leaf steps 20.8 -> 25.2 lanes, node steps 44.8 -> 44.3, C4 +1.3 % (8; 16: +0.9 %, 24 and 32: -1 %,
+        // profiles/r03k_ab_c4_leaf_min.log)
+        const bool do_leaf = n_leaf >= LEAF_MIN || !(descending || n_enter >= ENTER_MIN);
+        const bool others = descending || (do_leaf && n_leaf > 0);
         const bool do_enter = n_enter >= ENTER_MIN || !others;
         if (have) {
-            if (at_leaf && in_blas) {
+            if (at_leaf && in_blas && do_leaf) {
                 const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
                 if (COUNT) { c_tris += cnt; c_leaf_lanes += PAIRS ? 1u : cnt; }
                 if (PAIRS) { PT_COUNT_WAVE(c_tri_steps); }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                     }
                 }
                 cur = pop();
-            } else if (at_leaf && do_enter) {
+            } else if (at_leaf && !in_blas && do_enter) {
                 // TLAS leaf: one instance.  The ray goes to object space un-normalised (t is the same parameter)
                 const uint32_t first = cur & 0x7FFFu;
                 PT_COUNT_WAVE(c_enter_steps);

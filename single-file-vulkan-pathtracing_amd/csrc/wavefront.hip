@@ -1195,6 +1195,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
                               s->tlas_norm_rs[0], s->tlas_norm_rs[1], s->tlas_norm_rs[2] };
         const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
         const int enter_min = pt_tuned(s->ctx->tune.enter_min, 16, 1, 64);  // lanes that wait to enter an instance together (8, 16, 24 measured alike within 1 %)
+        const int leaf_min = pt_tuned(s->ctx->tune.leaf_min, 8, 1, 64);    // ... and lanes that wait with a triangle leaf (extend_inst16.h)
         // the node loop yields to the lanes waiting with a leaf once fewer than 1/6 of the wave's rays still descend
         // (C4 11.7 -> 12.2 Grays/s; 2, 3, 4, 8 measured within 1 % of it, 0 = never: profiles/r02i_ab_c4_node_yield.log)
         const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
@@ -1202,7 +1203,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     hipExtLaunchKernelGGL((k_extend_inst16<C, P, S>), dim3(pl.grid), dim3(TB), (uint32_t)pl.smem, st, ev0, ev1, 0u, s->d_tlas16, nbt, \
                           reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->n_wide, s->n_tris, s->d_inst6,     \
                           s->d_tlas_prim_of, rayA, rayB, hit, hit_inst, count_in, count_zero, stats, sp32, str, pl.refill, tmin, \
-                          tmax, raw, pl.lds_stack, enter_min, node_yield, pl.n_tlas_lds, ray_tmax)
+                          tmax, raw, pl.lds_stack, enter_min, leaf_min, node_yield, pl.n_tlas_lds, ray_tmax)
         if (ray_tmax) { if (s->pair_leaves) PT_LAUNCH_INST16(false, true, true); else PT_LAUNCH_INST16(false, false, true); }  // shadow rays (NEE)
         else if (s->pair_leaves) { if (count) PT_LAUNCH_INST16(true, true, false); else PT_LAUNCH_INST16(false, true, false); }
         else { if (count) PT_LAUNCH_INST16(true, false, false); else PT_LAUNCH_INST16(false, false, false); }
