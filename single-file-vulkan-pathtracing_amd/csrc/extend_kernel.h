@@ -281,7 +281,11 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= refill_min_idle) {
             if (!have) {
-                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
+                // rank among the idle lanes: the pair-leaf kernel counts with v_mbcnt (the 64-bit prefix mask `lt` is two more
+                // registers live through the whole kernel: 70 instead of 72, same speed); the others keep the mask (v_mbcnt in the
+                // HBM kernel: C5 -5 %, measured twice; in k_extend_lds7: two spills -- different schedules, nothing else)
+                const uint32_t v = cursor + (PAIRS ? __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u))
+                                                       : (uint32_t)__popcll(idle & lt));
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
@@ -290,7 +294,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     const float2 rb = rayB[q];
                     const ptm::f3 org = { ra.x, ra.y, ra.z };
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
-                    pre = ptm::ray_setup(org, dir);
+                    pre = ptm::ray_setup<!(LDS_SCENE && !PAIRS)>(org, dir);  // (k_extend_lds7: pt_math.h)
                     inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
                     if (LDS_SCENE) {
                         slab_setup(org, inv, invf, on, of);
@@ -440,23 +444,27 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     auto inside = [](float U, float V, float W) {
                         return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
                     };
-                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
+                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos) {
                         const float det = (U + V) + W;
                         PT_COUNT_WAVE(c_hit_blocks);
                         if (COUNT) c_hit_lanes++;
                         const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
                         const float t = ptm::fdiv(T, det);
                         if (!(t > tmin && t < tmax)) return;
-                        // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads)
-                        if (t < best_t || (t == best_t && prim < best_prim)) {
-                            best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
+                        // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads).  The ids of the two rivals are
+                        // read when it happens (the third vertex of every record carries its triangle's id, k_pack), not kept
+                        bool closer = t < best_t;
+                        if (!closer && t == best_t)
+                            closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
+                                                                __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
+                        if (closer) {
+                            best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos;
                             if (ray_tmax) sp = 0;  // any hit will do: nothing pending any more
                         }
                     };
                     const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
                     const bool inA = inside(UA, VA, WA);
                     float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
-                    uint32_t primB = 0u;
                     bool inB = false;
                     if (two) {
                         const float4 d = tri4[ti + 5];  // third vertex of the second half; .w = its primitive id (k_pack)
@@ -464,7 +472,6 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                         const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
                         // (v0, v2, v3): U = Dx*Cy - Dy*Cx, V = Ax*Dy - Ay*Dx, W = Cx*Ay - Cy*Ax = qAC - pAC
                         UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
-                        primB = __float_as_uint(d.w);
                         inB = inside(UB, VB, WB);
                     }
                     // A wave nearly always holds lanes inside the first half AND lanes inside the second, so two separate
@@ -474,10 +481,9 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     // in primitive order as before.  Same operations on the same operands: same bits.
                     if (inA || inB) {
                         const bool sb = !inA;
-                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first,
-                               sb ? primB : __float_as_uint(a.w));
+                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first);
                     }
-                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u, primB);
+                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u);
                     cur = pop();
                 }
             } else

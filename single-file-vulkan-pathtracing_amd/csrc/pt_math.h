@@ -52,6 +52,52 @@ __device__ __forceinline__ void div3_by_pdf(float &x, float &y, float &z)
         x = fdiv(x, PT_PDF); y = fdiv(y, PT_PDF); z = fdiv(z, PT_PDF);
     }
 }
+// ---- the correctly rounded quotient by fused multiply-adds (Markstein 1990) ------------------------------------------
+// recip_rn(b) = RN(1/b) and quot_rn(a, b, recip_rn(b)) = RN(a/b): three instructions each instead of the ten of the IEEE
+// divide expansion (v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup), and quotients that share a divisor share the
+// reciprocal.  The results ARE the IEEE quotients, bit for bit -- not by argument but by enumeration on this chip
+// (scripts/ubench/exact_div.hip, profiles/r03_exact_div_proof.txt): the reciprocal for every normal b with
+// 2^-126 <= |b| < 2^126, the quotient for all 2^46 pairs of significands -- provided nothing overflows, underflows or
+// turns denormal on the way (the sequences are exact scalings by powers of two away from 1 <= a, b < 2 otherwise), which
+// is what the guards of the callers below establish: the divisor within 2^+-20 (2^+-40) and every dividend at least
+// 2^-100 (2^-60) in magnitude and no larger than the divisor (than 2^60).  A zero dividend takes the IEEE path too (the
+// residual would lose the sign of a -0).  Operands outside the guards take the real divide: same bits, old speed.
+__device__ __forceinline__ float recip_rn(float b)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float quot_rn(float a, float b, float y)
+{
+    const float q0 = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+}
+// |b| in [2^-20, 2^20] and the smaller dividend at least 2^-100 (the callers' dividends never exceed the divisor in magnitude)
+__device__ __forceinline__ bool quot_guard_dominant(float b, float amin_abs)
+{
+    const float ab = fabsf(b);
+    return __builtin_amdgcn_fmed3f(ab, 0x1p-20f, 0x1p+20f) == ab && amin_abs >= 0x1p-100f;
+}
+// a1 / b, a2 / b with |a1|, |a2| <= |b| (a hit's barycentric numerators over their sum; direction components over the dominant one)
+__device__ __forceinline__ void div2_dominant(float a1, float a2, float b, float &q1, float &q2)
+{
+    if (quot_guard_dominant(b, fminf(fabsf(a1), fabsf(a2)))) {
+        const float y = recip_rn(b);
+        q1 = quot_rn(a1, b, y); q2 = quot_rn(a2, b, y);
+    } else {
+        q1 = fdiv(a1, b); q2 = fdiv(a2, b);
+    }
+}
+// a1 / b, a2 / b, a3 / b with |a_i| <= |b| (a vector over its length)
+__device__ __forceinline__ void div3_dominant(float a1, float a2, float a3, float b, float &q1, float &q2, float &q3)
+{
+    if (quot_guard_dominant(b, fminf(fminf(fabsf(a1), fabsf(a2)), fabsf(a3)))) {
+        const float y = recip_rn(b);
+        q1 = quot_rn(a1, b, y); q2 = quot_rn(a2, b, y); q3 = quot_rn(a3, b, y);
+    } else {
+        q1 = fdiv(a1, b); q2 = fdiv(a2, b); q3 = fdiv(a3, b);
+    }
+}
 // NOTE: __fsqrt_rn() lowers to the bare 1-ulp v_sqrt_f32 on gfx950 (ROCm 7.2); __builtin_sqrtf
 // gets the correctly rounded expansion (v_sqrt_f32 + two fma corrections), which is what the
 // canonical arithmetic requires.
@@ -145,7 +191,7 @@ __device__ __forceinline__ void primary_ray(const Camera &cam, uint32_t px, uint
     const float vz = cam.tz - cam.oz;
     const float len = fsqrt((vx * vx + vy * vy) + vz * vz);
     org = { cam.ox, cam.oy, cam.oz };
-    dir = { fdiv(vx, len), fdiv(vy, len), fdiv(vz, len) };
+    div3_dominant(vx, vy, vz, len, dir.x, dir.y, dir.z);
 }
 
 // ---- bounce: raygen.rgen:14-39 ---------------------------------------------------------
@@ -218,6 +264,9 @@ struct RayPre {
 
 __device__ __forceinline__ float sel3(int k, float x, float y, float z) { return k == 0 ? x : (k == 1 ? y : z); }
 
+// SHORT_DIV = false keeps the IEEE expansion: its three divides run one after the other (they pass VCC along), which the
+// per-triangle leaf loop of k_extend_lds7 needs to stay within 72 registers
+template <bool SHORT_DIV = true>
 __device__ __forceinline__ RayPre ray_setup(const f3 org, const f3 dir)
 {
     RayPre r;
@@ -228,9 +277,17 @@ __device__ __forceinline__ RayPre ray_setup(const f3 org, const f3 dir)
     const float dkx = sel3(kz, dir.y, dir.z, dir.x);
     const float dky = sel3(kz, dir.z, dir.x, dir.y);
     const float dkz = sel3(kz, dir.x, dir.y, dir.z);
-    r.Sx = fdiv(dkx, dkz);
-    r.Sy = fdiv(dky, dkz);
-    r.Sz = fdiv(1.0f, dkz);
+    // three true divides by the dominant component: |dkx|, |dky| <= |dkz|, and 1/dkz is the reciprocal itself
+    if (SHORT_DIV && quot_guard_dominant(dkz, fminf(fabsf(dkx), fabsf(dky)))) {
+        const float y = recip_rn(dkz);
+        r.Sx = quot_rn(dkx, dkz, y);
+        r.Sy = quot_rn(dky, dkz, y);
+        r.Sz = y;
+    } else {
+        r.Sx = fdiv(dkx, dkz);
+        r.Sy = fdiv(dky, dkz);
+        r.Sz = fdiv(1.0f, dkz);
+    }
     r.kz = kz;
     r.org = org;
     return r;

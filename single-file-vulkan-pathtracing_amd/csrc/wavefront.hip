@@ -575,7 +575,7 @@ __device__ __forceinline__ bool nee_sample(const float4 *__restrict__ lights, ui
     const float d2 = (dx * dx + dy * dy) + dz * dz;
     if (!(d2 > 0.0f)) return false;
     const float dist = ptm::fsqrt(d2);
-    wi = { ptm::fdiv(dx, dist), ptm::fdiv(dy, dist), ptm::fdiv(dz, dist) };
+    ptm::div3_dominant(dx, dy, dz, dist, wi.x, wi.y, wi.z);
     const float cs = (wi.x * n.x + wi.y * n.y) + wi.z * n.z;
     const float cl = fabsf((wi.x * N.x + wi.y * N.y) + wi.z * N.z);
     if (!(cs > 0.0f && cl > 0.0f)) return false;
@@ -748,7 +748,8 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                     }
                     // closesthit.rchit:56-57: position from barycentrics, (v0*b0 + v1*b1) + v2*b2
                     // the hit record carries (V, W, det) of the watertight test; attribs = (V/det, W/det)
-                    const float hu = ptm::fdiv(h.y, h.w), hv = ptm::fdiv(h.z, h.w);
+                    float hu, hv;  // (0 <= V/det, W/det <= 1: ptm::div2_dominant's exact short division)
+                    ptm::div2_dominant(h.y, h.z, h.w, hu, hv);
                     const float b0 = (1.0f - hu) - hv;
                     org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv,
                             (a.z * b0 + b.z * hu) + c.z * hv };

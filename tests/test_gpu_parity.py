@@ -277,6 +277,52 @@ def test_trace_random_rays_soup_bit_exact(pt, orc, gpu_ctx):
     gs.close()
 
 
+def test_ray_setup_divides_inside_and_outside_the_short_division_guards(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    """ptm::ray_setup takes its three quotients by the exact short division (recip_rn / quot_rn) when the dominant direction
+    component lies within 2^+-20 and the others are at least 2^-100 in magnitude, and by the IEEE divide otherwise: rays on
+    both sides of every guard -- un-normalised directions from 2^-30 to 2^30 long, components that are zero, -0, denormal,
+    2^-110, just inside and just outside the bounds -- must give the oracle's records on every kernel (single-level LDS /
+    HBM / flat / 8-wide, and the two-level kernel, whose instance entry divides in object space)."""
+    rng = np.random.default_rng(77)
+    n = 6000
+    org = (rng.uniform(-0.9, 0.9, (n, 3)) + np.array([0, -1, 0])).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    scale = 2.0 ** rng.integers(-30, 31, n)                      # the dominant component on either side of 2^+-20
+    scale[: n // 3] = 1.0
+    d = (d * scale[:, None]).astype(np.float32)
+    tiny = np.float32([0.0, -0.0, 1e-45, -3e-42, 2.0 ** -110, -(2.0 ** -101), 2.0 ** -100, -(2.0 ** -99)])
+    k = np.arange(n)
+    sel = k % 5 == 0
+    d[sel, (k[sel] // 5) % 3] = tiny[(k[sel] // 15) % len(tiny)]   # one small / zero component
+    sel2 = k % 35 == 0
+    d[sel2, (k[sel2] // 5 + 1) % 3] = tiny[(k[sel2] // 7) % len(tiny)]  # sometimes two
+    edge = np.float32([2.0 ** -20, np.nextafter(np.float32(2.0 ** -20), np.float32(0)), 2.0 ** 20, np.nextafter(np.float32(2.0 ** 20), np.float32(np.inf))])
+    for j, e in enumerate(edge):                                  # exactly on and one ulp off the divisor's bounds
+        d[100 + j] = np.float32([0.3, -0.2, 1.0]) * e
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    ohits, _ = cornell_oracle.trace(rays, mode=0, tmax=1e30)
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_FLAT, pt.EXTEND_LDS, pt.EXTEND_HBM):
+        hits = cornell_gpu.trace(rays, extend=variant, tmax=1e30)
+        assert hits.tobytes() == ohits.tobytes(), variant
+    assert (ohits["prim"] != pt.MISS).mean() > 0.3
+    v, i, f = _soup(20000, 23, spread=0.05)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    rays[:, :3] = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32)
+    want, _ = osc.trace(rays, mode=1, tmax=1e30)
+    for variant in (pt.EXTEND_HBM, pt.EXTEND_HBM8):
+        assert gs.trace(rays, extend=variant, tmax=1e30).tobytes() == want.tobytes(), variant
+    gs.close()
+    v, i, f = pt.load_obj(pt.ASSET_CORNELL)
+    inst = _random_instances(7, 3)
+    gi, oi = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    gi.set_instances(inst)
+    oi.set_instances(inst)
+    want, _ = oi.trace(rays, mode=1, tmax=1e30)
+    assert gi.trace(rays, tmax=1e30).tobytes() == want.tobytes()
+    gi.close()
+
+
 def test_c1_render_bit_exact(pt, orc, gpu_ctx, cornell_gpu):
     """BASELINE.json config 1: 256x256, 1 spp, depth 4 -- against the committed golden."""
     g = np.load(os.path.join(HERE, "golden", "c1_256_1spp_d4.npz"))
