@@ -142,6 +142,10 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->h_poll) (void)hipHostFree(ctx->h_poll);
+    for (int k = 0; k < PT_MAX_PIPES; k++)
+        for (int j = 0; j < 2; j++)
+            if (ctx->ev_poll[k][j]) (void)hipEventDestroy(ctx->ev_poll[k][j]);
     for (int k = 0; k < PT_MAX_PIPES; k++) {
         if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
         if (ctx->pipe_stream[k]) (void)hipStreamDestroy(ctx->pipe_stream[k]);

@@ -34,6 +34,10 @@ struct pt_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipStream_t pipe_stream[PT_MAX_PIPES] = {};  // extra pipelines of pt_render ([0] unused: that is `stream`)
     hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_PIPES] = {};
+    // live-count polls of the round loop (wavefront.hip): per pipeline two pinned words and two events, used alternately,
+    // so the host reads the count of eight rounds ago while the stream still holds eight rounds of work
+    uint32_t *h_poll = nullptr;                      // [PT_MAX_PIPES][2], hipHostMalloc
+    hipEvent_t ev_poll[PT_MAX_PIPES][2] = {};
     std::vector<hipEvent_t> ev_pool;  // PT_FLAG_PROFILE start/stop events, reused across pt_render calls
     void *d_spill = nullptr;   // HBM overflow of the traversal short stack: [level][thread] uint2
     size_t spill_bytes = 0;

@@ -1618,6 +1618,10 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
             PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         }
     if (!ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->h_poll) PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_poll, sizeof(uint32_t) * 2 * PT_MAX_PIPES, hipHostMallocDefault));
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < 2; j++)
+            if (!ctx->ev_poll[k][j]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_poll[k][j], hipEventDisableTiming));
     if (p->flags & PT_FLAG_PROFILE) {
         const size_t batches = ((size_t)p->frame_count + sh.lanes - 1) / sh.lanes;
         const size_t want = std::min<size_t>(4ull * sh.group_size * p->max_depth * 2ull * batches, 1u << 16);
@@ -1700,6 +1704,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
         uint32_t *count;  // [2] queue sizes of this pipeline
         int cur;
         bool done;
+        int polls;        // live-count polls queued on this pipeline's stream in the current batch
     };
     // two pipelines overlap one's traversal with the other's shading.  A third: C2 +2 % on one box and -1 % on another
     // (interleaved repetitions), C4 -3 %, C5 -3 %, C5x -5 %; a fourth loses everywhere.  Capping the persistent extend
@@ -1714,6 +1719,10 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
             PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         }
     if (n_pipes > 1 && !ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->h_poll) PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_poll, sizeof(uint32_t) * 2 * PT_MAX_PIPES, hipHostMallocDefault));
+    for (int k = 0; k < n_pipes; k++)
+        for (int j = 0; j < 2; j++)
+            if (!ctx->ev_poll[k][j]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_poll[k][j], hipEventDisableTiming));
 
     // ray sorting (ray_sort.hip): the HBM kernels only; AUTO when the traversal working set does not fit the Infinity Cache
     bool sort_rays = false;
@@ -1791,6 +1800,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                 pp.count = w.d_count + 2 * k;
                 pp.cur = 0;
                 pp.done = false;
+                pp.polls = 0;
             }
             if (pipes_now > 1) {  // the other streams start after the counters are cleared
                 PT_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
@@ -1869,18 +1879,26 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                     pp.cur ^= 1;
                 }
                 ctx->stats.rounds++;
-                // every slot needs >= group_size rounds; after that poll the live counts now and then
+                // Every slot needs >= group_size rounds; after that the live counts are polled every eighth round so that a batch
+                // whose paths have all ended stops early.  The host reads the count of the PREVIOUS poll -- eight rounds back --
+                // while each stream still holds eight rounds of launches: waiting for the newest count drained both streams,
+                // restarted the pipelines in phase (traversal beside traversal) and left one of them idle until the other had
+                // caught up: 5.3 ms of the 147 ms of 16 C2 frames (kernel timeline, profiles/r03r_c2_timeline_before.txt).
+                // A pipeline found empty has at most sixteen empty rounds queued behind it.
                 if (!async && round + 1 >= group_size && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
-                    uint32_t h_count[PT_MAX_PIPES] = {};
-                    for (int k = 0; k < pipes_now; k++)
-                        if (!pipe[k].done)
-                            PT_HIP(ctx, hipMemcpyAsync(&h_count[k], &pipe[k].count[pipe[k].cur], sizeof(uint32_t), hipMemcpyDeviceToHost, pipe[k].st));
                     bool all_done = true;
                     for (int k = 0; k < pipes_now; k++) {
-                        if (pipe[k].done) continue;
-                        PT_HIP(ctx, hipStreamSynchronize(pipe[k].st));
-                        if (h_count[k] == 0) pipe[k].done = true;
-                        else all_done = false;
+                        Pipe &pp = pipe[k];
+                        if (pp.done) continue;
+                        const int j = pp.polls & 1;
+                        PT_HIP(ctx, hipMemcpyAsync(ctx->h_poll + 2 * k + j, &pp.count[pp.cur], sizeof(uint32_t), hipMemcpyDeviceToHost, pp.st));
+                        PT_HIP(ctx, hipEventRecord(ctx->ev_poll[k][j], pp.st));
+                        if (pp.polls > 0) {
+                            PT_HIP(ctx, hipEventSynchronize(ctx->ev_poll[k][j ^ 1]));
+                            if (ctx->h_poll[2 * k + (j ^ 1)] == 0u) pp.done = true;
+                        }
+                        pp.polls++;
+                        if (!pp.done) all_done = false;
                     }
                     if (all_done) break;
                 }
