@@ -542,7 +542,8 @@ def main():
                                    f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
-                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "sort_rays": args.sort_rays},
+                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "pipelines": st.pipelines,
+                       "sort_rays": args.sort_rays},
             # the timed region repeated: value / ms_per_step are the median repetition
             "reps": len(reps), "value_min": min(values), "value_max": max(values), "values": values,
             "timed_seconds_total": round(sum(r[0] for r in reps), 4),
@@ -579,6 +580,11 @@ def main():
             # SURVEY 8d's canonical whole-pipeline figure: (extend + 104 shade + 96 per path / mean length) B per ray over the
             # device time of the timed region, of the HBM peak
             out["roofline"]["pipeline_frac"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # `frac` prices ONE launch against its own duration, and the launches of the concurrent pipelines share the chip:
+            # with three pipelines a launch carries a third of the rays and lasts about as long as one of two did.  The same
+            # algorithmic bytes over the device time of the timed region do not depend on how the work is cut into launches
+            out["roofline"]["pipelines"] = st.pipelines
+            out["roofline"]["frac_all_launches_over_device_time"] = round(bytes_extend * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if world == 1 and not args.no_extra_legs and args.config in ("c2", "c3"):
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()

@@ -291,7 +291,8 @@ typedef struct pt_stats {
      * tris_tested / (64 * tri_steps) that of the triangle tests.                                        */
     uint64_t node_steps, tri_steps;
     /* batches whose sample-group term log filled up and that were rendered again with one group (exact either way) */
-    uint32_t redone_batches, reserved_;
+    uint32_t redone_batches;
+    uint32_t pipelines;        /* concurrent wavefront pipelines (streams) of the last pt_render */
     /* PT_FLAG_COUNT_VISITS, single-level extend kernel: how often a WAVE executed the other blocks of the kernel --
      * the refill block, one iteration of the stack-pop loop, the hit block of the triangle test (the true divide),
      * the block that writes a hit record, one iteration of the outer loop.  With the per-block instruction counts

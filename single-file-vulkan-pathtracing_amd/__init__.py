@@ -72,7 +72,7 @@ class Stats(C.Structure):
                 ("extend_variant", C.c_uint32), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("frames_in_flight", C.c_uint32), ("sample_groups", C.c_uint32),
                 ("node_steps", C.c_uint64), ("tri_steps", C.c_uint64),
-                ("redone_batches", C.c_uint32), ("reserved_", C.c_uint32),
+                ("redone_batches", C.c_uint32), ("pipelines", C.c_uint32),
                 ("wave_refills", C.c_uint64), ("wave_pops", C.c_uint64), ("wave_hit_blocks", C.c_uint64),
                 ("wave_finishes", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("leaf_lanes", C.c_uint64), ("pop_lanes", C.c_uint64), ("hit_lanes", C.c_uint64),

@@ -1612,19 +1612,19 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     // the other one-time objects of a render: pipeline streams, fork / join events and, with PT_FLAG_PROFILE, the
     // pooled (start, stop) events of every extend / shade launch of one batch (4 per round and pipeline)
     pt_ctx *ctx = s->ctx;
-    for (int k = 1; k < 2; k++)
+    for (int k = 1; k < 3; k++)
         if (!ctx->pipe_stream[k]) {
             PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[k], hipStreamNonBlocking));
             PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         }
     if (!ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     if (!ctx->h_poll) PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_poll, sizeof(uint32_t) * 2 * PT_MAX_PIPES, hipHostMallocDefault));
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 3; k++)
         for (int j = 0; j < 2; j++)
             if (!ctx->ev_poll[k][j]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_poll[k][j], hipEventDisableTiming));
     if (p->flags & PT_FLAG_PROFILE) {
         const size_t batches = ((size_t)p->frame_count + sh.lanes - 1) / sh.lanes;
-        const size_t want = std::min<size_t>(4ull * sh.group_size * p->max_depth * 2ull * batches, 1u << 16);
+        const size_t want = std::min<size_t>(4ull * sh.group_size * p->max_depth * 3ull * batches, 1u << 16);
         while (ctx->ev_pool.size() < want) {
             hipEvent_t e = nullptr;
             PT_HIP(ctx, hipEventCreate(&e));
@@ -1687,7 +1687,6 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
 
     // measured on MI355X: 4 paths per thread (one queue-tail atomic per 1024 paths) and 8 blocks per CU;
     // 1 path/thread is 40 % slower, 2 equal, grid size flat between 4 and 16 blocks per CU
-    const bool stagger = ctx->tune.stagger != 0;
     const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 8 * (size_t)s->n_tris;  // tri4 + shade4 + the tangent frames
     const bool shade_lds = shade_smem <= 16 * 1024 && !pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
@@ -1710,15 +1709,25 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     // (interleaved repetitions), C4 -3 %, C5 -3 %, C5x -5 %; a fourth loses everywhere.  Capping the persistent extend
     // grid below the register-file limit (PT_TUNE_EXTEND_BLOCKS) so that k_shade of the other pipeline can be co-resident
     // changes nothing measurable (C2, 7 -> 5 blocks per CU: within +-1 %).
-    int n_pipes = (uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1;
+    // Round 3, with the pipelines free-running (no stream is drained inside a batch any more): two pipelines can still settle
+    // with traversal beside traversal and shade beside shade for a whole process (C2, K = 8 ... 16: 22.3-23.0 Grays/s in one
+    // pass of a box, 24.0-24.6 in the next), three started together cannot -- 24.1-25.3 in every pass, K = 32: 25.2-25.3
+    // against 23.8-24.0 -- where both kernels keep their tables in LDS, the scene has one level and each pipeline still gets
+    // >= 20 M slots; below that (K = 1, 2: -3 ... -5 %), on instanced scenes (C4 -2 %) and with the tables in HBM (C5 -6 %)
+    // two stay (profiles/r03v_c2_pipes.log, r03w_pipes_by_shape.log).
+    const bool three = shade_lds && !s->n_inst && (uint64_t)w.n_slots >= (60ull << 20);
+    int n_pipes = three ? 3 : ((uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1);
     n_pipes = pt_tuned(ctx->tune.pipes, n_pipes, 1, PT_MAX_PIPES);
     n_pipes = std::max(1, std::min(n_pipes, std::min<int>(PT_MAX_PIPES, (int)(lanes * groups))));
+    ctx->stats.pipelines = (uint32_t)n_pipes;
     for (int k = 1; k < n_pipes; k++)
         if (!ctx->pipe_stream[k]) {
             PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[k], hipStreamNonBlocking));
             PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         }
     if (n_pipes > 1 && !ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    // (two pipelines start half a round apart, below; three start together)
+    const bool stagger = ctx->tune.stagger < 0 ? n_pipes == 2 : ctx->tune.stagger != 0;
     if (!ctx->h_poll) PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_poll, sizeof(uint32_t) * 2 * PT_MAX_PIPES, hipHostMallocDefault));
     for (int k = 0; k < n_pipes; k++)
         for (int j = 0; j < 2; j++)
