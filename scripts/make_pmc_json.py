@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
 """dev tool: condense a scripts/gpu_profile.sh directory into the small per-config PMC record that bench.py
 reads (profiles/r01_pmc_extend*.json).  usage: make_pmc_json.py <prof dir> <out json> [config args string]
-Formulas: HBM bytes = 2 x FETCH_SIZE KiB (gfx950 read correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB;
+Formulas: HBM bytes = 2 x FETCH_SIZE KiB (gfx950 read correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB.
+Calibrated on kernels whose byte counts are known (scripts/ubench/fetch_calib.hip under rocprofv3 --pmc,
+profiles/r03_fetch_size_calibration.json, footprints 128 MB and 8 GB): streaming reads FETCH_SIZE = 0.500 x the bytes read
+(the guide's x2), streaming writes WRITE_SIZE = 1.000 x the bytes written, and DIVERGENT GATHERS of 64-B records -- what the
+big-scene traversal kernels do -- FETCH_SIZE = 0.97 ... 1.00 x the RECORD bytes = 0.49 ... 0.50 x the bytes of the distinct
+128-B lines touched.  So 2 x FETCH_SIZE is the traffic at line granularity for every pattern (what the fabric moved), and for a
+kernel that gathers 64-B records half of it is the neighbouring record nobody asked for: `hbm_read_bytes_per_ray_records64`
+(1 x FETCH_SIZE) is the figure to hold against algorithmic bytes counted in 64-B records, `hbm_bytes_per_ray` (2 x FETCH_SIZE +
+WRITE_SIZE) the one to hold against the 8 TB/s;
 VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz, rocprofv3 --stats average);
 wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; L2 hit = TCC_HIT / TCC_REQ."""
 import json
@@ -35,6 +43,11 @@ rec = {
     "hbm_read_bytes_per_launch_x2_gfx950": e["hbm_read_bytes_per_launch_gfx950_x2"],
     "hbm_write_bytes_per_launch": e["hbm_write_bytes_per_launch"], "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
     "hbm_bytes_per_ray": e["hbm_bytes_per_launch"] / rays_per_launch,
+    "hbm_read_bytes_per_ray_lines128": e["hbm_read_bytes_per_launch_gfx950_x2"] / rays_per_launch,
+    "hbm_read_bytes_per_ray_records64": 0.5 * e["hbm_read_bytes_per_launch_gfx950_x2"] / rays_per_launch,
+    "hbm_write_bytes_per_ray": e["hbm_write_bytes_per_launch"] / rays_per_launch,
+    "counter_calibration": "profiles/r03_fetch_size_calibration.json: FETCH_SIZE x2 = bytes of the 128-B lines moved (streams and gathers alike), "
+                           "x1 = the 64-B records a divergent gather asked for; WRITE_SIZE x1",
     "valu_busy_fraction": pl("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * avg_us * 2400.0),
     "valu_wave_instr_per_64_rays": pl("SQ_INSTS_VALU") / (rays_per_launch / 64.0),
     "valu_active_lanes_per_instr": pl("SQ_THREAD_CYCLES_VALU") / pl("SQ_INSTS_VALU"),
