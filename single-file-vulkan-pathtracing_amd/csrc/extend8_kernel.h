@@ -40,14 +40,21 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
     unsigned long long *my_spill = reinterpret_cast<unsigned long long *>(spill) + (size_t)blockIdx.x * TB + threadIdx.x;
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
 
     bool have = false, exhausted = false;
     uint32_t q = 0;
     const uint32_t wave_base = (blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) * 64u;
     const uint32_t wave_stride = gridDim.x * TB;
     uint32_t cursor = 0;
-    ptm::f3 inv{}, orgn{};            // the ray in the normalised scene box: reciprocal direction and origin
+    ptm::f3 inv{};                    // the ray in the normalised scene box: reciprocal direction ...
+    // ... and its origin as the two folded terms of the slab test, -(org * inv) moved down (near planes) and up (far planes) by
+    // 2^-21 (|org| + 2) |inv|: a node's planes live on the node's own grid, origin + q * step, so a plane distance is
+    // q * (step * inv) + (origin * inv + b) and the second term costs a multiply and an add (near) or a multiply-add (far) per
+    // axis and visit instead of the subtraction, the set-up and the margins of a relative origin (33 -> 15 instructions).  The
+    // margin covers the rounding of b, of the product and of the sum for any origin in [-2, 2) -- absolute, where the
+    // relative one was finer, which widens a box by 2^-20 of the scene per unit of |inv| against grid steps of >= 2^-16.
+    // C5 +1.0 %, same hits (profiles/r03ab_ab_c5_node8_variants.log, c0m1)
+    ptm::f3 bn{}, bf{};
     ptm::RayPre pre{};
     uint32_t oct = 0;                 // ray octant: bit k set where direction component k is negative
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
@@ -70,7 +77,8 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= refill_min_idle) {
             if (!have) {
-                const uint32_t v = cursor + (uint32_t)__popcll(idle & lt);
+                // (rank by v_mbcnt: the prefix mask would be two more registers live through the kernel, and at 80 one value spills)
+                const uint32_t v = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t qq = (v >> 6) * wave_stride + wave_base + (v & 63u);
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
@@ -81,8 +89,15 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup(org, dir);
                     inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
-                    orgn = { (org.x - nb.cx) * nb.rsx, (org.y - nb.cy) * nb.rsy, (org.z - nb.cz) * nb.rsz };
+                    const ptm::f3 orgn = { (org.x - nb.cx) * nb.rsx, (org.y - nb.cy) * nb.rsy, (org.z - nb.cz) * nb.rsz };
                     inv = { inv.x * nb.sx, inv.y * nb.sy, inv.z * nb.sz };
+                    {
+                        const float bx = -(orgn.x * inv.x), by = -(orgn.y * inv.y), bz = -(orgn.z * inv.z);
+                        const float px = (fabsf(orgn.x) + 2.0f) * fabsf(inv.x) * 0x1p-21f, py = (fabsf(orgn.y) + 2.0f) * fabsf(inv.y) * 0x1p-21f,
+                                    pz = (fabsf(orgn.z) + 2.0f) * fabsf(inv.z) * 0x1p-21f;
+                        bn = { bx - px, by - py, bz - pz };
+                        bf = { (bx + px) * 1.0000004f, (by + py) * 1.0000004f, (bz + pz) * 1.0000004f };
+                    }
                     oct = (inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u);
                     best_t = ray_tmax ? ray_tmax[q] : tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;  // (shadow rays: extend_kernel.h)
                     best_pos = PT_MISS;
@@ -119,17 +134,16 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 }
                 const uint4 *nd = nodes8 + 4 * (size_t)idx;
                 const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], hd = nd[3];  // the whole node: four 16-B loads of one 64-B record
-                // the node's grid: origin = o16 * 2^-14 - 2 (exact), step = 2^-e; the slab constants are those of slab_setup
-                // (extend_kernel.h) for the ray origin RELATIVE to the node's (one exactly rounded subtraction), so a plane
-                // distance is again ONE fma, q * (step * inv) + (-(org - origin) * inv), with the same outward margins
-                const ptm::f3 orel = { orgn.x - (__builtin_fmaf((float)(hd.x & 0xFFFFu), 0x1p-14f, -2.0f)),
-                                       orgn.y - (__builtin_fmaf((float)(hd.x >> 16), 0x1p-14f, -2.0f)),
-                                       orgn.z - (__builtin_fmaf((float)(hd.y & 0xFFFFu), 0x1p-14f, -2.0f)) };
+                // the node's grid: origin = o16 * 2^-14 - 2 (exact), step = 2^-e; a plane distance is ONE fma,
+                // q * (step * inv) + (origin * inv + b), b = the ray's folded origin term with its outward margin (above)
+                const ptm::f3 o = { __builtin_fmaf((float)(hd.x & 0xFFFFu), 0x1p-14f, -2.0f), __builtin_fmaf((float)(hd.x >> 16), 0x1p-14f, -2.0f),
+                                    __builtin_fmaf((float)(hd.y & 0xFFFFu), 0x1p-14f, -2.0f) };
                 const ptm::f3 stp = { __uint_as_float((127u - ((hd.y >> 16) & 31u)) << 23), __uint_as_float((127u - ((hd.y >> 21) & 31u)) << 23),
                                       __uint_as_float((127u - (hd.y >> 26)) << 23) };
-                ptm::f3 invf, on, of;
-                slab_setup(orel, inv, invf, on, of);
-                const ptm::f3 an = { stp.x * inv.x, stp.y * inv.y, stp.z * inv.z }, af = { stp.x * invf.x, stp.y * invf.y, stp.z * invf.z };
+                const ptm::f3 oi = { o.x * inv.x, o.y * inv.y, o.z * inv.z };
+                const ptm::f3 on = { oi.x + bn.x, oi.y + bn.y, oi.z + bn.z };
+                const ptm::f3 of = { __builtin_fmaf(oi.x, 1.0000004f, bf.x), __builtin_fmaf(oi.y, 1.0000004f, bf.y), __builtin_fmaf(oi.z, 1.0000004f, bf.z) };
+                const ptm::f3 an = { stp.x * inv.x, stp.y * inv.y, stp.z * inv.z }, af = { an.x * 1.0000004f, an.y * 1.0000004f, an.z * 1.0000004f };
                 // near / far rows by the ray's octant (bit-field insert with all-ones / all-zeros masks, as k_extend<hbm>):
                 // rows lo.x = q0.xy, lo.y = q0.zw, lo.z = q1.xy, hi.x = q1.zw, hi.y = q2.xy, hi.z = q2.zw (4 children per dword)
                 const uint32_t mx = (oct & 1u) ? 0xFFFFFFFFu : 0u, my = (oct & 2u) ? 0xFFFFFFFFu : 0u, mz = (oct & 4u) ? 0xFFFFFFFFu : 0u;
@@ -147,6 +161,8 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                     fyv = __builtin_fmaf(PT_BYTE(rfy[(K) >> 2], (K) & 3), af.y, of.y), fzv = __builtin_fmaf(PT_BYTE(rfz[(K) >> 2], (K) & 3), af.z, of.z); \
         const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                                            \
         const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                                            \
+        /* (a branch-free form -- the hit bit shifted into h through the carry, v_addc_co_u32, the minimum through a select --  \
+           is one 240-instruction block instead of nine and 4 % SLOWER on C5: profiles/r03ab_ab_c5_node8_variants.log) */          \
         const bool hk = tn <= tf;                                                                                 \
         h |= hk ? (1u << (K)) : 0u;                                                                               \
         gmin = hk ? min_raw(tn, gmin) : gmin;                                                                     \
