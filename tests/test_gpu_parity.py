@@ -323,6 +323,33 @@ def test_ray_setup_divides_inside_and_outside_the_short_division_guards(pt, orc,
     gi.close()
 
 
+@pytest.mark.parametrize("pipes", [1, 2, 3])
+def test_round_loop_stops_early_on_the_lagged_live_count(pt, orc, gpu_ctx, pipes):
+    """The round loop polls the live queue counts every eighth round and reads the count of the PREVIOUS poll (no stream is
+    drained inside a batch): a scene nearly every path leaves after its first ray -- one small triangle -- must stop long before
+    group_size x max_depth rounds (at most two poll intervals after the queues ran empty), with one, two and three pipelines,
+    and render the oracle's bits; the Cornell box, whose paths do run to full depth, must still run every round."""
+    v = np.float32([-0.1, -1.1, 0.0, 0.1, -1.1, 0.0, 0.0, -0.9, 0.0])
+    i = np.uint32([0, 1, 2])
+    f = np.float32([0.5, 0.5, 0.5, 0.0, 0.0, 0.0])
+    old = gpu_ctx.set_tuning(pipes=pipes)
+    try:
+        gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+        W, H = 1280, 1024                                   # 1.3 M pixels x 4 frames: enough slots for three pipelines
+        kw = dict(width=W, height=H, spp_per_frame=16, max_depth=16)
+        film = pt.Film(gpu_ctx, W, H)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(frame=0, frame_count=4, frames_in_flight=4, sample_groups=1, **kw))
+        st = gpu_ctx.stats()
+        assert st.pipelines == pipes
+        assert st.rounds <= 32 + 16, st.rounds              # a pixel on the triangle: 16 samples x 2 rays in sequence; + two poll intervals; not 256
+        ofilm, _, orays = _render_oracle(orc, osc, 4, **kw)
+        assert st.rays == orays and film.read_f32().tobytes() == ofilm.tobytes()
+        film.close(); gs.close()
+    finally:
+        gpu_ctx.set_tuning(**old)
+
+
 def test_c1_render_bit_exact(pt, orc, gpu_ctx, cornell_gpu):
     """BASELINE.json config 1: 256x256, 1 spp, depth 4 -- against the committed golden."""
     g = np.load(os.path.join(HERE, "golden", "c1_256_1spp_d4.npz"))
