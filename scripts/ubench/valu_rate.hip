@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
         if (OP == 42) { REP8(asm volatile("v_fma_f32 %0, %5, %1, %6\n v_fma_f32 %2, %6, %1, %5\n v_fma_f32 %3, %5, %1, %6\n v_fma_f32 %4, %6, %1, %5" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(r6), "v"(r7));) }
         if (OP == 43) { REP8(asm volatile("v_pk_fma_f32 %0, %5, %1, %6 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %2, %6, %1, %5 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %5, %1, %6 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %4, %6, %1, %5 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "+v"(p0), "+v"(pa), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(p3), "v"(p2));) }
         if (OP == 44) { REP8(asm volatile("v_max3_f32 %0, %5, %1, %6\n v_min3_f32 %2, %6, %1, %5\n v_max3_f32 %3, %5, %1, %6\n v_min3_f32 %4, %6, %1, %5" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(r6), "v"(r7));) }
+        if (OP == 45) { REP8(asm volatile("v_cvt_f32_ubyte0 %0, %1\n v_cvt_f32_ubyte1 %2, %1\n v_cvt_f32_ubyte2 %3, %1\n v_cvt_f32_ubyte3 %4, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 46) { REP8(asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3\n v_cvt_f32_u32 %4, %4" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 47) { REP8(asm volatile("v_cvt_f32_ubyte0 %0, %1\n v_fma_f32 %2, %0, %1, %1\n v_cvt_f32_ubyte2 %3, %1\n v_fma_f32 %4, %3, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 48) { REP8(asm volatile("v_bfe_u32 %0, %1, 8, 8\n v_bfe_u32 %2, %1, 16, 8\n v_bfe_u32 %3, %1, 0, 8\n v_bfe_u32 %4, %1, 24, 8" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 49) { REP8(asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %1, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %1, %4, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + a;
 }
@@ -82,6 +87,7 @@ int main()
     run<34>("cswap: cmp vcc + 4 cndmask e32 (x5/iter)", d); run<35>("cswap: cmp sgpr + 4 cndmask e64 (x5/iter)", d);
   run<36>("P1 cnd32vcc,add,cnd32vcc,add", d); run<37>("P2 cnd32vcc,cnd64sgpr alternating", d); run<38>("P3 cnd32vcc,s_nop alternating (2 valu/grp)", d); run<39>("P4 4x v_addc_co (vcc carry in/out)", d); run<40>("P5 4x cnd e32 vcc, distinct srcs", d); run<41>("P6 4x cnd e64 sgpr, distinct srcs", d);
   run<42>("v_fma_f32 3 distinct srcs", d); run<43>("v_pk_fma_f32 3 srcs, op_sel broadcast", d); run<44>("v_max3/min3 3 distinct srcs", d);
+  run<45>("v_cvt_f32_ubyte0..3", d); run<46>("v_cvt_f32_u32", d); run<47>("cvt_ubyte + fma alternating", d); run<48>("v_bfe_u32", d); run<49>("v_fma_mix_f32 (f16 src0)", d);
     printf("(the two cswap lines issue 5 instructions per group, not 4: multiply their figure by 4/5... i.e. cycles per GROUP = figure x 4)\n");
     return 0;
 }
