@@ -117,15 +117,25 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
             uint32_t e;
             if (sp < lds_stack) e = my_stack[sp * TB];
             else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if ((e & 0xFFFFu) == I16_EXIT) {  // the instance is done: back to the world-space ray and the TLAS, whose slab
-                inv = w_inv; invf = w_invf; on = w_on; of = w_of;  // constants wait in registers (four blocks per CU leave 128)
-                mx = w_mx; my = w_my; mz = w_mz;
+            if ((e & 0xFFFFu) == I16_EXIT) {  // the instance is done: back to the world-space ray and the TLAS
                 in_blas = false;
                 continue;
             }
             if (__uint_as_float(e & 0xFFFF0000u) <= best_t) return e & 0xFFFFu;
         }
         return I16_DONE;
+    };
+    // ... whose slab constants wait in registers (four blocks per CU leave 128) and come back ONCE after the pop loop, for all
+    // lanes that left an instance in it: inside the loop the fifteen moves ran in nearly every one of its 20 iterations per 64
+    // rays, each time for the one or two lanes that met their marker in that iteration
+    auto pop_and_restore = [&]() -> uint32_t {
+        const bool was_in = in_blas;
+        const uint32_t c = pop();
+        if (was_in && !in_blas) {
+            inv = w_inv; invf = w_invf; on = w_on; of = w_of;
+            mx = w_mx; my = w_my; mz = w_mz;
+        }
+        return c;
     };
 
     for (;;) {
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
             if (k3 < KINF) push(k3);  // farthest first
             if (k2 < KINF) push(k2);
             if (k1 < KINF) push(k1);
-            cur = k0 < KINF ? (k0 & 0xFFFFu) : pop();
+            cur = k0 < KINF ? (k0 & 0xFFFFu) : pop_and_restore();
             do_node = !(cur & I16_LEAF);
             if (node_yield > 0 && __popcll(__ballot(do_node)) * node_yield < n_have) break;
         }
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                         if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
                     }
                 }
-                cur = pop();
+                cur = pop_and_restore();
             } else if (at_leaf && !in_blas && do_enter) {
                 // TLAS leaf: one instance.  The ray goes to object space un-normalised (t is the same parameter)
                 const uint32_t first = cur & 0x7FFFu;
