@@ -54,7 +54,7 @@ typedef struct pt_tuning {
     int32_t lds_stack;      /* traversal-stack entries per lane kept in LDS (kernels with a spill path)                */
     int32_t extend_blocks;  /* cap on persistent extend blocks per CU                                                  */
     int32_t pipes;          /* concurrent wavefront pipelines (streams) per pt_render, 1..4                            */
-    int32_t stagger;        /* 0: the pipelines start together instead of half a round apart                          */
+    int32_t stagger;        /* 0: free-running pipelines; 1: started half a round apart (2 pipelines); 2: shade rule (3)  */
     int32_t sort_bits;      /* ray sorting: Morton bits per axis of the origin cell (1..9)                             */
     int32_t pair_leaves;    /* 0: small scenes get leaves of <= 4 independent triangles instead of one primitive each  */
     int32_t pair_kernel;    /* 0: the per-triangle leaf loop over a pair-leaf tree instead of the pair test            */

@@ -4,7 +4,7 @@
 TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_$TAG -o t -- python $GRAFT_REPO_ROOT/bench.py "$@" --reps 1 --no-cpu-baseline --no-extra-legs --no-kernel-events > $O/${TAG}_bench.json 2> $O/${TAG}.err )
+( cd /tmp && PT_TUNE=$PT_TUNE_TL timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_$TAG -o t -- python $GRAFT_REPO_ROOT/bench.py "$@" --reps 1 --no-cpu-baseline --no-extra-legs --no-kernel-events > $O/${TAG}_bench.json 2> $O/${TAG}.err )
 f=$(find $O/trace_$TAG -name "*kernel_trace.csv" | head -1)
 python - "$f" $O/${TAG}_timeline.csv <<'PY'
 import csv, sys

@@ -146,6 +146,8 @@ void pt_ctx_destroy(pt_ctx *ctx)
     for (int k = 0; k < PT_MAX_PIPES; k++)
         for (int j = 0; j < 2; j++)
             if (ctx->ev_poll[k][j]) (void)hipEventDestroy(ctx->ev_poll[k][j]);
+    for (int k = 0; k < PT_MAX_PIPES; k++)
+        if (ctx->ev_shade[k]) (void)hipEventDestroy(ctx->ev_shade[k]);
     for (int k = 0; k < PT_MAX_PIPES; k++) {
         if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
         if (ctx->pipe_stream[k]) (void)hipStreamDestroy(ctx->pipe_stream[k]);

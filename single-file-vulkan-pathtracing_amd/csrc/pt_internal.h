@@ -38,6 +38,7 @@ struct pt_ctx {
     // so the host reads the count of eight rounds ago while the stream still holds eight rounds of work
     uint32_t *h_poll = nullptr;                      // [PT_MAX_PIPES][2], hipHostMalloc
     hipEvent_t ev_poll[PT_MAX_PIPES][2] = {};
+    hipEvent_t ev_shade[PT_MAX_PIPES] = {};          // end of each pipeline's most recent shade launch (the shade rule of three pipelines)
     std::vector<hipEvent_t> ev_pool;  // PT_FLAG_PROFILE start/stop events, reused across pt_render calls
     void *d_spill = nullptr;   // HBM overflow of the traversal short stack: [level][thread] uint2
     size_t spill_bytes = 0;

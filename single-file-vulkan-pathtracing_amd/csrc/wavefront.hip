@@ -1622,6 +1622,8 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     for (int k = 0; k < 3; k++)
         for (int j = 0; j < 2; j++)
             if (!ctx->ev_poll[k][j]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_poll[k][j], hipEventDisableTiming));
+    for (int k = 0; k < 3; k++)
+        if (!ctx->ev_shade[k]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_shade[k], hipEventDisableTiming));
     if (p->flags & PT_FLAG_PROFILE) {
         const size_t batches = ((size_t)p->frame_count + sh.lanes - 1) / sh.lanes;
         const size_t want = std::min<size_t>(4ull * sh.group_size * p->max_depth * 3ull * batches, 1u << 16);
@@ -1726,12 +1728,14 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
             PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         }
     if (n_pipes > 1 && !ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    // (two pipelines start half a round apart, below; three start together)
-    const bool stagger = ctx->tune.stagger < 0 ? n_pipes == 2 : ctx->tune.stagger != 0;
+    // (two pipelines start half a round apart, below; three start together and keep the shade rule, below)
+    const bool stagger = ctx->tune.stagger < 0 ? n_pipes == 2 : ctx->tune.stagger == 1;
     if (!ctx->h_poll) PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_poll, sizeof(uint32_t) * 2 * PT_MAX_PIPES, hipHostMallocDefault));
     for (int k = 0; k < n_pipes; k++)
         for (int j = 0; j < 2; j++)
             if (!ctx->ev_poll[k][j]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_poll[k][j], hipEventDisableTiming));
+    for (int k = 0; k < n_pipes; k++)
+        if (!ctx->ev_shade[k]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_shade[k], hipEventDisableTiming));
 
     // ray sorting (ray_sort.hip): the HBM kernels only; AUTO when the traversal working set does not fit the Infinity Cache
     bool sort_rays = false;
@@ -1822,6 +1826,8 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                 ctx->stats.launches_other++;
             }
             const uint32_t max_rounds = group_size * p->max_depth;  // every sample of a slot at full depth
+            bool shade_recorded[PT_MAX_PIPES] = {};
+            const bool shade_rule = pipes_now == 3 && shade_lds && (ctx->tune.stagger < 0 || ctx->tune.stagger == 2);
             for (uint32_t round = 0; round < max_rounds; round++) {
                 for (int k = 0; k < pipes_now; k++) {
                     Pipe &pp = pipe[k];
@@ -1851,6 +1857,17 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                     launch_extend(pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1],
                                   ctx->d_stats, p->tmin, p->tmax, count_visits, true, pp.st, k, x0, x1, perm);
                     if (stag && k + 1 < pipes_now) PT_HIP(ctx, hipEventRecord(ctx->ev_fork, pp.st));
+                    // The shade rule (three pipelines): never all three in their shade launch at once.  Pipeline k's shade launch
+                    // waits for the end of the most recent shade launch of pipeline k + 1 -- the one a third of a rotation ahead,
+                    // whose launch is long over when the three are evenly spread, so in the pattern the rule aims at nobody
+                    // waits, and out of it the laggard is held back until the rotation is restored.  Free-running, the three
+                    // spend 11-19 % of a frame shade beside shade beside shade (latency-bound, VALUs idle) and which pattern a
+                    // process falls into is chance: 24.3-25.7 Grays/s over eight processes of one box; with the rule 25.8-27.1,
+                    // mean +6.0 % (profiles/r03ag_c2_rules_distribution.log).  The same rule on the traversal launches, on both,
+                    // one position further ahead (= one shade launch at a time), or with two / four pipelines: all slower
+                    // (r03af_c2_two_of_three.log, r03ah_c2_shade_rule_variants.log).
+                    const int ahead = (k + 1) % pipes_now;
+                    if (shade_rule && shade_recorded[ahead]) PT_HIP(ctx, hipStreamWaitEvent(pp.st, ctx->ev_shade[ahead], 0));
                     ShadowQueue sq{};
                     uint32_t *sq_count = nullptr;
                     if (nee) {
@@ -1879,6 +1896,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                     } else if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, false); }
                     else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, false); }
 #undef PT_LAUNCH_SHADE
+                    if (shade_rule) { PT_HIP(ctx, hipEventRecord(ctx->ev_shade[k], pp.st)); shade_recorded[k] = true; }
                     if (profile) {
                         ev_extend.push_back(x0); ev_extend.push_back(x1);
                         ev_shade.push_back(h0); ev_shade.push_back(h1);
