@@ -1713,11 +1713,11 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     // changes nothing measurable (C2, 7 -> 5 blocks per CU: within +-1 %).
     // Round 3, with the pipelines free-running (no stream is drained inside a batch any more): two pipelines can still settle
     // with traversal beside traversal and shade beside shade for a whole process (C2, K = 8 ... 16: 22.3-23.0 Grays/s in one
-    // pass of a box, 24.0-24.6 in the next), three started together cannot -- 24.1-25.3 in every pass, K = 32: 25.2-25.3
-    // against 23.8-24.0 -- where both kernels keep their tables in LDS, the scene has one level and each pipeline still gets
-    // >= 20 M slots; below that (K = 1, 2: -3 ... -5 %), on instanced scenes (C4 -2 %) and with the tables in HBM (C5 -6 %)
-    // two stay (profiles/r03v_c2_pipes.log, r03w_pipes_by_shape.log).
-    const bool three = shade_lds && !s->n_inst && (uint64_t)w.n_slots >= (60ull << 20);
+    // pass of a box, 24.0-24.6 in the next); three, held in rotation by the shade rule (below), cannot: C2 at K = 16 25.8-27.1
+    // against 23.2-24.6, K = 8 +6 %, K = 4 +2.3 %, K = 2 +1.7 %, K = 1 equal -- where both kernels keep their tables in LDS and
+    // the scene has one level.  Two stay on instanced scenes (C4 at K = 8: -1 % with three) and with the tables in HBM (C5 -6 %)
+    // (profiles/r03v_c2_pipes.log, r03w_pipes_by_shape.log, r03aj_shade_rule_other_shapes.log).
+    const bool three = shade_lds && !s->n_inst && (uint64_t)w.n_slots >= (24ull << 20);
     int n_pipes = three ? 3 : ((uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1);
     n_pipes = pt_tuned(ctx->tune.pipes, n_pipes, 1, PT_MAX_PIPES);
     n_pipes = std::max(1, std::min(n_pipes, std::min<int>(PT_MAX_PIPES, (int)(lanes * groups))));
@@ -1827,7 +1827,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
             }
             const uint32_t max_rounds = group_size * p->max_depth;  // every sample of a slot at full depth
             bool shade_recorded[PT_MAX_PIPES] = {};
-            const bool shade_rule = pipes_now == 3 && shade_lds && (ctx->tune.stagger < 0 || ctx->tune.stagger == 2);
+            const bool shade_rule = pipes_now == 3 && ((ctx->tune.stagger < 0 && shade_lds) || ctx->tune.stagger == 2);
             for (uint32_t round = 0; round < max_rounds; round++) {
                 for (int k = 0; k < pipes_now; k++) {
                     Pipe &pp = pipe[k];
