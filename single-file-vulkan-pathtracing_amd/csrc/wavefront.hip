@@ -1432,7 +1432,12 @@ struct RenderShape {
 // do not live longer than they have to
 // `shrink`: 0 for the first try; pt_render retries with 1, 2, ... after an out-of-memory workspace grow, each step
 // halving the memory the AUTO shape may plan for (explicit frames_in_flight / sample_groups are never overridden).
-RenderShape choose_shape(const pt_film *f, const pt_params *p, int shrink = 0)
+// `big_scene`: the traversal walks the scene out of L2 / MALL / HBM (no LDS copy).  Its launches take milliseconds per million
+// rays and what they gain from being LONG is measured: 1 M-triangle soup, 4 frames of 16 spp -- 4 groups (3.7 M rays per launch)
+// 2 617 Mrays/s, 8 groups 2 799, 16 groups (14.8 M) 2 889; 16 frames x 4 groups 2 886, x 8 (29.6 M) 2 926; the 8 M-triangle soup
+// at 2 frames +3 % from 8 to 16 groups (profiles/r03au_shapes_c5_c4.log).  So the sample groups of such scenes aim at 128 M live
+// paths where the Cornell-class scenes aim at 32 M (their shapes are box- and allocation-sensitive).
+RenderShape choose_shape(const pt_film *f, const pt_params *p, bool big_scene, int shrink = 0)
 {
     RenderShape sh;
     const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
@@ -1467,7 +1472,7 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, int shrink = 0)
     if (groups == 0) {
         groups = 1;
         const uint64_t have = std::max<uint64_t>((uint64_t)lanes * pixels_local, 1);
-        double want = (double)target / (double)have;
+        double want = (double)(big_scene ? 4 * target : target) / (double)have;
         const uint64_t slot_budget = 160ull << 20;
         if (can_redo && have * 4 <= slot_budget) want = std::max(want, 4.0);
         else if (can_redo && have * 2 <= slot_budget) want = std::max(want, 2.0);
@@ -1528,14 +1533,14 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, int shrink = 0)
 // The shape of a render and its workspace.  An AUTO shape that does not fit after all (another allocator took the
 // memory between hipMemGetInfo and hipMalloc) is planned again for half the memory, down to one frame and one group;
 // an explicit shape that does not fit is PT_ERR_OOM.  Either way a failure leaves the film usable.
-pt_status shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh)
+pt_status shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh, bool big_scene)
 {
     pt_status rc = PT_OK;
     pt_params p_local = *p_in;
     if (p_local.pipeline == PT_PIPELINE_WAVEFRONT_NEE) p_local.sample_groups = 1;  // up to max_depth + 1 radiance terms per sample: the plain accumulator
     const pt_params *p = &p_local;
     for (int attempt = 0; attempt < 12; attempt++) {
-        sh = choose_shape(f, p, attempt);
+        sh = choose_shape(f, p, big_scene, attempt);
         rc = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
         if (rc != PT_ERR_OOM) return rc;
         const bool can_shrink = (p->frames_in_flight == 0 && sh.lanes > 1) || (p->sample_groups == 0 && sh.groups > 1);
@@ -1604,7 +1609,7 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
     RenderShape sh;
-    rc_ = shape_and_work(f, p, sh);
+    rc_ = shape_and_work(f, p, sh, !pl.lds_scene && pl.variant != PT_EXTEND_FLAT);
     s->ctx->stats.frames_in_flight = sh.lanes;
     s->ctx->stats.sample_groups = sh.groups;
     if (rc_ != PT_OK) return rc_;
@@ -1646,7 +1651,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
     RenderShape sh;
-    rc_ = shape_and_work(f, p, sh);
+    rc_ = shape_and_work(f, p, sh, !pl.lds_scene && pl.variant != PT_EXTEND_FLAT);
     if (rc_ != PT_OK) return rc_;
     const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
     if (!nested) {
