@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS, best_ipos = PT_MISS, best_iid = PT_MISS;
     uint32_t cur = I16_DONE, cur_ipos = 0, cur_iid = 0;
-    int sp = 0;
+    int sp = 0, sp_exit = 0;
     unsigned long long c_nodes = 0, c_tris = 0;
     // PT_FLAG_COUNT_VISITS: wave executions of the kernel's blocks and the lanes inside them (pt_stats, include/pt_api.h)
     unsigned long long c_node_steps = 0, c_tri_steps = 0, c_leaf_lanes = 0, c_enter_steps = 0, c_enter_lanes = 0, c_iters = 0,
@@ -109,20 +109,20 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
         sp++;
     };
+    // (an instance visit ends when the stack is back at the height it had on entry, `sp_exit` -- no marker entry under the
+    // instance's own entries, which cost the pop loop one iteration per visit for the one or two lanes that met it)
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             PT_COUNT_WAVE(c_pops);
             if (COUNT) c_pop_lanes++;
+            if (in_blas && sp == sp_exit) in_blas = false;  // the instance is done: back to the world-space ray and the TLAS
             sp--;
             uint32_t e;
             if (sp < lds_stack) e = my_stack[sp * TB];
             else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if ((e & 0xFFFFu) == I16_EXIT) {  // the instance is done: back to the world-space ray and the TLAS
-                in_blas = false;
-                continue;
-            }
             if (__uint_as_float(e & 0xFFFF0000u) <= best_t) return e & 0xFFFFu;
         }
+        in_blas = false;
         return I16_DONE;
     };
     // ... whose slab constants wait in registers (four blocks per CU leave 128) and come back ONCE after the pop loop, for all
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 pre = ptm::ray_setup(oo, od);
                 tri_base = (uint32_t)pre.kz * 3u * n_tris;
                 orgp = { ptm::sel3(pre.kz, oo.y, oo.z, oo.x), ptm::sel3(pre.kz, oo.z, oo.x, oo.y), ptm::sel3(pre.kz, oo.x, oo.y, oo.z) };
-                push(I16_EXIT);
+                sp_exit = sp;
                 in_blas = true;
                 cur = 0u;  // BLAS root
             }
