@@ -71,7 +71,9 @@ typedef struct pt_tuning {
     int32_t hbm8;           /* 1: AUTO walks big scenes through the 8-wide compressed nodes (PT_EXTEND_HBM8)           */
     int32_t ploc_radius;    /* PLOC rebuild of big scenes' binary tree: neighbours searched on either side (1..32, 8)  */
     int32_t leaf_min;       /* compact two-level kernel: lanes that wait with a triangle leaf before the leaf step runs */
-    int32_t reserved[11];
+    int32_t tri_enter;      /* 8-wide tree kernel: lanes that wait with leaf triangles before a triangle step runs     */
+    int32_t tri_stay;       /* ... and triangle steps repeat while at least this many lanes still hold one (65 = never) */
+    int32_t reserved[9];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);

@@ -27,10 +27,12 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                                              const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                              float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                              uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
-                                             uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
+                                             uint32_t spill_stride, int refill_vote, float tmin, float tmax, int lds_stack,
                                              int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // refill_vote: idle lanes before a refill | tri_enter << 8 | tri_stay << 16 (pt_tuning; the vote below)
+    const int refill_min_idle = refill_vote & 0xFF, tri_enter = (refill_vote >> 8) & 0xFF, tri_stay = (refill_vote >> 16) & 0xFF;
     const uint32_t n = *count_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (count_zero) *count_zero = 0u;  // the queue the coming shade pass appends to
@@ -118,7 +120,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
         const bool want_tri = have && tg_hits != 0u;
         const bool want_node = have && tg_hits == 0u;
         const int nn = __popcll(__ballot(want_node)), nl = __popcll(__ballot(want_tri));
-        if (nn >= nl) {
+        if (!(nl > nn || nl >= tri_enter)) {
             if (want_node) {
                 if (COUNT) c_nodes++;
                 PT_COUNT_WAVE(c_node_steps);
@@ -162,7 +164,10 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
         const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                                            \
         const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                                            \
         /* (a branch-free form -- the hit bit shifted into h through the carry, v_addc_co_u32, the minimum through a select --  \
-           is one 240-instruction block instead of nine and 4 % SLOWER on C5: profiles/r03ab_ab_c5_node8_variants.log) */          \
+           is one 240-instruction block instead of nine and 4 % SLOWER on C5: profiles/r03ab_ab_c5_node8_variants.log;           \
+           two children per v_pk_fma_f32 -- 24 packed multiply-adds instead of 48 -- needs the twelve distances of a pair live   \
+           at once: 10 spilled registers at 6 waves (-30 %), -6 % at 5 waves without spills, -1.5 % with only the near planes   \
+           packed: profiles/r03be_ab_c5_pkfma.log) */                                                                           \
         const bool hk = tn <= tf;                                                                                 \
         h |= hk ? (1u << (K)) : 0u;                                                                               \
         gmin = hk ? min_raw(tn, gmin) : gmin;                                                                     \
@@ -187,7 +192,8 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 tg_hits = h & lm;
                 tg_lmask = lm;
             }
-        } else if (want_tri) {
+        } else for (;;) {
+          if (have && tg_hits != 0u) {
             if (COUNT) { c_tris++; c_leaf_lanes++; }
             PT_COUNT_WAVE(c_tri_steps);
             const uint32_t slot = (uint32_t)(__ffs((int)tg_hits) - 1);
@@ -209,6 +215,8 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 }
             }
             if (COUNT && divided) { PT_COUNT_WAVE(c_hit_blocks); c_hit_lanes++; }
+          }
+          if (__popcll(__ballot(have && tg_hits != 0u)) < tri_stay) break;
         }
         // ---- nothing left of the current node: the next pending group that can still hold the closest hit, or done
         if (have && tg_hits == 0u && (ng_meta & 0xFFu) == 0u) {

@@ -1104,7 +1104,9 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         int per_cu8 = 0;
         PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, ptw_extend8_fn(false), TB, pl.smem));
         per_cu8 = std::max(1, std::min(per_cu8, 8));
-        pl.refill = pt_tuned(ctx->tune.refill, 32, 1, 64);
+        // with the triangle vote at 16 lanes (launch_extend) the refill optimum moved from 32 idle lanes to 12: C5 2 907 ->
+        // 3 240 Mrays/s, C5x 2 715 -> 2 960 for both together (profiles/r03bb_*, r03bc_*: 32: 3 025, 24: 3 140, 16: 3 230, 8: 3 235, 4: 3 170)
+        pl.refill = pt_tuned(ctx->tune.refill, 12, 1, 64);
         pl.grid = ctx->num_cus * per_cu8;
         // one stack entry per visited node: at most one per level of the BVH8
         const uint32_t bound8 = s->levels8 + 1u;
@@ -1237,8 +1239,13 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;
     const uint32_t stride = (uint32_t)pl.grid * TB;
     if (pl.bvh8) {
+        // the vote of the 8-wide kernel (extend8_kernel.h): a triangle step runs once tri_enter lanes wait with leaf triangles
+        // (or more than descend), and repeats while tri_stay lanes still hold one.  Majority voting (64) parks ~25 lanes
+        // behind every node step -- a node step is 240 instructions, a triangle step 110: 16 measured best (8: -2 %, 12: -0.5 %,
+        // 20: equal on C5x, 24: -3 %; repeating triangle steps changes nothing: profiles/r03ba_ab_c5_vote.log)
+        const int tri_enter = pt_tuned(s->ctx->tune.tri_enter, 16, 1, 64), tri_stay = pt_tuned(s->ctx->tune.tri_stay, 65, 1, 65);
         ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, s->d_shade64_8, rayA, rayB, hit,
-                           count_in, count_zero, stats, spill, stride, pl.refill, tmin, tmax, pl.lds_stack, raw, perm, ray_tmax);
+                           count_in, count_zero, stats, spill, stride, pl.refill | (tri_enter << 8) | (tri_stay << 16), tmin, tmax, pl.lds_stack, raw, perm, ray_tmax);
         return;
     }
     const NormBox nbox = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2],

@@ -1589,6 +1589,37 @@ def test_bvh8_render_bit_exact_and_auto_selection(pt, orc, gpu_ctx):
     gs.close()
 
 
+@pytest.mark.parametrize("knobs", [dict(tri_enter=1, tri_stay=1), dict(tri_enter=8, tri_stay=4), dict(tri_enter=16, tri_stay=65),
+                                   dict(tri_enter=64, tri_stay=1), dict(tri_enter=24, tri_stay=12, refill=8)])
+def test_bvh8_vote_knobs_keep_the_bits(pt, orc, gpu_ctx, knobs):
+    """The vote of the 8-wide kernel (extend8_kernel.h: how many lanes wait with leaf triangles before a triangle step runs,
+    and how long triangle steps repeat) decides the order in which a ray's candidates are met, never which hit it returns:
+    hit records (closest-hit and a negative tmin) and a rendered film equal the oracle's under every setting."""
+    v, i, f = _soup(20000, 23, spread=0.05)
+    old = gpu_ctx.set_tuning(**knobs)
+    try:
+        gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+        rng = np.random.default_rng(5)
+        m = 30000
+        org = rng.uniform(-1.3, 1.3, (m, 3))
+        d = rng.normal(size=(m, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([org, d], 1).astype(np.float32)
+        for tmin in (0.001, -0.25):
+            want, _ = osc.trace(rays, tmin=tmin, tmax=50.0)
+            got = gs.trace(rays, tmin=tmin, tmax=50.0, extend=pt.EXTEND_HBM8)
+            assert got.tobytes() == want.tobytes(), (knobs, tmin)
+        kw = dict(width=160, height=96, spp_per_frame=4, max_depth=6)
+        ofilm, _, orays = _render_oracle(orc, osc, 2, **kw)
+        film = pt.Film(gpu_ctx, 160, 96)
+        gpu_ctx.reset_stats()
+        pt.render(gs, film, pt.default_params(frame=0, frame_count=2, extend=pt.EXTEND_HBM8, **kw))
+        assert gpu_ctx.stats().rays == orays and film.read_f32().tobytes() == ofilm.tobytes(), knobs
+        film.close(); gs.close()
+    finally:
+        gpu_ctx.set_tuning(**old)
+
+
 @pytest.mark.parametrize("extend", [3, 4])
 def test_ray_sorting_changes_no_bit(pt, orc, gpu_ctx, extend):
     """PT_FLAG_SORT_RAYS: before every extend pass after the first the queue is walked in (origin cell, direction octant)
