@@ -139,10 +139,13 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                                                const float2 *__restrict__ rayB, float4 *__restrict__ hit,
                                                const uint32_t *__restrict__ count_in, uint32_t *count_zero,
                                                unsigned long long *stats, uint2 *__restrict__ spill,
-                                               uint32_t spill_stride, int refill_min_idle, float tmin, float tmax,
+                                               uint32_t spill_stride, int refill_vote, float tmin, float tmax,
                                                int lds_stack, int raw_hit, const uint32_t *__restrict__ perm,
                                                const float *__restrict__ ray_tmax, const float4 *__restrict__ g_rec64 = nullptr)
 {
+    // refill_vote: idle lanes before a refill | (scenes in HBM) tri_enter << 8, the lanes that wait with a leaf before a leaf
+    // step runs even against a majority of descending lanes (pt_tuning.tri_enter; 0 = majority only)
+    const int refill_min_idle = refill_vote & 0xFF, tri_enter = (refill_vote >> 8) & 0xFF;
     // ray_tmax (shadow rays of the NEE pipeline): a per-ray upper bound instead of `tmax`, and ANY hit below it ends
     // the walk (the record then only says hit or miss)
     // Scenes in HBM (deep trees, incoherent rays): inside the classic while-while loop the node phase ran
@@ -332,7 +335,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
         if (VOTE) {
             const bool want_leaf = have && (cur & LEAF_BIT) && cur != DONE;
             const int nn = __popcll(__ballot(do_node)), nl = __popcll(__ballot(want_leaf));
-            const bool node_turn = nn * VOTE_NODE_NUM >= nl * VOTE_NODE_DEN;
+            const bool node_turn = nn * VOTE_NODE_NUM >= nl * VOTE_NODE_DEN && !(tri_enter && nl >= tri_enter);
             do_node = do_node && node_turn;
             do_leaf = !node_turn;
         }

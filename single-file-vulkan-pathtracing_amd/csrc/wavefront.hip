@@ -1279,8 +1279,8 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         if (count) PT_LAUNCH_EXTEND(true, true, true); else PT_LAUNCH_EXTEND(true, false, true);
     } else {
         ptw_launch_extend_hbm(count, s->ctx->tune.rec64 != 0, pl.grid, smem, st, ev0, ev1, s->d_wide, pl.topdown4 ? reinterpret_cast<const uint2 *>(s->d_wide16t) : s->d_wide16, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4,
-                              s->d_shade64, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride, pl.refill, tmin,
-                              tmax, pl.lds_stack, raw, perm, ray_tmax);
+                              s->d_shade64, s->n_wide, s->n_tris, rayA, rayB, hit, count_in, count_zero, stats, spill, stride,
+                              pl.refill | (pt_tuned(s->ctx->tune.tri_enter, 0, 0, 64) << 8), tmin, tmax, pl.lds_stack, raw, perm, ray_tmax);
     }
 #undef PT_LAUNCH_EXTEND
 }
