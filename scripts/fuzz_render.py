@@ -35,7 +35,7 @@ for k in range(N):
     for rank in range(world):
         film = pt.Film(ctx, w, h)
         gk = dict(kw, rank=rank, world=world, frames_in_flight=int(rng.choice([0, 1, 2, 5])), sample_groups=int(rng.choice([0, 1, 2, 3, spp])),
-                  extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_FLAT])))
+                  extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_FLAT])))
         if f0:
             pt.render(sc, film, pt.default_params(frame=0, frame_count=f0, **gk))
         pt.render(sc, film, pt.default_params(frame=f0, frame_count=nf, **gk))

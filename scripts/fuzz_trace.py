@@ -64,7 +64,7 @@ for seed in range(N):
     gs = pt.Scene(ctx, v, i, f)
     for q in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD):
         gs.set_bvh_quality(q)
-        for ext_v in (pt.EXTEND_AUTO, pt.EXTEND_HBM, pt.EXTEND_LDS, pt.EXTEND_FLAT):
+        for ext_v in (pt.EXTEND_AUTO, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_LDS, pt.EXTEND_FLAT):
             try:
                 got = gs.trace(rays, tmin=tmin, tmax=tmax, extend=ext_v)
             except pt.PtError:

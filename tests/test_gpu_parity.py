@@ -1607,8 +1607,9 @@ def test_bvh8_vote_knobs_keep_the_bits(pt, orc, gpu_ctx, knobs):
         rays = np.concatenate([org, d], 1).astype(np.float32)
         for tmin in (0.001, -0.25):
             want, _ = osc.trace(rays, tmin=tmin, tmax=50.0)
-            got = gs.trace(rays, tmin=tmin, tmax=50.0, extend=pt.EXTEND_HBM8)
-            assert got.tobytes() == want.tobytes(), (knobs, tmin)
+            for extend in (pt.EXTEND_HBM8, pt.EXTEND_HBM):     # (the BVH4 kernel of mid-size scenes takes the same knob)
+                got = gs.trace(rays, tmin=tmin, tmax=50.0, extend=extend)
+                assert got.tobytes() == want.tobytes(), (knobs, tmin, extend)
         kw = dict(width=160, height=96, spp_per_frame=4, max_depth=6)
         ofilm, _, orays = _render_oracle(orc, osc, 2, **kw)
         film = pt.Film(gpu_ctx, 160, 96)
