@@ -22,7 +22,9 @@
 
 namespace {
 
-template <bool COUNT>
+// SPILL = false: the tree's levels fit the LDS stack entries (every tree up to 8^12 leaves does with the default 12), so the
+// address arithmetic of the HBM spill column leaves the push and the pop loop
+template <bool COUNT, bool SPILL>
 __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
                                              const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                              float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
@@ -123,12 +125,13 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
             cursor += (uint32_t)n_idle;
             exhausted = (cursor >> 6) * wave_stride + wave_base >= n;
         }
-        if (__ballot(have) == 0ull) break;
+        const unsigned long long with_ray = __ballot(have);
+        if (with_ray == 0ull) break;
 
         // every lane with a ray has something to do here: triangles of the node it just visited, or a node to visit
         const bool want_tri = have && tg_hits != 0u;
         const bool want_node = have && tg_hits == 0u;
-        const int nn = __popcll(__ballot(want_node)), nl = __popcll(__ballot(want_tri));
+        const int nl = __popcll(__ballot(want_tri)), nn = __popcll(with_ray) - nl;
         if (!(nl > nn || nl >= tri_enter)) {
             if (want_node) {
                 if (COUNT) c_nodes++;
@@ -139,7 +142,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 const uint32_t idx = ng_base + (uint32_t)__popc(im & ((1u << slot) - 1u));
                 if (rest) {  // the other hit children of that node wait on the stack as ONE entry
                     const unsigned long long e = (unsigned long long)ng_base | ((unsigned long long)((ng_meta & 0xFFFFFF00u) | rest) << 32);
-                    if (sp < lds_stack) my_stack[sp * TB] = e;
+                    if (!SPILL || sp < lds_stack) my_stack[sp * TB] = e;
                     else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
                     sp++;
                 }
@@ -237,7 +240,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 if (COUNT) c_pop_lanes++;
                 sp--;
                 unsigned long long e;
-                if (sp < lds_stack) e = my_stack[sp * TB];
+                if (!SPILL || sp < lds_stack) e = my_stack[sp * TB];
                 else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
                 const uint32_t meta = (uint32_t)(e >> 32);
                 if (__uint_as_float(meta & 0xFFFF0000u) <= best_t) {
@@ -290,18 +293,18 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
     }
 }
 
-#ifndef PT_EXTEND8_WAVES
-#define PT_EXTEND8_WAVES 6
-#endif
-template <bool COUNT>
-__global__ __launch_bounds__(TB, PT_EXTEND8_WAVES) void k_extend8(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
+// WAVES per SIMD asked of the compiler: 6 (<= 80 VGPRs) everywhere, 7 (72 VGPRs, no spills in the no-spill kernel) for scenes
+// beyond the Infinity Cache, whose walk waits on HBM: C5x +1.5 % over 6 waves at the same 10 stack entries, C5 (cache-resident)
+// -3.5 % (profiles/r03bl_ab_c5_lds_stack.log)
+template <bool COUNT, bool SPILL, int WAVES>
+__global__ __launch_bounds__(TB, WAVES) void k_extend8(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
                                                 const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                                 float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
                                                 uint32_t *count_zero, unsigned long long *stats, uint2 *__restrict__ spill,
                                                 uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
                                                 int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
-    extend8_body<COUNT>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
+    extend8_body<COUNT, SPILL>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
                         tmax, lds_stack, raw_hit, perm, ray_tmax);
 }
 

@@ -45,22 +45,26 @@ void ptw_launch_extend_hbm(bool count, bool rec64, int grid, size_t smem, hipStr
 }
 
 // ---- BVH8 kernel (extend8_kernel.h), same translation unit for the same scheduler --------------------------------
-const void *ptw_extend8_fn(bool count)
+const void *ptw_extend8_fn(bool count, bool spills, bool waves7)
 {
-    return count ? reinterpret_cast<const void *>(k_extend8<true>) : reinterpret_cast<const void *>(k_extend8<false>);
+    if (spills) return count ? reinterpret_cast<const void *>(k_extend8<true, true, 6>) : reinterpret_cast<const void *>(k_extend8<false, true, 6>);
+    if (count) return reinterpret_cast<const void *>(k_extend8<true, false, 6>);
+    return waves7 ? reinterpret_cast<const void *>(k_extend8<false, false, 7>) : reinterpret_cast<const void *>(k_extend8<false, false, 6>);
 }
 
-void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
+void ptw_launch_extend8(bool count, bool spills, bool waves7, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
                         const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rec64, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                         uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
                         const uint32_t *perm, const float *ray_tmax)
 {
     const NormBox nb = { norm_c[0], norm_c[1], norm_c[2], norm_s[0], norm_s[1], norm_s[2], norm_rs[0], norm_rs[1], norm_rs[2] };
-    if (count)
-        hipExtLaunchKernelGGL((k_extend8<true>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rec64, rayA, rayB, hit,
-                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax);
-    else
-        hipExtLaunchKernelGGL((k_extend8<false>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rec64, rayA, rayB, hit,
-                              count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax);
+#define PT_LAUNCH8(C, S, W)                                                                                                           \
+    hipExtLaunchKernelGGL((k_extend8<C, S, W>), dim3(grid), dim3(TB), (uint32_t)smem, st, ev0, ev1, 0u, nodes8, nb, tri4, rec64, rayA, rayB, hit, \
+                          count_in, count_zero, stats, spill, spill_stride, refill, tmin, tmax, lds_stack, raw_hit, perm, ray_tmax)
+    if (spills) { if (count) PT_LAUNCH8(true, true, 6); else PT_LAUNCH8(false, true, 6); }
+    else if (count) PT_LAUNCH8(true, false, 6);
+    else if (waves7) PT_LAUNCH8(false, false, 7);
+    else PT_LAUNCH8(false, false, 6);
+#undef PT_LAUNCH8
 }

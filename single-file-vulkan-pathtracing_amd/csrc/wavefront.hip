@@ -41,8 +41,8 @@ void ptw_launch_extend_hbm(bool count, bool rec64, int grid, size_t smem, hipStr
                            float tmax, int lds_stack, int raw_hit, const uint32_t *perm, const float *ray_tmax);
 
 // extend_hbm.hip: k_extend8 (BVH8)
-const void *ptw_extend8_fn(bool count);
-void ptw_launch_extend8(bool count, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
+const void *ptw_extend8_fn(bool count, bool spills, bool waves7);
+void ptw_launch_extend8(bool count, bool spills, bool waves7, int grid, size_t smem, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const uint4 *nodes8,
                         const float *norm_c, const float *norm_s, const float *norm_rs, const float4 *tri4, const float4 *rec64, const float4 *rayA,
                         const float2 *rayB, float4 *hit, const uint32_t *count_in, uint32_t *count_zero, unsigned long long *stats,
                         uint2 *spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int raw_hit,
@@ -999,6 +999,7 @@ struct ExtendPlan {
     bool spill = true;          // false: the scene's exact stack bound fits lds_stack, kernel without spill path
                                 // (and with one-dword stack entries: COMPACT in k_extend)
     bool pairs = false;         // ... and every leaf of the BVH4 is one triangle or one fan pair: the PAIRS kernel
+    bool waves7 = false;        // 8-wide kernel: the 72-VGPR instantiation, 7 blocks per CU (scenes beyond the Infinity Cache)
     bool bvh8 = false;          // PT_EXTEND_HBM8: the BVH8 and ITS triangle order (s->d_tri4_8, d_shade64_8, d_ke4_8)
     bool topdown4 = false;      // HBM variant over the top-down BVH4 with contiguous children (s->d_wide16t)
     uint32_t n_tlas_lds = 0;    // k_extend_inst16: TLAS nodes staged in LDS (its top levels)
@@ -1099,17 +1100,25 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
         pl.variant = PT_EXTEND_HBM8;
         pl.bvh8 = true;
         pl.lds_scene = false;
-        pl.lds_stack = pt_tuned(ctx->tune.lds_stack, 12, 1, 32);
+        // one stack entry per visited node: at most one per level of the 8-wide tree.  The LDS stack is sized to exactly that (8 M
+        // triangles: 10 entries) -- then the kernel is instantiated without the spill column's address arithmetic (C5 +1.9 %, C5x
+        // +2.5 %) and the LDS it does not take is there for the co-resident k_shade (9 ... 11 entries instead of 12: C5 +1 %; one
+        // entry too few, i.e. the spill kernel: -1.7 %; profiles/r03bk_*, r03bl_*)
+        const uint32_t bound8 = s->levels8 + 1u;
+        pl.lds_stack = pt_tuned(ctx->tune.lds_stack, (int)std::min(std::max(bound8, 4u), 12u), 1, 32);
         pl.smem = (size_t)pl.lds_stack * TB * sizeof(uint2);
+        const bool spills8 = bound8 > (uint32_t)pl.lds_stack;
+        // 7 waves per SIMD where the walk waits on HBM (same rule as AUTO ray sorting: nodes + records beyond the Infinity Cache);
+        // pt_tuning.extend_blocks = 6 / 7 forces either
+        pl.waves7 = !spills8 && pl.lds_stack <= 10 &&
+                    (ctx->tune.extend_blocks == 7 || (ctx->tune.extend_blocks < 0 && 64ull * s->n_wide8 + 64ull * s->n_tris > (256ull << 20)));
         int per_cu8 = 0;
-        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, ptw_extend8_fn(false), TB, pl.smem));
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, ptw_extend8_fn(false, spills8, pl.waves7), TB, pl.smem));
         per_cu8 = std::max(1, std::min(per_cu8, 8));
         // with the triangle vote at 16 lanes (launch_extend) the refill optimum moved from 32 idle lanes to 12: C5 2 907 ->
         // 3 240 Mrays/s, C5x 2 715 -> 2 960 for both together (profiles/r03bb_*, r03bc_*: 32: 3 025, 24: 3 140, 16: 3 230, 8: 3 235, 4: 3 170)
         pl.refill = pt_tuned(ctx->tune.refill, 12, 1, 64);
         pl.grid = ctx->num_cus * per_cu8;
-        // one stack entry per visited node: at most one per level of the BVH8
-        const uint32_t bound8 = s->levels8 + 1u;
         pl.spill_levels = bound8 > (uint32_t)pl.lds_stack ? bound8 - (uint32_t)pl.lds_stack : 0u;
         const size_t need8 = PT_MAX_PIPES * (size_t)std::max(pl.spill_levels, 1u) * (size_t)pl.grid * TB * sizeof(uint2);
         if (need8 > ctx->spill_bytes) {
@@ -1244,7 +1253,7 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
         // behind every node step -- a node step is 240 instructions, a triangle step 110: 16 measured best (8: -2 %, 12: -0.5 %,
         // 20: equal on C5x, 24: -3 %; repeating triangle steps changes nothing: profiles/r03ba_ab_c5_vote.log)
         const int tri_enter = pt_tuned(s->ctx->tune.tri_enter, 16, 1, 64), tri_stay = pt_tuned(s->ctx->tune.tri_stay, 65, 1, 65);
-        ptw_launch_extend8(count, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, s->d_shade64_8, rayA, rayB, hit,
+        ptw_launch_extend8(count, pl.spill_levels > 0u, pl.waves7, pl.grid, pl.smem, st, ev0, ev1, s->d_wide8, s->norm_c, s->norm_s, s->norm_rs, s->d_tri4_8, s->d_shade64_8, rayA, rayB, hit,
                            count_in, count_zero, stats, spill, stride, pl.refill | (tri_enter << 8) | (tri_stay << 16), tmin, tmax, pl.lds_stack, raw, perm, ray_tmax);
         return;
     }

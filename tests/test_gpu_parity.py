@@ -1590,10 +1590,12 @@ def test_bvh8_render_bit_exact_and_auto_selection(pt, orc, gpu_ctx):
 
 
 @pytest.mark.parametrize("knobs", [dict(tri_enter=1, tri_stay=1), dict(tri_enter=8, tri_stay=4), dict(tri_enter=16, tri_stay=65),
-                                   dict(tri_enter=64, tri_stay=1), dict(tri_enter=24, tri_stay=12, refill=8)])
+                                   dict(tri_enter=64, tri_stay=1), dict(tri_enter=24, tri_stay=12, refill=8),
+                                   dict(extend_blocks=7), dict(extend_blocks=6, lds_stack=3), dict(lds_stack=1, tri_enter=5)])
 def test_bvh8_vote_knobs_keep_the_bits(pt, orc, gpu_ctx, knobs):
     """The vote of the 8-wide kernel (extend8_kernel.h: how many lanes wait with leaf triangles before a triangle step runs,
-    and how long triangle steps repeat) decides the order in which a ray's candidates are met, never which hit it returns:
+    and how long triangle steps repeat) decides the order in which a ray's candidates are met, never which hit it returns;
+    nor does the instantiation: 7 waves per SIMD (extend_blocks = 7), or the spill kernel (fewer LDS stack entries than levels):
     hit records (closest-hit and a negative tmin) and a rendered film equal the oracle's under every setting."""
     v, i, f = _soup(20000, 23, spread=0.05)
     old = gpu_ctx.set_tuning(**knobs)
