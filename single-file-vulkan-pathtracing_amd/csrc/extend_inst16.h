@@ -109,6 +109,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
         sp++;
     };
+    // (pushes and pop loop duplicated in a form without the spill test, taken while the whole wave is within the LDS entries:
+    // C4 -1.6 %, three of three rounds -- the second copy costs more than the test: profiles/r03bo_ab_c4_roomy.log)
     // (an instance visit ends when the stack is back at the height it had on entry, `sp_exit` -- no marker entry under the
     // instance's own entries, which cost the pop loop one iteration per visit for the one or two lanes that met it)
     auto pop = [&]() -> uint32_t {
