@@ -1448,12 +1448,12 @@ struct RenderShape {
 // do not live longer than they have to
 // `shrink`: 0 for the first try; pt_render retries with 1, 2, ... after an out-of-memory workspace grow, each step
 // halving the memory the AUTO shape may plan for (explicit frames_in_flight / sample_groups are never overridden).
-// `big_scene`: the traversal walks the scene out of L2 / MALL / HBM (no LDS copy).  Its launches take milliseconds per million
+// `launch_class`: 0 instanced scenes, 1 scenes walked out of L2 / MALL / HBM (no LDS copy), 2 single-level scenes in LDS.  Class 1: the launches take milliseconds per million
 // rays and what they gain from being LONG is measured: 1 M-triangle soup, 4 frames of 16 spp -- 4 groups (3.7 M rays per launch)
 // 2 617 Mrays/s, 8 groups 2 799, 16 groups (14.8 M) 2 889; 16 frames x 4 groups 2 886, x 8 (29.6 M) 2 926; the 8 M-triangle soup
 // at 2 frames +3 % from 8 to 16 groups (profiles/r03au_shapes_c5_c4.log).  So the sample groups of such scenes aim at 128 M live
-// paths where the Cornell-class scenes aim at 32 M (their shapes are box- and allocation-sensitive).
-RenderShape choose_shape(const pt_film *f, const pt_params *p, bool big_scene, int shrink = 0)
+// paths; the Cornell-class scenes followed in the round's last session (below), instanced scenes aim at 32 M.
+RenderShape choose_shape(const pt_film *f, const pt_params *p, int launch_class, int shrink = 0)
 {
     RenderShape sh;
     const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
@@ -1483,13 +1483,20 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, bool big_scene, i
     //  (a) few frames asked for: the frames in flight alone cannot fill the chip;
     //  (b) a slot lives group_size x depth rounds and every round costs ~27 us of launch-bound time per pipeline
     //      whatever its queue holds: 16 frames x 4 groups need 64 rounds instead of 256 (Cornell box, 1080p: +4 %),
-    //      as long as the slots (<= 160 M: 21 GB of queues + 25 GB of primary log) allow it.
+    //      as long as the slots (<= 160 M: 21 GB of queues + 25 GB of primary log; 288 M for single-level scenes in LDS) allow it.
     uint32_t groups = p->sample_groups;
     if (groups == 0) {
         groups = 1;
         const uint64_t have = std::max<uint64_t>((uint64_t)lanes * pixels_local, 1);
-        double want = (double)(big_scene ? 4 * target : target) / (double)have;
-        const uint64_t slot_budget = 160ull << 20;
+        // live paths aimed at: 128 M for scenes walked out of HBM (above), 32 M for instanced scenes (C4, K = 8: 4 groups 12.74
+        // Grays/s, 8 groups 12.52), and -- round 3, last session; 32 M until then -- 256 M for single-level scenes in LDS: a
+        // Cornell-class render is better off with MORE slots and fewer rounds.  K = 2 (config C2 exactly): 8 groups 23.7 Grays/s,
+        // 16: 25.4, 32: 26.5; K = 1: 16 groups 23.0, 32: 25.3; K = 4: 4 groups 23.7, 16: 26.3, 32 (266 M slots): 27.1; 16 frames as
+        // two batches of 8 with 16 groups: 27.1; K = 16: 4 groups (133 M slots, 51 GB) 23.0 / 26.6 / 26.3 in three
+        // processes, 8 groups (266 M, 70 GB) 26.5 / 27.1 / 26.5, 16 groups (109 GB) 26.3 / 27.3 / 27.0
+        // (profiles/r03br_*, r03bs_*, r03bt_*, r03bu_*)
+        double want = (double)((launch_class == 2 ? 8 : launch_class == 1 ? 4 : 1) * target) / (double)have;
+        const uint64_t slot_budget = (launch_class == 2 ? 288ull : 160ull) << 20;
         if (can_redo && have * 4 <= slot_budget) want = std::max(want, 4.0);
         else if (can_redo && have * 2 <= slot_budget) want = std::max(want, 2.0);
         if (want >= 2.0) {
@@ -1549,14 +1556,14 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, bool big_scene, i
 // The shape of a render and its workspace.  An AUTO shape that does not fit after all (another allocator took the
 // memory between hipMemGetInfo and hipMalloc) is planned again for half the memory, down to one frame and one group;
 // an explicit shape that does not fit is PT_ERR_OOM.  Either way a failure leaves the film usable.
-pt_status shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh, bool big_scene)
+pt_status shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh, int launch_class)
 {
     pt_status rc = PT_OK;
     pt_params p_local = *p_in;
     if (p_local.pipeline == PT_PIPELINE_WAVEFRONT_NEE) p_local.sample_groups = 1;  // up to max_depth + 1 radiance terms per sample: the plain accumulator
     const pt_params *p = &p_local;
     for (int attempt = 0; attempt < 12; attempt++) {
-        sh = choose_shape(f, p, big_scene, attempt);
+        sh = choose_shape(f, p, launch_class, attempt);
         rc = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap);
         if (rc != PT_ERR_OOM) return rc;
         const bool can_shrink = (p->frames_in_flight == 0 && sh.lanes > 1) || (p->sample_groups == 0 && sh.groups > 1);
@@ -1625,7 +1632,7 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
     RenderShape sh;
-    rc_ = shape_and_work(f, p, sh, !pl.lds_scene && pl.variant != PT_EXTEND_FLAT);
+    rc_ = shape_and_work(f, p, sh, s->n_inst || pl.variant == PT_EXTEND_FLAT ? 0 : pl.lds_scene ? 2 : 1);
     s->ctx->stats.frames_in_flight = sh.lanes;
     s->ctx->stats.sample_groups = sh.groups;
     if (rc_ != PT_OK) return rc_;
@@ -1667,7 +1674,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
     RenderShape sh;
-    rc_ = shape_and_work(f, p, sh, !pl.lds_scene && pl.variant != PT_EXTEND_FLAT);
+    rc_ = shape_and_work(f, p, sh, s->n_inst || pl.variant == PT_EXTEND_FLAT ? 0 : pl.lds_scene ? 2 : 1);
     if (rc_ != PT_OK) return rc_;
     const uint32_t lanes = sh.lanes, groups = sh.groups, group_size = sh.group_size, term_cap = sh.term_cap;
     if (!nested) {
