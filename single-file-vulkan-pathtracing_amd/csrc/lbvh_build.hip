@@ -1395,8 +1395,8 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     // the tree of the default quality (ePreferFastTrace, main.cpp:419): PLOC for big scenes; small scenes get the LBVH
     // here and the exact surface-area BVH4 below.  The 8-wide nodes only when the context asks AUTO to use them.
     // (small scenes get the 8-wide nodes at once -- a few KB; big ones on first request: 260 B per triangle nobody else needs)
-    // ... and scenes whose traversal working set will exceed the 32 MiB of L2 (~96 B per triangle), which AUTO walks through them
-    pt_status rc = build_tree_products(s, PT_BVH_PREFER_FAST_TRACE, ctx->tune.hbm8 == 1 || n <= PT_SAH_MAX_TRIS || (ctx->tune.hbm8 != 0 && 96ull * n > (32ull << 20)));
+    // ... and scenes AUTO walks through them: more than 1 MiB of BVH4 nodes + records, ~96 B per triangle (wavefront.hip plan_extend)
+    pt_status rc = build_tree_products(s, PT_BVH_PREFER_FAST_TRACE, ctx->tune.hbm8 == 1 || n <= PT_SAH_MAX_TRIS || (ctx->tune.hbm8 != 0 && 96ull * n > (1ull << 20)));
     if (rc != PT_OK) return rc;
     {   // emitters for the NEE pipeline: normal as closesthit.rchit:43-48, area = |cross| / 2, cdf = running float sum of the
         // areas in primitive order (this file is compiled with -ffp-contract=off on the host side too)

@@ -1012,12 +1012,16 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
     if (want > PT_EXTEND_HBM8) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
-    // AUTO walks scenes beyond L2 through the 8-wide tree (64-B nodes with byte planes): fewer distinct lines per ray -- measured on
+    // AUTO walks scenes beyond L2 (at first; now nearly every scene beyond LDS, below) through the 8-wide tree (64-B nodes with byte planes): fewer distinct lines per ray -- measured on
     // MI355X, same box, three rounds: C5 2 465 -> 2 547 Mrays/s (+3.4 %), C5x 2 405 -> 2 546 (+5.9 %), 36.2 -> 27.7 and 29.5 -> 24.2
     // node visits per ray (profiles/r03_ab_c5_c5x_hbm8_64B_nodes.log); pt_tuning.hbm8 = 0 keeps the BVH4, 1 takes the 8-wide tree
     // for every scene that does not fit LDS
     const uint64_t ws4 = 64ull * (s->n_wide16t ? s->n_wide16t : s->n_wide) + 64ull * s->n_tris;
-    const bool auto8_big = want == PT_EXTEND_AUTO && ctx->tune.hbm8 != 0 && ws4 > (32ull << 20) && s->n_tris > PT_SAH_MAX_TRIS;
+    // (round 3, last session: with the 8-wide kernel's new vote, refill threshold and spill-free instantiation the crossover fell from
+    // 32 MiB of BVH4 nodes + records to ~1 MiB, i.e. ~11 000 triangles -- soups of 2 500 / 5 000 / 12 000 / 20 000 / 50 000 / 100 000 /
+    // 200 000 / 400 000 triangles, 8-wide against BVH4 kernel: -4 / -1.7 / +1.7 / +3.8 / +11 / +11 / +18 / +21 %,
+    // profiles/r03ca_bvh4_vs_8wide_midsize.log, r03cb_bvh4_vs_8wide_small.log)
+    const bool auto8_big = want == PT_EXTEND_AUTO && ctx->tune.hbm8 != 0 && ws4 > (1ull << 20) && s->n_tris > PT_SAH_MAX_TRIS;
     if ((want == PT_EXTEND_HBM8 || (want == PT_EXTEND_AUTO && ctx->tune.hbm8 == 1) || auto8_big) && !s->n_inst && !s->d_wide8) {
         const pt_status rc8 = ptb_ensure_wide8(s);   // built on first request (260 B per triangle nobody else needs)
         if (rc8 != PT_OK) return rc8;

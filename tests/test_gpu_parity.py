@@ -464,7 +464,7 @@ def test_soup_render_bit_exact_global_memory_variant(pt, orc, gpu_ctx):
     gpu_ctx.reset_stats()
     pt.render(gs, film, pt.default_params(width=96, height=96, spp_per_frame=4, max_depth=6, frame_count=2))
     st = gpu_ctx.stats()
-    assert st.extend_variant == pt.EXTEND_HBM
+    assert st.extend_variant == pt.EXTEND_HBM8      # (AUTO beyond ~11 000 triangles since round 3; the BVH4 kernel: tests below)
     ofilm, obgra, orays = _render_oracle(orc, osc, 2, width=96, height=96, spp_per_frame=4, max_depth=6)
     assert st.rays == orays
     assert film.read_f32().tobytes() == ofilm.tobytes()
@@ -1570,14 +1570,15 @@ def test_bvh8_structure_and_hits(pt, orc, gpu_ctx, cornell_arrays, n, seed, spre
 
 
 def test_bvh8_render_bit_exact_and_auto_selection(pt, orc, gpu_ctx):
-    """A 30 000-triangle soup (does not fit LDS): AUTO and PT_EXTEND_HBM walk the BVH4, PT_EXTEND_HBM8 the BVH8; all render the oracle's
-    film and ray count, progressive frames, sample groups and two pipelines included (k_shade reads the per-triangle tables in
-    the order of whichever tree was walked)."""
+    """A 30 000-triangle soup (does not fit LDS): PT_EXTEND_HBM walks the BVH4, PT_EXTEND_HBM8 and -- beyond 1 MiB of nodes + records,
+    about 11 000 triangles -- AUTO the 8-wide tree; all render the oracle's film and ray count, progressive frames, sample groups
+    and two pipelines included (k_shade reads the per-triangle tables in the order of whichever tree was walked).  A 6 000-triangle
+    soup stays with the BVH4 kernel under AUTO."""
     v, i, f = _soup(30000, 11, spread=0.05)
     gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
     kw = dict(width=160, height=96, spp_per_frame=4, max_depth=6)
     ofilm, obgra, orays = _render_oracle(orc, osc, 3, **kw)
-    for extend, name in ((pt.EXTEND_AUTO, 3), (pt.EXTEND_HBM8, 4), (pt.EXTEND_HBM, 3)):
+    for extend, name in ((pt.EXTEND_AUTO, 4), (pt.EXTEND_HBM8, 4), (pt.EXTEND_HBM, 3)):
         film = pt.Film(gpu_ctx, 160, 96)
         gpu_ctx.reset_stats()
         pt.render(gs, film, pt.default_params(frame=0, frame_count=1, extend=extend, **kw))
@@ -1586,6 +1587,16 @@ def test_bvh8_render_bit_exact_and_auto_selection(pt, orc, gpu_ctx):
         assert st.extend_variant == name and st.rays == orays and st.nodes_visited > 0 and st.tris_tested > 0
         assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes()
         film.close()
+    gs.close()
+    v, i, f = _soup(6000, 12, spread=0.05)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
+    film = pt.Film(gpu_ctx, 160, 96)
+    gpu_ctx.reset_stats()
+    pt.render(gs, film, pt.default_params(frame=0, frame_count=1, **kw))
+    assert gpu_ctx.stats().extend_variant == pt.EXTEND_HBM and gpu_ctx.stats().rays == orays
+    assert film.read_f32().tobytes() == ofilm.tobytes()
+    film.close()
     gs.close()
 
 
