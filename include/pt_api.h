@@ -73,7 +73,9 @@ typedef struct pt_tuning {
     int32_t leaf_min;       /* compact two-level kernel: lanes that wait with a triangle leaf before the leaf step runs */
     int32_t tri_enter;      /* 8-wide tree kernel: lanes that wait with leaf triangles before a triangle step runs     */
     int32_t tri_stay;       /* ... and triangle steps repeat while at least this many lanes still hold one (65 = never) */
-    int32_t reserved[9];
+    int32_t inst_frames;    /* 0: instanced scenes transform the normal and build its tangent frame per hit instead of reading
+                               the per-(instance, triangle) table                                                         */
+    int32_t reserved[8];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);

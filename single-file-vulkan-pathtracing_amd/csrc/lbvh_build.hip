@@ -1505,6 +1505,8 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
                                            s->d_shade4, s->d_shade64, s->d_ke4, s->d_frame4);
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
+    (void)hipFree(s->d_inst_frame);  // (the triangle order changed: ptb_ensure_inst_frames builds it again on the next render)
+    s->d_inst_frame = nullptr;
     s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
     s->quality = quality;
     return make_wide16(s);
@@ -1585,8 +1587,47 @@ static void invert_3x4(const float m[12], float inv[12])
     inv[8] = (float)i20; inv[9] = (float)i21; inv[10] = (float)i22; inv[11] = (float)(-((i20 * tx + i21 * ty) + i22 * tz));
 }
 
+// World-space normal and tangent of every (instance, triangle): what k_shade's instanced branch used to evaluate per hit -- the
+// normal by the inverse transpose, renormalised (a square root and three true divides), and createCoordinateSystem on it (another
+// square root and two divides) -- evaluated ONCE with exactly those operations (wavefront.hip k_shade; pt_math.h tangent_frame),
+// so the bits are the same.  32 B per entry: {n.xyz, T.x} {T.yz, -, -}; the bitangent is the cross product k_shade forms anyway.
+// Instance order = d_inst6's (TLAS leaf order), triangle order = d_shade4's (BVH4 leaf order): rebuilt when either changes.
+__global__ __launch_bounds__(TB) void k_inst_frames(const float4 *__restrict__ inst6, const float4 *__restrict__ shade4, uint32_t n_inst,
+                                                    uint32_t n_tris, float4 *__restrict__ out)
+{
+    const size_t idx = (size_t)blockIdx.x * TB + threadIdx.x;
+    if (idx >= (size_t)n_inst * n_tris) return;
+    const uint32_t ip = (uint32_t)(idx / n_tris), pos = (uint32_t)(idx - (size_t)ip * n_tris);
+    const float4 s0 = shade4[3 * (size_t)pos];
+    const float4 i0 = inst6[6 * (size_t)ip + 3], i1 = inst6[6 * (size_t)ip + 4], i2 = inst6[6 * (size_t)ip + 5];
+    const float nx = (i0.x * s0.x + i1.x * s0.y) + i2.x * s0.z;
+    const float ny = (i0.y * s0.x + i1.y * s0.y) + i2.y * s0.z;
+    const float nz = (i0.z * s0.x + i1.z * s0.y) + i2.z * s0.z;
+    const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
+    const ptm::f3 n = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
+    ptm::f3 T, B;
+    ptm::tangent_frame(n, T, B);
+    out[2 * idx + 0] = make_float4(n.x, n.y, n.z, T.x);
+    out[2 * idx + 1] = make_float4(T.y, T.z, 0.f, 0.f);
+}
+
+pt_status ptb_ensure_inst_frames(pt_scene *s)
+{
+    pt_ctx *ctx = s->ctx;
+    if (!s->n_inst || s->d_inst_frame) return PT_OK;
+    const size_t entries = (size_t)s->n_inst * s->n_tris;
+    if (entries * 32 > (512ull << 20)) return PT_OK;  // (a table beyond the caches would cost more than it saves: the per-hit transform stays)
+    PT_HIP(ctx, hipMalloc((void **)&s->d_inst_frame, 32 * entries));
+    k_inst_frames<<<(unsigned)((entries + TB - 1) / TB), TB, 0, ctx->stream>>>(s->d_inst6, s->d_shade4, s->n_inst, s->n_tris, s->d_inst_frame);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 void ptb_free_instances(pt_scene *s)
 {
+    (void)hipFree(s->d_inst_frame);
+    s->d_inst_frame = nullptr;
     (void)hipFree(s->d_lights_inst);
     s->d_lights_inst = nullptr; s->n_lights_inst = 0; s->light_area_inst = 0.f;
     (void)hipFree(s->d_inst6); (void)hipFree(s->d_tlas_wide); (void)hipFree(s->d_tlas_prim_of); (void)hipFree(s->d_tlas16);

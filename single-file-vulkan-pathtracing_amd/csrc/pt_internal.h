@@ -114,6 +114,7 @@ struct pt_scene {
     // two-level scenes: instances in TLAS leaf order, 6 float4 each {object->world rows, world->object rows}
     uint32_t n_inst = 0, n_tlas_wide = 0, tlas_height = 0;
     float4 *d_inst6 = nullptr;
+    float4 *d_inst_frame = nullptr;  // [n_inst][n_tris][2]: world-space normal + tangent of every instanced triangle (ptb_ensure_inst_frames)
     float4 *d_tlas_wide = nullptr;        // BVH4 over the instances' world boxes
     uint32_t *d_tlas_prim_of = nullptr;   // sorted position -> instance id (gl_InstanceID)
     // the TLAS k_extend_inst16 walks: 64-B fp16 nodes (normalised to the TLAS box), built top-down, 16-bit child codes
@@ -175,6 +176,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
 pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
 pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality);
 void ptb_free_scene_buffers(pt_scene *s);
+pt_status ptb_ensure_inst_frames(pt_scene *s);  // the table k_shade reads instead of transforming the normal per hit (instanced scenes)
 pt_status ptb_ensure_wide8(pt_scene *s);  // builds the 8-wide nodes of a scene that was created without them
 constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
 // bvh4_sah_device.hip: surface-area sweep on the device (one workgroup) -> BVH4 rows (32 dwords each) + leaf order

@@ -608,6 +608,11 @@ __global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad,
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 7
 #endif
+// (the instanced instantiation carries the position transform and the table gather on top: 25 spilled registers at 7 waves = C4
+// -8 %, 8 at 6 waves = +2 %, none at 5 waves / 96 VGPRs = +4 % over the kernel before: profiles/r03cf_ab_c4_inst_frames.log)
+#ifndef PT_SHADE_WAVES_INST
+#define PT_SHADE_WAVES_INST 5
+#endif
 // PT_SHADE_PRELOAD=1 requests every queue record of a chunk before the first is used (one memory round trip per chunk
 // instead of one per item).  Alone on the chip (one pipeline) k_shade gets 13 % faster with it at 5 waves (91 VGPRs, no
 // spills: 104 -> 90 ms per 16 C2 frames); next to the other pipeline's traversal kernel, which is how it runs, nothing
@@ -616,8 +621,9 @@ __global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad,
 #ifndef PT_SHADE_PRELOAD
 #define PT_SHADE_PRELOAD 0
 #endif
-template <int SH_ITEMS, bool LDS_TABLES, bool NEE = false>
-__global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
+// INST: the scene is instanced (position and normal go to world space per hit; the single-level instantiations carry none of that code)
+template <int SH_ITEMS, bool LDS_TABLES, bool NEE = false, bool INST = false>
+__global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
                                               uint32_t n_tris,
                                               const float4 *__restrict__ hit, Radiance rad, QueueView in,
@@ -625,7 +631,8 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                                               const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst,
                                               const float4 *__restrict__ shade64, const float4 *__restrict__ ke4,
                                               const float4 *__restrict__ lights, uint32_t n_lights, float light_area,
-                                              ShadowQueue sq, uint32_t *sq_count, const float4 *__restrict__ g_frame4)
+                                              ShadowQueue sq, uint32_t *sq_count, const float4 *__restrict__ g_frame4,
+                                              const float4 *__restrict__ inst_frame)
 {
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
@@ -754,21 +761,31 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                     org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv,
                             (a.z * b0 + b.z * hu) + c.z * hv };
                     ptm::f3 nrm = { s0.x, s0.y, s0.z };
-                    if (inst6) {
+                    ptm::f3 tng{};  // instanced scenes with the (instance, triangle) table: the tangent of createCoordinateSystem
+                    if (INST) {
                         // instanced scene: position by the object->world matrix, normal by the inverse
                         // transpose, renormalised (the reference's closesthit has one identity instance)
                         const uint32_t ip = hit_inst[q];
                         const float4 m0 = inst6[6 * (size_t)ip + 0], m1 = inst6[6 * (size_t)ip + 1], m2 = inst6[6 * (size_t)ip + 2];
-                        const float4 i0 = inst6[6 * (size_t)ip + 3], i1 = inst6[6 * (size_t)ip + 4], i2 = inst6[6 * (size_t)ip + 5];
                         const ptm::f3 pw = { ((m0.x * org.x + m0.y * org.y) + m0.z * org.z) + m0.w,
                                              ((m1.x * org.x + m1.y * org.y) + m1.z * org.z) + m1.w,
                                              ((m2.x * org.x + m2.y * org.y) + m2.z * org.z) + m2.w };
-                        const float nx = (i0.x * nrm.x + i1.x * nrm.y) + i2.x * nrm.z;
-                        const float ny = (i0.y * nrm.x + i1.y * nrm.y) + i2.y * nrm.z;
-                        const float nz = (i0.z * nrm.x + i1.z * nrm.y) + i2.z * nrm.z;
-                        const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
                         org = pw;
-                        nrm = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
+                        if (inst_frame) {
+                            // ... both evaluated once per (instance, triangle) with these very operations (lbvh_build.hip
+                            // k_inst_frames): a 32-B gather instead of two square roots and five true divides per hit
+                            const size_t e = 2 * ((size_t)ip * n_tris + pos);
+                            const float4 f0 = inst_frame[e], f1 = inst_frame[e + 1];
+                            nrm = { f0.x, f0.y, f0.z };
+                            tng = { f0.w, f1.x, f1.y };
+                        } else {
+                            const float4 i0 = inst6[6 * (size_t)ip + 3], i1 = inst6[6 * (size_t)ip + 4], i2 = inst6[6 * (size_t)ip + 5];
+                            const float nx = (i0.x * nrm.x + i1.x * nrm.y) + i2.x * nrm.z;
+                            const float ny = (i0.y * nrm.x + i1.y * nrm.y) + i2.y * nrm.z;
+                            const float nz = (i0.z * nrm.x + i1.z * nrm.y) + i2.z * nrm.z;
+                            const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
+                            nrm = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
+                        }
                     }
                     if (NEE && n_lights) {  // one light sample -> shadow queue (three random numbers, drawn before the bounce's)
                         ptm::f3 wi;
@@ -782,9 +799,12 @@ __global__ __launch_bounds__(TB, NEE ? 4 : PT_SHADE_WAVES) void k_shade(RenderCo
                     }
                     const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
                     const float r2 = ptm::rnd(seed);
-                    if (LDS_TABLES && !inst6) {  // the triangle's tangent frame was evaluated once, by k_pack, with the same operations
+                    if (LDS_TABLES && !INST) {  // the triangle's tangent frame was evaluated once, by k_pack, with the same operations
                         const float4 f0 = frame4[2 * pos + 0], f1 = frame4[2 * pos + 1];
                         dir = ptm::sample_direction_frame(r1, r2, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
+                    } else if (INST && inst_frame) {  // bitangent = the cross product of tangent_frame, same operands
+                        const ptm::f3 btg = { nrm.y * tng.z - nrm.z * tng.y, nrm.z * tng.x - nrm.x * tng.z, nrm.x * tng.y - nrm.y * tng.x };
+                        dir = ptm::sample_direction_frame(r1, r2, nrm, tng, btg);
                     } else {
                         dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
                     }
@@ -1724,6 +1744,13 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     const int shade_grid = ctx->num_cus * 8;
     const size_t shade_smem = sizeof(float4) * 8 * (size_t)s->n_tris;  // tri4 + shade4 + the tangent frames
     const bool shade_lds = shade_smem <= 16 * 1024 && !pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
+    // instanced scenes: world-space normal + tangent per (instance, triangle), built once (lbvh_build.hip); pt_tuning.inst_frames = 0
+    // keeps the per-hit transform
+    if (s->n_inst && !pl.bvh8 && ctx->tune.inst_frames != 0) {
+        const pt_status rcf = ptb_ensure_inst_frames(s);
+        if (rcf != PT_OK) return rcf;
+    }
+    const float4 *inst_frame = s->n_inst && !pl.bvh8 && ctx->tune.inst_frames != 0 ? s->d_inst_frame : nullptr;
     // Several pipelines on separate streams: the slot lanes of a batch are split into parts that run their
     // rounds independently, so the VALU-bound extend of one overlaps the HBM-bound shade of another
     // (measured on MI355X, Cornell box: 1 pipeline 13.4, 2: 15.2, 3: 15.0, 4: 14.1 Grays/s; restricting the
@@ -1909,11 +1936,13 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                         PT_HIP(ctx, hipMemsetAsync(sq_count, 0, sizeof(uint32_t), pp.st));
                     }
 #define PT_LAUNCH_SHADE(N, L, E)                                                                                               \
-    hipExtLaunchKernelGGL((k_shade<N, L, E>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
+    if (s->n_inst) PT_LAUNCH_SHADE_I(N, L, E, true); else PT_LAUNCH_SHADE_I(N, L, E, false)
+#define PT_LAUNCH_SHADE_I(N, L, E, I)                                                                                          \
+    hipExtLaunchKernelGGL((k_shade<N, L, E, I>), dim3(shade_grid), dim3(TB), (uint32_t)((L) ? shade_smem : 0), pp.st, h0, h1, 0u, rc, \
                           w.d_tiles, s->d_tri4, s->d_shade4, s->n_tris, pp.hit, rad, pp.qv[cur], pp.qv[cur ^ 1],                \
                           &pp.count[cur], &pp.count[cur ^ 1], s->n_inst ? s->d_inst6 : nullptr, pp.hit_inst,                    \
                           pl.bvh8 ? s->d_shade64_8 : s->d_shade64, pl.bvh8 ? s->d_ke4_8 : s->d_ke4, nee_lights, nee_n_lights,      \
-                          nee_light_area, sq, sq_count, s->d_frame4)
+                          nee_light_area, sq, sq_count, s->d_frame4, inst_frame)
                     if (nee) {
                         if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, true); }
                         else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, true); }
@@ -1928,6 +1957,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
                     } else if (shade_lds) { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, true, false); }
                     else { PT_LAUNCH_SHADE(PT_SHADE_ITEMS, false, false); }
 #undef PT_LAUNCH_SHADE
+#undef PT_LAUNCH_SHADE_I
                     if (shade_rule) { PT_HIP(ctx, hipEventRecord(ctx->ev_shade[k], pp.st)); shade_recorded[k] = true; }
                     if (profile) {
                         ev_extend.push_back(x0); ev_extend.push_back(x1);

@@ -586,10 +586,11 @@ def test_c4_grid_of_10000_instances(pt, orc, gpu_ctx, cornell_arrays):
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [dict(node_yield=0), dict(node_yield=2), dict(tlas_lds_kb=0),
                                    dict(tlas_lds_kb=24, node_yield=8), dict(inst16=0), dict(leaf_min=1), dict(leaf_min=24, enter_min=4),
-                                   dict(leaf_min=64, enter_min=64)])
+                                   dict(leaf_min=64, enter_min=64), dict(inst_frames=0)])
 def test_two_level_kernel_scheduling_knobs_keep_the_bits(pt, orc, gpu_ctx, cornell_arrays, knobs):
     """The scheduling of the compact two-level kernel (when the node loop yields to waiting leaves, how many TLAS nodes are
-    staged in LDS, how many lanes wait before a leaf step or an instance entry runs; inst16 = 0: the general two-level kernel) must not show in the results: the 10 000-instance grid -- a partly LDS-resident
+    staged in LDS, how many lanes wait before a leaf step or an instance entry runs; inst16 = 0: the general two-level kernel; inst_frames = 0: k_shade
+    transforms the normal per hit instead of reading the per-(instance, triangle) table) must not show in the results: the 10 000-instance grid -- a partly LDS-resident
     TLAS -- and a 7-instance set -- an entirely LDS-resident one -- render and trace to the oracle's bits under every setting."""
     old = gpu_ctx.set_tuning(**knobs)      # include/pt_api.h pt_tuning (the library reads no tuning from the environment)
     try:
