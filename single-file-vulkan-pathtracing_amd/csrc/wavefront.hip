@@ -605,6 +605,8 @@ __global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad,
 #ifndef PT_SHADE_ITEMS
 #define PT_SHADE_ITEMS 2
 #endif
+// (round 3, after the instancing template -- 70 VGPRs, no spills at 7 waves: ten interleaved processes each, 7 waves median 26.8
+// Grays/s, 6 waves 25.8; 5 waves with PT_SHADE_PRELOAD 25.2: profiles/r03ck_ab_c2_shade_7_vs_6_waves.log, r03cj_*)
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 7
 #endif
