@@ -96,8 +96,8 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
                     q = perm ? perm[qq] : qq;  // ray_sort.hip
-                    const float4 ra = rayA[q];
-                    const float2 rb = rayB[q];
+                    const float4 ra = ptm::ld_stream<false>(rayA + q);
+                    const float2 rb = ptm::ld_stream<false>(rayB + q);
                     const ptm::f3 org = { ra.x, ra.y, ra.z };
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup(org, dir);
@@ -253,9 +253,9 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
             if (!got) {
                 PT_COUNT_WAVE(c_finishes);
                 const bool miss = best_pos == PT_MISS;
-                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                ptm::st_stream<false>(hit + q, raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
                                  : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det)));
                 have = false;
             }
         }

@@ -151,8 +151,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
                     q = qq;
-                    const float4 ra = rayA[q];
-                    const float2 rb = rayB[q];
+                    const float4 ra = ptm::ld_stream<true>(rayA + q);
+                    const float2 rb = ptm::ld_stream<true>(rayB + q);
                     org_w = { ra.x, ra.y, ra.z };
                     dir_w = { ra.w, rb.x, rb.y };
                     level_setup(org_w, dir_w, nbt);
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
             if (cur == I16_DONE) {
                 PT_COUNT_WAVE(c_finishes);
                 const bool miss = best_pos == PT_MISS;
-                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                ptm::st_stream<true>(hit + q, raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
                                  : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det)));
                 if (!SHADOW) hit_inst[q] = best_ipos;
                 have = false;
             }

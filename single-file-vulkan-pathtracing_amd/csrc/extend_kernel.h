@@ -293,8 +293,8 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 if (qq < n) {
                     PT_COUNT_WAVE(c_refills);
                     q = (!LDS_SCENE && perm) ? perm[qq] : qq;  // ray_sort.hip: the queue is walked in (cell, octant) order
-                    const float4 ra = rayA[q];
-                    const float2 rb = rayB[q];
+                    const float4 ra = ptm::ld_stream<false>(rayA + q);
+                    const float2 rb = ptm::ld_stream<false>(rayB + q);
                     const ptm::f3 org = { ra.x, ra.y, ra.z };
                     const ptm::f3 dir = { ra.w, rb.x, rb.y };
                     pre = ptm::ray_setup<!(LDS_SCENE && !PAIRS)>(org, dir);  // (k_extend_lds7: pt_math.h)
@@ -534,9 +534,9 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 const bool miss = best_pos == PT_MISS;
                 // raw_hit (render path): (V, W, det) go out undivided and k_shade takes the two quotients at
                 // full lane occupancy; here they would run once per finishing lane group
-                hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
+                ptm::st_stream<false>(hit + q, raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
                                  : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t,
-                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det));
+                                               miss ? 0.f : ptm::fdiv(best_V, best_det), miss ? 0.f : ptm::fdiv(best_W, best_det)));
                 have = false;
             }
         }

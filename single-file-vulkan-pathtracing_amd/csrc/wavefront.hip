@@ -710,9 +710,9 @@ __global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE
             const float4 st = in_st[it];
             const float4 h = in_hit[it];
 #else
-            const uint2 id = in.id[q];
-            const float4 st = in.state[q];
-            const float4 h = hit[q];
+            const uint2 id = ptm::ld_stream<INST>(in.id + q);
+            const float4 st = ptm::ld_stream<INST>(in.state + q);
+            const float4 h = ptm::ld_stream<INST>(hit + q);
 #endif
             const uint32_t slot = id.x, ctr = id.y;
             uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
@@ -909,10 +909,10 @@ __global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE
 #pragma unroll
         for (int it = 0; it < SH_ITEMS; it++) {
             if (alive[it]) {
-                out.id[dst[it]] = make_uint2(o_slot[it], o_ctr[it]);
-                out.state[dst[it]] = o_state[it];
-                out.rayA[dst[it]] = o_rayA[it];
-                out.rayB[dst[it]] = o_rayB[it];
+                ptm::st_stream<INST>(out.id + dst[it], make_uint2(o_slot[it], o_ctr[it]));
+                ptm::st_stream<INST>(out.state + dst[it], o_state[it]);
+                ptm::st_stream<INST>(out.rayA + dst[it], o_rayA[it]);
+                ptm::st_stream<INST>(out.rayB + dst[it], o_rayB[it]);
             }
         }
     }
