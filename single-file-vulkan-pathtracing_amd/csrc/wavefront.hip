@@ -909,10 +909,10 @@ __global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE
 #pragma unroll
         for (int it = 0; it < SH_ITEMS; it++) {
             if (alive[it]) {
-                ptm::st_stream<INST>(out.id + dst[it], make_uint2(o_slot[it], o_ctr[it]));
-                ptm::st_stream<INST>(out.state + dst[it], o_state[it]);
-                ptm::st_stream<INST>(out.rayA + dst[it], o_rayA[it]);
-                ptm::st_stream<INST>(out.rayB + dst[it], o_rayB[it]);
+                ptm::st_stream<true>(out.id + dst[it], make_uint2(o_slot[it], o_ctr[it]));
+                ptm::st_stream<true>(out.state + dst[it], o_state[it]);
+                ptm::st_stream<true>(out.rayA + dst[it], o_rayA[it]);
+                ptm::st_stream<true>(out.rayB + dst[it], o_rayB[it]);
             }
         }
     }
