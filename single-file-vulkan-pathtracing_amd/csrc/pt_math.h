@@ -386,10 +386,14 @@ __device__ __forceinline__ bool box_test(const f3 mn, const f3 mx, const f3 org,
 
 // ---- streamed-once queue traffic ---------------------------------------------------------------
 // Queue records, hit records and rays are written by one kernel and read exactly once by the next, tens of MB to GB later.
-// NT = true gives them the `nt` cache policy (non-temporal: do not keep the line).  Measured, same box, interleaved: the kernels of
-// instanced scenes gain (C4 13.41 -> 13.73 Grays/s, three of three rounds), the Cornell kernels lose (C2 27.2 -> 26.3: their 266 M
-// slots cycle through a queue that the Infinity Cache partly holds), the big-scene kernels do not care (C5 +0.5 %, C5x -0.5 %):
-// profiles/r03cl_ab_nt.log.  So only k_extend_inst16 and k_shade<..., INST> ask for it.
+// NT = true gives them the `nt` cache policy (non-temporal: do not keep the line).  Measured per component, same box, interleaved
+// processes (profiles/r03cl_* ... r03cp_*):
+//   * k_shade's queue STORES (48 B per surviving path, read by the extend launch after next at the earliest): nt for every scene
+//     class -- C2 27.1 -> 28.15 Grays/s (+3.8 %, six of six rounds, tighter spread), config C2 exactly 25.0 -> 27.2, C4 / C5 / C5x +0.3 %;
+//   * the extend kernels' hit-record store: plain for the Cornell kernel (nt: -7 %, its reader is the very next launch) and the
+//     big-scene kernels; nt in k_extend_inst16 together with its ray loads (C4 +2.4 % with the shade side);
+//   * queue LOADS: neutral everywhere (nt only in the instanced kernels, where the whole set was measured together);
+//   * term-log stores and k_generate's queue stores: nt (C4 +2.2 %, C2 neutral).
 namespace ptm {
 typedef float f4v_ __attribute__((ext_vector_type(4)));
 typedef float f2v_ __attribute__((ext_vector_type(2)));

@@ -112,6 +112,14 @@ struct Radiance {
 constexpr uint32_t SPILL_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SPILL_POOL_ENTRIES = 4u << 20;  // 64 MB
 
+// (the term logs are read once, by k_resolve at the end of the batch, k_generate's queue by the first extend launch: `nt` stores,
+// pt_math.h st_stream -- C4 +2.2 %, C2 +0.5 % / -1 % at K = 16 / 2, i.e. neutral: profiles/r03cp_ab_nt_terms_generate.log)
+#ifndef PT_NT_TERMS
+#define PT_NT_TERMS true
+#endif
+#ifndef PT_NT_GEN
+#define PT_NT_GEN true
+#endif
 __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radiance &rad, uint32_t slot, float r, float g,
                                              float b)
 {
@@ -123,8 +131,8 @@ __device__ __forceinline__ void add_radiance(const RenderConst &rc, const Radian
         rad.color[slot] = c;
     } else {
         const uint32_t k = rad.nterm[slot];
-        if (k < rc.term_pcap) rad.terms[(size_t)k * rc.n_slots + slot] = make_float4(r, g, b, 0.f);
-        else if (k < rc.term_cap) rad.terms_over[(size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)] = make_float4(r, g, b, 0.f);
+        if (k < rc.term_pcap) ptm::st_stream<PT_NT_TERMS>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(r, g, b, 0.f));
+        else if (k < rc.term_cap) ptm::st_stream<PT_NT_TERMS>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(r, g, b, 0.f));
         else {
             const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
             if (idx < rad.spill_cap) {
@@ -234,10 +242,10 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
 #pragma unroll
         for (int it = 0; it < GEN_ITEMS; it++) {
             if (alive[it]) {
-                out.id[dst[it]] = make_uint2(o_slot[it], o_sample[it]);
-                out.state[dst[it]] = make_float4(__uint_as_float(o_seed[it]), 1.f, 1.f, 1.f);  // raygen.rgen:59
-                out.rayA[dst[it]] = make_float4(o_org[it].x, o_org[it].y, o_org[it].z, o_dir[it].x);
-                out.rayB[dst[it]] = make_float2(o_dir[it].y, o_dir[it].z);
+                ptm::st_stream<PT_NT_GEN>(out.id + dst[it], make_uint2(o_slot[it], o_sample[it]));
+                ptm::st_stream<PT_NT_GEN>(out.state + dst[it], make_float4(__uint_as_float(o_seed[it]), 1.f, 1.f, 1.f));  // raygen.rgen:59
+                ptm::st_stream<PT_NT_GEN>(out.rayA + dst[it], make_float4(o_org[it].x, o_org[it].y, o_org[it].z, o_dir[it].x));
+                ptm::st_stream<PT_NT_GEN>(out.rayB + dst[it], make_float2(o_dir[it].y, o_dir[it].z));
             }
         }
     }
