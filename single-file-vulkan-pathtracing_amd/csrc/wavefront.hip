@@ -1529,7 +1529,9 @@ RenderShape choose_shape(const pt_film *f, const pt_params *p, int launch_class,
         // two batches of 8 with 16 groups: 27.1; K = 16: 4 groups (133 M slots, 51 GB) 23.0 / 26.6 / 26.3 in three
         // processes, 8 groups (266 M, 70 GB) 26.5 / 27.1 / 26.5, 16 groups (109 GB) 26.3 / 27.3 / 27.0
         // (profiles/r03br_*, r03bs_*, r03bt_*, r03bu_*)
-        double want = (double)((launch_class == 2 ? 8 : launch_class == 1 ? 4 : 1) * target) / (double)have;
+        // (instanced scenes, on the round's final kernels: C4 at K = 8 with 2 / 4 / 8 / 16 groups 13.40 / 13.77 / 13.88 / 13.70 Grays/s,
+        // profiles/r03cs_c4_shapes_final.log -- so they aim at 128 M now as well; the 32 M of the comment above was measured before)
+        double want = (double)((launch_class == 2 ? 8 : 4) * target) / (double)have;
         const uint64_t slot_budget = (launch_class == 2 ? 288ull : 160ull) << 20;
         if (can_redo && have * 4 <= slot_budget) want = std::max(want, 4.0);
         else if (can_redo && have * 2 <= slot_budget) want = std::max(want, 2.0);
