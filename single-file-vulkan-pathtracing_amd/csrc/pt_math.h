@@ -392,7 +392,8 @@ __device__ __forceinline__ bool box_test(const f3 mn, const f3 mx, const f3 org,
 //     class -- C2 27.1 -> 28.15 Grays/s (+3.8 %, six of six rounds, tighter spread), config C2 exactly 25.0 -> 27.2, C4 / C5 / C5x +0.3 %;
 //   * the extend kernels' hit-record store: plain for the Cornell kernel (nt: -7 %, its reader is the very next launch) and the
 //     big-scene kernels; nt in k_extend_inst16 together with its ray loads (C4 +2.4 % with the shade side);
-//   * queue LOADS: neutral everywhere (nt only in the instanced kernels, where the whole set was measured together);
+//   * queue LOADS: neutral everywhere (nt only in the instanced kernels, where the whole set was measured together); the 8-wide
+//     kernel's ray loads alone: C5 -0.2 %, C5x -1.8 % (profiles/r03ct_ab_e8_nt_loads.log): plain;
 //   * term-log stores and k_generate's queue stores: nt (C4 +2.2 %, C2 neutral).
 namespace ptm {
 typedef float f4v_ __attribute__((ext_vector_type(4)));
