@@ -105,7 +105,7 @@ def effective_cores():
 def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, instances=None):
     """The oracle (a CPU port of the reference shaders + software LBVH) timed on this host, on a
     bounded sample of the same workload: the same image, all cores, as many samples per pixel as fit
-    into ~budget_s seconds (calibrated with a 1-spp pass, at most spp_max); then ONE thread on a crop."""
+    into ~budget_s seconds (calibrated with a 1-spp pass, at most spp_max); then ONE thread on every 16th tile of it."""
     from oracle import pt_oracle as orc
     osc = orc.Scene(*arrays)
     if instances is not None:
@@ -119,27 +119,31 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
     t0 = time.perf_counter()
     img, rays, cnt, _ = osc.render_frame(p, mode=1, nthreads=cores)
     dt = time.perf_counter() - t0
-    # single thread: the central 1/16 of the image (a quarter of each side) at 1 spp, scaled to ~budget_s / 4
-    cw, ch = max(width // 4, 1), max(height // 4, 1)
+    # single thread: every 16th 16x16 tile of the WHOLE image (row-major tile index % 16 == 0 -- 510 of the 8 160 tiles of a
+    # 1080p frame: 120 tiles per row, so the subset walks down the columns 0, 16, 32 ... 112 of tiles and takes border and
+    # centre in the image's own proportion): the same ray population as the all-core run, so `scaling_efficiency` compares
+    # like with like and cannot exceed 1 by construction (round 3 timed the single thread on the central crop, which has none
+    # of the cheap border pixels, and read 1.18)
+    stride = 16
     p1 = orc.default_params(width=width, height=height, spp_per_frame=1, max_depth=depth)
     t0 = time.perf_counter()
-    _, r1 = orc.render_rect(osc, p1, (width - cw) // 2, (height - ch) // 2, cw, ch, mode=1, nthreads=1)
+    _, r1 = orc.render_tile_subset(osc, p1, stride, 0, mode=1, nthreads=1)
     d1 = time.perf_counter() - t0
     spp1 = int(max(1, min(spp_max, budget_s / 4 / max(d1, 1e-3))))
     if spp1 > 1:
         p1 = orc.default_params(width=width, height=height, spp_per_frame=spp1, max_depth=depth)
         t0 = time.perf_counter()
-        _, r1 = orc.render_rect(osc, p1, (width - cw) // 2, (height - ch) // 2, cw, ch, mode=1, nthreads=1)
+        _, r1 = orc.render_tile_subset(osc, p1, stride, 0, mode=1, nthreads=1)
         d1 = time.perf_counter() - t0
     all_mrays, one_mrays = rays / dt / 1e6, r1 / d1 / 1e6
     base = {"value": round(all_mrays, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
             "cpu_model": cpu_model(), "cores_available": cores_how, "single_thread_mrays": round(one_mrays, 4),
-            # all threads against `cores` x the single thread (the single thread runs the central crop, which has no
-            # cheap border pixels: an upper bound on perfect scaling)
+            # all threads against `cores` x the single thread on the same ray population (every 16th tile of the same image)
             "scaling_efficiency": round(all_mrays / (cores * one_mrays), 4),
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
                       f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O3 -march=native -ffp-contract=off, {cores} threads "
-                      f"pulling 16x16 tiles from one counter; single thread: central {cw}x{ch} crop, {spp1} spp, {r1} rays in {d1:.2f} s"}
+                      f"pulling 16x16 tiles from one counter; single thread: every {stride}th 16x16 tile of the same image, {spp1} spp, "
+                      f"{r1} rays in {d1:.2f} s"}
     return base, cnt.nodes_visited / max(rays, 1), cnt.tris_tested / max(rays, 1)
 
 
@@ -331,6 +335,48 @@ def extra_leg(pt, ctx, W, H, config, frames, rank):
     return out
 
 
+def fused_leg(pt, ctx, scene, film, W, H, spp, depth, steps, wavefront_mrays):
+    """The same Cornell frames through PT_PIPELINE_FUSED (csrc/fused_kernel.h: the loop as ONE persistent kernel, the shape of the
+    reference's own raygen shader), outside the timed region: K = steps, K = 2 (config C2 exactly) and one blocking call per frame,
+    with the workspace each shape holds -- what the wavefront's 150 B per ray of queue traffic and tens of GB buy, and cost."""
+    import statistics
+    kw = dict(width=W, height=H, spp_per_frame=spp, max_depth=depth, pipeline=pt.PIPELINE_FUSED)
+    out = {"pipeline": "PT_PIPELINE_FUSED", "wavefront_mrays_per_s_same_run": round(wavefront_mrays, 2)}
+    for name, k in (("k_steps", steps), ("k2", 2)):
+        p = pt.default_params(frame=0, frame_count=k, **kw)
+        scratch = pt.Film(ctx, W, H)
+        pt.render(scene, scratch, p)                  # allocates, warms up
+        vals = []
+        for _ in range(5):
+            scratch.clear()
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            pt.render(scene, scratch, p)
+            d = time.perf_counter() - t0
+            vals.append(ctx.stats().rays / d / 1e6)
+        s_ = ctx.stats()
+        out[name] = {"frames": k, "mrays_per_s": round(statistics.median(vals), 2), "min": round(min(vals), 2), "max": round(max(vals), 2),
+                     "ms_per_frame": round(s_.rays / statistics.median(vals) / 1e3 / k, 3), "frames_in_flight": s_.frames_in_flight,
+                     "sample_groups": s_.sample_groups, "workspace_bytes": s_.workspace_bytes, "rays": s_.rays}
+        scratch.close()
+    scratch = pt.Film(ctx, W, H)
+    one = dict(frame_count=1, **kw)
+    pt.render(scene, scratch, pt.default_params(frame=0, **one))
+    lat = []
+    ctx.reset_stats()
+    for k in range(1, 9):
+        t0 = time.perf_counter()
+        pt.render(scene, scratch, pt.default_params(frame=k, **one))
+        lat.append((time.perf_counter() - t0) * 1e3)
+    s1 = ctx.stats()
+    lat.sort()
+    out["latency_1frame"] = {"median_ms": round(lat[len(lat) // 2], 3), "min_ms": round(lat[0], 3), "max_ms": round(lat[-1], 3),
+                             "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 2), "sample_groups": s1.sample_groups,
+                             "workspace_bytes": s1.workspace_bytes}
+    scratch.close()
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, exactly as
     torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, rendezvous
@@ -388,6 +434,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--sample-groups", type=int, default=0)
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm", "hbm8"], default="auto", help="closest-hit kernel variant")
+    ap.add_argument("--pipeline", choices=["wavefront", "fused"], default="wavefront",
+                    help="wavefront = generate / extend / shade queues (the default, the north star's design); fused = PT_PIPELINE_FUSED, "
+                         "the whole loop as one persistent kernel (scenes in LDS only: c2 / c3)")
     ap.add_argument("--bvh-quality", choices=["fast_trace", "fast_build"], default="fast_trace",
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--sort-rays", choices=["auto", "on", "off"], default="auto",
@@ -459,6 +508,7 @@ def main():
     flags |= sort_flag
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
                   frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
+                  pipeline={"wavefront": pt.PIPELINE_WAVEFRONT, "fused": pt.PIPELINE_FUSED}[args.pipeline],
                   extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM, "hbm8": pt.EXTEND_HBM8}[args.extend])
 
     def barrier():
@@ -539,7 +589,7 @@ def main():
                      + (", written as OBJ+MTL and parsed by the host loader" if args.config == "c5" else ""))
                     + "; rays are generated on device",
             "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
-                                   f"{args.depth} bounces, wavefront pipeline; step = 1 frame",
+                                   f"{args.depth} bounces, {args.pipeline} pipeline; step = 1 frame",
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
                        "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "pipelines": st.pipelines,
@@ -570,7 +620,23 @@ def main():
         # BVH4 (untimed extra frames): feeds the scene-gather term of the algorithmic bytes and the VALU model
         frame0_rays_gpu = frame0_film_gpu = None
         cst = None
-        if st.extend_variant != pt.EXTEND_FLAT:
+        if args.pipeline == "fused":   # (no instrumented form: frame 0 alone for the film / ray-count comparison)
+            if not args.no_cpu_baseline and world == 1:
+                scratch = pt.Film(ctx, W, H)
+                ctx.reset_stats()
+                pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, **common))
+                frame0_rays_gpu, frame0_film_gpu = ctx.stats().rays, scratch.read_f32()
+                scratch.close()
+            pipeline_bytes = (BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
+            out["roofline"] = {"bound": "hbm", "kernel": "k_fused", "variant": "fused: path state stays in LDS / registers, HBM sees 16 B per slot or logged term",
+                               # a fused variant is still priced by the wavefront's algorithmic bytes so that designs compare
+                               "achieved": round(pipeline_bytes / (st.ms_extend * 1e-3) / 1e9, 2) if st.ms_extend else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(pipeline_bytes / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st.ms_extend else None, "traffic": None,
+                               "launches": st.launches_extend, "rays_per_launch": round(st.rays / max(st.launches_extend, 1), 1),
+                               "avg_launch_us": round(st.ms_extend * 1e3 / max(st.launches_extend, 1), 3),
+                               "algorithmic_bytes_per_ray": round(BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len, 1),
+                               "note": "the kernel moves none of these bytes: it is VALU-issue bound like k_extend_lds7p"}
+        elif st.extend_variant != pt.EXTEND_FLAT:
             cst, frame0_film_gpu, frame0_rays_gpu = count_visits(pt, ctx, scene, W, H, common, args.steps, frame0=not args.no_cpu_baseline and world == 1)   # (rank 0's shard when N > 1)
         if flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
             out["roofline"] = roofline_block(pt, st, cst, info, scene_config, NOTES[args.config])
@@ -619,6 +685,11 @@ def main():
                                      "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 2), "frames": len(lat),
                                      "sample_groups": s1.sample_groups,
                                      "shape": "K = 1: one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle, main.cpp:656-683)"}
+            if args.pipeline == "wavefront":
+                try:
+                    out["c2_fused"] = fused_leg(pt, ctx, scene, film, W, H, args.spp, args.depth, args.steps, st.rays / dt / 1e6)
+                except Exception as e:
+                    out["c2_fused"] = {"error": repr(e)}
             # ---- the other BASELINE configs' traversal kernels: C4 (two-level), C5 (where HBM-side bandwidth is the
             # bound), C5x (beyond the Infinity Cache) -- never lose the headline to an extra leg
             for leg, frames in (("c4", args.c4_frames), ("c5", args.c5_frames), ("c5x", args.c5x_frames)):

@@ -116,8 +116,8 @@ typedef struct pt_scene_info {
     uint32_t bvh4_builder;    /* which BVH4 is traversed: 0 collapsed LBVH, 1 surface-area sweep (small scenes), 2 PLOC tree */
     float    bbox_min[3], bbox_max[3];
     float    build_ms;        /* device time of the LBVH build (reported apart from rendering) */
-    uint64_t device_bytes;    /* resident scene + BVH bytes of the BVH4 path                    */
-    uint32_t n_wide8_nodes;   /* BVH8 nodes (128 B each) of the PT_EXTEND_HBM8 path, levels of that tree */
+    uint64_t device_bytes;    /* resident scene + BVH bytes of the BVH4 path, incl. the source arrays kept for rebuilds (72 B per triangle) */
+    uint32_t n_wide8_nodes;   /* 8-wide nodes (64 B each: byte planes) of the PT_EXTEND_HBM8 path, levels of that tree */
     uint32_t wide8_levels;
     uint64_t device_bytes8;   /* resident triangle tables + BVH8 bytes of that path             */
     /* big scenes (> 2048 triangles): sum of the surface areas of the binary tree's internal nodes over the root's, for
@@ -180,7 +180,13 @@ enum {
      * SHADOW ray queued -- a third queue, compacted like the others and traced by the same extend kernels as an
      * any-hit query; the emission of a surface the path runs into counts for camera rays only.  Same random stream
      * otherwise (three more numbers per hit).  Fully specified arithmetic like the reference path's (the tests' CPU checker restates it bit for bit).  Instanced scenes sample every instance's copy of the emitters (world space, one cdf). */
-    PT_PIPELINE_WAVEFRONT_NEE = 1
+    PT_PIPELINE_WAVEFRONT_NEE = 1,
+    /* The reference's estimator, bit for bit, as ONE persistent kernel -- the shape of the reference's own raygen shader
+     * (raygen.rgen:41-91: one invocation owns its path): traversal and shading in the same lane, path state in LDS, no
+     * queues in HBM; the workspace is the per-slot radiance only (16 B per slot instead of ~150).  Only for single-level
+     * scenes that fit LDS (the Cornell-box class; PT_ERR_UNSUPPORTED otherwise), blocking calls only.  Same films, same
+     * ray counts as PT_PIPELINE_WAVEFRONT.                                                                              */
+    PT_PIPELINE_FUSED = 2
 };
 enum {
     PT_FLAG_PROFILE = 1u,      /* hipEvent-time every extend/shade launch (adds events to the stream)       */

@@ -727,12 +727,15 @@ typedef struct job {
     float *frame_color; orc_hit *first_hits; orc_counters cnt;
     uint32_t x0, y0, rw, rh; /* rectangle to render; output is rw x rh, row-major */
     atomic_uint *next_tile;  /* shared by the workers of one call: the next 16x16 tile to take */
+    uint32_t tile_stride, tile_offset; /* only the 16x16 tiles t with t % tile_stride == tile_offset (1, 0: all of them) */
+    uint32_t *ray_map;       /* optional: traceRayEXT calls of every pixel of the rectangle (per-rank counts of a tile-sharded job) */
 } job;
 
 static void render_pixel(job *jb, uint32_t px, uint32_t py)
 {
     const orc_scene *s = jb->s; const orc_params *p = jb->p;
     float color[3] = { 0.0f, 0.0f, 0.0f };
+    const uint64_t rays_before = jb->cnt.rays;
     for (uint32_t sample = 0; sample < p->spp_per_frame; sample++) { /* raygen.rgen:45 */
         uint32_t seed = orc_seed(px, py, sample, p->frame, p->spp_per_frame);
         float org[3], dir[3];
@@ -795,6 +798,7 @@ static void render_pixel(job *jb, uint32_t px, uint32_t py)
     }
     float *out = jb->frame_color + 3 * ((size_t)(py - jb->y0) * jb->rw + (px - jb->x0));
     for (int k = 0; k < 3; k++) out[k] = color[k] / (float)p->spp_per_frame; /* :86 */
+    if (jb->ray_map) jb->ray_map[(size_t)(py - jb->y0) * jb->rw + (px - jb->x0)] = (uint32_t)(jb->cnt.rays - rays_before);
 }
 
 /* Work distribution: the workers pull 16x16-pixel tiles from one shared counter (dynamic: the border of the image --
@@ -810,7 +814,7 @@ static void *worker(void *arg)
     const uint32_t tx_n = (jb.rw + ORC_TILE - 1u) / ORC_TILE, ty_n = (jb.rh + ORC_TILE - 1u) / ORC_TILE;
     const uint32_t n_tiles = tx_n * ty_n;
     for (;;) {
-        const uint32_t t = atomic_fetch_add_explicit(jb.next_tile, 1u, memory_order_relaxed);
+        const uint32_t t = atomic_fetch_add_explicit(jb.next_tile, 1u, memory_order_relaxed) * jb.tile_stride + jb.tile_offset;
         if (t >= n_tiles) break;
         const uint32_t ty = t / tx_n, tx = t - ty * tx_n;
         const uint32_t y1 = jb.y0 + (ty + 1u) * ORC_TILE < jb.y0 + jb.rh ? jb.y0 + (ty + 1u) * ORC_TILE : jb.y0 + jb.rh;
@@ -831,6 +835,31 @@ uint64_t orc_render_frame(const orc_scene *s, const orc_params *p, int mode, int
 uint64_t orc_render_rect(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0, uint32_t y0,
                          uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits, orc_counters *cnt)
 {
+    return orc_render_rect_map(s, p, mode, nthreads, x0, y0, rw, rh, frame_color, first_hits, cnt, NULL);
+}
+
+static uint64_t render_tiles(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0, uint32_t y0,
+                             uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits, orc_counters *cnt,
+                             uint32_t *ray_map, uint32_t tile_stride, uint32_t tile_offset);
+
+uint64_t orc_render_tile_subset(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t tile_stride,
+                                uint32_t tile_offset, float *frame_color, orc_counters *cnt)
+{
+    if (tile_stride == 0u || tile_offset >= tile_stride) return 0;
+    return render_tiles(s, p, mode, nthreads, 0, 0, p->width, p->height, frame_color, NULL, cnt, NULL, tile_stride, tile_offset);
+}
+
+uint64_t orc_render_rect_map(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0, uint32_t y0,
+                             uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits, orc_counters *cnt,
+                             uint32_t *ray_map)
+{
+    return render_tiles(s, p, mode, nthreads, x0, y0, rw, rh, frame_color, first_hits, cnt, ray_map, 1u, 0u);
+}
+
+static uint64_t render_tiles(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0, uint32_t y0,
+                             uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits, orc_counters *cnt,
+                             uint32_t *ray_map, uint32_t tile_stride, uint32_t tile_offset)
+{
     if (x0 + rw > p->width || y0 + rh > p->height) return 0;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
@@ -843,6 +872,8 @@ uint64_t orc_render_rect(const orc_scene *s, const orc_params *p, int mode, int 
         jobs[t].s = s; jobs[t].p = p; jobs[t].mode = mode; jobs[t].tid = t; jobs[t].nthreads = nthreads;
         jobs[t].frame_color = frame_color; jobs[t].first_hits = first_hits;
         jobs[t].x0 = x0; jobs[t].y0 = y0; jobs[t].rw = rw; jobs[t].rh = rh;
+        jobs[t].ray_map = ray_map;
+        jobs[t].tile_stride = tile_stride; jobs[t].tile_offset = tile_offset;
         memset(&jobs[t].cnt, 0, sizeof(orc_counters));
     }
     if (nthreads == 1) worker(&jobs[0]);

@@ -133,6 +133,18 @@ uint64_t orc_render_rect(const orc_scene *s, const orc_params *p, int mode, int 
                          uint32_t y0, uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits,
                          orc_counters *cnt);
 
+/* ... and, if ray_map != NULL (rw*rh entries), the number of traceRayEXT calls every pixel made: what a rank of a
+ * tile-sharded render (BASELINE config C3) must count is the sum over its own pixels.                              */
+uint64_t orc_render_rect_map(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t x0,
+                             uint32_t y0, uint32_t rw, uint32_t rh, float *frame_color, orc_hit *first_hits,
+                             orc_counters *cnt, uint32_t *ray_map);
+
+/* Only the 16x16-pixel tiles t (row-major over the whole image) with t % tile_stride == tile_offset; the other pixels of
+ * frame_color (W*H*3) are left as they are.  bench.py's cpu_baseline times one thread on every 16th tile -- the same ray
+ * population as the all-core run of the whole image (border and centre in the image's own proportion).                */
+uint64_t orc_render_tile_subset(const orc_scene *s, const orc_params *p, int mode, int nthreads, uint32_t tile_stride,
+                                uint32_t tile_offset, float *frame_color, orc_counters *cnt);
+
 /* raygen.rgen:88-90 in float32 (canonical film): film = (color + film*frame)/(frame+1) */
 void orc_accumulate_f32(float *film_rgb, const float *frame_color, int32_t frame, uint64_t n_pixels);
 /* raygen.rgen:88-90 as the reference displays it: rgba8 image in B,G,R,A byte order

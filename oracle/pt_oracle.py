@@ -96,6 +96,12 @@ def lib():
         L.orc_render_rect.restype = C.c_uint64
         L.orc_render_rect.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+        L.orc_render_rect_map.restype = C.c_uint64
+        L.orc_render_rect_map.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_void_p]
+        L.orc_render_tile_subset.restype = C.c_uint64
+        L.orc_render_tile_subset.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
+                                             C.POINTER(Counters)]
         L.orc_accumulate_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]
         L.orc_accumulate_bgra8.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]
         _LIB = L
@@ -198,16 +204,20 @@ class Scene:
         lib().orc_shade_hit(self.h, h.ctypes.data, *out)
         return [np.array(list(o), dtype=np.float32) for o in out]
 
-    def render_frame(self, params, mode=1, nthreads=None, want_first_hits=False):
-        """-> (frame_color[H,W,3] f32, rays, counters, first_hits or None)"""
+    def render_frame(self, params, mode=1, nthreads=None, want_first_hits=False, ray_map=None):
+        """-> (frame_color[H,W,3] f32, rays, counters, first_hits or None); ray_map: optional uint32[H,W] that receives the
+        number of rays every pixel traced"""
         if nthreads is None:
             nthreads = os.cpu_count() or 1
         w, h = params.width, params.height
         img = np.zeros((h, w, 3), dtype=np.float32)
         fh = np.zeros(h * w, dtype=HIT_DTYPE) if want_first_hits else None
         cnt = Counters()
-        rays = lib().orc_render_frame(self.h, C.byref(params), mode, nthreads, img.ctypes.data,
-                                      fh.ctypes.data if want_first_hits else None, C.byref(cnt))
+        if ray_map is not None:
+            assert ray_map.dtype == np.uint32 and ray_map.shape == (h, w) and ray_map.flags.c_contiguous
+        rays = lib().orc_render_rect_map(self.h, C.byref(params), mode, nthreads, 0, 0, w, h, img.ctypes.data,
+                                         fh.ctypes.data if want_first_hits else None, C.byref(cnt),
+                                         ray_map.ctypes.data if ray_map is not None else None)
         return img, int(rays), cnt, fh
 
 
@@ -219,6 +229,14 @@ def render_rect(scene, params, x0, y0, rw, rh, mode=1, nthreads=None):
     cnt = Counters()
     rays = lib().orc_render_rect(scene.h, C.byref(params), mode, nthreads, x0, y0, rw, rh, img.ctypes.data, None,
                                  C.byref(cnt))
+    return img, int(rays)
+
+
+def render_tile_subset(scene, params, stride, offset=0, mode=1, nthreads=1):
+    """-> (frame_color[H,W,3] f32 with only the 16x16 tiles t % stride == offset rendered, rays)"""
+    img = np.zeros((params.height, params.width, 3), dtype=np.float32)
+    cnt = Counters()
+    rays = lib().orc_render_tile_subset(scene.h, C.byref(params), mode, nthreads, stride, offset, img.ctypes.data, C.byref(cnt))
     return img, int(rays)
 
 

@@ -16,8 +16,10 @@ import json
 import os
 import sys
 
-root, out = sys.argv[1], sys.argv[2]
-cfg = sys.argv[3] if len(sys.argv) > 3 else ""
+args = [a for a in sys.argv[1:] if not a.startswith("--kernel=")]
+want_kernel = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--kernel=")), None)   # e.g. --kernel=k_shade
+root, out = args[0], args[1]
+cfg = args[2] if len(args) > 2 else ""
 s = json.load(open(os.path.join(root, "summary.json")))
 bench = None
 for line in open(os.path.join(root, "stats.log")):
@@ -28,17 +30,19 @@ for line in open(os.path.join(root, "stats.log")):
 # instantiation only runs the one extra untimed frame)
 import re
 counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations (PT_FLAG_COUNT_VISITS frame)
-name = max((k for k in s["kernels"] if k.startswith("k_extend") and not counting.match(k)), key=lambda k: s["kernels"][k]["total_ns"])
+prefix = want_kernel or "k_extend"
+name = max((k for k in s["kernels"] if k.startswith(prefix) and not counting.match(k)), key=lambda k: s["kernels"][k]["total_ns"])
 e, kt = s["pmc"][name], s["kernels"][name]
-pl = lambda c: e[c + "_per_launch"]
-rays_per_launch = bench["rays"] / bench["roofline"]["launches"]
+pl = lambda c: e.get(c + "_per_launch", 0.0)
+rays_per_launch = bench["rays"] / bench["roofline"]["launches"]   # (a shade launch handles the rays of the extend launch before it)
 avg_us = kt["avg_ns"] / 1e3
 rec = {
     "kernel": name, "config": cfg,
     "source": f"{os.path.basename(root.rstrip('/'))}: rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set "
               f"(scripts/gpu_profile.sh) on `python bench.py {cfg} --warmup 0 --no-cpu-baseline`",
     "launches": kt["calls"], "rays_per_launch_in_profile_run": rays_per_launch,
-    "rocprof_avg_launch_us": avg_us, "bench_hipext_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"],
+    "rocprof_avg_launch_us": avg_us,
+    "bench_hipext_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"] if prefix == "k_extend" else bench["roofline"]["shade_ms"] * 1e3 / bench["roofline"]["launches"],
     "fetch_size_kib_per_launch": pl("FETCH_SIZE"), "write_size_kib_per_launch": pl("WRITE_SIZE"),
     "hbm_read_bytes_per_launch_x2_gfx950": e["hbm_read_bytes_per_launch_gfx950_x2"],
     "hbm_write_bytes_per_launch": e["hbm_write_bytes_per_launch"], "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
@@ -53,7 +57,24 @@ rec = {
     "valu_active_lanes_per_instr": pl("SQ_THREAD_CYCLES_VALU") / pl("SQ_INSTS_VALU"),
     "wait_any_fraction_of_wave_cycles": pl("SQ_WAIT_ANY") / pl("SQ_WAVE_CYCLES"),
     "lds_bank_conflict_fraction_of_lds_cycles": (pl("SQ_LDS_BANK_CONFLICT") / pl("SQ_LDS_IDX_ACTIVE")) if pl("SQ_LDS_IDX_ACTIVE") else None,
-    "l2_hit_rate": pl("TCC_HIT_sum") / pl("TCC_REQ_sum"),
+    "l2_hit_rate": pl("TCC_HIT_sum") / pl("TCC_REQ_sum") if pl("TCC_REQ_sum") else None,
 }
+rec["hbm_GBps"] = rec["hbm_bytes_per_launch"] / (avg_us * 1e-6) / 1e9
+# optional counter sets (scripts/gpu_profile.sh PMC_EXTRA=1): the vector L1's translation cache and its stalls, the L2 <-> fabric queues
+for c in ("TCP_UTCL1_REQUEST_sum", "TCP_UTCL1_TRANSLATION_MISS_sum", "TCP_UTCL1_TRANSLATION_HIT_sum", "TCP_PENDING_STALL_CYCLES_sum",
+          "TCP_TCR_TCP_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TCP_TOTAL_CACHE_ACCESSES_sum",
+          "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_WRITE_REQ_LATENCY_sum",
+          "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_STALL_sum", "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum",
+          "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", "TCC_TAG_STALL_sum", "TCC_BUSY_sum", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+          "SQ_ACTIVE_INST_VMEM", "SQ_INST_CYCLES_VMEM"):
+    if c + "_per_launch" in e:
+        rec.setdefault("extra_per_launch", {})[c] = pl(c)
+x = rec.get("extra_per_launch", {})
+if x.get("TCP_UTCL1_REQUEST_sum"):
+    rec["utcl1_miss_rate"] = x.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0.0) / x["TCP_UTCL1_REQUEST_sum"]
+if x.get("TCP_TCC_READ_REQ_sum") and x.get("TCP_TCC_READ_REQ_LATENCY_sum"):
+    rec["l1_to_l2_read_latency_cycles"] = x["TCP_TCC_READ_REQ_LATENCY_sum"] / x["TCP_TCC_READ_REQ_sum"]
+if x.get("TCP_TCC_WRITE_REQ_sum") and x.get("TCP_TCC_WRITE_REQ_LATENCY_sum"):
+    rec["l1_to_l2_write_latency_cycles"] = x["TCP_TCC_WRITE_REQ_LATENCY_sum"] / x["TCP_TCC_WRITE_REQ_sum"]
 json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps(rec, indent=1))

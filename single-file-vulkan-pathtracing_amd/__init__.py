@@ -27,6 +27,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "
                 5: "PT_ERR_UNSUPPORTED"}
 PIPELINE_WAVEFRONT = 0
 PIPELINE_WAVEFRONT_NEE = 1
+PIPELINE_FUSED = 2
 FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4

@@ -1,0 +1,331 @@
+// fused_kernel.h -- PT_PIPELINE_FUSED: the radiance loop as ONE persistent kernel for scenes that live in LDS.
+//
+// The reference's raygen shader is itself a megakernel: one invocation owns its path state from the first sample of its
+// pixel to the last (raygen.rgen:41-91), and traceRayEXT / the closest-hit and miss shaders run inside it.  The wavefront
+// pipeline (wavefront.hip) splits that into k_extend / k_shade over queues in HBM -- 150 B of queue traffic per ray and a
+// workspace of tens of GB -- because big scenes need the sorting, the compaction and the long launches.  A scene of a few
+// dozen triangles needs none of it: nodes, triangles and the shading tables fit LDS, so here a lane keeps its path from
+// bounce to bounce and HBM sees the radiance of a slot only (16 B per slot, or 16 B per logged term with sample groups).
+//
+//   * traversal: the compact pair-leaf walk of extend_kernel.h (`extend_body<true, false, false, true>`: one-dword stack
+//     entries in LDS, key-sorted children, fan pairs tested together), restated here operation for operation -- the hot
+//     instantiation of that template is register-allocated to the last VGPR and must not grow a second use;
+//   * a lane whose ray is finished WAITS with its hit in registers until a quarter of the wave's live lanes wait too
+//     (`refill`), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
+//     raygen.rgen:76-83, the next sample's camera ray (raygen.rgen:45-60), or the first sample of a NEW slot -- and set up
+//     their next ray; the same operations in the same order as k_shade, so the film is the wavefront pipeline's bit for bit;
+//   * slots (frame, sample group, pixel) are handed out in order by one device-scope counter: one atomic per shade block
+//     of a wave (~13 per microsecond at 28 Grays/s, the chip sustains ~88 on one word), so a wave that drew cheap border
+//     pixels simply takes more of them -- no batch tail beyond the last slot's own length;
+//   * path state that only the shade block touches (slot, sample | depth, seed, weight, pixel, the slot's colour or its
+//     term count) lives in LDS, [field][thread]: the traversal loop keeps the registers it has in k_extend_lds7p.
+//
+// Radiance goes where the wavefront pipeline puts it (struct Radiance): one accumulator per slot written when the slot is
+// complete (one sample group), or the ordered term logs that k_resolve replays (several groups) -- k_resolve is shared.
+#pragma once
+
+#ifndef PT_FUSED_WAVES
+#define PT_FUSED_WAVES 5   // waves per SIMD asked of the compiler (LDS: ~30 KB per block -> 5 blocks per CU)
+#endif
+
+// path state in LDS, [field][thread]
+enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS_B, FS_C, FS_FIELDS };
+// FS_A..C: the slot's colour (one sample group) | FS_A: its term count (several groups)
+
+template <bool GROUPED>
+__global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+                                                              const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
+                                                              const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
+                                                              uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
+                                                              uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
+                                                              float tmax, int lds_stack)
+{
+    constexpr uint32_t LEAF_BIT = 0x2000u, DONE = 0x3FFFu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- LDS: stack | BVH4 nodes | three permuted triangle copies | shade4 | tangent frames | path state
+    float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * TB * sizeof(uint32_t));
+    float4 *s_tri = s_wide + LDS_NODE_F4 * (size_t)n_wide;
+    float4 *s_shade = s_tri + 9 * (size_t)n_tris;
+    float4 *s_frame = s_shade + 3 * (size_t)n_tris;
+    lds_u32 *my_state = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) {
+        float4 v = g_wide[i];
+        if ((i & 7u) == 6u) {  // the four child words -> 14-bit codes (extend_kernel.h COMPACT)
+            auto cw = [](float f) {
+                const uint32_t w = __float_as_uint(f);
+                const uint32_t c = (w & PT_LEAF) ? (0x2000u | (((w >> 28) & 3u) << 11) | (w & 0x7FFu)) : (w & 0x1FFFu);
+                return __uint_as_float(w == SENTINEL ? 0x3FFFu : c);
+            };
+            v = make_float4(cw(v.x), cw(v.y), cw(v.z), cw(v.w));
+        }
+        s_wide[(i >> 3) * LDS_NODE_F4 + (i & 7u)] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
+        const float4 v = g_tri4[i];
+        s_tri[i] = make_float4(v.y, v.z, v.x, v.w);               // kz = 0: (kx,ky,kz) = (1,2,0)
+        s_tri[3 * n_tris + i] = make_float4(v.z, v.x, v.y, v.w);  // kz = 1: (2,0,1)
+        s_tri[6 * n_tris + i] = v;                                // kz = 2: (0,1,2) -- also what the shade block reads
+        s_shade[i] = g_shade4[i];
+    }
+    for (uint32_t i = threadIdx.x; i < 2 * n_tris; i += TB) s_frame[i] = g_frame4[i];
+    __syncthreads();
+    const float4 *wide = s_wide, *tri4 = s_tri;
+    const float4 *verts = s_tri + 6 * (size_t)n_tris;
+
+    lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
+    const float INF = __builtin_inff();
+    const int lane = threadIdx.x & 63;
+
+    bool have = false;          // the lane traces a ray
+    bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
+    bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
+    uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
+    ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
+    ptm::RayPre pre{};
+    uint32_t ax = 0, ay = 0, az = 0, tri_base = 0;
+    float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
+    uint32_t best_pos = PT_MISS;
+    uint32_t cur = DONE;
+    int sp = 0;
+
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            sp--;
+            const uint32_t e = my_stack32[sp * TB];
+            if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
+        }
+        return DONE;
+    };
+
+    for (;;) {
+        // ---- shade block: the lanes that wait with a hit (or with nothing, while slots are left) -- once enough of them do
+        const unsigned long long m_have = __ballot(have);
+        const unsigned long long m_work = __ballot(!have && (path || !out_of_slots));
+        const int n_work = __popcll(m_work);
+        if (n_work && (m_have == 0ull || n_work * 64 >= refill * (n_work + __popcll(m_have)))) {
+            if (!have && (path || !out_of_slots)) {
+                uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
+                float wr = 0.f, wg = 0.f, wb = 0.f;
+                ptm::f3 org{}, dir{};
+                bool got_ray = false, need_primary = false;
+                if (path) {
+                    slot = my_state[FS_SLOT * TB]; ctr = my_state[FS_CTR * TB]; seed = my_state[FS_SEED * TB];
+                    wr = __uint_as_float(my_state[FS_WR * TB]); wg = __uint_as_float(my_state[FS_WG * TB]); wb = __uint_as_float(my_state[FS_WB * TB]);
+                    pxy = my_state[FS_PXY * TB];
+                    uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
+                    // radiance of this hit, if any: raygen.rgen:76 `color += weight * emission` (adding +0 changes no bit of a
+                    // non-negative accumulator, so non-emitters are skipped -- as k_shade does; NaN compares false and adds)
+                    float er, eg, eb;
+                    bool terminated, add;
+                    const uint32_t pos = best_pos;
+                    float4 s0{}, s1{};
+                    if (pos == PT_MISS) {  // miss.rmiss:10-11 then raygen.rgen:76, 81-83
+                        er = wr * rc.env[0]; eg = wg * rc.env[1]; eb = wb * rc.env[2];
+                        add = true;
+                        terminated = true;
+                    } else {
+                        s0 = s_shade[3 * pos + 0]; s1 = s_shade[3 * pos + 1];
+                        const float4 s2 = s_shade[3 * pos + 2];
+                        er = wr * s1.z; eg = wg * s1.w; eb = wb * s2.x;
+                        add = !(er == 0.f && eg == 0.f && eb == 0.f);
+                        depth++;
+                        terminated = depth >= rc.max_depth;  // raygen.rgen:62
+                    }
+                    if (add) {
+                        if (!GROUPED) {
+                            my_state[FS_A * TB] = __float_as_uint(__uint_as_float(my_state[FS_A * TB]) + er);
+                            my_state[FS_B * TB] = __float_as_uint(__uint_as_float(my_state[FS_B * TB]) + eg);
+                            my_state[FS_C * TB] = __float_as_uint(__uint_as_float(my_state[FS_C * TB]) + eb);
+                        } else {  // the ordered term log of add_radiance (wavefront.hip), the count kept in LDS
+                            const uint32_t k = my_state[FS_A * TB];
+                            if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
+                            else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
+                            else {
+                                const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
+                                if (idx < rad.spill_cap) {
+                                    rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(rad.spill_head[slot]));
+                                    rad.spill_head[slot] = (uint32_t)idx;
+                                } else {
+                                    *rad.overflow = 1ull;
+                                }
+                            }
+                            my_state[FS_A * TB] = k + 1u;
+                        }
+                    }
+                    if (!terminated) {
+                        // closesthit.rchit:56-57 position from the barycentrics; raygen.rgen:77-80 the bounce
+                        const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
+                        float hu, hv;
+                        ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
+                        const float b0 = (1.0f - hu) - hv;
+                        org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
+                        const ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                        const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
+                        const float r2 = ptm::rnd(seed);
+                        const float4 f0 = s_frame[2 * pos + 0], f1 = s_frame[2 * pos + 1];
+                        dir = ptm::sample_direction_frame(r1, r2, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
+                        const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
+                        float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
+                        ptm::div3_by_pdf(fr, fg, fb);
+                        wr = wr * fr; wg = wg * fg; wb = wb * fb;
+                        got_ray = true;
+                    } else {
+                        sample++;
+                        depth = 0;
+                        const uint32_t lane_slot = rc.div_spl.div(slot);  // = frame lane * groups + sample group (slot_pixel)
+                        const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
+                        if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {
+                            need_primary = true;  // the slot's next sample: raygen.rgen:45-60
+                        } else {  // the slot is complete
+                            if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * TB]), __uint_as_float(my_state[FS_B * TB]),
+                                                                       __uint_as_float(my_state[FS_C * TB]), 0.f);
+                            else rad.nterm[slot] = my_state[FS_A * TB];
+                            path = false;
+                        }
+                    }
+                    ctr = sample | (depth << 16);
+                }
+                // ---- new slots for the lanes without a path: one atomic per wave
+                if (!out_of_slots) {
+                    const bool want = !path;
+                    const unsigned long long m_want = __ballot(want);
+                    if (m_want) {
+                        const uint32_t n_want = (uint32_t)__popcll(m_want);
+                        uint32_t base = 0;
+                        if (lane == __ffsll((long long)m_want) - 1) base = atomicAdd(next_slot, n_want);
+                        base = __shfl(base, __ffsll((long long)m_want) - 1, 64);
+                        const uint32_t mine = base + (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
+                        if (want && mine < n_slots) {
+                            slot = slot_base + mine;
+                            uint32_t f, g, px, py;
+                            slot_pixel(rc, tiles, slot, f, g, px, py);
+                            const uint32_t sample0 = g * rc.group_size;
+                            if (GROUPED) { rad.nterm[slot] = 0u; rad.spill_head[slot] = SPILL_NONE; }
+                            else rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // (slots that trace nothing still resolve to black)
+                            if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
+                                pxy = px | (py << 16);
+                                ctr = sample0;
+                                my_state[FS_A * TB] = 0u;  // colour.r = +0.0f | term count = 0
+                                if (!GROUPED) { my_state[FS_B * TB] = 0u; my_state[FS_C * TB] = 0u; }
+                                path = true;
+                                need_primary = true;
+                            }
+                        }
+                        if (base + n_want >= n_slots) out_of_slots = true;
+                    }
+                }
+                if (need_primary) {
+                    const uint32_t f = rc.div_groups.div(rc.div_spl.div(slot));
+                    const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
+                    seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
+                    ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                    wr = wg = wb = 1.0f;  // raygen.rgen:59
+                    got_ray = true;
+                }
+                if (got_ray) {
+                    my_state[FS_SLOT * TB] = slot; my_state[FS_CTR * TB] = ctr; my_state[FS_SEED * TB] = seed;
+                    my_state[FS_WR * TB] = __float_as_uint(wr); my_state[FS_WG * TB] = __float_as_uint(wg); my_state[FS_WB * TB] = __float_as_uint(wb);
+                    my_state[FS_PXY * TB] = pxy;
+                    // the refill block of extend_body<true, false, false, true>
+                    pre = ptm::ray_setup<true>(org, dir);
+                    inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
+                    slab_setup(org, inv, invf, on, of);
+                    ax = inv.x < 0.f ? 48u : 0u;
+                    ay = inv.y < 0.f ? 48u : 0u;
+                    az = inv.z < 0.f ? 48u : 0u;
+                    tri_base = (uint32_t)pre.kz * 3u * n_tris;
+                    orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y), ptm::sel3(pre.kz, org.x, org.y, org.z) };
+                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                    best_pos = PT_MISS;
+                    cur = 0u;
+                    sp = 0;
+                    have = true;
+                }
+                n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (__ballot(path) == 0ull && out_of_slots) break;
+            continue;  // (lanes with a pending hit and nobody tracing: the shade block runs in the next iteration)
+        }
+
+        // ---- node phase (extend_body, LDS_SCENE && COMPACT): every lane descends until it holds a leaf
+        bool do_node = have && !(cur & LEAF_BIT);
+        const int n_have = __popcll(__ballot(have));
+        while (do_node) {
+            float t0, t1, t2, t3;
+            uint32_t w0, w1, w2, w3;
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wide) + __umul24(cur, 16u * LDS_NODE_F4));
+            PT_NODE_LOAD(nd)
+            w0 = __float_as_uint(cw.x); w1 = __float_as_uint(cw.y); w2 = __float_as_uint(cw.z); w3 = __float_as_uint(cw.w);
+            PT_SLAB4(t0, x)
+            PT_SLAB4(t1, y)
+            PT_SLAB4(t2, z)
+            PT_SLAB4(t3, w)
+            uint32_t k0 = (__float_as_uint(t0) & 0xFFFFC000u) | w0, k1 = (__float_as_uint(t1) & 0xFFFFC000u) | w1,
+                     k2 = (__float_as_uint(t2) & 0xFFFFC000u) | w2, k3 = (__float_as_uint(t3) & 0xFFFFC000u) | w3;
+#define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
+            PT_KSWAP(k0, k1)
+            PT_KSWAP(k2, k3)
+            PT_KSWAP(k0, k2)
+            PT_KSWAP(k1, k3)
+            PT_KSWAP(k1, k2)
+#undef PT_KSWAP
+            constexpr uint32_t KINF = 0x7F800000u;
+            if (k3 < KINF) { my_stack32[sp * TB] = k3; sp++; }
+            if (k2 < KINF) { my_stack32[sp * TB] = k2; sp++; }
+            if (k1 < KINF) { my_stack32[sp * TB] = k1; sp++; }
+            cur = k0 < KINF ? (k0 & 0x3FFFu) : pop();
+            do_node = !(cur & LEAF_BIT);
+            const int n_cont = __popcll(__ballot(do_node));
+            if (n_cont * 6 < n_have) break;
+        }
+        // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
+        if (have) {
+            if (cur != DONE && (cur & LEAF_BIT)) {
+                const uint32_t first = cur & 0x7FFu;
+                const bool two = ((cur >> 11) & 3u) != 0u;
+                const size_t ti = (size_t)tri_base + 3 * (size_t)first;
+                const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
+                const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
+                const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
+                const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
+                const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
+                const float pAC = Ax * Cy, qAC = Ay * Cx;
+                auto inside = [](float U, float V, float W) {
+                    return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
+                };
+                auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos) {
+                    const float det = (U + V) + W;
+                    const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
+                    const float t = ptm::fdiv(T, det);
+                    if (!(t > tmin && t < tmax)) return;
+                    bool closer = t < best_t;
+                    if (!closer && t == best_t)
+                        closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
+                                                            __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
+                    if (closer) { best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; }
+                };
+                const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
+                const bool inA = inside(UA, VA, WA);
+                float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
+                bool inB = false;
+                if (two) {
+                    const float4 d = tri4[ti + 5];
+                    Dz_ = d.z - orgp.z;
+                    const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
+                    UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
+                    inB = inside(UB, VB, WB);
+                }
+                if (inA || inB) {
+                    const bool sb = !inA;
+                    finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first);
+                }
+                if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u);
+                cur = pop();
+            }
+            if (cur == DONE) have = false;  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block
+        }
+    }
+    if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);
+}

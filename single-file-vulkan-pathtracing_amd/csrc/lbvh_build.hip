@@ -1302,7 +1302,32 @@ static void free_tree_products(pt_scene *s)
     s->n_wide8 = s->levels8 = 0; s->n_wide16t = s->levels4t = 0;
 }
 
+static pt_status build_tree_products_unguarded(pt_scene *s, uint32_t quality, bool want8);
+
+// A rebuild frees the old products first (peak memory = one set, and a scene of 8 M triangles holds 2.6 GB of them), so a
+// rebuild that fails part-way -- out of memory beside a 70-100 GB film workspace is the plausible case -- leaves the scene
+// WITHOUT a tree.  It is then marked broken: every product pointer null, every count zero, and plan_extend / pt_scene_read_* /
+// pt_scene_set_instances answer PT_ERR_UNSUPPORTED instead of launching kernels on null tables.  The triangles and materials
+// (d_tri_orig, d_faces) are untouched, so a later pt_scene_set_bvh_quality -- or the next render's request for the 8-wide
+// nodes -- can build again; success clears the mark.
 static pt_status build_tree_products(pt_scene *s, uint32_t quality, bool want8)
+{
+    const pt_status rc = build_tree_products_unguarded(s, quality, want8);
+    if (rc != PT_OK) {
+        (void)hipGetLastError();  // an out-of-memory error is sticky until read
+        free_tree_products(s);
+        s->n_nodes = s->n_wide = s->n_wide_lbvh = 0;
+        s->stack_need = s->stack_need_lbvh = 0xFFFFFFFFu;
+        s->device_bytes = s->device_bytes8 = 0;
+        s->quality = quality;  // what the scene is meant to have: ptb_repair / the next pt_scene_set_bvh_quality build exactly that
+        s->broken = true;
+    } else {
+        s->broken = false;
+    }
+    return rc;
+}
+
+static pt_status build_tree_products_unguarded(pt_scene *s, uint32_t quality, bool want8)
 {
     pt_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
@@ -1347,9 +1372,10 @@ static pt_status build_tree_products(pt_scene *s, uint32_t quality, bool want8)
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventElapsedTime(&s->build_ms, ctx->ev_a, ctx->ev_b));
-    // resident bytes of the BVH4 path: triangle tables (tri4 48 + shade4 48 + shade64 64 + ke4 16 + frames 32 B each) + the
-    // 128-B and the two 64-B node arrays; of the 8-wide path: its tables + nodes
-    s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
+    // resident bytes of the BVH4 path: triangle tables (tri4 48 + shade4 48 + shade64 64 + ke4 16 + frames 32 B each), the kept
+    // source arrays a rebuild re-packs from (d_tri_orig 48 + d_faces 24) + the 128-B and the two 64-B node arrays; of the
+    // 8-wide path: its tables + nodes
+    s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32 + PT_SOURCE_BYTES_PER_TRI) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
     s->device_bytes8 = s->d_wide8 ? (uint64_t)n * (48 + 64 + 16 + 4) + 64ull * s->n_wide8 : 0ull;
     s->quality = quality;
     return make_wide16(s);
@@ -1361,6 +1387,18 @@ pt_status ptb_ensure_wide8(pt_scene *s)
     if (s->d_wide8 || s->n_tris < 2 || s->n_inst) return PT_OK;
     PT_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
     return build_tree_products(s, s->quality, true);
+}
+
+// a scene whose last rebuild failed (above) gets one more try per render / trace / read-back: the film whose workspace
+// crowded it out may be gone by now
+pt_status ptb_repair(pt_scene *s)
+{
+    if (!s->broken) return PT_OK;
+    if (s->n_inst) { s->ctx->err = PT_BROKEN_SCENE_MSG; return PT_ERR_UNSUPPORTED; }  // (cannot happen: rebuilds are refused on instanced scenes)
+    PT_HIP(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    const pt_status rc = build_tree_products(s, s->quality, s->ctx->tune.hbm8 != 0);
+    if (rc != PT_OK) s->ctx->err = std::string(PT_BROKEN_SCENE_MSG) + " [" + s->ctx->err + "]";
+    return rc;
 }
 
 pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
@@ -1465,7 +1503,7 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
     if (quality > PT_BVH_PREFER_FAST_BUILD) { ctx->err = "unknown BVH quality"; return PT_ERR_INVALID_ARG; }
     if (s->n_inst) { ctx->err = "set the BVH quality before the instances"; return PT_ERR_UNSUPPORTED; }
     if (s->n_tris > PT_SAH_MAX_TRIS) {  // big scene: PLOC tree <-> LBVH, everything that hangs off the tree is rebuilt
-        if (quality == s->quality) return PT_OK;
+        if (quality == s->quality && !s->broken) return PT_OK;
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return build_tree_products(s, quality, s->d_wide8 != nullptr);
     }
@@ -1507,7 +1545,7 @@ pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality)
     PT_HIP(ctx, hipGetLastError());
     (void)hipFree(s->d_inst_frame);  // (the triangle order changed: ptb_ensure_inst_frames builds it again on the next render)
     s->d_inst_frame = nullptr;
-    s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
+    s->device_bytes = (uint64_t)n * (48 + 48 + 64 + 16 + 32 + PT_SOURCE_BYTES_PER_TRI) + 128ull * s->n_wide + 64ull * s->n_wide + 64ull * s->n_wide16t;
     s->quality = quality;
     return make_wide16(s);
 }
@@ -1624,8 +1662,61 @@ pt_status ptb_ensure_inst_frames(pt_scene *s)
     return PT_OK;
 }
 
+// Emitters of the NEE pipeline for an instanced scene: every instance's copy, in gl_InstanceID order, vertices taken to world
+// space by the instance's matrix with the operation order of the shading transform; normal and area from the world-space
+// triangle; one running cdf over all of them (the tests' CPU checker restates this loop).  Built on the first NEE render of
+// the instance set -- 80 B per (instance, emitter) on host and device, nothing a scene that never samples lights should pay --
+// and refused beyond 2^24 copies (1.3 GB; the float running sum of the areas stops resolving small emitters well before).
+pt_status ptb_ensure_inst_lights(pt_scene *s)
+{
+    pt_ctx *ctx = s->ctx;
+    if (!s->n_inst || !s->n_lights || s->d_lights_inst) return PT_OK;
+    const uint64_t copies = (uint64_t)s->n_inst * s->n_lights;
+    if (copies > (1ull << 24) || s->h_xforms.size() != 12 * (size_t)s->n_inst) {
+        ctx->err = "the NEE pipeline would need " + std::to_string(copies) + " world-space emitter copies (instances x emitters); the limit is 16 777 216";
+        return PT_ERR_UNSUPPORTED;
+    }
+    const uint32_t n = s->n_inst;
+    const float *xforms3x4 = s->h_xforms.data();
+    std::vector<float4> wl;
+    wl.reserve(5 * (size_t)copies);
+    float run = 0.f;
+    for (uint32_t i = 0; i < n; i++) {
+        const float *m = xforms3x4 + 12 * (size_t)i;
+        for (uint32_t k = 0; k < s->n_lights; k++) {
+            float w[3][3];
+            for (int c = 0; c < 3; c++) {
+                const float4 v = s->h_lights[5 * (size_t)k + c];
+                for (int r = 0; r < 3; r++) w[c][r] = ((m[4 * r] * v.x + m[4 * r + 1] * v.y) + m[4 * r + 2] * v.z) + m[4 * r + 3];
+            }
+            const float e1[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, e2[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
+            const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const float len = sqrtf((cx * cx + cy * cy) + cz * cz);
+            run = run + 0.5f * len;
+            wl.push_back(make_float4(w[0][0], w[0][1], w[0][2], run));
+            wl.push_back(make_float4(w[1][0], w[1][1], w[1][2], 0.f));
+            wl.push_back(make_float4(w[2][0], w[2][1], w[2][2], 0.f));
+            wl.push_back(make_float4(-(cx / len), -(cy / len), -(cz / len), 0.f));
+            wl.push_back(s->h_lights[5 * (size_t)k + 4]);
+        }
+    }
+    const hipError_t e = hipMalloc((void **)&s->d_lights_inst, sizeof(float4) * wl.size());
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        s->d_lights_inst = nullptr;
+        ctx->err = std::string("hipMalloc of the instanced emitter table: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP;
+    }
+    PT_HIP(ctx, hipMemcpy(s->d_lights_inst, wl.data(), sizeof(float4) * wl.size(), hipMemcpyHostToDevice));
+    s->n_lights_inst = (uint32_t)copies;
+    s->light_area_inst = run;
+    return PT_OK;
+}
+
 void ptb_free_instances(pt_scene *s)
 {
+    s->h_xforms.clear();
+    s->h_xforms.shrink_to_fit();
     (void)hipFree(s->d_inst_frame);
     s->d_inst_frame = nullptr;
     (void)hipFree(s->d_lights_inst);
@@ -1642,6 +1733,7 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     PT_HIP(ctx, hipStreamSynchronize(st));
     ptb_free_instances(s);
     if (n == 0) return PT_OK;
+    if (s->broken) { ctx->err = PT_BROKEN_SCENE_MSG; return PT_ERR_UNSUPPORTED; }
     std::vector<float> rec(24 * (size_t)n);
     for (uint32_t i = 0; i < n; i++) {
         const float *m = xforms3x4 + 12 * (size_t)i;
@@ -1674,37 +1766,8 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     for (int k = 0; k < 3; k++) { s->tlas_norm_c[k] = o.norm_c[k]; s->tlas_norm_s[k] = o.norm_s[k]; s->tlas_norm_rs[k] = o.norm_rs[k]; }
     if (rc != PT_OK) { ptb_free_instances(s); return rc; }
     PT_HIP(ctx, hipMalloc((void **)&s->d_inst6, sizeof(float4) * 6 * (size_t)n));
-    if (s->n_lights) {
-        // emitters of the NEE pipeline for an instanced scene: every instance's copy, in gl_InstanceID order, vertices taken to
-        // world space by the instance's matrix with the operation order of the shading transform; normal and area from the
-        // world-space triangle; one running cdf over all of them (the tests' CPU checker restates this loop)
-        std::vector<float4> wl;
-        wl.reserve(5 * (size_t)n * s->n_lights);
-        float run = 0.f;
-        for (uint32_t i = 0; i < n; i++) {
-            const float *m = xforms3x4 + 12 * (size_t)i;
-            for (uint32_t k = 0; k < s->n_lights; k++) {
-                float w[3][3];
-                for (int c = 0; c < 3; c++) {
-                    const float4 v = s->h_lights[5 * (size_t)k + c];
-                    for (int r = 0; r < 3; r++) w[c][r] = ((m[4 * r] * v.x + m[4 * r + 1] * v.y) + m[4 * r + 2] * v.z) + m[4 * r + 3];
-                }
-                const float e1[3] = { w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2] }, e2[3] = { w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2] };
-                const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
-                const float len = sqrtf((cx * cx + cy * cy) + cz * cz);
-                run = run + 0.5f * len;
-                wl.push_back(make_float4(w[0][0], w[0][1], w[0][2], run));
-                wl.push_back(make_float4(w[1][0], w[1][1], w[1][2], 0.f));
-                wl.push_back(make_float4(w[2][0], w[2][1], w[2][2], 0.f));
-                wl.push_back(make_float4(-(cx / len), -(cy / len), -(cz / len), 0.f));
-                wl.push_back(s->h_lights[5 * (size_t)k + 4]);
-            }
-        }
-        PT_HIP(ctx, hipMalloc((void **)&s->d_lights_inst, sizeof(float4) * wl.size()));
-        PT_HIP(ctx, hipMemcpy(s->d_lights_inst, wl.data(), sizeof(float4) * wl.size(), hipMemcpyHostToDevice));
-        s->n_lights_inst = (uint32_t)(wl.size() / 5);
-        s->light_area_inst = run;
-    }
+    // (the emitters' world-space copies for the NEE pipeline are made on that pipeline's first render: ptb_ensure_inst_lights)
+    s->h_xforms.assign(xforms3x4, xforms3x4 + 12 * (size_t)n);
     k_inst_sort<<<g, TB, 0, st>>>(d_in.p, s->d_tlas_prim_of, n, s->d_inst6);
     PT_HIP(ctx, hipStreamSynchronize(st));
     PT_HIP(ctx, hipGetLastError());

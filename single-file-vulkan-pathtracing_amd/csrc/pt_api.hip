@@ -3,6 +3,8 @@
 #include "pt_math.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -61,7 +63,7 @@ static bool tuning_parse(const char *text, pt_tuning *t, std::string &err)
                 if (pair.compare(0, eq, k_tune_names[k]) == 0) idx = k;
         char *end = nullptr;
         const long v = eq != std::string::npos ? std::strtol(pair.c_str() + eq + 1, &end, 10) : 0;
-        if (idx < 0 || !end || *end != 0 || end == pair.c_str() + eq + 1) { err = "PT_TUNE: cannot use '" + pair + "'"; return false; }
+        if (idx < 0 || !end || *end != 0 || end == pair.c_str() + eq + 1 || v < INT32_MIN || v > INT32_MAX) { err = "PT_TUNE: cannot use '" + pair + "'"; return false; }
         f[idx] = (int32_t)v;
     }
     return true;
@@ -80,7 +82,9 @@ pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in)
 {
     if (!ctx || !in) return PT_ERR_INVALID_ARG;
     ctx->tune = *in;
-    if (in->mem_budget_mb >= 0) ctx->mem_budget = (size_t)in->mem_budget_mb << 20;
+    // mem_budget_mb: > 0 a budget, 0 and -1 (the built-in choice) none -- so writing back what pt_ctx_get_tuning returned
+    // restores the state it described (pt_ctx_create applies the same rule)
+    ctx->mem_budget = in->mem_budget_mb > 0 ? (size_t)in->mem_budget_mb << 20 : 0;
     return PT_OK;
 }
 
@@ -236,6 +240,7 @@ pt_status pt_scene_read_bvh(const pt_scene *s, uint64_t *keys, uint32_t *prim_of
 {
     if (!s) return PT_ERR_INVALID_ARG;
     pt_ctx *ctx = s->ctx;
+    if (s->broken) { const pt_status rb = guarded(ctx, [&] { return ptb_repair(const_cast<pt_scene *>(s)); }); if (rb != PT_OK) return rb; }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (keys) PT_HIP(ctx, hipMemcpy(keys, s->d_keys, sizeof(uint64_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
     if (prim_of_pos) PT_HIP(ctx, hipMemcpy(prim_of_pos, s->d_prim_of, sizeof(uint32_t) * (size_t)s->n_tris, hipMemcpyDeviceToHost));
@@ -247,6 +252,7 @@ pt_status pt_scene_read_bvh4(const pt_scene *s, uint32_t *nodes32)
 {
     if (!s || !nodes32) return PT_ERR_INVALID_ARG;
     pt_ctx *ctx = s->ctx;
+    if (s->broken) { const pt_status rb = guarded(ctx, [&] { return ptb_repair(const_cast<pt_scene *>(s)); }); if (rb != PT_OK) return rb; }
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(nodes32, s->d_wide, 128 * (size_t)s->n_wide, hipMemcpyDeviceToHost));
     return PT_OK;
@@ -256,6 +262,7 @@ pt_status pt_scene_read_bvh8(const pt_scene *s, uint32_t *nodes32, uint32_t *pri
 {
     if (!s) return PT_ERR_INVALID_ARG;
     pt_ctx *ctx = s->ctx;
+    if (s->broken) { const pt_status rb = guarded(ctx, [&] { return ptb_repair(const_cast<pt_scene *>(s)); }); if (rb != PT_OK) return rb; }
     if (!s->d_wide8) {   // big scenes build their 8-wide nodes on first request
         const pt_status rc = guarded(ctx, [&] { return ptb_ensure_wide8(const_cast<pt_scene *>(s)); });
         if (rc != PT_OK) return rc;

@@ -72,6 +72,7 @@ struct pt_scene {
     // d_wide aliases one of the two owned arrays below.
     uint32_t bvh4_builder = 0;            // 0 collapsed LBVH, 1 surface-area sweep (small scenes), 2 PLOC rebuild of the binary tree (big scenes)
     uint32_t quality = 0;                 // pt_bvh_quality the products were built for
+    bool broken = false;                  // a rebuild of the tree products failed (lbvh_build.hip build_tree_products): nothing to traverse
     double area_lbvh = 0.0, area_ploc = 0.0;  // big scenes: sum of the internal nodes' surface areas of the two binary trees (0 = not built)
     // 64-B copy of the traversed BVH4 for scenes that are walked in HBM/L2 (lbvh_build.hip make_wide16):
     // boxes as fp16 of coordinates normalised to the scene box, rounded outwards; halves the bytes per node
@@ -108,7 +109,8 @@ struct pt_scene {
     float light_area = 0.f;
     std::vector<float4> h_lights;   // host copy of d_lights: instancing makes its world-space copies from it
     // instanced scenes: every instance's emitters in world space, gl_InstanceID-major, same 5-float4 layout and running cdf
-    float4 *d_lights_inst = nullptr;
+    std::vector<float> h_xforms;    // the instance set's object->world matrices as given (gl_InstanceID order): ptb_ensure_inst_lights
+    float4 *d_lights_inst = nullptr;  // built on the first NEE render of the instance set
     uint32_t n_lights_inst = 0;
     float light_area_inst = 0.f;
     // two-level scenes: instances in TLAS leaf order, 6 float4 each {object->world rows, world->object rows}
@@ -150,7 +152,7 @@ struct pt_film {
         float4 *d_hit = nullptr;                      // {bits(pos), t, u, v}
         uint32_t *d_hit_inst = nullptr;               // instance (TLAS sorted position); only for two-level scenes
         uint32_t *d_count = nullptr;                  // [2] queue sizes
-        size_t cap_slots = 0, cap_color = 0, cap_terms = 0, cap_terms_over = 0;  // allocated capacities (buffers only grow)
+        size_t cap_slots = 0, cap_meta = 0, cap_color = 0, cap_terms = 0, cap_terms_over = 0;  // allocated capacities (buffers only grow); cap_slots: queues + hit records, cap_meta: d_nterm / d_spill_head
         size_t bytes = 0;                             // device bytes held by the buffers above
         // shadow queue of the NEE pipeline (one entry per hit whose light sample faces it)
         float4 *d_sq_rayA = nullptr; float2 *d_sq_rayB = nullptr; float4 *d_sq_contrib = nullptr;  // {r, g, b, tmax}
@@ -170,13 +172,17 @@ struct pt_film {
         }                                                                                         \
     } while (0)
 
+#define PT_BROKEN_SCENE_MSG "the scene lost its acceleration structure in a failed rebuild (out of memory?): call pt_scene_set_bvh_quality again, or recreate it"
 // lbvh_build.hip
 pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts, const uint32_t *h_indices,
                           uint32_t n_tris, const float *h_faces);
 pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n);
 pt_status ptb_set_bvh_quality(pt_scene *s, uint32_t quality);
 void ptb_free_scene_buffers(pt_scene *s);
+pt_status ptb_ensure_inst_lights(pt_scene *s);  // world-space emitter copies of an instanced scene (NEE pipeline only)
+constexpr uint64_t PT_SOURCE_BYTES_PER_TRI = 72;  // d_tri_orig + d_faces, kept for rebuilds: part of pt_scene_info.device_bytes
 pt_status ptb_ensure_inst_frames(pt_scene *s);  // the table k_shade reads instead of transforming the normal per hit (instanced scenes)
+pt_status ptb_repair(pt_scene *s);        // no-op unless a rebuild of the tree products failed earlier: then one more try
 pt_status ptb_ensure_wide8(pt_scene *s);  // builds the 8-wide nodes of a scene that was created without them
 constexpr uint32_t PT_SAH_MAX_TRIS = 2048;
 // bvh4_sah_device.hip: surface-area sweep on the device (one workgroup) -> BVH4 rows (32 dwords each) + leaf order

@@ -1000,6 +1000,8 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
     reinterpret_cast<uchar4 *>(bgra)[pix] = img;
 }
 
+#include "fused_kernel.h"  // k_fused: PT_PIPELINE_FUSED, the whole loop as one persistent kernel (scenes in LDS)
+
 // hit records of the internal layout (sorted position) -> API layout (gl_PrimitiveID)
 __global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ hit, const float4 *__restrict__ tri4,
                                                     const uint32_t *__restrict__ hit_inst,
@@ -1042,6 +1044,10 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
     if (want > PT_EXTEND_HBM8) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
+    if (s->broken) {  // an earlier rebuild of the tree ran out of memory (lbvh_build.hip): never launch on null tables
+        const pt_status rcb = ptb_repair(s);
+        if (rcb != PT_OK) return rcb;
+    }
     // AUTO walks scenes beyond L2 (at first; now nearly every scene beyond LDS, below) through the 8-wide tree (64-B nodes with byte planes): fewer distinct lines per ray -- measured on
     // MI355X, same box, three rounds: C5 2 465 -> 2 547 Mrays/s (+3.4 %), C5x 2 405 -> 2 546 (+5.9 %), 36.2 -> 27.7 and 29.5 -> 24.2
     // node visits per ray (profiles/r03_ab_c5_c5x_hbm8_64B_nodes.log); pt_tuning.hbm8 = 0 keeps the BVH4, 1 takes the 8-wide tree
@@ -1091,7 +1097,9 @@ pt_status plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
                                               : reinterpret_cast<const void *>(k_extend_inst16<false, false>);
             if (pl.smem > 48 * 1024)
                 for (const void *f : { reinterpret_cast<const void *>(k_extend_inst16<false, true>), reinterpret_cast<const void *>(k_extend_inst16<false, false>),
-                                       reinterpret_cast<const void *>(k_extend_inst16<true, true>), reinterpret_cast<const void *>(k_extend_inst16<true, false>) })
+                                       reinterpret_cast<const void *>(k_extend_inst16<true, true>), reinterpret_cast<const void *>(k_extend_inst16<true, false>),
+                                       // (the shadow-ray twins of the NEE pipeline: the same launch shape)
+                                       reinterpret_cast<const void *>(k_extend_inst16<false, true, true>), reinterpret_cast<const void *>(k_extend_inst16<false, false, true>) })
                     PT_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
             int per16 = 0;
             PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per16, fn16, TB, pl.smem));
@@ -1330,17 +1338,19 @@ void launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, const 
 
 // Bytes of workspace per path slot that do not depend on the sample-group shape: two queue sets
 // (id 8 + state 16 + rayA 16 + rayB 8), hit 16 + instance 4, term count 4, pool head 4.
-constexpr size_t SLOT_BYTES = 2 * (8 + 16 + 16 + 8) + 16 + 4 + 4 + 4;
+// (PT_PIPELINE_FUSED has no queues: 8 B per slot)
+constexpr size_t SLOT_BYTES_QUEUES = 2 * (8 + 16 + 16 + 8) + 16 + 4, SLOT_BYTES_META = 4 + 4;
+constexpr size_t SLOT_BYTES = SLOT_BYTES_QUEUES + SLOT_BYTES_META;
 
 struct WorkNeed { size_t slots, color, terms, terms_over, total; };
-WorkNeed work_need(uint64_t n_slots, uint32_t groups, uint32_t term_cap, uint32_t term_pcap)
+WorkNeed work_need(uint64_t n_slots, uint32_t groups, uint32_t term_cap, uint32_t term_pcap, bool queues = true)
 {
     WorkNeed n{};
     n.slots = (size_t)std::max<uint64_t>(n_slots, 1);
     n.color = groups == 1 ? n.slots : 0;
     n.terms = groups > 1 ? n.slots * (size_t)term_pcap : 0;
     n.terms_over = groups > 1 ? n.slots * (size_t)(term_cap - term_pcap) : 0;
-    n.total = n.slots * SLOT_BYTES + sizeof(float4) * (n.color + n.terms + n.terms_over) +
+    n.total = n.slots * (queues ? SLOT_BYTES : SLOT_BYTES_META) + sizeof(float4) * (n.color + n.terms + n.terms_over) +
               (groups > 1 ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0);
     return n;
 }
@@ -1378,7 +1388,7 @@ void free_shape_buffers(pt_film::Work &w)
     (void)hipFree(w.d_color); (void)hipFree(w.d_terms); (void)hipFree(w.d_terms_over); (void)hipFree(w.d_spill);
     w.d_hit = nullptr; w.d_hit_inst = nullptr; w.d_nterm = nullptr; w.d_spill_head = nullptr;
     w.d_color = nullptr; w.d_terms = nullptr; w.d_terms_over = nullptr; w.d_spill = nullptr;
-    w.cap_slots = w.cap_color = w.cap_terms = w.cap_terms_over = 0;
+    w.cap_slots = w.cap_meta = w.cap_color = w.cap_terms = w.cap_terms_over = 0;
     w.bytes = w.sort_bytes;  // (the ray-sort scratch is not a shape buffer)
 }
 
@@ -1386,8 +1396,9 @@ void free_shape_buffers(pt_film::Work &w)
 // ever grow: a later call with a smaller shape reuses them (hipMalloc of tens of GB costs 100s of ms).
 // A grow that does not fit returns PT_ERR_OOM and leaves the film WITHOUT shape buffers (all freed, capacities 0).
 pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap,
-                      uint32_t term_pcap)
+                      uint32_t term_pcap, bool queues = true)
 {
+    // queues = false (PT_PIPELINE_FUSED): no path queues and no hit records, only the per-slot radiance arrays
     pt_ctx *ctx = f->ctx;
     pt_film::Work &w = f->work;
     if (!w.d_tiles || w.rank != rank || w.world != world) {
@@ -1410,21 +1421,22 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         return PT_ERR_INVALID_ARG;
     }
     if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
-    const WorkNeed need = work_need(n_slots64, groups, term_cap, term_pcap);
+    const WorkNeed need = work_need(n_slots64, groups, term_cap, term_pcap, queues);
     const size_t ns = need.slots;
     const size_t limit = ctx->mem_budget;
     pt_status rc = PT_OK;
 #define PT_WORK_ALLOC(PTR, BYTES) \
     if (rc == PT_OK) rc = work_alloc(ctx, w, (void **)&(PTR), (BYTES), limit)
-    if (ns > w.cap_slots) {
+    if (queues && ns > w.cap_slots) {
         // the queue set goes as a whole: free first (peak = the new size, not old + new)
-        const size_t keep_color = w.cap_color, keep_terms = w.cap_terms, keep_over = w.cap_terms_over;
-        float4 *const color = w.d_color, *const terms = w.d_terms, *const over = w.d_terms_over, *const pool = w.d_spill;
-        w.d_color = w.d_terms = w.d_terms_over = w.d_spill = nullptr;
-        free_shape_buffers(w);
-        w.d_color = color; w.d_terms = terms; w.d_terms_over = over; w.d_spill = pool;
-        w.cap_color = keep_color; w.cap_terms = keep_terms; w.cap_terms_over = keep_over;
-        w.bytes = sizeof(float4) * (keep_color + keep_terms + keep_over) + (pool ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0) + w.sort_bytes;
+        for (int i = 0; i < 2; i++) {
+            (void)hipFree(w.d_qid[i]); (void)hipFree(w.d_qstate[i]); (void)hipFree(w.d_qrayA[i]); (void)hipFree(w.d_qrayB[i]);
+            w.d_qid[i] = nullptr; w.d_qstate[i] = w.d_qrayA[i] = nullptr; w.d_qrayB[i] = nullptr;
+        }
+        (void)hipFree(w.d_hit); (void)hipFree(w.d_hit_inst);
+        w.d_hit = nullptr; w.d_hit_inst = nullptr;
+        w.bytes -= w.cap_slots * SLOT_BYTES_QUEUES;
+        w.cap_slots = 0;
         for (int i = 0; i < 2; i++) {
             PT_WORK_ALLOC(w.d_qid[i], sizeof(uint2) * ns);
             PT_WORK_ALLOC(w.d_qstate[i], sizeof(float4) * ns);
@@ -1433,9 +1445,16 @@ pt_status ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes,
         }
         PT_WORK_ALLOC(w.d_hit, sizeof(float4) * ns);
         PT_WORK_ALLOC(w.d_hit_inst, sizeof(uint32_t) * ns);
+        if (rc == PT_OK) w.cap_slots = ns;
+    }
+    if (rc == PT_OK && ns > w.cap_meta) {
+        (void)hipFree(w.d_nterm); (void)hipFree(w.d_spill_head);
+        w.d_nterm = nullptr; w.d_spill_head = nullptr;
+        w.bytes -= w.cap_meta * SLOT_BYTES_META;
+        w.cap_meta = 0;
         PT_WORK_ALLOC(w.d_nterm, sizeof(uint32_t) * ns);
         PT_WORK_ALLOC(w.d_spill_head, sizeof(uint32_t) * ns);
-        if (rc == PT_OK) w.cap_slots = ns;
+        if (rc == PT_OK) w.cap_meta = ns;
     }
     if (rc == PT_OK && need.color > w.cap_color) {
         (void)hipFree(w.d_color);
@@ -1596,7 +1615,7 @@ pt_status shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh, int
 {
     pt_status rc = PT_OK;
     pt_params p_local = *p_in;
-    if (p_local.pipeline == PT_PIPELINE_WAVEFRONT_NEE) p_local.sample_groups = 1;  // up to max_depth + 1 radiance terms per sample: the plain accumulator
+    if (p_local.pipeline == PT_PIPELINE_WAVEFRONT_NEE) p_local.sample_groups = 1;  // (up to two radiance terms per hit -- a camera ray's emitter hit, the light sample -- so a sample has more than group_size + 2: the plain accumulator)
     const pt_params *p = &p_local;
     for (int attempt = 0; attempt < 12; attempt++) {
         sh = choose_shape(f, p, launch_class, attempt);
@@ -1618,7 +1637,11 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
         return PT_ERR_INVALID_ARG;
     }
     if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
-    if (p->pipeline > PT_PIPELINE_WAVEFRONT_NEE) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+    if (p->pipeline > PT_PIPELINE_FUSED) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+    if (p->pipeline == PT_PIPELINE_FUSED && (p->flags & (PT_FLAG_ASYNC | PT_FLAG_COUNT_VISITS))) {
+        ctx->err = "the fused pipeline has no asynchronous and no instrumented form";
+        return PT_ERR_UNSUPPORTED;
+    }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT_NEE) {
         if (p->extend == PT_EXTEND_FLAT) { ctx->err = "the NEE pipeline has no flat extend variant (shadow rays need a per-ray tmax)"; return PT_ERR_UNSUPPORTED; }
         if (p->sample_groups > 1) { ctx->err = "the NEE pipeline runs one sample group per pixel"; return PT_ERR_UNSUPPORTED; }
@@ -1626,14 +1649,193 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
     return PT_OK;
 }
 
-}  // namespace
+RenderConst make_render_const(const pt_params *p, const pt_film::Work &w, const RenderShape &sh)
+{
+    RenderConst rc{};
+    rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
+               (float)p->width, (float)p->height };
+    for (int k = 0; k < 3; k++) rc.env[k] = p->env[k];
+    rc.tmin = p->tmin; rc.tmax = p->tmax;
+    rc.width = p->width; rc.height = p->height; rc.tiles_x = (p->width + 7) / 8;
+    rc.spp = p->spp_per_frame; rc.max_depth = p->max_depth;
+    rc.slots_per_lane = w.n_tiles * 64u;
+    rc.groups = sh.groups; rc.group_size = sh.group_size; rc.term_cap = sh.term_cap;
+    rc.div_spl.init(std::max(rc.slots_per_lane, 1u)); rc.div_groups.init(std::max(sh.groups, 1u));
+    rc.term_pcap = sh.term_pcap;
+    rc.n_slots = w.n_slots;
+    return rc;
+}
+
+// pixels of this rank's 8x8 tiles that lie inside the image (samples started = that x spp x frames)
+uint64_t valid_local_pixels(const pt_film *f, const pt_params *p)
+{
+    uint64_t valid = 0;
+    const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++)
+            if ((tx + ty) % p->world == p->rank)
+                valid += (uint64_t)std::min(8u, f->w - tx * 8) * std::min(8u, f->h - ty * 8);
+    return valid;
+}
 
 // what pt_stats.workspace_bytes reports: everything the film's wavefront workspace holds + the context's stack-spill area
-static uint64_t workspace_bytes(const pt_film *f)
+uint64_t workspace_bytes(const pt_film *f)
 {
     const pt_film::Work &w = f->work;
     return (uint64_t)w.bytes + (uint64_t)w.cap_sq * (16 + 8 + 16 + 4 + 4 + 16) + (uint64_t)f->ctx->spill_bytes;
 }
+
+// ---- PT_PIPELINE_FUSED (fused_kernel.h): host side -------------------------------------------------------------------
+struct FusedPlan { size_t smem = 0; int grid = 0, lds_stack = 0, refill = 16; };
+
+pt_status plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp)
+{
+    pt_ctx *ctx = s->ctx;
+    const size_t tables = sizeof(float4) * 5 * (size_t)s->n_tris;  // shade4 + tangent frames (the vertices are the kz = 2 triangle copy)
+    if (s->n_inst || pl.variant != PT_EXTEND_LDS || pl.spill || !pl.pairs || !(tmin > 0.f) || tables > 16 * 1024) {
+        ctx->err = "PT_PIPELINE_FUSED is for single-level scenes whose BVH4, triangles and shading tables fit LDS (the compact pair-leaf "
+                   "kernel's class: <= 2047 triangles in <= 24 KB, stack bound <= 16, tmin > 0)";
+        return PT_ERR_UNSUPPORTED;
+    }
+    fp.lds_stack = pl.lds_stack;
+    fp.smem = pl.smem + tables + sizeof(uint32_t) * FS_FIELDS * TB;
+    for (const void *fn : { reinterpret_cast<const void *>(k_fused<false>), reinterpret_cast<const void *>(k_fused<true>) })
+        if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
+    int per_cu = 0;
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fused<false>), TB, fp.smem));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
+    fp.grid = ctx->num_cus * per_cu;
+    fp.refill = pt_tuned(ctx->tune.refill, 16, 1, 64);  // of 64: the share of a wave's live lanes that must wait before the shade block runs
+    return PT_OK;
+}
+
+// The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches); sample groups
+// only to shorten the tail of a batch -- the last slots handed out run alone at the end, and a slot of 32 samples is up to 256
+// rays = ~4 ms of a lane's time against 8 ms for a whole frame: frames x groups >= 16 keeps that tail under ~2 % of a batch.
+// Explicit frames_in_flight / sample_groups are taken as given.
+void fused_shape_defaults(const pt_params *p, pt_params &q)
+{
+    q = *p;
+    if (q.frames_in_flight == 0) {
+        const uint32_t cap = 32;
+        const uint32_t batches = (p->frame_count + cap - 1) / cap;
+        q.frames_in_flight = (p->frame_count + batches - 1) / batches;
+    }
+    q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
+    if (q.sample_groups == 0) {
+        uint32_t g = 1;
+        while (g < p->spp_per_frame && (g * q.frames_in_flight < 16u || p->spp_per_frame % g)) g++;
+        q.sample_groups = g;
+    }
+}
+
+pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const ExtendPlan &pl, bool nested, bool prepare_only)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    FusedPlan fp;
+    pt_status rc_ = plan_fused(s, pl, p_in->tmin, fp);
+    if (rc_ != PT_OK) return rc_;
+    pt_params q;
+    fused_shape_defaults(p_in, q);
+    const pt_params *p = &q;
+    RenderShape sh;
+    for (int attempt = 0; attempt < 12; attempt++) {  // (memory taken between hipMemGetInfo and hipMalloc: plan again for half of it)
+        sh = choose_shape(f, p, 2, attempt);
+        rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap, false);
+        if (rc_ != PT_ERR_OOM) break;
+    }
+    if (!nested) {
+        ctx->stats.frames_in_flight = sh.lanes;
+        ctx->stats.sample_groups = sh.groups;
+    }
+    if (rc_ != PT_OK) return rc_;
+    ctx->stats.workspace_bytes = workspace_bytes(f);
+    if (prepare_only) return PT_OK;
+    pt_film::Work &w = f->work;
+    unsigned long long *const d_overflow = ctx->d_stats + 6, *const d_spill_count = ctx->d_stats + 7;
+    uint32_t spill_cap = sh.bounded ? SPILL_POOL_ENTRIES : 0u;
+    if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);
+    Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+    RenderConst rc = make_render_const(p, w, sh);
+    const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;
+    ctx->stats.extend_variant = pl.variant;
+    ctx->stats.pipelines = 1;
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    std::vector<hipEvent_t> evs;
+    size_t ev_used = 0;
+    for (uint32_t done = 0; w.n_slots > 0 && done < p->frame_count; done += sh.lanes) {
+        rc.frame_base = p->frame + (int32_t)done;
+        rc.lanes_active = std::min(sh.lanes, p->frame_count - done);
+        unsigned long long rays_before = 0;
+        if (sh.bounded) {
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
+            PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
+        }
+        PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t), st));  // the slot counter
+        const uint32_t n_slots = rc.lanes_active * sh.groups * rc.slots_per_lane;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) {
+            while (ctx->ev_pool.size() < ev_used + 2) {
+                hipEvent_t e = nullptr;
+                PT_HIP(ctx, hipEventCreate(&e));
+                ctx->ev_pool.push_back(e);
+            }
+            e0 = ctx->ev_pool[ev_used++]; e1 = ctx->ev_pool[ev_used++];
+            evs.push_back(e0); evs.push_back(e1);
+        }
+        if (sh.groups > 1)
+            hipExtLaunchKernelGGL((k_fused<true>), dim3(fp.grid), dim3(TB), (uint32_t)fp.smem, st, e0, e1, 0u, rc, w.d_tiles, rad, s->d_wide, s->d_tri4,
+                                  s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, w.d_count, ctx->d_stats, fp.refill, p->tmin, p->tmax, fp.lds_stack);
+        else
+            hipExtLaunchKernelGGL((k_fused<false>), dim3(fp.grid), dim3(TB), (uint32_t)fp.smem, st, e0, e1, 0u, rc, w.d_tiles, rad, s->d_wide, s->d_tri4,
+                                  s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, w.d_count, ctx->d_stats, fp.refill, p->tmin, p->tmax, fp.lds_stack);
+        PT_HIP(ctx, hipGetLastError());
+        ctx->stats.launches_extend++;
+        ctx->stats.rounds++;
+        bool redo = false;
+        if (sh.bounded) {
+            unsigned long long flag = 0;
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            PT_HIP(ctx, hipMemcpy(&flag, d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+            redo = flag != 0ull;
+        }
+        if (!redo) {
+            k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra);
+            ctx->stats.launches_other++;
+        } else {  // a slot filled its term log (scenes where most surfaces emit): the same frames once more with one group
+            PT_HIP(ctx, hipMemcpy(ctx->d_stats, &rays_before, sizeof(rays_before), hipMemcpyHostToDevice));
+            PT_HIP(ctx, hipMemset(d_overflow, 0, sizeof(unsigned long long)));
+            ctx->stats.redone_batches++;
+            pt_params r = *p;
+            r.frame = rc.frame_base; r.frame_count = rc.lanes_active; r.frames_in_flight = rc.lanes_active; r.sample_groups = 1;
+            rc_ = render_fused(s, f, &r, pl, true, false);
+            if (rc_ != PT_OK) return rc_;
+            rc_ = ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap, false);
+            if (rc_ != PT_OK) return rc_;
+            rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+        }
+    }
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    if (!nested) {
+        float ms = 0.f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+        ctx->stats.ms_total += ms;
+        ctx->stats.workspace_bytes = workspace_bytes(f);
+        ctx->stats.paths += valid_local_pixels(f, p) * p->spp_per_frame * p->frame_count;
+    }
+    for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+        float a = 0.f;
+        if (hipEventElapsedTime(&a, evs[i], evs[i + 1]) == hipSuccess) ctx->stats.ms_extend += a;
+    }
+    return PT_OK;
+}
+
+}  // namespace
 
 void ptw_free_work(pt_film *f)
 {
@@ -1667,6 +1869,7 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     ExtendPlan pl;
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
+    if (p->pipeline == PT_PIPELINE_FUSED) return render_fused(s, f, p, pl, false, true);
     RenderShape sh;
     rc_ = shape_and_work(f, p, sh, s->n_inst || pl.variant == PT_EXTEND_FLAT ? 0 : pl.lds_scene ? 2 : 1);
     s->ctx->stats.frames_in_flight = sh.lanes;
@@ -1709,6 +1912,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     ExtendPlan pl;
     rc_ = plan_extend(s, p->extend, pl);
     if (rc_ != PT_OK) return rc_;
+    if (p->pipeline == PT_PIPELINE_FUSED) return render_fused(s, f, p, pl, nested, false);
     RenderShape sh;
     rc_ = shape_and_work(f, p, sh, s->n_inst || pl.variant == PT_EXTEND_FLAT ? 0 : pl.lds_scene ? 2 : 1);
     if (rc_ != PT_OK) return rc_;
@@ -1723,18 +1927,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);  // tests
     Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
 
-    RenderConst rc{};
-    rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
-               (float)p->width, (float)p->height };
-    for (int k = 0; k < 3; k++) rc.env[k] = p->env[k];
-    rc.tmin = p->tmin; rc.tmax = p->tmax;
-    rc.width = p->width; rc.height = p->height; rc.tiles_x = (p->width + 7) / 8;
-    rc.spp = p->spp_per_frame; rc.max_depth = p->max_depth;
-    rc.slots_per_lane = w.n_tiles * 64u;
-    rc.groups = groups; rc.group_size = group_size; rc.term_cap = term_cap;
-    rc.div_spl.init(std::max(rc.slots_per_lane, 1u)); rc.div_groups.init(std::max(groups, 1u));
-    rc.term_pcap = sh.term_pcap;
-    rc.n_slots = w.n_slots;
+    RenderConst rc = make_render_const(p, w, sh);
 
     const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;  // (a redo would re-record the pooled events of its caller)
     const bool count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
@@ -1835,6 +2028,10 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     }
     const bool nee = p->pipeline == PT_PIPELINE_WAVEFRONT_NEE;
     // the emitters the NEE pipeline samples: the scene's, or -- instanced -- every instance's copy of them in world space
+    if (nee && s->n_inst) {
+        const pt_status rcl = ptb_ensure_inst_lights(s);
+        if (rcl != PT_OK) return rcl;
+    }
     const float4 *const nee_lights = s->n_inst ? s->d_lights_inst : s->d_lights;
     const uint32_t nee_n_lights = s->n_inst ? s->n_lights_inst : s->n_lights;
     const float nee_light_area = s->n_inst ? s->light_area_inst : s->light_area;
@@ -2050,14 +2247,7 @@ static pt_status render_impl(pt_scene *s, pt_film *f, const pt_params *p, bool n
     }
     if (!nested) {
         ctx->stats.workspace_bytes = workspace_bytes(f);
-        // samples started = valid local pixels x spp x frames
-        uint64_t valid = 0;
-        const uint32_t tiles_x = (f->w + 7) / 8, tiles_y = (f->h + 7) / 8;
-        for (uint32_t ty = 0; ty < tiles_y; ty++)
-            for (uint32_t tx = 0; tx < tiles_x; tx++)
-                if ((tx + ty) % p->world == p->rank)
-                    valid += (uint64_t)std::min(8u, f->w - tx * 8) * std::min(8u, f->h - ty * 8);
-        ctx->stats.paths += valid * p->spp_per_frame * p->frame_count;
+        ctx->stats.paths += valid_local_pixels(f, p) * p->spp_per_frame * p->frame_count;
     }
     if (profile) {
         for (size_t i = 0; i + 1 < ev_extend.size(); i += 2) {

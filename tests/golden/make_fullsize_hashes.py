@@ -7,6 +7,14 @@ check of 6.2 M floats per config that needs no oracle run on the GPU box.  (benc
 LIVE oracle run inside its cpu_baseline leg; the numbers agree: C2 224 112 445 rays, C4 163 213 621, C5 118 193 858.)
 
     python tests/golden/make_fullsize_hashes.py [c2 c4 c5]      # ~2 min for C2+C4, ~10 min for C5 on 8 cores
+    python tests/golden/make_fullsize_hashes.py c3              # ~20 min on 8 cores
+
+`c3` is BASELINE config C3 at its size: the Cornell box, 1920x1080, 1024 spp = frames 0..31 of 32 spp (seed multipliers
+m = 1..1024, raygen.rgen:47), depth 8, blended progressively as raygen.rgen:88-90 does -- the float film AND the reference's rgba8
+storage image.  Recorded: the exact ray count of every frame (their sum is the 8-GPU job's total), the SHA-256 of the float
+film and of the bgra8 image after frames 0, 1, 3, 7, 15 and 31, and for the world-8 decomposition (8x8 tiles, tile (tx,ty) ->
+rank (tx+ty) % 8) the exact number of rays each rank traces: `test_c3_*` renders the same 32 frames on
+the GPU as one device and as the eight ranks one after the other and requires all of it to the bit.
 """
 import hashlib
 import importlib
@@ -29,9 +37,52 @@ CONFIGS = {
 }
 
 
+C3_FRAMES = 32
+C3_MARKS = (0, 1, 3, 7, 15, 31)
+C3_WORLD = 8
+
+
+def make_c3(res):
+    import numpy as np
+    osc = orc.Scene(*pt.load_obj(os.path.join(REPO, "assets", "CornellBox-Original.obj")))
+    w, h = 1920, 1080
+    film = np.zeros((h, w, 3), np.float32)
+    bgra = np.zeros((h, w, 4), np.uint8)
+    # rank of every pixel under the world-8 tile decomposition (csrc/wavefront.hip ensure_work: (tx + ty) % world)
+    ty, tx = np.meshgrid(np.arange(h) // 8, np.arange(w) // 8, indexing="ij")
+    rank_of = ((tx + ty) % C3_WORLD).astype(np.int64)
+    rays_frame, rays_rank = [], np.zeros(C3_WORLD, np.int64)
+    marks = {}
+    t0 = time.perf_counter()
+    for frame in range(C3_FRAMES):
+        p = orc.default_params(width=w, height=h, spp_per_frame=32, max_depth=8, frame=frame)
+        ray_map = np.zeros((h, w), np.uint32)
+        img, rays, _, _ = osc.render_frame(p, mode=1, nthreads=os.cpu_count() or 1, ray_map=ray_map)
+        assert int(ray_map.sum(dtype=np.int64)) == rays
+        rays_rank += np.bincount(rank_of.ravel(), weights=ray_map.ravel().astype(np.float64), minlength=C3_WORLD).astype(np.int64)
+        orc.accumulate_f32(film, img, frame)
+        orc.accumulate_bgra8(bgra, img, frame)
+        rays_frame.append(int(rays))
+        if frame in C3_MARKS:
+            marks[str(frame)] = {"film_sha256": hashlib.sha256(film.astype("<f4").tobytes()).hexdigest(),
+                                 "bgra8_sha256": hashlib.sha256(bgra.tobytes()).hexdigest(),
+                                 "rays_so_far": int(sum(rays_frame))}
+        print("c3 frame", frame, rays, round(time.perf_counter() - t0, 1), "s", flush=True)
+    res["c3"] = {"width": w, "height": h, "spp_per_frame": 32, "max_depth": 8, "frames": C3_FRAMES, "world": C3_WORLD,
+                 "rays": int(sum(rays_frame)), "rays_per_frame": rays_frame, "after_frame": marks,
+                 "rays_per_rank_world8": [int(x) for x in rays_rank],
+                 "film_sum_f64": float(film.astype("float64").sum()), "scene": "CornellBox-Original.obj",
+                 "oracle_seconds": round(time.perf_counter() - t0, 1)}
+    print("c3", {k: v for k, v in res["c3"].items() if k != "rays_per_frame"}, flush=True)
+
+
 def main():
     want = sys.argv[1:] or list(CONFIGS)
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    if "c3" in want:
+        make_c3(res)
+        json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+        want = [x for x in want if x != "c3"]
     for name in want:
         c = CONFIGS[name]
         arrays = (pt.load_obj(os.path.join(REPO, "assets", "CornellBox-Original.obj")) if c["scene"] == "cornell"

@@ -1974,3 +1974,207 @@ def test_full_size_frames_equal_the_oracle_known_answers(pt, gpu_ctx, config):
         assert hashlib.sha256(got.astype("<f4").tobytes()).hexdigest() == gold["film_sha256"], (config, kw, float(got.astype(np.float64).sum()), gold["film_sum_f64"])
     film.close()
     scene.close()
+
+
+def _c3_gold():
+    import json
+    path = os.path.join(HERE, "golden", "fullsize_hashes.json")
+    gold = json.load(open(path)).get("c3")
+    if gold is None:
+        pytest.skip(f"no known answer for c3 in {path}")
+    return gold
+
+
+def test_c3_full_size_1024spp_progressive_equals_the_oracle_known_answer(pt, gpu_ctx, cornell_gpu):
+    """BASELINE config C3 at its size on ONE device: the Cornell box at 1920x1080, 1024 spp = frames 0..31 of 32 spp (seed
+    multipliers m = 1 .. 1024, raygen.rgen:47), depth 8, blended progressively (raygen.rgen:88-90).  The oracle's known
+    answer (tests/golden/fullsize_hashes.json `c3`, tests/golden/make_fullsize_hashes.py) holds the SHA-256 of the float film
+    and of the reference's rgba8 storage image after frames 0, 1, 3, 7, 15 and 31 and the exact ray count of every frame:
+    the GPU renders the 32 frames in six calls that end on those frames (1 + 1 + 2 + 4 + 8 + 16 frames in flight) and has
+    to meet every one of them to the bit -- 7.2 G rays, 6.2 M floats."""
+    import hashlib
+    gold = _c3_gold()
+    w, h = gold["width"], gold["height"]
+    kw = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"])
+    film = pt.Film(gpu_ctx, w, h)
+    gpu_ctx.reset_stats()
+    first = 0
+    for mark in sorted(int(k) for k in gold["after_frame"]):
+        pt.render(cornell_gpu, film, pt.default_params(frame=first, frame_count=mark + 1 - first, **kw))
+        first = mark + 1
+        g = gold["after_frame"][str(mark)]
+        assert gpu_ctx.stats().rays == g["rays_so_far"] == sum(gold["rays_per_frame"][:mark + 1]), mark
+        assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == g["film_sha256"], mark
+        assert hashlib.sha256(film.read_bgra8().tobytes()).hexdigest() == g["bgra8_sha256"], mark
+    assert first == gold["frames"] and gpu_ctx.stats().rays == gold["rays"]
+    # and the whole job as ONE call (what bench.py --config c3 times): AUTO batches the 32 frames itself
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=gold["frames"], **kw))
+    last = gold["after_frame"][str(gold["frames"] - 1)]
+    assert gpu_ctx.stats().rays == gold["rays"]
+    assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == last["film_sha256"]
+    assert hashlib.sha256(film.read_bgra8().tobytes()).hexdigest() == last["bgra8_sha256"]
+    film.close()
+
+
+def test_c3_full_size_as_eight_ranks_in_sequence_assembles_the_same_image(pt, gpu_ctx, cornell_gpu):
+    """BASELINE config C3 as the 8-GPU job it is, on the one GPU there is: ranks 0..7 of world 8 render their 8x8 tiles of
+    the 1920x1080 x 1024-spp image one after the other (32 frames each, one call), pt_film_pack_tiles / _unpack_tiles --
+    the two kernels of pt_film_present either side of the RCCL gather -- assemble one image: the oracle's film to the bit
+    (same SHA-256 as the single-device render), every rank traces exactly the number of rays the oracle counted for its
+    pixels, the counts add up to the job's 7.2 G rays and no rank is more than 1 % away from an eighth of them; each
+    rank's rgba8 tiles are the oracle's too (the gather moves the float film only)."""
+    import hashlib
+    import importlib
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    gold = _c3_gold()
+    w, h, world = gold["width"], gold["height"], gold["world"]
+    kw = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"], frame=0, frame_count=gold["frames"])
+    last = gold["after_frame"][str(gold["frames"] - 1)]
+    image = pt.DeviceBuffer(gpu_ctx, w * h * 12)
+    bgra = np.zeros((h, w, 4), np.uint8)
+    rays, tiles = [], 0
+    for rank in range(world):
+        film = pt.Film(gpu_ctx, w, h)
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(rank=rank, world=world, **kw))
+        rays.append(gpu_ctx.stats().rays)
+        n = pt.film_tile_count(film, rank, world)
+        tiles += n
+        packed = pt.DeviceBuffer(gpu_ctx, n * 192 * 4)
+        pt.film_pack_tiles(film, rank, world, packed.ptr)
+        pt.film_unpack_tiles(film, rank, world, packed.ptr, image.ptr)
+        mask = d.owned_mask(w, h, rank, world)
+        part = film.read_bgra8()
+        bgra[mask] = part[mask]
+        packed.close(); film.close()
+    assert tiles == ((w + 7) // 8) * ((h + 7) // 8)
+    assert rays == gold["rays_per_rank_world8"], (rays, gold["rays_per_rank_world8"])
+    assert sum(rays) == gold["rays"]
+    assert max(abs(r - gold["rays"] / world) for r in rays) <= 0.01 * gold["rays"] / world, rays
+    got = image.read(np.float32, (h, w, 3))
+    assert hashlib.sha256(got.astype("<f4").tobytes()).hexdigest() == last["film_sha256"]
+    assert hashlib.sha256(bgra.tobytes()).hexdigest() == last["bgra8_sha256"]
+    image.close()
+
+
+# ---- PT_PIPELINE_FUSED: the whole loop as one persistent kernel (csrc/fused_kernel.h) ----------------------------------
+def test_fused_pipeline_bit_exact_vs_oracle_and_wavefront(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    """The fused kernel (one lane owns its path like a raygen.rgen:41-91 invocation; traversal + closesthit.rchit:50-65 +
+    miss.rmiss:8-12 + the bounce in the same lane, path state in LDS, no queues) renders the oracle's film, rgba8 image and ray
+    count bit for bit: progressive frames one call each and batched, every sample-group shape (plain accumulator, term logs),
+    a ragged image with partial 8x8 tiles, the reference's 32 spp."""
+    for (w, h, spp, depth, frames) in ((64, 64, 4, 8, 3), (100, 37, 8, 5, 2), (120, 68, 32, 8, 2), (1, 1, 2, 3, 1)):
+        kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=depth)
+        ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, frames, **kw)
+        shapes = [dict(), dict(frames_in_flight=1, sample_groups=1), dict(frames_in_flight=frames, sample_groups=1),
+                  dict(sample_groups=2), dict(frames_in_flight=1, sample_groups=spp)]
+        for shape in shapes:
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=frames, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
+            st = gpu_ctx.stats()
+            assert st.rays == orays, (w, h, shape, st.rays, orays)
+            assert film.read_f32().tobytes() == ofilm.tobytes(), (w, h, shape)
+            assert film.read_bgra8().tobytes() == obgra.tobytes(), (w, h, shape)
+            assert st.paths == w * h * spp * frames
+            film.close()
+        # one blocking call per frame, as main.cpp:647-685 dispatches
+        film = pt.Film(gpu_ctx, w, h)
+        for k in range(frames):
+            pt.render(cornell_gpu, film, pt.default_params(frame=k, frame_count=1, pipeline=pt.PIPELINE_FUSED, **kw))
+        assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes()
+        film.close()
+
+
+def test_fused_pipeline_shards_term_log_tiers_and_refusals(pt, orc, gpu_ctx, cornell_gpu):
+    """Fused renders of (rank, world) shards add up to the single-device film; the three tiers of the term log (primary,
+    overflow, shared pool) and the redo of a batch whose pool overflowed give the same bits; the tuning knobs change no bit;
+    what the kernel is not built for is refused with PT_ERR_UNSUPPORTED (instanced scenes, scenes beyond LDS, NEE, async)."""
+    import importlib
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    w, h = 200, 120
+    kw = dict(width=w, height=h, spp_per_frame=8, max_depth=8, frame=0, frame_count=2)
+    ref = pt.Film(gpu_ctx, w, h)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, ref, pt.default_params(**kw))                                   # the wavefront pipeline
+    want, rays_want = ref.read_f32(), gpu_ctx.stats().rays
+    ref.close()
+    for world in (2, 8):
+        acc, rays = np.zeros_like(want), 0
+        for rank in range(world):
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(rank=rank, world=world, pipeline=pt.PIPELINE_FUSED, **kw))
+            rays += gpu_ctx.stats().rays
+            part = film.read_f32()
+            assert (part[~d.owned_mask(w, h, rank, world)] == 0).all()
+            acc += part
+            film.close()
+        assert acc.tobytes() == want.tobytes() and rays == rays_want
+    for knobs in (dict(term_ocap=0, term_spill=1 << 20), dict(term_ocap=1, term_spill=1 << 20), dict(term_ocap=0, term_spill=3),
+                  dict(refill=1), dict(refill=40), dict(refill=64), dict(extend_blocks=2)):
+        old = gpu_ctx.set_tuning(**knobs)
+        try:
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, sample_groups=4, **kw))
+            st = gpu_ctx.stats()
+            assert film.read_f32().tobytes() == want.tobytes() and st.rays == rays_want, knobs
+            if knobs.get("term_spill") == 3:
+                assert st.redone_batches >= 1
+            film.close()
+        finally:
+            gpu_ctx.set_tuning(**old)
+    film = pt.Film(gpu_ctx, w, h)
+    for bad in (dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_ASYNC), dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_COUNT_VISITS),
+                dict(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_HBM), dict(pipeline=pt.PIPELINE_FUSED, tmin=0.0), dict(pipeline=3)):
+        with pytest.raises(pt.PtError) as e:
+            pt.render(cornell_gpu, film, pt.default_params(**{**kw, **bad}))
+        assert e.value.status == 5, bad                                                     # PT_ERR_UNSUPPORTED
+    inst = pt.Scene(gpu_ctx, *pt.load_obj(pt.ASSET_CORNELL))
+    inst.set_instances(pt.cornell_grid_instances()[:16])
+    with pytest.raises(pt.PtError):
+        pt.render(inst, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, **kw))
+    inst.close()
+    v, i, f = _soup(3000, 5)
+    big = pt.Scene(gpu_ctx, v, i, f)
+    with pytest.raises(pt.PtError):
+        pt.render(big, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, **kw))
+    big.close()
+    # the film is still usable by the wavefront pipeline after the refusals and after fused renders (shared workspace)
+    film.clear()
+    pt.render(cornell_gpu, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, **kw))
+    film.clear()
+    pt.render(cornell_gpu, film, pt.default_params(**kw))
+    assert film.read_f32().tobytes() == want.tobytes()
+    film.close()
+
+
+def test_fused_pipeline_full_size_c2_frame_equals_the_oracle_known_answer(pt, gpu_ctx, cornell_gpu):
+    """BASELINE config C2's frame 0 at 1920x1080 through the fused kernel: the oracle's exact ray count and SHA-256, for one
+    and for several sample groups; then frames 0..3 in one call against the C3 known answer after frame 3."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(HERE, "golden", "fullsize_hashes.json")))
+    g2 = gold["c2"]
+    w, h = g2["width"], g2["height"]
+    kw = dict(width=w, height=h, spp_per_frame=g2["spp_per_frame"], max_depth=g2["max_depth"], pipeline=pt.PIPELINE_FUSED)
+    film = pt.Film(gpu_ctx, w, h)
+    for shape in (dict(), dict(sample_groups=1), dict(sample_groups=4)):
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=1, **kw, **shape))
+        assert gpu_ctx.stats().rays == g2["rays"], shape
+        assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == g2["film_sha256"], shape
+    g3 = gold.get("c3")
+    if g3 is not None:
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=4, **kw))
+        m = g3["after_frame"]["3"]
+        assert gpu_ctx.stats().rays == m["rays_so_far"]
+        assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
+        assert hashlib.sha256(film.read_bgra8().tobytes()).hexdigest() == m["bgra8_sha256"]
+    film.close()
