@@ -65,6 +65,7 @@ _MODEL = os.path.join(REPO, "profiles", "isa_valu_model.json")
 ISA_VALU_MODEL = json.load(open(_MODEL)) if os.path.exists(_MODEL) else None
 # which PMC record (scripts/make_pmc_json.py) carries the HBM-side traffic of a config's traversal kernel
 PMC_RECORD = "r03_pmc_extend_{config}.json"
+PMC_RECORD_SHADE = "r04_pmc_shade_{config}.json"
 
 
 def cpu_model():
@@ -235,6 +236,9 @@ def roofline_block(pt, st, cst, info, config, note):
         try:
             pmc = json.load(open(prof))
             r["traffic"] = round(pmc["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
+            # the counter side of `frac`: counted HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE: MALL hits included) instead of
+            # algorithmic ones over the same launch time -- what "rocprof HBM GB/s against the chip's peak" reads
+            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             r["pmc_profile"] = {k: (round(pmc[k], 3) if isinstance(pmc[k], float) else pmc[k]) for k in
                                 ("hbm_bytes_per_ray", "hbm_read_requests_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays",
                                  "valu_active_lanes_per_instr", "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "rocprof_avg_launch_us") if k in pmc}
@@ -250,6 +254,40 @@ def roofline_block(pt, st, cst, info, config, note):
         r["valu_model"] = {"peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR, "isa_revision": vm["revision"], "blocks": vm["blocks"],
                            "source": "live wave-level block counts (PT_FLAG_COUNT_VISITS) x VALU instructions per block of the shipped ISA "
                                      "(profiles/isa_valu_model.json, scripts/isa_blocks.py)"}
+    return r
+
+
+def roofline_shade_block(st, config):
+    """`roofline_shade`: the other kernel of a wavefront round -- closest-hit shading, bounce, regeneration, compaction
+    (closesthit.rchit:50-65, raygen.rgen:76-83) -- priced like the traversal kernel: SURVEY 8d's 104 algorithmic bytes per ray
+    (read queue index 4 + hit 12 + path state 32, write next ray 24 + state 28 + index 4) x the rays of a launch / its average
+    duration / 8 TB/s, every factor from this run's per-launch events; `traffic` = the counted HBM bytes per ray of the
+    committed PMC pass x this run's rays per launch, like the traversal kernel's."""
+    if not st.launches_shade or not st.ms_shade:
+        return None
+    rays_per_launch = st.rays / st.launches_shade
+    avg_us = st.ms_shade * 1e3 / st.launches_shade
+    gbs = BYTES_SHADE * rays_per_launch / (avg_us * 1e-6) / 1e9
+    r = {"bound": "hbm", "kernel": "k_shade", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+         "traffic": None, "launches": st.launches_shade, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_us": round(avg_us, 3),
+         "algorithmic_bytes_per_ray": BYTES_SHADE, "algorithmic_bytes_per_launch": round(BYTES_SHADE * rays_per_launch, 1),
+         # the same bytes over the device time of the whole timed region (the launches of the pipelines overlap)
+         "frac_all_launches_over_device_time": round(BYTES_SHADE * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+         "pipelines": st.pipelines, "shade_ms": round(st.ms_shade, 3),
+         "note": "memory-latency bound: dense coalesced queue streams in and out + the scattered radiance term log; see pmc_profile"}
+    prof = os.path.join(REPO, "profiles", PMC_RECORD_SHADE.format(config=config))
+    if os.path.exists(prof):
+        try:
+            pmc = json.load(open(prof))
+            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * rays_per_launch, 1)
+            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * rays_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            r["pmc_profile"] = {k: (round(pmc[k], 4) if isinstance(pmc[k], float) else pmc[k]) for k in
+                                ("hbm_bytes_per_ray", "hbm_write_bytes_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays",
+                                 "valu_active_lanes_per_instr", "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "utcl1_miss_rate",
+                                 "l1_to_l2_read_latency_cycles", "l1_to_l2_write_latency_cycles", "rocprof_avg_launch_us") if k in pmc}
+            r["pmc_profile"]["source"] = os.path.relpath(prof, REPO)
+        except Exception:
+            pass
     return r
 
 
@@ -651,6 +689,7 @@ def main():
             # algorithmic bytes over the device time of the timed region do not depend on how the work is cut into launches
             out["roofline"]["pipelines"] = st.pipelines
             out["roofline"]["frac_all_launches_over_device_time"] = round(bytes_extend * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            out["roofline_shade"] = roofline_shade_block(st, scene_config)
         if world == 1 and not args.no_extra_legs and args.config in ("c2", "c3"):
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()

@@ -14,9 +14,9 @@
 //     (`refill`), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
 //     raygen.rgen:76-83, the next sample's camera ray (raygen.rgen:45-60), or the first sample of a NEW slot -- and set up
 //     their next ray; the same operations in the same order as k_shade, so the film is the wavefront pipeline's bit for bit;
-//   * slots (frame, sample group, pixel) are handed out in order by one device-scope counter: one atomic per shade block
-//     of a wave (~13 per microsecond at 28 Grays/s, the chip sustains ~88 on one word), so a wave that drew cheap border
-//     pixels simply takes more of them -- no batch tail beyond the last slot's own length;
+//   * slots (frame, sample group, pixel) are handed out in order by one device-scope counter, PT_FUSED_BATCH at a time per
+//     wave (one atomic per ~27 000 rays: the counter sees ~1 atomic per microsecond, the chip sustains ~88 on one word),
+//     so a wave that drew cheap border pixels simply takes more of them -- no tail beyond the last batch's own length;
 //   * path state that only the shade block touches (slot, sample | depth, seed, weight, pixel, the slot's colour or its
 //     term count) lives in LDS, [field][thread]: the traversal loop keeps the registers it has in k_extend_lds7p.
 //
@@ -26,6 +26,10 @@
 
 #ifndef PT_FUSED_WAVES
 #define PT_FUSED_WAVES 5   // waves per SIMD asked of the compiler (LDS: ~30 KB per block -> 5 blocks per CU)
+#endif
+
+#ifndef PT_FUSED_BATCH
+#define PT_FUSED_BATCH 256  // slots a wave draws per atomic (a multiple of 64 and a power of two: 64 consecutive slots are one 8x8 tile)
 #endif
 
 // path state in LDS, [field][thread]
@@ -80,6 +84,8 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
+    uint32_t w_next = 0, w_end = 0;  // wave-uniform: what is left of the wave's current batch of slots
+    lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * TB + (threadIdx.x >> 6) * (PT_FUSED_BATCH / 64);
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
     uint32_t ax = 0, ay = 0, az = 0, tri_base = 0;
@@ -100,153 +106,169 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
     for (;;) {
         // ---- shade block: the lanes that wait with a hit (or with nothing, while slots are left) -- once enough of them do
         const unsigned long long m_have = __ballot(have);
-        const unsigned long long m_work = __ballot(!have && (path || !out_of_slots));
-        const int n_work = __popcll(m_work);
+        const bool in_blk = !have && (path || !out_of_slots);
+        const int n_work = __popcll(__ballot(in_blk));
         if (n_work && (m_have == 0ull || n_work * 64 >= refill * (n_work + __popcll(m_have)))) {
-            if (!have && (path || !out_of_slots)) {
-                uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
-                float wr = 0.f, wg = 0.f, wb = 0.f;
-                ptm::f3 org{}, dir{};
-                bool got_ray = false, need_primary = false;
-                if (path) {
-                    slot = my_state[FS_SLOT * TB]; ctr = my_state[FS_CTR * TB]; seed = my_state[FS_SEED * TB];
-                    wr = __uint_as_float(my_state[FS_WR * TB]); wg = __uint_as_float(my_state[FS_WG * TB]); wb = __uint_as_float(my_state[FS_WB * TB]);
-                    pxy = my_state[FS_PXY * TB];
-                    uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
-                    // radiance of this hit, if any: raygen.rgen:76 `color += weight * emission` (adding +0 changes no bit of a
-                    // non-negative accumulator, so non-emitters are skipped -- as k_shade does; NaN compares false and adds)
-                    float er, eg, eb;
-                    bool terminated, add;
-                    const uint32_t pos = best_pos;
-                    float4 s0{}, s1{};
-                    if (pos == PT_MISS) {  // miss.rmiss:10-11 then raygen.rgen:76, 81-83
-                        er = wr * rc.env[0]; eg = wg * rc.env[1]; eb = wb * rc.env[2];
-                        add = true;
-                        terminated = true;
-                    } else {
-                        s0 = s_shade[3 * pos + 0]; s1 = s_shade[3 * pos + 1];
-                        const float4 s2 = s_shade[3 * pos + 2];
-                        er = wr * s1.z; eg = wg * s1.w; eb = wb * s2.x;
-                        add = !(er == 0.f && eg == 0.f && eb == 0.f);
-                        depth++;
-                        terminated = depth >= rc.max_depth;  // raygen.rgen:62
-                    }
-                    if (add) {
-                        if (!GROUPED) {
-                            my_state[FS_A * TB] = __float_as_uint(__uint_as_float(my_state[FS_A * TB]) + er);
-                            my_state[FS_B * TB] = __float_as_uint(__uint_as_float(my_state[FS_B * TB]) + eg);
-                            my_state[FS_C * TB] = __float_as_uint(__uint_as_float(my_state[FS_C * TB]) + eb);
-                        } else {  // the ordered term log of add_radiance (wavefront.hip), the count kept in LDS
-                            const uint32_t k = my_state[FS_A * TB];
-                            if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
-                            else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
-                            else {
-                                const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
-                                if (idx < rad.spill_cap) {
-                                    rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(rad.spill_head[slot]));
-                                    rad.spill_head[slot] = (uint32_t)idx;
-                                } else {
-                                    *rad.overflow = 1ull;
-                                }
-                            }
-                            my_state[FS_A * TB] = k + 1u;
-                        }
-                    }
-                    if (!terminated) {
-                        // closesthit.rchit:56-57 position from the barycentrics; raygen.rgen:77-80 the bounce
-                        const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
-                        float hu, hv;
-                        ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
-                        const float b0 = (1.0f - hu) - hv;
-                        org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
-                        const ptm::f3 nrm = { s0.x, s0.y, s0.z };
-                        const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
-                        const float r2 = ptm::rnd(seed);
-                        const float4 f0 = s_frame[2 * pos + 0], f1 = s_frame[2 * pos + 1];
-                        dir = ptm::sample_direction_frame(r1, r2, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
-                        const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
-                        float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
-                        ptm::div3_by_pdf(fr, fg, fb);
-                        wr = wr * fr; wg = wg * fg; wb = wb * fb;
-                        got_ray = true;
-                    } else {
-                        sample++;
-                        depth = 0;
-                        const uint32_t lane_slot = rc.div_spl.div(slot);  // = frame lane * groups + sample group (slot_pixel)
-                        const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
-                        if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {
-                            need_primary = true;  // the slot's next sample: raygen.rgen:45-60
-                        } else {  // the slot is complete
-                            if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * TB]), __uint_as_float(my_state[FS_B * TB]),
-                                                                       __uint_as_float(my_state[FS_C * TB]), 0.f);
-                            else rad.nterm[slot] = my_state[FS_A * TB];
-                            path = false;
-                        }
-                    }
-                    ctr = sample | (depth << 16);
+            uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
+            float wr = 0.f, wg = 0.f, wb = 0.f;
+            ptm::f3 org{}, dir{};
+            bool got_ray = false, need_primary = false;
+            // (1) the hit of the ray that just ended: radiance, then bounce / next sample / slot complete
+            if (in_blk && path) {
+                slot = my_state[FS_SLOT * TB]; ctr = my_state[FS_CTR * TB]; seed = my_state[FS_SEED * TB];
+                wr = __uint_as_float(my_state[FS_WR * TB]); wg = __uint_as_float(my_state[FS_WG * TB]); wb = __uint_as_float(my_state[FS_WB * TB]);
+                pxy = my_state[FS_PXY * TB];
+                uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
+                // raygen.rgen:76 `color += weight * emission` (adding +0 changes no bit of a non-negative accumulator, so
+                // non-emitters are skipped -- as k_shade does; NaN compares false and still adds)
+                float er, eg, eb;
+                bool terminated, add;
+                const uint32_t pos = best_pos;
+                float4 s0{}, s1{};
+                if (pos == PT_MISS) {  // miss.rmiss:10-11 then raygen.rgen:76, 81-83
+                    er = wr * rc.env[0]; eg = wg * rc.env[1]; eb = wb * rc.env[2];
+                    add = true;
+                    terminated = true;
+                } else {
+                    s0 = s_shade[3 * pos + 0]; s1 = s_shade[3 * pos + 1];
+                    const float4 s2 = s_shade[3 * pos + 2];
+                    er = wr * s1.z; eg = wg * s1.w; eb = wb * s2.x;
+                    add = !(er == 0.f && eg == 0.f && eb == 0.f);
+                    depth++;
+                    terminated = depth >= rc.max_depth;  // raygen.rgen:62
                 }
-                // ---- new slots for the lanes without a path: one atomic per wave
-                if (!out_of_slots) {
-                    const bool want = !path;
-                    const unsigned long long m_want = __ballot(want);
-                    if (m_want) {
-                        const uint32_t n_want = (uint32_t)__popcll(m_want);
-                        uint32_t base = 0;
-                        if (lane == __ffsll((long long)m_want) - 1) base = atomicAdd(next_slot, n_want);
-                        base = __shfl(base, __ffsll((long long)m_want) - 1, 64);
-                        const uint32_t mine = base + (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
-                        if (want && mine < n_slots) {
-                            slot = slot_base + mine;
-                            uint32_t f, g, px, py;
-                            slot_pixel(rc, tiles, slot, f, g, px, py);
-                            const uint32_t sample0 = g * rc.group_size;
-                            if (GROUPED) { rad.nterm[slot] = 0u; rad.spill_head[slot] = SPILL_NONE; }
-                            else rad.color[slot] = make_float4(0.f, 0.f, 0.f, 0.f);  // (slots that trace nothing still resolve to black)
-                            if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
-                                pxy = px | (py << 16);
-                                ctr = sample0;
-                                my_state[FS_A * TB] = 0u;  // colour.r = +0.0f | term count = 0
-                                if (!GROUPED) { my_state[FS_B * TB] = 0u; my_state[FS_C * TB] = 0u; }
-                                path = true;
-                                need_primary = true;
+                if (add) {
+                    if (!GROUPED) {
+                        my_state[FS_A * TB] = __float_as_uint(__uint_as_float(my_state[FS_A * TB]) + er);
+                        my_state[FS_B * TB] = __float_as_uint(__uint_as_float(my_state[FS_B * TB]) + eg);
+                        my_state[FS_C * TB] = __float_as_uint(__uint_as_float(my_state[FS_C * TB]) + eb);
+                    } else {  // the ordered term log of add_radiance (wavefront.hip), the count kept in LDS
+                        const uint32_t k = my_state[FS_A * TB];
+                        if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
+                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
+                        else {
+                            const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
+                            if (idx < rad.spill_cap) {
+                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(rad.spill_head[slot]));
+                                rad.spill_head[slot] = (uint32_t)idx;
+                            } else {
+                                *rad.overflow = 1ull;
                             }
                         }
-                        if (base + n_want >= n_slots) out_of_slots = true;
+                        my_state[FS_A * TB] = k + 1u;
                     }
                 }
-                if (need_primary) {
-                    const uint32_t f = rc.div_groups.div(rc.div_spl.div(slot));
-                    const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
-                    seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
-                    ptm::primary_ray(rc.cam, px, py, seed, org, dir);
-                    wr = wg = wb = 1.0f;  // raygen.rgen:59
+                if (!terminated) {
+                    // closesthit.rchit:56-57 position from the barycentrics; raygen.rgen:77-80 the bounce
+                    const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
+                    float hu, hv;
+                    ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
+                    const float b0 = (1.0f - hu) - hv;
+                    org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
+                    const ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                    const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
+                    const float r2 = ptm::rnd(seed);
+                    const float4 f0 = s_frame[2 * pos + 0], f1 = s_frame[2 * pos + 1];
+                    dir = ptm::sample_direction_frame(r1, r2, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
+                    const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
+                    float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
+                    ptm::div3_by_pdf(fr, fg, fb);
+                    wr = wr * fr; wg = wg * fg; wb = wb * fb;
                     got_ray = true;
+                } else {
+                    sample++;
+                    depth = 0;
+                    const uint32_t lane_slot = rc.div_spl.div(slot);  // = frame lane * groups + sample group (slot_pixel)
+                    const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
+                    if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {
+                        need_primary = true;  // the slot's next sample: raygen.rgen:45-60
+                    } else {  // the slot is complete
+                        if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * TB]), __uint_as_float(my_state[FS_B * TB]),
+                                                                   __uint_as_float(my_state[FS_C * TB]), 0.f);
+                        else rad.nterm[slot] = my_state[FS_A * TB];
+                        path = false;
+                    }
                 }
-                if (got_ray) {
-                    my_state[FS_SLOT * TB] = slot; my_state[FS_CTR * TB] = ctr; my_state[FS_SEED * TB] = seed;
-                    my_state[FS_WR * TB] = __float_as_uint(wr); my_state[FS_WG * TB] = __float_as_uint(wg); my_state[FS_WB * TB] = __float_as_uint(wb);
-                    my_state[FS_PXY * TB] = pxy;
-                    // the refill block of extend_body<true, false, false, true>
-                    pre = ptm::ray_setup<true>(org, dir);
-                    inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
-                    slab_setup(org, inv, invf, on, of);
-                    ax = inv.x < 0.f ? 48u : 0u;
-                    ay = inv.y < 0.f ? 48u : 0u;
-                    az = inv.z < 0.f ? 48u : 0u;
-                    tri_base = (uint32_t)pre.kz * 3u * n_tris;
-                    orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y), ptm::sel3(pre.kz, org.x, org.y, org.z) };
-                    best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
-                    best_pos = PT_MISS;
-                    cur = 0u;
-                    sp = 0;
-                    have = true;
-                }
-                n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));
+                ctr = sample | (depth << 16);
             }
+            // (2) new slots for the lanes without a path (wave-uniform part).  A wave draws PT_FUSED_BATCH consecutive slots per
+            // atomic and the tile words that give them their pixels with it: the two dependent round trips to memory (~3 us) are
+            // paid once per batch -- per lane and shade block, as the first version did, they were 3/4 of the kernel's time.
+            const unsigned long long m_want = __ballot(in_blk && !path);
+            if (m_want && !out_of_slots) {
+                if (w_next >= w_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(next_slot, (uint32_t)PT_FUSED_BATCH);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    w_next = base;
+                    w_end = min(base + (uint32_t)PT_FUSED_BATCH, n_slots);
+                    if (base >= n_slots) { out_of_slots = true; w_end = w_next; }
+                    else if (lane < PT_FUSED_BATCH / 64) {
+                        const uint32_t c = slot_base + base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
+                        uint32_t word = 0u;
+                        if (base + 64u * (uint32_t)lane < n_slots) word = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
+                        s_wtile[lane] = word;
+                    }
+                    __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order: the reads below see these words)
+                }
+                const uint32_t take = min((uint32_t)__popcll(m_want), w_end - w_next);
+                const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
+                if (in_blk && !path && rank < take) {
+                    const uint32_t mine = w_next + rank;
+                    slot = slot_base + mine;
+                    const uint32_t lane_slot = rc.div_spl.div(slot);
+                    const uint32_t f = rc.div_groups.div(lane_slot), g = lane_slot - f * rc.groups;
+                    const uint32_t local = slot - lane_slot * rc.slots_per_lane;
+                    const uint32_t tw = s_wtile[(mine >> 6) & (PT_FUSED_BATCH / 64 - 1)];
+                    const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
+                    const uint32_t sample0 = g * rc.group_size;
+                    if (GROUPED) rad.spill_head[slot] = SPILL_NONE;
+                    if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
+                        pxy = px | (py << 16);
+                        ctr = sample0;
+                        my_state[FS_A * TB] = 0u;  // colour.r = +0.0f | term count = 0
+                        if (!GROUPED) { my_state[FS_B * TB] = 0u; my_state[FS_C * TB] = 0u; }
+                        path = true;
+                        need_primary = true;
+                    } else if (GROUPED) {
+                        rad.nterm[slot] = 0u;  // (a slot outside the image or the batch: k_resolve never reads it, kept defined anyway)
+                    }
+                }
+                w_next += take;
+            }
+            // (3) camera ray of a slot's next (or first) sample
+            if (need_primary) {
+                const uint32_t f = rc.div_groups.div(rc.div_spl.div(slot));
+                const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
+                seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
+                ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                wr = wg = wb = 1.0f;  // raygen.rgen:59
+                got_ray = true;
+            }
+            // (4) state back to LDS, ray set-up (the refill block of extend_body<true, false, false, true>)
+            if (got_ray) {
+                my_state[FS_SLOT * TB] = slot; my_state[FS_CTR * TB] = ctr; my_state[FS_SEED * TB] = seed;
+                my_state[FS_WR * TB] = __float_as_uint(wr); my_state[FS_WG * TB] = __float_as_uint(wg); my_state[FS_WB * TB] = __float_as_uint(wb);
+                my_state[FS_PXY * TB] = pxy;
+                pre = ptm::ray_setup<true>(org, dir);
+                inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
+                slab_setup(org, inv, invf, on, of);
+                ax = inv.x < 0.f ? 48u : 0u;
+                ay = inv.y < 0.f ? 48u : 0u;
+                az = inv.z < 0.f ? 48u : 0u;
+                tri_base = (uint32_t)pre.kz * 3u * n_tris;
+                orgp = { ptm::sel3(pre.kz, org.y, org.z, org.x), ptm::sel3(pre.kz, org.z, org.x, org.y), ptm::sel3(pre.kz, org.x, org.y, org.z) };
+                best_t = tmax; best_V = 0.f; best_W = 0.f; best_det = 1.f;
+                best_pos = PT_MISS;
+                cur = 0u;
+                sp = 0;
+                have = true;
+            }
+            n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));  // (wave-uniform control flow here: every lane keeps the same count)
         }
         if (__ballot(have) == 0ull) {
             if (__ballot(path) == 0ull && out_of_slots) break;
-            continue;  // (lanes with a pending hit and nobody tracing: the shade block runs in the next iteration)
+            continue;  // (lanes with a pending hit, or slots left, and nobody tracing: the shade block runs in the next iteration)
         }
 
         // ---- node phase (extend_body, LDS_SCENE && COMPACT): every lane descends until it holds a leaf

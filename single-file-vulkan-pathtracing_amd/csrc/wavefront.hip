@@ -1698,7 +1698,7 @@ pt_status plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &f
         return PT_ERR_UNSUPPORTED;
     }
     fp.lds_stack = pl.lds_stack;
-    fp.smem = pl.smem + tables + sizeof(uint32_t) * FS_FIELDS * TB;
+    fp.smem = pl.smem + tables + sizeof(uint32_t) * FS_FIELDS * TB + sizeof(uint32_t) * (TB / 64) * (PT_FUSED_BATCH / 64);
     for (const void *fn : { reinterpret_cast<const void *>(k_fused<false>), reinterpret_cast<const void *>(k_fused<true>) })
         if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
     int per_cu = 0;
