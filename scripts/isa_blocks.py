@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VALU instructions per basic block of one kernel of the shipped HIP library, for the live VALU model of bench.py.
 
-    python scripts/isa_blocks.py [--kernel k_extend_lds7] [--src wavefront.hip] [--extra flags]
+    python scripts/isa_blocks.py [--kernel k_extend_lds7] [--src extend_launch.hip] [--extra flags]
 
 Compiles the translation unit to gfx950 assembly with the flags of csrc/Makefile (`hipcc -S --cuda-device-only`), cuts
 the kernel at its labels and prints, per block: loop depth (LLVM's loop comments), VALU / SALU / LDS / VMEM instruction
@@ -86,7 +86,7 @@ def blocks(klines):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel", default="k_extend_lds7")
-    ap.add_argument("--src", default="wavefront.hip")
+    ap.add_argument("--src", default="extend_launch.hip")
     ap.add_argument("--extra", default="", help="extra compiler flags of that translation unit (extend_hbm.hip: -mllvm -amdgpu-sched-strategy=max-ilp)")
     args = ap.parse_args()
     bl = blocks(kernel_lines(assembly(args.src, args.extra.split()), args.kernel))

@@ -335,7 +335,7 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
 }
 
 // Most entries a depth-first walk of a BVH4 (rows of 32 dwords, child words at 24..27) can have pending: what the LDS-only
-// traversal kernels size their stacks by (plan_extend in wavefront.hip).
+// traversal kernels size their stacks by (ptw_plan_extend, extend_launch.hip).
 uint32_t pt_wide_stack_need(const std::vector<uint32_t> &w)
 {
     // a node with k children pushes at most k-1 of them before descending:

@@ -10,6 +10,7 @@
 // and the same flag on the LDS-resident Cornell kernel: -4 % (VALU-bound, the longer live ranges cost 4 spills
 // at 72 VGPRs) -- hence two translation units rather than one flag.  Other strategies tried: max-memory-clause
 // +6 % C5 / -7 % C2, iterative-ilp -1.5 % / -13 %, iterative-maxocc 0 / -6 %.
+#define PT_EXTEND_TEMPLATES_ONLY  // (k_extend_lds7 & co. live in extend_launch.hip)
 #include "extend_kernel.h"
 #include "extend8_kernel.h"
 

@@ -1,6 +1,6 @@
 // extend_inst16.h -- two-level closest hit (BASELINE config C4), round-2 kernel.
 //
-// Same contract and same hit records as k_extend_inst (wavefront.hip), which stays as the general fallback; this one is
+// Same contract and same hit records as k_extend_inst (extend_inst.h), which stays as the general fallback; this one is
 // for scenes whose TLAS and BLAS fit 15-bit child codes (< 32768 instances, BLAS <= 2047 triangles staged in LDS) and
 // tmin > 0.  What differs:
 //   * BOTH levels are 64-B nodes with fp16 planes (TLAS: normalised to the box of all instances, built top-down with

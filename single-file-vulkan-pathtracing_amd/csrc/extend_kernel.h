@@ -1,7 +1,7 @@
 // extend_kernel.h -- the single-level closest-hit kernel (k_extend) and what it is made of.
 //
 // A header because its instantiations are compiled in two translation units with different instruction
-// schedulers: wavefront.hip (scene staged in LDS: the default scheduler) and extend_hbm.hip (scene walked out of
+// schedulers: extend_launch.hip (scene staged in LDS: the default scheduler) and extend_hbm.hip (scene walked out of
 // L2/MALL/HBM: -mllvm -amdgpu-sched-strategy=max-ilp, +10 % on the 1M-triangle soup, -4 % on the Cornell box).
 // Everything sits in an anonymous namespace: each translation unit has its own copy.
 #pragma once
@@ -10,10 +10,15 @@
 
 #include <hip/hip_ext.h>
 
+#ifndef PT_TB_DEFINED
+#define PT_TB_DEFINED
 namespace {
+constexpr int TB = 256;                     // threads per block of every kernel of the library
+constexpr uint32_t SENTINEL = 0xFFFFFFFFu;  // "no child" / "no node" in the BVH4 child words
+}  // namespace
+#endif
 
-constexpr int TB = 256;
-constexpr uint32_t SENTINEL = 0xFFFFFFFFu;
+namespace {
 
 // ---- extend: closest hit for every queued ray (traceRayEXT, raygen.rgen:63-75) ---------------
 // Persistent grid (gridDim = CUs x resident blocks); each block walks 256-ray chunks of the
@@ -589,6 +594,7 @@ __global__ __launch_bounds__(TB) void k_extend(PT_EXTEND_PARAMS)
 {
     extend_body<LDS_SCENE, COUNT, SPILL, PAIRS, REC64>(PT_EXTEND_ARGS);
 }
+#ifndef PT_EXTEND_TEMPLATES_ONLY  // (fused.hip and extend_hbm.hip take the helpers and the templates, not these four kernels)
 // The instantiation the Cornell box runs (scene in LDS, no spill path, one-dword stack entries) as its own kernel:
 // asking for PT_EXTEND_WAVES waves per SIMD makes the compiler fit 72 VGPRs instead of 76; the other instantiations
 // keep the plain launch bounds they were tuned with.
@@ -615,6 +621,7 @@ __global__ __launch_bounds__(TB, PT_EXTEND_WAVES) void k_extend_lds7p_sh(PT_EXTE
     extend_body<true, false, false, true>(PT_EXTEND_ARGS);
 }
 #undef PT_EXTEND_ARGS_PLAIN
+#endif  // PT_EXTEND_TEMPLATES_ONLY
 #undef PT_EXTEND_PARAMS
 #undef PT_EXTEND_ARGS
 

@@ -2,7 +2,7 @@
 //
 // The reference's raygen shader is itself a megakernel: one invocation owns its path state from the first sample of its
 // pixel to the last (raygen.rgen:41-91), and traceRayEXT / the closest-hit and miss shaders run inside it.  The wavefront
-// pipeline (wavefront.hip) splits that into k_extend / k_shade over queues in HBM -- 150 B of queue traffic per ray and a
+// pipeline (render.hip, shade_kernels.hip) splits that into k_extend / k_shade over queues in HBM -- 150 B of queue traffic per ray and a
 // workspace of tens of GB -- because big scenes need the sorting, the compaction and the long launches.  A scene of a few
 // dozen triangles needs none of it: nodes, triangles and the shading tables fit LDS, so here a lane keeps its path from
 // bounce to bounce and HBM sees the radiance of a slot only (16 B per slot, or 16 B per logged term with sample groups).
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
                         my_state[FS_A * TB] = __float_as_uint(__uint_as_float(my_state[FS_A * TB]) + er);
                         my_state[FS_B * TB] = __float_as_uint(__uint_as_float(my_state[FS_B * TB]) + eg);
                         my_state[FS_C * TB] = __float_as_uint(__uint_as_float(my_state[FS_C * TB]) + eb);
-                    } else {  // the ordered term log of add_radiance (wavefront.hip), the count kept in LDS
+                    } else {  // the ordered term log of add_radiance (wavefront_types.h), the count kept in LDS
                         const uint32_t k = my_state[FS_A * TB];
                         if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
                         else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));

@@ -1381,7 +1381,7 @@ static pt_status build_tree_products_unguarded(pt_scene *s, uint32_t quality, bo
     return make_wide16(s);
 }
 
-// PT_EXTEND_HBM8 / pt_tuning.hbm8 on a scene that was built without the 8-wide nodes: build them now (wavefront.hip asks)
+// PT_EXTEND_HBM8 / pt_tuning.hbm8 on a scene that was built without the 8-wide nodes: build them now (extend_launch.hip asks)
 pt_status ptb_ensure_wide8(pt_scene *s)
 {
     if (s->d_wide8 || s->n_tris < 2 || s->n_inst) return PT_OK;
@@ -1433,7 +1433,7 @@ pt_status ptb_build_scene(pt_scene *s, const float *h_vertices, uint32_t n_verts
     // the tree of the default quality (ePreferFastTrace, main.cpp:419): PLOC for big scenes; small scenes get the LBVH
     // here and the exact surface-area BVH4 below.  The 8-wide nodes only when the context asks AUTO to use them.
     // (small scenes get the 8-wide nodes at once -- a few KB; big ones on first request: 260 B per triangle nobody else needs)
-    // ... and scenes AUTO walks through them: more than 1 MiB of BVH4 nodes + records, ~96 B per triangle (wavefront.hip plan_extend)
+    // ... and scenes AUTO walks through them: more than 1 MiB of BVH4 nodes + records, ~96 B per triangle (extend_launch.hip ptw_plan_extend)
     pt_status rc = build_tree_products(s, PT_BVH_PREFER_FAST_TRACE, ctx->tune.hbm8 == 1 || n <= PT_SAH_MAX_TRIS || (ctx->tune.hbm8 != 0 && 96ull * n > (1ull << 20)));
     if (rc != PT_OK) return rc;
     {   // emitters for the NEE pipeline: normal as closesthit.rchit:43-48, area = |cross| / 2, cdf = running float sum of the
@@ -1627,7 +1627,7 @@ static void invert_3x4(const float m[12], float inv[12])
 
 // World-space normal and tangent of every (instance, triangle): what k_shade's instanced branch used to evaluate per hit -- the
 // normal by the inverse transpose, renormalised (a square root and three true divides), and createCoordinateSystem on it (another
-// square root and two divides) -- evaluated ONCE with exactly those operations (wavefront.hip k_shade; pt_math.h tangent_frame),
+// square root and two divides) -- evaluated ONCE with exactly those operations (shade_kernels.hip k_shade; pt_math.h tangent_frame),
 // so the bits are the same.  32 B per entry: {n.xyz, T.x} {T.yz, -, -}; the bitangent is the cross product k_shade forms anyway.
 // Instance order = d_inst6's (TLAS leaf order), triangle order = d_shade4's (BVH4 leaf order): rebuilt when either changes.
 __global__ __launch_bounds__(TB) void k_inst_frames(const float4 *__restrict__ inst6, const float4 *__restrict__ shade4, uint32_t n_inst,

@@ -34,7 +34,7 @@ struct pt_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipStream_t pipe_stream[PT_MAX_PIPES] = {};  // extra pipelines of pt_render ([0] unused: that is `stream`)
     hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_PIPES] = {};
-    // live-count polls of the round loop (wavefront.hip): per pipeline two pinned words and two events, used alternately,
+    // live-count polls of the round loop (render.hip): per pipeline two pinned words and two events, used alternately,
     // so the host reads the count of eight rounds ago while the stream still holds eight rounds of work
     uint32_t *h_poll = nullptr;                      // [PT_MAX_PIPES][2], hipHostMalloc
     hipEvent_t ev_poll[PT_MAX_PIPES][2] = {};
@@ -191,7 +191,7 @@ uint32_t pt_wide_stack_need(const std::vector<uint32_t> &rows32);
 pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *thi, uint32_t n, const uint8_t *pair_with_next, float pad,
                                    uint32_t leaf_max_prims, std::vector<uint32_t> &rows32, std::vector<uint32_t> &order);
 void ptb_free_instances(pt_scene *s);
-// wavefront.hip
+// render.hip / film_work.hip
 pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p);
 pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p);
 pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits);

@@ -1,0 +1,681 @@
+// render.hip -- pt_render / pt_render_prepare / pt_trace: what runs behind vkCmdTraceRaysKHR (main.cpp:659) on the host side.
+//
+// A call renders its frames in batches of `frames in flight`; a batch is
+//     set-up      its slot lanes (frame x sample group) are split over 1-3 PIPELINES, each with its own stream, queue pair and
+//                 counters; k_generate fills queue 0 of each
+//     rounds      per pipeline and round: [ray sort] -> closest hit -> k_shade [-> shadow rays -> k_shadow_add]; no stream is
+//                 drained inside a batch: queue sizes live on the device, the live counts are polled one poll behind
+//     finish      the pipelines join, a batch whose term log overflowed is redone with one sample group, k_resolve blends the
+//                 batch's frames into the film in frame order (raygen.rgen:86-90)
+// The scheduling rules (stagger of two pipelines, the shade rule of three, the lagged poll) are measured choices; each is
+// documented where it is applied.  PT_PIPELINE_FUSED replaces rounds by one persistent kernel per batch (fused.hip).
+#include "wavefront_host.h"
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+using namespace ptw;
+
+pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    pt_ctx *ctx = s->ctx;
+    if (p->width != f->w || p->height != f->h) { ctx->err = "params width/height differ from the film's"; return PT_ERR_INVALID_ARG; }
+    if (p->world == 0 || p->rank >= p->world) { ctx->err = "rank/world invalid"; return PT_ERR_INVALID_ARG; }
+    if (p->spp_per_frame == 0 || p->spp_per_frame > 0xFFFFu || p->max_depth == 0 || p->max_depth > 0xFFFFu) {
+        ctx->err = "spp_per_frame and max_depth must be in 1..65535";
+        return PT_ERR_INVALID_ARG;
+    }
+    if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
+    if (p->pipeline > PT_PIPELINE_FUSED) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+    if (p->pipeline == PT_PIPELINE_FUSED && (p->flags & (PT_FLAG_ASYNC | PT_FLAG_COUNT_VISITS))) {
+        ctx->err = "the fused pipeline has no asynchronous and no instrumented form";
+        return PT_ERR_UNSUPPORTED;
+    }
+    if (p->pipeline == PT_PIPELINE_WAVEFRONT_NEE) {
+        if (p->extend == PT_EXTEND_FLAT) { ctx->err = "the NEE pipeline has no flat extend variant (shadow rays need a per-ray tmax)"; return PT_ERR_UNSUPPORTED; }
+        if (p->sample_groups > 1) { ctx->err = "the NEE pipeline runs one sample group per pixel"; return PT_ERR_UNSUPPORTED; }
+    }
+    return PT_OK;
+}
+
+
+// 0 instanced scenes, 1 scenes walked out of L2 / MALL / HBM, 2 single-level scenes in LDS (film_work.hip ptw_choose_shape)
+int launch_class(const pt_scene *s, const ExtendPlan &pl) { return s->n_inst || pl.variant == PT_EXTEND_FLAT ? 0 : pl.lds_scene ? 2 : 1; }
+
+// The one-time objects of a context's renders: side streams, fork / join / poll / shade events, the pinned poll words.
+pt_status ensure_schedule_objects(pt_ctx *ctx, int n_pipes)
+{
+    for (int k = 1; k < n_pipes; k++)
+        if (!ctx->pipe_stream[k]) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[k], hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+        }
+    if (!ctx->ev_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->h_poll) PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_poll, sizeof(uint32_t) * 2 * PT_MAX_PIPES, hipHostMallocDefault));
+    for (int k = 0; k < n_pipes; k++) {
+        for (int j = 0; j < 2; j++)
+            if (!ctx->ev_poll[k][j]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_poll[k][j], hipEventDisableTiming));
+        if (!ctx->ev_shade[k]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_shade[k], hipEventDisableTiming));
+    }
+    return PT_OK;
+}
+
+pt_status grow_event_pool(pt_ctx *ctx, size_t want)
+{
+    while (ctx->ev_pool.size() < want) {
+        hipEvent_t e = nullptr;
+        PT_HIP(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    return PT_OK;
+}
+
+// One wavefront pipeline of a batch: a contiguous range of slot lanes with its own stream, queue pair and counters.
+struct Pipe {
+    hipStream_t st;
+    uint32_t slot_begin, n_slots;
+    QueueView qv[2];
+    float4 *hit;
+    uint32_t *hit_inst;
+    uint32_t *count;  // [2] queue sizes of this pipeline
+    int cur;
+    bool done;
+    int polls;        // live-count polls queued on this pipeline's stream in the current batch
+};
+
+// What one pt_render call (wavefront pipelines) decides once and every batch uses.
+struct Job {
+    pt_scene *s; pt_film *f; const pt_params *p; pt_ctx *ctx;
+    ExtendPlan pl;
+    RenderShape sh;
+    RenderConst rc;
+    Radiance rad;
+    bool nested = false, profile = false, count_visits = false, async = false, nee = false;
+    bool shade_lds = false, sort_rays = false, stagger = false;
+    int n_pipes = 1, sort_bits = 4, shade_grid = 0;
+    size_t shade_smem = 0;
+    uint32_t spill_cap = 0;
+    const float4 *inst_frame = nullptr, *nee_lights = nullptr;
+    uint32_t nee_n_lights = 0;
+    float nee_light_area = 0.f;
+    unsigned long long *d_overflow = nullptr, *d_spill_count = nullptr;
+    std::vector<hipEvent_t> ev_extend, ev_shade;  // (start, stop) pairs filled in by the launches (PT_FLAG_PROFILE)
+    size_t ev_used = 0;
+};
+
+Radiance job_radiance(const Job &j)
+{
+    const pt_film::Work &w = j.f->work;
+    return { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, j.d_spill_count, j.spill_cap, j.d_overflow };
+}
+
+// ---- once per call: kernel plan, shape + workspace, number of pipelines, ray-sort scratch, shadow queue -----------------
+pt_status job_setup(Job &j)
+{
+    pt_scene *s = j.s; pt_film *f = j.f; const pt_params *p = j.p; pt_ctx *ctx = j.ctx;
+    pt_film::Work &w = f->work;
+    const uint32_t lanes = j.sh.lanes, groups = j.sh.groups;
+    if (!j.nested) {
+        ctx->stats.frames_in_flight = lanes;
+        ctx->stats.sample_groups = groups;
+    }
+    j.d_overflow = ctx->d_stats + 6; j.d_spill_count = ctx->d_stats + 7;
+    j.spill_cap = j.sh.bounded ? SPILL_POOL_ENTRIES : 0u;  // worst-case logs never reach the pool
+    if (ctx->tune.term_spill >= 0) j.spill_cap = std::min<uint32_t>(j.spill_cap, (uint32_t)ctx->tune.term_spill);  // tests
+    j.rad = job_radiance(j);
+    j.rc = ptw_render_const(p, w, j.sh);
+    j.profile = !j.nested && (p->flags & PT_FLAG_PROFILE) != 0;  // (a redo would re-record the pooled events of its caller)
+    j.count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
+    j.async = (p->flags & PT_FLAG_ASYNC) != 0;
+    if (j.async && j.profile) { ctx->err = "PT_FLAG_ASYNC and PT_FLAG_PROFILE exclude each other"; return PT_ERR_INVALID_ARG; }
+
+    // k_shade: 2 paths per thread (one queue-tail atomic per 512 paths), 8 blocks per CU (flat between 4 and 16)
+    j.shade_grid = ctx->num_cus * 8;
+    j.shade_smem = sizeof(float4) * 8 * (size_t)s->n_tris;  // tri4 + shade4 + the tangent frames
+    j.shade_lds = j.shade_smem <= 16 * 1024 && !j.pl.bvh8;  // per-triangle tables of small scenes are staged in LDS (in the BVH4's order)
+    // instanced scenes: world-space normal + tangent per (instance, triangle), built once (lbvh_build.hip); pt_tuning.inst_frames = 0
+    // keeps the per-hit transform
+    if (s->n_inst && !j.pl.bvh8 && ctx->tune.inst_frames != 0) {
+        const pt_status rcf = ptb_ensure_inst_frames(s);
+        if (rcf != PT_OK) return rcf;
+        j.inst_frame = s->d_inst_frame;
+    }
+    // Pipelines: the slot lanes of a batch are split into parts that run their rounds independently on separate streams, so
+    // the VALU-bound traversal of one overlaps the memory-bound shading of another.  Two for most shapes (a third: C4 -1 ... -3 %,
+    // C5 -3 ... -6 %; a fourth loses everywhere).  THREE where both kernels keep their tables in LDS, the scene has one level and
+    // the batch holds >= 24 M slots: free-running, two pipelines can settle with traversal beside traversal and shade beside
+    // shade for a whole process (C2: 22.3-23.0 Grays/s in one pass of a box, 24.0-24.6 in the next); three, held in rotation by
+    // the shade rule (run_rounds), cannot: C2 at K = 16 25.8-27.1 against 23.2-24.6, K = 8 +6 %, K = 4 +2.3 %, K = 2 +1.7 %
+    // (profiles/r03v_c2_pipes.log, r03w_pipes_by_shape.log, r03aj_shade_rule_other_shapes.log).  Small batches keep one pipeline.
+    const bool three = j.shade_lds && !s->n_inst && (uint64_t)w.n_slots >= (24ull << 20);
+    int n_pipes = three ? 3 : ((uint64_t)w.n_slots >= (4ull << 20) ? 2 : 1);
+    n_pipes = pt_tuned(ctx->tune.pipes, n_pipes, 1, PT_MAX_PIPES);
+    j.n_pipes = std::max(1, std::min(n_pipes, std::min<int>(PT_MAX_PIPES, (int)(lanes * groups))));
+    ctx->stats.pipelines = (uint32_t)j.n_pipes;
+    const pt_status rce = ensure_schedule_objects(ctx, j.n_pipes);
+    if (rce != PT_OK) return rce;
+    // (two pipelines start half a round apart; three start together and keep the shade rule: run_rounds)
+    j.stagger = ctx->tune.stagger < 0 ? j.n_pipes == 2 : ctx->tune.stagger == 1;
+
+    // ray sorting (ray_sort.hip): the HBM kernels only; AUTO when the traversal working set does not fit the Infinity Cache
+    if ((j.pl.variant == PT_EXTEND_HBM || j.pl.variant == PT_EXTEND_HBM8) && !s->n_inst) {
+        const uint64_t working_set = j.pl.bvh8 ? 64ull * s->n_wide8 + 64ull * s->n_tris
+                                               : 64ull * (j.pl.topdown4 ? s->n_wide16t : s->n_wide) + 48ull * s->n_tris;
+        j.sort_rays = working_set > (256ull << 20);
+        if (p->flags & PT_FLAG_SORT_RAYS) j.sort_rays = true;
+        if (p->flags & PT_FLAG_NO_SORT_RAYS) j.sort_rays = false;
+    }
+    // 4 bits per axis + octant = 15-bit keys = two 8-bit passes (C5x: 6 bits, three passes: +0 %, 4 bits: +3.5 %)
+    j.sort_bits = pt_tuned(ctx->tune.sort_bits, 4, 1, 9);
+    if (j.sort_rays) {
+        // one scratch area per pipeline, sized for that pipeline's share of the slots (+ slack for the uneven split)
+        const size_t per_pipe = ptw_ray_sort_bytes((size_t)w.n_slots / (size_t)j.n_pipes + (size_t)j.rc.slots_per_lane + 1);
+        const size_t need = per_pipe * (size_t)j.n_pipes;
+        if (need > w.sort_bytes) {
+            (void)hipFree(w.d_sort);
+            w.d_sort = nullptr;
+            w.bytes -= w.sort_bytes;
+            w.sort_bytes = 0;
+            const hipError_t e = hipMalloc(&w.d_sort, need);
+            if (e != hipSuccess) { (void)hipGetLastError(); j.sort_rays = false; }  // no room: render unsorted
+            else { w.sort_bytes = need; w.bytes += need; }
+        }
+    }
+    j.nee = p->pipeline == PT_PIPELINE_WAVEFRONT_NEE;
+    // the emitters the NEE pipeline samples: the scene's, or -- instanced -- every instance's copy of them in world space
+    if (j.nee && s->n_inst) {
+        const pt_status rcl = ptb_ensure_inst_lights(s);
+        if (rcl != PT_OK) return rcl;
+    }
+    j.nee_lights = s->n_inst ? s->d_lights_inst : s->d_lights;
+    j.nee_n_lights = s->n_inst ? s->n_lights_inst : s->n_lights;
+    j.nee_light_area = s->n_inst ? s->light_area_inst : s->light_area;
+    if (j.nee && (size_t)w.n_slots > w.cap_sq) {  // the shadow queue: at most one entry per live path and round
+        (void)hipFree(w.d_sq_rayA); (void)hipFree(w.d_sq_rayB); (void)hipFree(w.d_sq_contrib); (void)hipFree(w.d_sq_slot);
+        (void)hipFree(w.d_sq_tmax); (void)hipFree(w.d_sq_hit);
+        w.d_sq_rayA = w.d_sq_contrib = w.d_sq_hit = nullptr; w.d_sq_rayB = nullptr; w.d_sq_slot = nullptr; w.d_sq_tmax = nullptr;
+        w.cap_sq = 0;
+        const size_t ns = w.n_slots;
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_rayA, sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_rayB, sizeof(float2) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_contrib, sizeof(float4) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_slot, sizeof(uint32_t) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_tmax, sizeof(float) * ns));
+        PT_HIP(ctx, hipMalloc((void **)&w.d_sq_hit, sizeof(float4) * ns));
+        if (!w.d_sq_count) PT_HIP(ctx, hipMalloc((void **)&w.d_sq_count, sizeof(uint32_t) * PT_MAX_PIPES));
+        w.cap_sq = ns;
+    }
+    ctx->stats.extend_variant = j.pl.variant;
+    return PT_OK;
+}
+
+// ---- per batch: the slot lanes split over the pipelines, queue 0 of each filled ---------------------------------------------
+pt_status batch_begin(Job &j, Pipe *pipe, int &pipes_now, unsigned long long &rays_before)
+{
+    pt_ctx *ctx = j.ctx;
+    pt_film::Work &w = j.f->work;
+    hipStream_t st = ctx->stream;
+    rays_before = 0;
+    if (j.sh.bounded) {  // the exact ray counter as it is before this batch, should the batch have to be redone
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
+    }
+    PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 2 * PT_MAX_PIPES, st));
+    if (j.sh.bounded) PT_HIP(ctx, hipMemsetAsync(j.d_spill_count, 0, sizeof(unsigned long long), st));
+    const uint32_t slot_lanes = j.rc.lanes_active * j.sh.groups;
+    pipes_now = std::min<int>(j.n_pipes, (int)slot_lanes);
+    for (int k = 0; k < pipes_now; k++) {
+        const uint32_t l0 = (uint32_t)((uint64_t)slot_lanes * k / pipes_now);
+        const uint32_t l1 = (uint32_t)((uint64_t)slot_lanes * (k + 1) / pipes_now);
+        Pipe &pp = pipe[k];
+        pp.st = k == 0 ? st : ctx->pipe_stream[k];
+        pp.slot_begin = l0 * j.rc.slots_per_lane;
+        pp.n_slots = (l1 - l0) * j.rc.slots_per_lane;
+        for (int i = 0; i < 2; i++)
+            pp.qv[i] = { w.d_qid[i] + pp.slot_begin, w.d_qstate[i] + pp.slot_begin, w.d_qrayA[i] + pp.slot_begin, w.d_qrayB[i] + pp.slot_begin };
+        pp.hit = w.d_hit + pp.slot_begin;
+        pp.hit_inst = w.d_hit_inst + pp.slot_begin;
+        pp.count = w.d_count + 2 * k;
+        pp.cur = 0;
+        pp.done = false;
+        pp.polls = 0;
+    }
+    if (pipes_now > 1) {  // the other streams start after the counters are cleared
+        PT_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+        for (int k = 1; k < pipes_now; k++) PT_HIP(ctx, hipStreamWaitEvent(ctx->pipe_stream[k], ctx->ev_fork, 0));
+    }
+    for (int k = 0; k < pipes_now; k++) {
+        Pipe &pp = pipe[k];
+        ptw_launch_generate(j.rc, w.d_tiles, pp.slot_begin, pp.n_slots, j.rad, pp.qv[0], &pp.count[0], ctx->num_cus, pp.st);
+        ctx->stats.launches_other++;
+    }
+    return PT_OK;
+}
+
+// ---- one round of one pipeline: [sort] -> closest hit -> shade [-> shadow rays -> add] ---------------------------------
+pt_status pipe_round(Job &j, Pipe *pipe, int k, int pipes_now, uint32_t round, bool shade_rule, bool *shade_recorded)
+{
+    pt_ctx *ctx = j.ctx; pt_scene *s = j.s; const pt_params *p = j.p;
+    pt_film::Work &w = j.f->work;
+    Pipe &pp = pipe[k];
+    const int cur = pp.cur;
+    hipEvent_t x0 = nullptr, x1 = nullptr, h0 = nullptr, h1 = nullptr;
+    if (j.profile) {  // from the context's pool: creating ~2000 events per call showed in the wall time
+        const pt_status rce = grow_event_pool(ctx, j.ev_used + 4);
+        if (rce != PT_OK) return rce;
+        x0 = ctx->ev_pool[j.ev_used++]; x1 = ctx->ev_pool[j.ev_used++]; h0 = ctx->ev_pool[j.ev_used++]; h1 = ctx->ev_pool[j.ev_used++];
+    }
+    const uint32_t *perm = nullptr;
+    if (j.sort_rays && round > 0) {  // (round 0 is the primary rays: one origin, generated tile by tile)
+        const size_t per_pipe = w.sort_bytes / (size_t)j.n_pipes;
+        perm = ptw_sort_rays(pp.st, pp.qv[cur].rayA, pp.qv[cur].rayB, &pp.count[cur], pp.n_slots, s->bmin, s->bmax, j.sort_bits, ctx->num_cus,
+                             static_cast<char *>(w.d_sort) + per_pipe * (size_t)k);
+        ctx->stats.launches_other += 1 + 5 * (uint32_t)((3 * j.sort_bits + 3 + 7) / 8);
+    }
+    // Two pipelines start half a round apart: pipeline k > 0 begins its first traversal launch when pipeline k-1's first one
+    // has finished.  Started together they can lock in phase -- traversal beside traversal, shade beside shade -- and whether
+    // they do depended on the box: same-box A/B 22.45 -> 23.99 Grays/s where all plain runs were slow, no change where they
+    // were fast; C4 unchanged (profiles/r02i_ab_stagger.log).  Only where the two kernels are of similar length (tables in
+    // LDS) and more than one frame is in flight.  A strict token (one traversal launch at a time) is 20 % slower.
+    const bool stag = j.stagger && j.shade_lds && j.rc.lanes_active > 1 && round == 0;
+    if (stag && k > 0) PT_HIP(ctx, hipStreamWaitEvent(pp.st, ctx->ev_fork, 0));
+    ptw_launch_extend(j.pl, s, pp.qv[cur].rayA, pp.qv[cur].rayB, pp.hit, pp.hit_inst, &pp.count[cur], &pp.count[cur ^ 1], ctx->d_stats, p->tmin,
+                      p->tmax, j.count_visits, true, pp.st, k, x0, x1, perm);
+    if (stag && k + 1 < pipes_now) PT_HIP(ctx, hipEventRecord(ctx->ev_fork, pp.st));
+    // The shade rule (three pipelines): never all three in their shade launch at once.  Pipeline k's shade launch waits for the
+    // end of the most recent shade launch of pipeline k + 1 -- the one a third of a rotation ahead, long over when the three are
+    // evenly spread, so in the pattern the rule aims at nobody waits, and out of it the laggard is held back until the rotation
+    // is restored.  Free-running, the three spend 11-19 % of a frame shade beside shade beside shade (latency-bound, VALUs
+    // idle) and which pattern a process falls into is chance: 24.3-25.7 Grays/s over eight processes of one box; with the rule
+    // 25.8-27.1, mean +6.0 % (profiles/r03ag_c2_rules_distribution.log).  The same rule on the traversal launches, on both, one
+    // position further ahead, or with two / four pipelines: all slower (r03af_*, r03ah_*).
+    const int ahead = (k + 1) % pipes_now;
+    if (shade_rule && shade_recorded[ahead]) PT_HIP(ctx, hipStreamWaitEvent(pp.st, ctx->ev_shade[ahead], 0));
+    ShadeLaunch sl;
+    sl.rc = j.rc; sl.tiles = w.d_tiles; sl.scene = s; sl.bvh8 = j.pl.bvh8; sl.lds_tables = j.shade_lds; sl.nee = j.nee;
+    sl.grid = j.shade_grid; sl.smem = j.shade_smem; sl.rad = j.rad; sl.hit = pp.hit; sl.hit_inst = pp.hit_inst;
+    sl.in = pp.qv[cur]; sl.out = pp.qv[cur ^ 1]; sl.count_in = &pp.count[cur]; sl.count_out = &pp.count[cur ^ 1];
+    sl.inst_frame = j.inst_frame; sl.lights = j.nee_lights; sl.n_lights = j.nee_n_lights; sl.light_area = j.nee_light_area;
+    if (j.nee) {
+        sl.sq = { w.d_sq_rayA + pp.slot_begin, w.d_sq_rayB + pp.slot_begin, w.d_sq_contrib + pp.slot_begin, w.d_sq_tmax + pp.slot_begin,
+                  w.d_sq_slot + pp.slot_begin };
+        sl.sq_count = w.d_sq_count + k;
+        PT_HIP(ctx, hipMemsetAsync(sl.sq_count, 0, sizeof(uint32_t), pp.st));
+    }
+    ptw_launch_shade(sl, pp.st, h0, h1);
+    if (j.nee && j.nee_n_lights) {
+        // the shadow rays of this round: any-hit queries with their own tmax, then the unoccluded terms
+        ptw_launch_extend(j.pl, s, sl.sq.rayA, sl.sq.rayB, w.d_sq_hit + pp.slot_begin, nullptr, sl.sq_count, nullptr, ctx->d_stats, p->tmin, p->tmax,
+                          false, true, pp.st, k, nullptr, nullptr, nullptr, sl.sq.tmax);
+        ptw_launch_shadow_add(j.rc, j.rad, w.d_sq_hit + pp.slot_begin, sl.sq.contrib, sl.sq.slot, sl.sq_count, j.shade_grid, pp.st);
+        ctx->stats.launches_extend++;
+        ctx->stats.launches_other++;
+    }
+    PT_HIP(ctx, hipGetLastError());  // a launch the runtime refused (LDS size, grid) must not pass for a rendered round
+    if (shade_rule) { PT_HIP(ctx, hipEventRecord(ctx->ev_shade[k], pp.st)); shade_recorded[k] = true; }
+    if (j.profile) {
+        j.ev_extend.push_back(x0); j.ev_extend.push_back(x1);
+        j.ev_shade.push_back(h0); j.ev_shade.push_back(h1);
+    }
+    ctx->stats.launches_extend++;
+    ctx->stats.launches_shade++;
+    pp.cur ^= 1;
+    return PT_OK;
+}
+
+// The live counts, one poll behind.  Every slot needs >= group_size rounds; after that the counts are polled every eighth
+// round so that a batch whose paths have all ended stops early.  The host reads the count of the PREVIOUS poll -- eight rounds
+// back -- while each stream still holds eight rounds of launches: waiting for the newest count drained the streams, restarted
+// the pipelines in phase and left one of them idle until the other had caught up: 5.3 ms of the 147 ms of 16 C2 frames
+// (profiles/r03r_c2_timeline_before.txt).  A pipeline found empty has at most sixteen empty rounds queued behind it.
+pt_status poll_live_counts(Job &j, Pipe *pipe, int pipes_now, bool &all_done)
+{
+    pt_ctx *ctx = j.ctx;
+    all_done = true;
+    for (int k = 0; k < pipes_now; k++) {
+        Pipe &pp = pipe[k];
+        if (pp.done) continue;
+        const int jj = pp.polls & 1;
+        PT_HIP(ctx, hipMemcpyAsync(ctx->h_poll + 2 * k + jj, &pp.count[pp.cur], sizeof(uint32_t), hipMemcpyDeviceToHost, pp.st));
+        PT_HIP(ctx, hipEventRecord(ctx->ev_poll[k][jj], pp.st));
+        if (pp.polls > 0) {
+            PT_HIP(ctx, hipEventSynchronize(ctx->ev_poll[k][jj ^ 1]));
+            if (ctx->h_poll[2 * k + (jj ^ 1)] == 0u) pp.done = true;
+        }
+        pp.polls++;
+        if (!pp.done) all_done = false;
+    }
+    return PT_OK;
+}
+
+pt_status run_rounds(Job &j, Pipe *pipe, int pipes_now)
+{
+    pt_ctx *ctx = j.ctx;
+    const uint32_t group_size = j.sh.group_size;
+    const uint32_t max_rounds = group_size * j.p->max_depth;  // every sample of a slot at full depth
+    bool shade_recorded[PT_MAX_PIPES] = {};
+    const bool shade_rule = pipes_now == 3 && ((ctx->tune.stagger < 0 && j.shade_lds) || ctx->tune.stagger == 2);
+    for (uint32_t round = 0; round < max_rounds; round++) {
+        for (int k = 0; k < pipes_now; k++) {
+            if (pipe[k].done) continue;
+            const pt_status rc = pipe_round(j, pipe, k, pipes_now, round, shade_rule, shade_recorded);
+            if (rc != PT_OK) return rc;
+        }
+        ctx->stats.rounds++;
+        if (!j.async && round + 1 >= group_size && ((round + 1) & 7u) == 0u && round + 1 < max_rounds) {
+            bool all_done = false;
+            const pt_status rc = poll_live_counts(j, pipe, pipes_now, all_done);
+            if (rc != PT_OK) return rc;
+            if (all_done) break;
+        }
+    }
+    return PT_OK;
+}
+
+// A failure between batch_begin and the join leaves launches queued on the side streams that read and write the film's
+// workspace: nothing may free or reuse it before they have drained.
+void drain_side_streams(pt_ctx *ctx, int pipes_now)
+{
+    for (int k = 1; k < pipes_now; k++)
+        if (ctx->pipe_stream[k]) (void)hipStreamSynchronize(ctx->pipe_stream[k]);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+}
+
+pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const ExtendPlan &pl, bool nested);
+
+// ---- per batch: join, term-log overflow check, resolve (or the same frames once more with one sample group) -----------------
+pt_status batch_finish(Job &j, int pipes_now, unsigned long long rays_before)
+{
+    pt_ctx *ctx = j.ctx; pt_film *f = j.f; const pt_params *p = j.p;
+    hipStream_t st = ctx->stream;
+    for (int k = 1; k < pipes_now; k++) {  // join before the resolve reads every pipeline's slots
+        PT_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->pipe_stream[k]));
+        PT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[k], 0));
+    }
+    bool redo = false;
+    if (j.sh.bounded) {  // did a slot fill its term log?
+        unsigned long long flag = 0;
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        PT_HIP(ctx, hipMemcpy(&flag, j.d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+        redo = flag != 0ull;
+    }
+    if (!redo) {
+        ptw_launch_resolve(j.rc, f->work.d_tiles, j.rad, f->d_rgb, f->d_bgra, st);
+        ctx->stats.launches_other++;
+        return PT_OK;
+    }
+    // Rare (scenes where most surfaces emit): nothing of this batch has touched the film yet.  Put the ray counter back, clear
+    // the flag and render the same frames with one slot per (frame, pixel) -- the plain accumulator needs no log -- then return
+    // to this call's workspace shape.
+    PT_HIP(ctx, hipMemcpy(ctx->d_stats, &rays_before, sizeof(rays_before), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemset(j.d_overflow, 0, sizeof(unsigned long long)));
+    ctx->stats.redone_batches++;
+    pt_params q = *p;
+    q.frame = j.rc.frame_base;
+    q.frame_count = j.rc.lanes_active;
+    q.frames_in_flight = j.rc.lanes_active;
+    q.sample_groups = 1;
+    pt_status rc = render_wavefront(j.s, f, &q, j.pl, true);
+    if (rc != PT_OK) return rc;
+    rc = ptw_ensure_work(f, p->rank, p->world, j.sh.lanes, j.sh.groups, j.sh.term_cap, j.sh.term_pcap);
+    if (rc != PT_OK) return rc;
+    j.rad = job_radiance(j);
+    return PT_OK;
+}
+
+// ---- the wavefront pipelines (PT_PIPELINE_WAVEFRONT, _NEE) ---------------------------------------------------------------
+pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const ExtendPlan &pl, bool nested)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    Job j{};
+    j.s = s; j.f = f; j.p = p; j.ctx = ctx; j.pl = pl; j.nested = nested;
+    pt_status rc = ptw_shape_and_work(f, p, j.sh, launch_class(s, pl));
+    if (rc != PT_OK) return rc;
+    rc = job_setup(j);
+    if (rc != PT_OK) return rc;
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    for (uint32_t done = 0; f->work.n_slots > 0 && done < p->frame_count; done += j.sh.lanes) {
+        j.rc.frame_base = p->frame + (int32_t)done;
+        j.rc.lanes_active = std::min(j.sh.lanes, p->frame_count - done);
+        Pipe pipe[PT_MAX_PIPES];
+        int pipes_now = 0;
+        unsigned long long rays_before = 0;
+        rc = batch_begin(j, pipe, pipes_now, rays_before);
+        if (rc == PT_OK) rc = run_rounds(j, pipe, pipes_now);
+        if (rc == PT_OK) rc = batch_finish(j, pipes_now, rays_before);
+        if (rc != PT_OK) {
+            drain_side_streams(ctx, std::max(pipes_now, j.n_pipes));
+            return rc;
+        }
+    }
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    if (!j.async) {
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        PT_HIP(ctx, hipGetLastError());
+        if (!nested) {
+            float ms = 0.f;
+            PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+            ctx->stats.ms_total += ms;
+        }
+    }
+    if (!nested) {
+        ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
+        ctx->stats.paths += ptw_valid_local_pixels(f, p) * p->spp_per_frame * p->frame_count;  // samples started
+    }
+    if (j.profile) {
+        for (size_t i = 0; i + 1 < j.ev_extend.size(); i += 2) {
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, j.ev_extend[i], j.ev_extend[i + 1]) == hipSuccess) ctx->stats.ms_extend += a;
+            if (hipEventElapsedTime(&b, j.ev_shade[i], j.ev_shade[i + 1]) == hipSuccess) ctx->stats.ms_shade += b;
+        }
+    }
+    return PT_OK;
+}
+
+// ---- PT_PIPELINE_FUSED (fused.hip, fused_kernel.h) ---------------------------------------------------------------------------
+// The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches); sample groups
+// only to shorten the tail of a batch -- the last slots handed out run alone at the end, and a slot of 32 samples is up to 256
+// rays = ~4 ms of a lane's time against 6-7 ms for a whole frame: frames x groups >= 16 keeps that tail under ~2 % of a batch.
+// Explicit frames_in_flight / sample_groups are taken as given.
+void fused_shape_defaults(const pt_params *p, pt_params &q)
+{
+    q = *p;
+    if (q.frames_in_flight == 0) {
+        const uint32_t cap = 32;
+        const uint32_t batches = (p->frame_count + cap - 1) / cap;
+        q.frames_in_flight = (p->frame_count + batches - 1) / batches;
+    }
+    q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
+    if (q.sample_groups == 0) {
+        uint32_t g = 1;
+        while (g < p->spp_per_frame && (g * q.frames_in_flight < 16u || p->spp_per_frame % g)) g++;
+        q.sample_groups = g;
+    }
+}
+
+pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const ExtendPlan &pl, bool nested, bool prepare_only)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    FusedPlan fp;
+    pt_status rc_ = ptw_plan_fused(s, pl, p_in->tmin, fp);
+    if (rc_ != PT_OK) return rc_;
+    pt_params q;
+    fused_shape_defaults(p_in, q);
+    const pt_params *p = &q;
+    RenderShape sh;
+    rc_ = ptw_shape_and_work(f, p, sh, 3, false);
+    if (!nested) {
+        ctx->stats.frames_in_flight = sh.lanes;
+        ctx->stats.sample_groups = sh.groups;
+    }
+    if (rc_ != PT_OK) return rc_;
+    ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
+    if (prepare_only) return PT_OK;
+    pt_film::Work &w = f->work;
+    unsigned long long *const d_overflow = ctx->d_stats + 6, *const d_spill_count = ctx->d_stats + 7;
+    uint32_t spill_cap = sh.bounded ? SPILL_POOL_ENTRIES : 0u;
+    if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);
+    Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+    RenderConst rc = ptw_render_const(p, w, sh);
+    const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;
+    ctx->stats.extend_variant = pl.variant;
+    ctx->stats.pipelines = 1;
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    std::vector<hipEvent_t> evs;
+    size_t ev_used = 0;
+    for (uint32_t done = 0; w.n_slots > 0 && done < p->frame_count; done += sh.lanes) {
+        rc.frame_base = p->frame + (int32_t)done;
+        rc.lanes_active = std::min(sh.lanes, p->frame_count - done);
+        unsigned long long rays_before = 0;
+        if (sh.bounded) {
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
+            PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
+        }
+        PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t), st));  // the slot counter
+        const uint32_t n_slots = rc.lanes_active * sh.groups * rc.slots_per_lane;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) {
+            rc_ = grow_event_pool(ctx, ev_used + 2);
+            if (rc_ != PT_OK) return rc_;
+            e0 = ctx->ev_pool[ev_used++]; e1 = ctx->ev_pool[ev_used++];
+            evs.push_back(e0); evs.push_back(e1);
+        }
+        ptw_launch_fused(fp, sh.groups > 1, rc, w.d_tiles, rad, s, n_slots, w.d_count, ctx->d_stats, p->tmin, p->tmax, st, e0, e1);
+        PT_HIP(ctx, hipGetLastError());
+        ctx->stats.launches_extend++;
+        ctx->stats.rounds++;
+        bool redo = false;
+        if (sh.bounded) {
+            unsigned long long flag = 0;
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            PT_HIP(ctx, hipMemcpy(&flag, d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+            redo = flag != 0ull;
+        }
+        if (!redo) {
+            ptw_launch_resolve(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra, st);
+            ctx->stats.launches_other++;
+        } else {  // a slot filled its term log (scenes where most surfaces emit): the same frames once more with one group
+            PT_HIP(ctx, hipMemcpy(ctx->d_stats, &rays_before, sizeof(rays_before), hipMemcpyHostToDevice));
+            PT_HIP(ctx, hipMemset(d_overflow, 0, sizeof(unsigned long long)));
+            ctx->stats.redone_batches++;
+            pt_params r = *p;
+            r.frame = rc.frame_base; r.frame_count = rc.lanes_active; r.frames_in_flight = rc.lanes_active; r.sample_groups = 1;
+            rc_ = render_fused(s, f, &r, pl, true, false);
+            if (rc_ != PT_OK) return rc_;
+            rc_ = ptw_ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap, false);
+            if (rc_ != PT_OK) return rc_;
+            rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+        }
+    }
+    if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    PT_HIP(ctx, hipGetLastError());
+    if (!nested) {
+        float ms = 0.f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+        ctx->stats.ms_total += ms;
+        ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
+        ctx->stats.paths += ptw_valid_local_pixels(f, p) * p->spp_per_frame * p->frame_count;
+    }
+    for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+        float a = 0.f;
+        if (hipEventElapsedTime(&a, evs[i], evs[i + 1]) == hipSuccess) ctx->stats.ms_extend += a;
+    }
+    return PT_OK;
+}
+
+}  // namespace
+
+// pt_render_prepare: exactly the shape and workspace pt_render would pick, and the one-time objects of its schedule
+pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    pt_ctx *ctx = s->ctx;
+    pt_status rc_ = check_params(s, f, p);
+    if (rc_ != PT_OK) return rc_;
+    ExtendPlan pl;
+    rc_ = ptw_plan_extend(s, p->extend, pl);
+    if (rc_ != PT_OK) return rc_;
+    if (p->pipeline == PT_PIPELINE_FUSED) return render_fused(s, f, p, pl, false, true);
+    RenderShape sh;
+    rc_ = ptw_shape_and_work(f, p, sh, launch_class(s, pl));
+    ctx->stats.frames_in_flight = sh.lanes;
+    ctx->stats.sample_groups = sh.groups;
+    if (rc_ != PT_OK) return rc_;
+    ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
+    rc_ = ensure_schedule_objects(ctx, 3);
+    if (rc_ != PT_OK) return rc_;
+    if (p->flags & PT_FLAG_PROFILE) {  // the pooled (start, stop) events of every extend / shade launch of one batch (4 per round and pipeline)
+        const size_t batches = ((size_t)p->frame_count + sh.lanes - 1) / sh.lanes;
+        rc_ = grow_event_pool(ctx, std::min<size_t>(4ull * sh.group_size * p->max_depth * 3ull * batches, 1u << 16));
+        if (rc_ != PT_OK) return rc_;
+    }
+    return PT_OK;
+}
+
+pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
+{
+    pt_status rc_ = check_params(s, f, p);
+    if (rc_ != PT_OK) return rc_;
+    ExtendPlan pl;
+    rc_ = ptw_plan_extend(s, p->extend, pl);
+    if (rc_ != PT_OK) return rc_;
+    if (p->pipeline == PT_PIPELINE_FUSED) return render_fused(s, f, p, pl, false, false);
+    return render_wavefront(s, f, p, pl, false);
+}
+
+pt_status ptw_trace(pt_scene *s, const float *rays6, uint32_t n, float tmin, float tmax, uint32_t extend, pt_hit *hits)
+{
+    pt_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    if (n == 0) return PT_OK;
+    ExtendPlan pl;
+    pt_status rc_ = ptw_plan_extend(s, extend, pl);
+    if (rc_ != PT_OK) return rc_;
+    std::vector<float4> a(n);
+    std::vector<float2> b(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *r = rays6 + 6 * (size_t)i;
+        a[i] = make_float4(r[0], r[1], r[2], r[3]);
+        b[i] = make_float2(r[4], r[5]);
+    }
+    float4 *d_a = nullptr, *d_hit = nullptr;
+    float2 *d_b = nullptr;
+    uint32_t *d_cnt = nullptr, *d_hi = nullptr;
+    pt_hit *d_out = nullptr;
+    pt_status ret = PT_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        ret = PT_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_a, sizeof(float4) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_b, sizeof(float2) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_hit, sizeof(float4) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_out, sizeof(pt_hit) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_cnt, sizeof(uint32_t) * 2)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK && (e = hipMalloc((void **)&d_hi, sizeof(uint32_t) * n)) != hipSuccess) fail(e, "hipMalloc");
+    if (ret == PT_OK) {
+        (void)hipMemcpyAsync(d_a, a.data(), sizeof(float4) * n, hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(d_b, b.data(), sizeof(float2) * n, hipMemcpyHostToDevice, st);
+        const uint32_t cnt_head[2] = { n, 0u };
+        (void)hipMemcpyAsync(d_cnt, cnt_head, sizeof(cnt_head), hipMemcpyHostToDevice, st);
+        (void)hipEventRecord(ctx->ev_a, st);
+        ptw_launch_extend(pl, s, d_a, d_b, d_hit, d_hi, d_cnt, nullptr, ctx->d_stats, tmin, tmax, false, false, st);
+        (void)hipEventRecord(ctx->ev_b, st);
+        ptw_launch_hits_to_api(d_hit, pl.bvh8 ? s->d_tri4_8 : s->d_tri4, s->n_inst ? d_hi : nullptr, s->d_tlas_prim_of, n, d_out, st);
+        (void)hipMemcpyAsync(hits, d_out, sizeof(pt_hit) * n, hipMemcpyDeviceToHost, st);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) fail(e, "pt_trace");
+        else if ((e = hipGetLastError()) != hipSuccess) fail(e, "pt_trace");
+        float ms = 0.f;
+        if (ret == PT_OK && hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b) == hipSuccess) ctx->stats.ms_extend += ms;
+        ctx->stats.launches_extend++;
+    }
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_hit); (void)hipFree(d_out); (void)hipFree(d_cnt); (void)hipFree(d_hi);
+    return ret;
+}

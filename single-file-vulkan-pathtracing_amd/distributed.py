@@ -23,7 +23,7 @@ TILE = 8
 
 def tile_owner(width, height, world):
     """-> int array [H, W]: the rank that renders each pixel (mirror of ensure_work() in
-    csrc/wavefront.hip)."""
+    csrc/film_work.hip ptw_ensure_work)."""
     ty, tx = np.meshgrid(np.arange(height) // TILE, np.arange(width) // TILE, indexing="ij")
     return (tx + ty) % world
 

@@ -48,7 +48,7 @@ def make_c3(res):
     w, h = 1920, 1080
     film = np.zeros((h, w, 3), np.float32)
     bgra = np.zeros((h, w, 4), np.uint8)
-    # rank of every pixel under the world-8 tile decomposition (csrc/wavefront.hip ensure_work: (tx + ty) % world)
+    # rank of every pixel under the world-8 tile decomposition (csrc/film_work.hip ptw_ensure_work: (tx + ty) % world)
     ty, tx = np.meshgrid(np.arange(h) // 8, np.arange(w) // 8, indexing="ij")
     rank_of = ((tx + ty) % C3_WORLD).astype(np.int64)
     rays_frame, rays_rank = [], np.zeros(C3_WORLD, np.int64)

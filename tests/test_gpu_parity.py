@@ -716,7 +716,7 @@ def test_c5_full_size_soup_structure_and_hits(pt, orc, gpu_ctx, tmp_path):
     kw = dict(width=128, height=72, spp_per_frame=2, max_depth=16)
     pt.render(gs, film, pt.default_params(**kw))
     ofilm, _, orays = _render_oracle(orc, osc, 1, **kw)
-    # 128 MB of nodes + records: beyond L2, so AUTO walks the 8-wide tree (wavefront.hip plan_extend)
+    # 128 MB of nodes + records: beyond L2, so AUTO walks the 8-wide tree (extend_launch.hip ptw_plan_extend)
     assert gpu_ctx.stats().rays == orays and gpu_ctx.stats().extend_variant == pt.EXTEND_HBM8
     assert film.read_f32().tobytes() == ofilm.tobytes()
     gpu_ctx.reset_stats()
