@@ -21,11 +21,12 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
         return PT_ERR_UNSUPPORTED;
     }
     fp.lds_stack = pl.lds_stack;
-    fp.smem = pl.smem + tables + sizeof(uint32_t) * FS_FIELDS * TB + sizeof(uint32_t) * (TB / 64) * (PT_FUSED_BATCH / 64);
+    fp.smem = (size_t)pl.lds_stack * FTB * sizeof(uint32_t) + (pl.smem - (size_t)pl.lds_stack * TB * sizeof(uint32_t)) + tables +
+              sizeof(uint32_t) * FS_FIELDS * FTB + sizeof(uint32_t) * (FTB / 64) * (PT_FUSED_BATCH / 64);
     for (const void *fn : { reinterpret_cast<const void *>(k_fused<false>), reinterpret_cast<const void *>(k_fused<true>) })
         if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
     int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fused<false>), TB, fp.smem));
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fused<false>), FTB, fp.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
     per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
     fp.grid = ctx->num_cus * per_cu;
@@ -41,9 +42,9 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     if (grouped)
-        hipExtLaunchKernelGGL((k_fused<true>), dim3(fp.grid), dim3(TB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
+        hipExtLaunchKernelGGL((k_fused<true>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
                               s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack);
     else
-        hipExtLaunchKernelGGL((k_fused<false>), dim3(fp.grid), dim3(TB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
+        hipExtLaunchKernelGGL((k_fused<false>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
                               s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack);
 }

@@ -28,6 +28,11 @@
 #define PT_FUSED_WAVES 5   // waves per SIMD asked of the compiler (LDS: ~30 KB per block -> 5 blocks per CU)
 #endif
 
+#ifndef PT_FUSED_TB
+#define PT_FUSED_TB 256    // threads per block: the scene tables are per block, the stack and the path state per thread
+#endif
+constexpr int FTB = PT_FUSED_TB;
+
 #ifndef PT_FUSED_BATCH
 #define PT_FUSED_BATCH 256  // slots a wave draws per atomic (a multiple of 64 and a power of two: 64 consecutive slots are one 8x8 tile)
 #endif
@@ -37,7 +42,7 @@ enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS
 // FS_A..C: the slot's colour (one sample group) | FS_A: its term count (several groups)
 
 template <bool GROUPED>
-__global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+__global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
                                                               const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
                                                               const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
                                                               uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
@@ -47,12 +52,12 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
     constexpr uint32_t LEAF_BIT = 0x2000u, DONE = 0x3FFFu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS: stack | BVH4 nodes | three permuted triangle copies | shade4 | tangent frames | path state
-    float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * TB * sizeof(uint32_t));
+    float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * FTB * sizeof(uint32_t));
     float4 *s_tri = s_wide + LDS_NODE_F4 * (size_t)n_wide;
     float4 *s_shade = s_tri + 9 * (size_t)n_tris;
     float4 *s_frame = s_shade + 3 * (size_t)n_tris;
     lds_u32 *my_state = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + threadIdx.x;
-    for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += TB) {
+    for (uint32_t i = threadIdx.x; i < 8 * n_wide; i += FTB) {
         float4 v = g_wide[i];
         if ((i & 7u) == 6u) {  // the four child words -> 14-bit codes (extend_kernel.h COMPACT)
             auto cw = [](float f) {
@@ -64,14 +69,14 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
         }
         s_wide[(i >> 3) * LDS_NODE_F4 + (i & 7u)] = v;
     }
-    for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += TB) {
+    for (uint32_t i = threadIdx.x; i < 3 * n_tris; i += FTB) {
         const float4 v = g_tri4[i];
         s_tri[i] = make_float4(v.y, v.z, v.x, v.w);               // kz = 0: (kx,ky,kz) = (1,2,0)
         s_tri[3 * n_tris + i] = make_float4(v.z, v.x, v.y, v.w);  // kz = 1: (2,0,1)
         s_tri[6 * n_tris + i] = v;                                // kz = 2: (0,1,2) -- also what the shade block reads
         s_shade[i] = g_shade4[i];
     }
-    for (uint32_t i = threadIdx.x; i < 2 * n_tris; i += TB) s_frame[i] = g_frame4[i];
+    for (uint32_t i = threadIdx.x; i < 2 * n_tris; i += FTB) s_frame[i] = g_frame4[i];
     __syncthreads();
     const float4 *wide = s_wide, *tri4 = s_tri;
     const float4 *verts = s_tri + 6 * (size_t)n_tris;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t w_next = 0, w_end = 0;  // wave-uniform: what is left of the wave's current batch of slots
-    lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * TB + (threadIdx.x >> 6) * (PT_FUSED_BATCH / 64);
+    lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * (PT_FUSED_BATCH / 64);
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
     uint32_t ax = 0, ay = 0, az = 0, tri_base = 0;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             sp--;
-            const uint32_t e = my_stack32[sp * TB];
+            const uint32_t e = my_stack32[sp * FTB];
             if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
         }
         return DONE;
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
             bool got_ray = false, need_primary = false;
             // (1) the hit of the ray that just ended: radiance, then bounce / next sample / slot complete
             if (in_blk && path) {
-                slot = my_state[FS_SLOT * TB]; ctr = my_state[FS_CTR * TB]; seed = my_state[FS_SEED * TB];
-                wr = __uint_as_float(my_state[FS_WR * TB]); wg = __uint_as_float(my_state[FS_WG * TB]); wb = __uint_as_float(my_state[FS_WB * TB]);
-                pxy = my_state[FS_PXY * TB];
+                slot = my_state[FS_SLOT * FTB]; ctr = my_state[FS_CTR * FTB]; seed = my_state[FS_SEED * FTB];
+                wr = __uint_as_float(my_state[FS_WR * FTB]); wg = __uint_as_float(my_state[FS_WG * FTB]); wb = __uint_as_float(my_state[FS_WB * FTB]);
+                pxy = my_state[FS_PXY * FTB];
                 uint32_t sample = ctr & 0xFFFFu, depth = ctr >> 16;
                 // raygen.rgen:76 `color += weight * emission` (adding +0 changes no bit of a non-negative accumulator, so
                 // non-emitters are skipped -- as k_shade does; NaN compares false and still adds)
@@ -139,11 +144,11 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
                 }
                 if (add) {
                     if (!GROUPED) {
-                        my_state[FS_A * TB] = __float_as_uint(__uint_as_float(my_state[FS_A * TB]) + er);
-                        my_state[FS_B * TB] = __float_as_uint(__uint_as_float(my_state[FS_B * TB]) + eg);
-                        my_state[FS_C * TB] = __float_as_uint(__uint_as_float(my_state[FS_C * TB]) + eb);
+                        my_state[FS_A * FTB] = __float_as_uint(__uint_as_float(my_state[FS_A * FTB]) + er);
+                        my_state[FS_B * FTB] = __float_as_uint(__uint_as_float(my_state[FS_B * FTB]) + eg);
+                        my_state[FS_C * FTB] = __float_as_uint(__uint_as_float(my_state[FS_C * FTB]) + eb);
                     } else {  // the ordered term log of add_radiance (wavefront_types.h), the count kept in LDS
-                        const uint32_t k = my_state[FS_A * TB];
+                        const uint32_t k = my_state[FS_A * FTB];
                         if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
                         else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
                         else {
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
                                 *rad.overflow = 1ull;
                             }
                         }
-                        my_state[FS_A * TB] = k + 1u;
+                        my_state[FS_A * FTB] = k + 1u;
                     }
                 }
                 if (!terminated) {
@@ -183,9 +188,9 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
                     if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {
                         need_primary = true;  // the slot's next sample: raygen.rgen:45-60
                     } else {  // the slot is complete
-                        if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * TB]), __uint_as_float(my_state[FS_B * TB]),
-                                                                   __uint_as_float(my_state[FS_C * TB]), 0.f);
-                        else rad.nterm[slot] = my_state[FS_A * TB];
+                        if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FTB]), __uint_as_float(my_state[FS_B * FTB]),
+                                                                   __uint_as_float(my_state[FS_C * FTB]), 0.f);
+                        else rad.nterm[slot] = my_state[FS_A * FTB];
                         path = false;
                     }
                 }
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
                     if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
                         pxy = px | (py << 16);
                         ctr = sample0;
-                        my_state[FS_A * TB] = 0u;  // colour.r = +0.0f | term count = 0
-                        if (!GROUPED) { my_state[FS_B * TB] = 0u; my_state[FS_C * TB] = 0u; }
+                        my_state[FS_A * FTB] = 0u;  // colour.r = +0.0f | term count = 0
+                        if (!GROUPED) { my_state[FS_B * FTB] = 0u; my_state[FS_C * FTB] = 0u; }
                         path = true;
                         need_primary = true;
                     } else if (GROUPED) {
@@ -247,9 +252,9 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
             }
             // (4) state back to LDS, ray set-up (the refill block of extend_body<true, false, false, true>)
             if (got_ray) {
-                my_state[FS_SLOT * TB] = slot; my_state[FS_CTR * TB] = ctr; my_state[FS_SEED * TB] = seed;
-                my_state[FS_WR * TB] = __float_as_uint(wr); my_state[FS_WG * TB] = __float_as_uint(wg); my_state[FS_WB * TB] = __float_as_uint(wb);
-                my_state[FS_PXY * TB] = pxy;
+                my_state[FS_SLOT * FTB] = slot; my_state[FS_CTR * FTB] = ctr; my_state[FS_SEED * FTB] = seed;
+                my_state[FS_WR * FTB] = __float_as_uint(wr); my_state[FS_WG * FTB] = __float_as_uint(wg); my_state[FS_WB * FTB] = __float_as_uint(wb);
+                my_state[FS_PXY * FTB] = pxy;
                 pre = ptm::ray_setup<true>(org, dir);
                 inv = { ptm::safe_inv(dir.x), ptm::safe_inv(dir.y), ptm::safe_inv(dir.z) };
                 slab_setup(org, inv, invf, on, of);
@@ -294,9 +299,9 @@ __global__ __launch_bounds__(TB, PT_FUSED_WAVES) void k_fused(RenderConst rc, co
             PT_KSWAP(k1, k2)
 #undef PT_KSWAP
             constexpr uint32_t KINF = 0x7F800000u;
-            if (k3 < KINF) { my_stack32[sp * TB] = k3; sp++; }
-            if (k2 < KINF) { my_stack32[sp * TB] = k2; sp++; }
-            if (k1 < KINF) { my_stack32[sp * TB] = k1; sp++; }
+            if (k3 < KINF) { my_stack32[sp * FTB] = k3; sp++; }
+            if (k2 < KINF) { my_stack32[sp * FTB] = k2; sp++; }
+            if (k1 < KINF) { my_stack32[sp * FTB] = k1; sp++; }
             cur = k0 < KINF ? (k0 & 0x3FFFu) : pop();
             do_node = !(cur & LEAF_BIT);
             const int n_cont = __popcll(__ballot(do_node));
