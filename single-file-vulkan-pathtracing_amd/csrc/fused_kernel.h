@@ -24,12 +24,16 @@
 // complete (one sample group), or the ordered term logs that k_resolve replays (several groups) -- k_resolve is shared.
 #pragma once
 
+// Block shape: the scene tables (10.5 KB for the Cornell box) are per block, the stack and the path state (19 KB per 256 threads) per
+// thread, so bigger blocks leave more of the 160 KB to waves: 256 threads = 30 KB = 5 blocks = 5 waves per SIMD; 512 threads =
+// 49.6 KB = 3 blocks = 6 waves per SIMD at 80 VGPRs (2 / 7 dwords spilled).  Same box, interleaved: 36.2 -> 38.1 Grays/s
+// (profiles/r04d_ab_fused_tb.log); 4 waves: 31.4.
 #ifndef PT_FUSED_WAVES
-#define PT_FUSED_WAVES 5   // waves per SIMD asked of the compiler (LDS: ~30 KB per block -> 5 blocks per CU)
+#define PT_FUSED_WAVES 6
 #endif
 
 #ifndef PT_FUSED_TB
-#define PT_FUSED_TB 256    // threads per block: the scene tables are per block, the stack and the path state per thread
+#define PT_FUSED_TB 512
 #endif
 constexpr int FTB = PT_FUSED_TB;
 
