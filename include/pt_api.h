@@ -75,7 +75,9 @@ typedef struct pt_tuning {
     int32_t tri_stay;       /* ... and triangle steps repeat while at least this many lanes still hold one (65 = never) */
     int32_t inst_frames;    /* 0: instanced scenes transform the normal and build its tangent frame per hit instead of reading
                                the per-(instance, triangle) table                                                         */
-    int32_t reserved[8];
+    int32_t tlas_ploc;      /* 1: the TLAS of an instanced scene is rebuilt by PLOC like a big scene's binary tree (0: LBVH)   */
+    int32_t ploc_adopt_pct; /* a PLOC tree is kept when its area sum is below this percentage of the LBVH's (90; 1000 = always) */
+    int32_t reserved[6];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);

@@ -38,7 +38,7 @@
 constexpr int FTB = PT_FUSED_TB;
 
 #ifndef PT_FUSED_BATCH
-#define PT_FUSED_BATCH 256  // slots a wave draws per atomic (a multiple of 64 and a power of two: 64 consecutive slots are one 8x8 tile)
+#define PT_FUSED_BATCH 256  // most slots a wave draws per atomic (a multiple of 64: 64 consecutive slots are one 8x8 tile)
 #endif
 
 // path state in LDS, [field][thread]
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
-    uint32_t w_next = 0, w_end = 0;  // wave-uniform: what is left of the wave's current batch of slots
+    uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
     lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * (PT_FUSED_BATCH / 64);
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
@@ -206,13 +206,24 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             const unsigned long long m_want = __ballot(in_blk && !path);
             if (m_want && !out_of_slots) {
                 if (w_next >= w_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(next_slot, (uint32_t)PT_FUSED_BATCH);
+                    // guided self-scheduling: PT_FUSED_BATCH slots while plenty are left, then -- from a (possibly stale) look at
+                    // the counter -- no more than what is left / (2 x the grid's waves), down to one tile: the last batches
+                    // handed out run alone at the end of the launch, and 256 slots of 32 samples are ~3 ms of a wave's time
+                    // (a rank of world 8 at config C3's size lost 23 % of a perfect split to that tail, 11 % of world 4)
+                    uint32_t base = 0, size = 0;
+                    if (lane == 0) {
+                        const uint32_t seen = __atomic_load_n(next_slot, __ATOMIC_RELAXED);
+                        const uint32_t left = seen < n_slots ? n_slots - seen : 0u;
+                        const uint32_t share = left / (2u * gridDim.x * (uint32_t)(FTB / 64));
+                        size = min((uint32_t)PT_FUSED_BATCH, max(64u, share & ~63u));
+                        base = atomicAdd(next_slot, size);
+                    }
                     base = __builtin_amdgcn_readfirstlane(base);
-                    w_next = base;
-                    w_end = min(base + (uint32_t)PT_FUSED_BATCH, n_slots);
+                    size = __builtin_amdgcn_readfirstlane(size);
+                    w_base = w_next = base;
+                    w_end = min(base + size, n_slots);
                     if (base >= n_slots) { out_of_slots = true; w_end = w_next; }
-                    else if (lane < PT_FUSED_BATCH / 64) {
+                    else if ((uint32_t)lane < size / 64u) {
                         const uint32_t c = slot_base + base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
                         uint32_t word = 0u;
                         if (base + 64u * (uint32_t)lane < n_slots) word = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     const uint32_t lane_slot = rc.div_spl.div(slot);
                     const uint32_t f = rc.div_groups.div(lane_slot), g = lane_slot - f * rc.groups;
                     const uint32_t local = slot - lane_slot * rc.slots_per_lane;
-                    const uint32_t tw = s_wtile[(mine >> 6) & (PT_FUSED_BATCH / 64 - 1)];
+                    const uint32_t tw = s_wtile[(mine - w_base) >> 6];
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
                     const uint32_t sample0 = g * rc.group_size;
                     if (GROUPED) rad.spill_head[slot] = SPILL_NONE;

@@ -284,7 +284,7 @@ pt_status ptb_ploc_refine(pt_ctx *ctx, uint32_t n, int radius, double area_lbvh,
         // adopted only when clearly cheaper: on uniformly distributed, equally sized triangles (the soup of config C5) the
         // two sums are within 1 % of each other and the LBVH's balanced tree collapses into the better BVH4 (measured:
         // 36.2 against 38.9 node visits per ray, profiles/r03_probe_stress_scene.txt)
-        if (!(*area_ploc < 0.9 * area_lbvh)) return PT_ERR_UNSUPPORTED;
+        if (!(*area_ploc < 0.01 * pt_tuned(ctx->tune.ploc_adopt_pct, 90, 0, 1000) * area_lbvh)) return PT_ERR_UNSUPPORTED;
     }
     const uint32_t n_int = n - 1u, gi = (n_int + TB - 1) / TB, gl = (n + TB - 1) / TB;
     PT_HIP(ctx, hipMemsetAsync(height.p, 0, sizeof(uint32_t), st));

@@ -115,6 +115,7 @@ struct pt_scene {
     float light_area_inst = 0.f;
     // two-level scenes: instances in TLAS leaf order, 6 float4 each {object->world rows, world->object rows}
     uint32_t n_inst = 0, n_tlas_wide = 0, tlas_height = 0;
+    double tlas_area_lbvh = 0.0, tlas_area_ploc = 0.0;  // area sums of the TLAS's binary trees (ploc: 0 = not built)
     float4 *d_inst6 = nullptr;
     float4 *d_inst_frame = nullptr;  // [n_inst][n_tris][2]: world-space normal + tangent of every instanced triangle (ptb_ensure_inst_frames)
     float4 *d_tlas_wide = nullptr;        // BVH4 over the instances' world boxes

@@ -7,6 +7,7 @@
 
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -617,11 +618,15 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     k_inst_boxes<<<g, TB, 0, st>>>(s->d_wide, d_in.p, n, d_tlo.p, d_thi.p);
     BvhOut o;
     // (n < 32768: also the top-down 64-B TLAS with 16-bit child codes that k_extend_inst16 walks)
-    pt_status rc = ptb_build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_TLAS_LEAF_MAX, o, (n > 1 && n < 32768u && PT_TLAS_LEAF_MAX == 1u) ? 6 : 0);
+    // (pt_tuning.tlas_ploc = 1: the TLAS's binary tree by PLOC, as for big single-level scenes; kept under the same area rule)
+    pt_status rc = ptb_build_bvh(ctx, d_tlo.p, d_thi.p, n, PT_TLAS_LEAF_MAX, o, (n > 1 && n < 32768u && PT_TLAS_LEAF_MAX == 1u) ? 6 : 0,
+                                 ctx->tune.tlas_ploc == 1 && n > 2);
     (void)hipFree(o.d_keys);
     (void)hipFree(o.d_nodes);
     s->d_tlas_wide = o.d_wide;
-    s->d_tlas_prim_of = o.d_prim_of;
+    if (o.d_prim_q) { (void)hipFree(o.d_prim_of); s->d_tlas_prim_of = o.d_prim_q; }   // the leaf order of the tree that is walked
+    else s->d_tlas_prim_of = o.d_prim_of;
+    s->tlas_area_lbvh = o.area_lbvh; s->tlas_area_ploc = o.area_ploc;
     s->d_tlas16 = o.d_wide16t; s->n_tlas16 = o.n_wide16t; s->tlas16_levels = o.levels4t;
     for (int k = 0; k < 3; k++) { s->tlas_norm_c[k] = o.norm_c[k]; s->tlas_norm_s[k] = o.norm_s[k]; s->tlas_norm_rs[k] = o.norm_rs[k]; }
     if (rc != PT_OK) { ptb_free_instances(s); return rc; }
@@ -633,6 +638,6 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     PT_HIP(ctx, hipGetLastError());
     s->n_inst = n;
     s->n_tlas_wide = o.n_wide;
-    s->tlas_height = o.height;
+    s->tlas_height = std::max(o.height, o.height_tree);  // (of the tree the TLAS was collapsed from: the stack bound)
     return PT_OK;
 }
