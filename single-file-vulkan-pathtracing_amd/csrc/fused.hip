@@ -30,6 +30,7 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     per_cu = std::max(1, std::min(per_cu, 8));
     per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
     fp.grid = ctx->num_cus * per_cu;
+    fp.block = FTB;
     // of 64: the share of a wave's live lanes that must wait with a finished ray before the shade block runs for them.  The block
     // is ~4x a node step, so it pays to run it fuller than k_extend's refill (16): 8 / 16 / 24 / 32 / 40 -> 33.9 / 34.1 / 34.6 /
     // 35.7 / 36.3 Grays/s on the Cornell box at 1080p (profiles/r04b_fused_refill_sweep.txt)

@@ -76,7 +76,7 @@ void ptw_launch_hits_to_api(const float4 *hit, const float4 *tri4, const uint32_
                             hipStream_t st);
 
 // ---- fused.hip ---------------------------------------------------------------------------------------------------------
-struct FusedPlan { size_t smem = 0; int grid = 0, lds_stack = 0, refill = 40; };
+struct FusedPlan { size_t smem = 0; int grid = 0, block = 0, lds_stack = 0, refill = 40; };
 pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp);
 void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst &rc, const uint32_t *tiles, const ptw::Radiance &rad,
                       const pt_scene *s, uint32_t n_slots, uint32_t *next_slot, unsigned long long *stats, float tmin, float tmax,
