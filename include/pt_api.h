@@ -77,7 +77,8 @@ typedef struct pt_tuning {
                                the per-(instance, triangle) table                                                         */
     int32_t tlas_ploc;      /* 1: the TLAS of an instanced scene is rebuilt by PLOC like a big scene's binary tree (0: LBVH)   */
     int32_t ploc_adopt_pct; /* a PLOC tree is kept when its area sum is below this percentage of the LBVH's (90; 1000 = always) */
-    int32_t reserved[6];
+    int32_t fail_rebuild;   /* tests: > 0 makes the next rebuilds of a scene's tree products fail after the old ones were freed */
+    int32_t reserved[5];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);

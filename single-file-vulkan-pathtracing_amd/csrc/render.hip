@@ -505,6 +505,10 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
 {
     pt_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
+    if (p_in->width > 0xFFFFu || p_in->height > 0xFFFFu) {  // (the kernel keeps a path's pixel as two 16-bit halves of one LDS word)
+        ctx->err = "PT_PIPELINE_FUSED renders images up to 65535 x 65535";
+        return PT_ERR_UNSUPPORTED;
+    }
     FusedPlan fp;
     pt_status rc_ = ptw_plan_fused(s, pl, p_in->tmin, fp);
     if (rc_ != PT_OK) return rc_;

@@ -194,6 +194,11 @@ static pt_status build_tree_products_unguarded(pt_scene *s, uint32_t quality, bo
     hipStream_t st = ctx->stream;
     const uint32_t n = s->n_tris, gt = (n + TB - 1) / TB;
     free_tree_products(s);
+    if (ctx->tune.fail_rebuild > 0 && (s->broken || s->n_nodes)) {  // tests: an out-of-memory rebuild, without the memory
+        ctx->tune.fail_rebuild--;
+        ctx->err = "hipMalloc: out of memory (pt_tuning.fail_rebuild)";
+        return PT_ERR_OOM;
+    }
     DevBuf<float4> d_tlo, d_thi;
     PT_HIP(ctx, d_tlo.alloc(n));
     PT_HIP(ctx, d_thi.alloc(n));

@@ -2178,3 +2178,56 @@ def test_fused_pipeline_full_size_c2_frame_equals_the_oracle_known_answer(pt, gp
         assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
         assert hashlib.sha256(film.read_bgra8().tobytes()).hexdigest() == m["bgra8_sha256"]
     film.close()
+
+
+def test_failed_rebuild_marks_the_scene_broken_and_the_next_use_repairs_it(pt, orc, gpu_ctx):
+    """a rebuild of a big scene's tree products frees the old ones first; if it then fails (out of memory
+    beside a large film workspace) the scene must not be traversed on null tables.  pt_tuning.fail_rebuild makes the next rebuild
+    fail right after the free: the call returns an error, the scene is unusable for exactly as long as rebuilds fail -- every
+    render / trace / read-back answers with a clean status, the film stays usable -- and the first call after that repairs it
+    and renders the same bits as before."""
+    v, i, f = _soup(6000, 77, spread=0.05)
+    v = v.reshape(-1, 3) * np.float32([0.9, 0.9, 0.9]) + np.float32([0, -1, 0])
+    scene = pt.Scene(gpu_ctx, v.reshape(-1), i, f)
+    w, h = 96, 64
+    kw = dict(width=w, height=h, spp_per_frame=4, max_depth=5, frame=0, frame_count=1)
+    film = pt.Film(gpu_ctx, w, h)
+    pt.render(scene, film, pt.default_params(**kw))
+    want = film.read_f32().tobytes()
+    rays = np.zeros((16, 6), np.float32); rays[:, 2] = 5; rays[:, 1] = -1; rays[:, 5] = -1
+    hits_before = scene.trace(rays).tobytes()
+    old = gpu_ctx.set_tuning(fail_rebuild=2)
+    try:
+        with pytest.raises(pt.PtError):
+            scene.set_bvh_quality(pt.BVH_PREFER_FAST_BUILD)          # the rebuild fails after the old tree is gone
+        film.clear()
+        with pytest.raises(pt.PtError):
+            pt.render(scene, film, pt.default_params(**kw))           # the repair attempt fails too (second forced failure)
+        assert not film.read_f32().any()                              # nothing touched the film
+        assert scene.info().n_wide_nodes == 0
+    finally:
+        gpu_ctx.set_tuning(**old)
+    film.clear()
+    pt.render(scene, film, pt.default_params(**kw))                   # repaired on this call (the quality that was asked for)
+    assert film.read_f32().tobytes() == want
+    assert scene.trace(rays).tobytes() == hits_before
+    scene.set_bvh_quality(pt.BVH_PREFER_FAST_TRACE)
+    film.clear()
+    pt.render(scene, film, pt.default_params(**kw))
+    assert film.read_f32().tobytes() == want
+    film.close(); scene.close()
+
+
+def test_sah_device_builder_makes_its_committed_trees(pt, gpu_ctx):
+    """The device surface-area BVH4 builder against the rows committed in tests/golden/sah_rows.npz (made on a GPU box by
+    tests/golden/make_sah_rows.py): the Cornell box and a 700-triangle soup, every node word."""
+    path = os.path.join(HERE, "golden", "sah_rows.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/sah_rows.npz not generated yet")
+    g = np.load(path)
+    for name, arrays in (("cornell", pt.load_obj(pt.ASSET_CORNELL)), ("soup700", _soup(700, 11))):
+        sc = pt.Scene(gpu_ctx, *arrays)
+        assert sc.info().bvh4_builder == 1
+        got = sc.read_bvh4()
+        assert got.shape == g[name].shape and got.tobytes() == g[name].tobytes(), name
+        sc.close()
