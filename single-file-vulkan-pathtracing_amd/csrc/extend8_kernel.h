@@ -20,9 +20,6 @@
 #pragma once
 #include "extend_kernel.h"
 
-#ifndef PT_NODE8_PERM
-#define PT_NODE8_PERM 0  // 1: plane bytes through v_perm_b32 + v_fma_mix_f32 instead of v_cvt_f32_ubyte + v_fma_f32 (A/B: profiles/r04g_*)
-#endif
 
 namespace {
 
@@ -159,26 +156,9 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 const ptm::f3 stp = { __uint_as_float((127u - ((hd.y >> 16) & 31u)) << 23), __uint_as_float((127u - ((hd.y >> 21) & 31u)) << 23),
                                       __uint_as_float((127u - (hd.y >> 26)) << 23) };
                 const ptm::f3 oi = { o.x * inv.x, o.y * inv.y, o.z * inv.z };
-                ptm::f3 on = { oi.x + bn.x, oi.y + bn.y, oi.z + bn.z };
-                ptm::f3 of = { __builtin_fmaf(oi.x, 1.0000004f, bf.x), __builtin_fmaf(oi.y, 1.0000004f, bf.y), __builtin_fmaf(oi.z, 1.0000004f, bf.z) };
+                const ptm::f3 on = { oi.x + bn.x, oi.y + bn.y, oi.z + bn.z };
+                const ptm::f3 of = { __builtin_fmaf(oi.x, 1.0000004f, bf.x), __builtin_fmaf(oi.y, 1.0000004f, bf.y), __builtin_fmaf(oi.z, 1.0000004f, bf.z) };
                 const ptm::f3 an = { stp.x * inv.x, stp.y * inv.y, stp.z * inv.z }, af = { an.x * 1.0000004f, an.y * 1.0000004f, an.z * 1.0000004f };
-#if PT_NODE8_PERM
-                // The plane bytes are not converted one by one (48 v_cvt_f32_ubyte at 4.2 cycles each, profiles/r04_valu_rate_ubench.txt):
-                // ONE v_perm_b32 with 0x64646464 turns two bytes of a row into two halves 0x6400 | q -- the fp16 number 1024 + q,
-                // exactly -- which v_fma_mix_f32 reads in place of the float: 24 permutes instead of 48 conversions per node.  The
-                // 1024 goes into the constant term, on - 1024 * an, whose own rounding (<= 2^-14 |an|: 1/16 000 of a grid step) is
-                // covered by moving it 2^-12 |an| down for near and up for far planes: one multiply-add per axis and side with
-                // -(1024 +- 2^-12), the sign by the ray's octant.  Box tests only have to be conservative; the hits are the same.
-                {
-                    const float kA = -1024.000244140625f, kB = -1023.999755859375f;   // -(1024 + 2^-12), -(1024 - 2^-12)
-                    const uint32_t uA = __float_as_uint(kA), uB = __float_as_uint(kB);
-                    const uint32_t mxm = (oct & 1u) ? 0xFFFFFFFFu : 0u, mym = (oct & 2u) ? 0xFFFFFFFFu : 0u, mzm = (oct & 4u) ? 0xFFFFFFFFu : 0u;
-                    on = { __builtin_fmaf(__uint_as_float(PT_BFI(mxm, uB, uA)), an.x, on.x), __builtin_fmaf(__uint_as_float(PT_BFI(mym, uB, uA)), an.y, on.y),
-                           __builtin_fmaf(__uint_as_float(PT_BFI(mzm, uB, uA)), an.z, on.z) };
-                    of = { __builtin_fmaf(__uint_as_float(PT_BFI(mxm, uA, uB)), af.x, of.x), __builtin_fmaf(__uint_as_float(PT_BFI(mym, uA, uB)), af.y, of.y),
-                           __builtin_fmaf(__uint_as_float(PT_BFI(mzm, uA, uB)), af.z, of.z) };
-                }
-#endif
                 // near / far rows by the ray's octant (bit-field insert with all-ones / all-zeros masks, as k_extend<hbm>):
                 // rows lo.x = q0.xy, lo.y = q0.zw, lo.z = q1.xy, hi.x = q1.zw, hi.y = q2.xy, hi.z = q2.zw (4 children per dword)
                 const uint32_t mx = (oct & 1u) ? 0xFFFFFFFFu : 0u, my = (oct & 2u) ? 0xFFFFFFFFu : 0u, mz = (oct & 4u) ? 0xFFFFFFFFu : 0u;
@@ -188,34 +168,6 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 // hit mask and the smallest entry distance, child by child (nothing per child stays live)
                 uint32_t h = 0;
                 float gmin = INF;
-#if PT_NODE8_PERM
-#define PT_PERM16(D, W, SEL) asm("v_perm_b32 %0, %1, %2, %3" : "=v"(D) : "v"(c64), "v"(W), "s"(SEL))
-#define PT_HIT8(K, HALF)                                                                                         \
-    {                                                                                                            \
-        float nxv, nyv, nzv, fxv, fyv, fzv;                                                                      \
-        PT_MIXH(nxv, pnx, HALF, an.x, on.x); PT_MIXH(nyv, pny, HALF, an.y, on.y); PT_MIXH(nzv, pnz, HALF, an.z, on.z); \
-        PT_MIXH(fxv, pfx, HALF, af.x, of.x); PT_MIXH(fyv, pfy, HALF, af.y, of.y); PT_MIXH(fzv, pfz, HALF, af.z, of.z); \
-        const float tn = fmaxf(fmaxf(nxv, nyv), max_raw_s(nzv, tmin));                                           \
-        const float tf = fminf(fminf(fxv, fyv), min_raw(fzv, best_t));                                           \
-        const bool hk = tn <= tf;                                                                                \
-        h |= hk ? (1u << (K)) : 0u;                                                                              \
-        gmin = hk ? min_raw(tn, gmin) : gmin;                                                                    \
-    }
-#define PT_SLAB8P(J)   /* children 2J and 2J + 1: bytes (2J & 3), (2J & 3) + 1 of row dword J >> 1 */                       \
-    {                                                                                                            \
-        uint32_t pnx, pny, pnz, pfx, pfy, pfz;                                                                   \
-        const uint32_t sel_ = ((J) & 1) ? 0x04030402u : 0x04010400u;                                             \
-        PT_PERM16(pnx, rnx[(J) >> 1], sel_); PT_PERM16(pny, rny[(J) >> 1], sel_); PT_PERM16(pnz, rnz[(J) >> 1], sel_); \
-        PT_PERM16(pfx, rfx[(J) >> 1], sel_); PT_PERM16(pfy, rfy[(J) >> 1], sel_); PT_PERM16(pfz, rfz[(J) >> 1], sel_); \
-        PT_HIT8(2 * (J), 0)                                                                                      \
-        PT_HIT8(2 * (J) + 1, 1)                                                                                  \
-    }
-                const uint32_t c64 = 0x64646464u;
-                PT_SLAB8P(0) PT_SLAB8P(1) PT_SLAB8P(2) PT_SLAB8P(3)
-#undef PT_SLAB8P
-#undef PT_HIT8
-#undef PT_PERM16
-#else
 #define PT_BYTE(W, B) ((float)(((W) >> (8 * (B))) & 0xFFu))   /* v_cvt_f32_ubyteB */
 #define PT_SLAB8(K)                                                                                               \
     {                                                                                                             \
@@ -228,7 +180,10 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
            is one 240-instruction block instead of nine and 4 % SLOWER on C5: profiles/r03ab_ab_c5_node8_variants.log;           \
            two children per v_pk_fma_f32 -- 24 packed multiply-adds instead of 48 -- needs the twelve distances of a pair live   \
            at once: 10 spilled registers at 6 waves (-30 %), -6 % at 5 waves without spills, -1.5 % with only the near planes   \
-           packed: profiles/r03be_ab_c5_pkfma.log) */                                                                           \
+           packed: profiles/r03be_ab_c5_pkfma.log; round 4: the bytes through ONE v_perm_b32 per pair of children into halves     \
+           0x6400 | q = 1024 + q that v_fma_mix_f32 reads, the 1024 folded into the constant term with a 2^-12-step margin -- 24  \
+           permutes instead of 48 conversions, and v_cvt_f32_ubyte issues at 4.2 cycles like a permute, not at 2.5: the node     \
+           step loses 7 instructions of 240, C5 -1 %, C5x -20 % (6 dwords spilled at 72 VGPRs): profiles/r04g_ab_node8_perm_*)  */ \
         const bool hk = tn <= tf;                                                                                 \
         h |= hk ? (1u << (K)) : 0u;                                                                               \
         gmin = hk ? min_raw(tn, gmin) : gmin;                                                                     \
@@ -236,7 +191,6 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 PT_SLAB8(0) PT_SLAB8(1) PT_SLAB8(2) PT_SLAB8(3) PT_SLAB8(4) PT_SLAB8(5) PT_SLAB8(6) PT_SLAB8(7)
 #undef PT_SLAB8
 #undef PT_BYTE
-#endif
                 const uint32_t nim = hd.z >> 24, lm = hd.w >> 24;
                 h &= nim | lm;   // (empty slots are inverted intervals, never hit; the mask costs one instruction)
                 uint32_t hi_ = h & nim;

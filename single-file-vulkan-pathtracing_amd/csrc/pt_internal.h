@@ -135,6 +135,7 @@ struct pt_film {
     // wavefront workspace, (re)allocated by pt_render for (rank, world, frames_in_flight)
     struct Work {
         uint32_t rank = 0, world = 0, lanes = 0;  // lanes = frames in flight
+        uint32_t tile_order = 0;                  // 0: the rank's tiles row by row, 1: centre first (fused pipeline; film_work.hip)
         uint32_t groups = 0, term_cap = 0;        // sample groups per pixel, radiance-term log capacity per slot
         uint32_t n_tiles = 0;                     // local 8x8 tiles
         uint32_t n_slots = 0;                     // lanes * n_tiles * 64

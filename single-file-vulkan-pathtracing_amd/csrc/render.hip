@@ -477,13 +477,12 @@ pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const Ex
 }
 
 // ---- PT_PIPELINE_FUSED (fused.hip, fused_kernel.h) ---------------------------------------------------------------------------
-// The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches); sample groups
-// only to shorten the tail of a batch.  The slot counter balances the waves until it runs out; after that every lane finishes
-// the slot it holds, so a batch ends with about one slot's time at half occupancy, and a slot of 32 samples is up to 256 rays:
-// the groups are chosen so that a lane works through >= 64 slots per batch (a whole 1080p image: 16 frames x 1 group, 2 x 8,
-// 1 x 16; a rank of world 8 at 32 frames: 4 groups -- with one it reached 83 % of a perfect split, profiles/r04_shard_efficiency_fused.json).
-// Explicit frames_in_flight / sample_groups are taken as given.
-void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan &fp, pt_params &q)
+// The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches); sample groups only
+// where a batch would otherwise hold too few slots to balance: frames x groups >= 16.  (Groups cost the fused kernel ~10 % -- a
+// scattered 16-B store per radiance term instead of an add in LDS -- so they are not used to shorten the drain of a launch: a
+// rule that gave every lane >= 64 slots per batch was slower at world 4 and equal at world 8, profiles/r04g_fused_shards_by_shape.txt;
+// the centre-first tile order of film_work.hip does that.)  Explicit frames_in_flight / sample_groups are taken as given.
+void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &, pt_params &q)
 {
     q = *p;
     if (q.frames_in_flight == 0) {
@@ -493,10 +492,8 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
     }
     q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
     if (q.sample_groups == 0) {
-        const uint64_t pixels_local = ((uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull + p->world - 1) / p->world;
-        const uint64_t want_slots = 64ull * (uint64_t)fp.grid * (uint64_t)fp.block;
         uint32_t g = 1;
-        while (g < p->spp_per_frame && ((uint64_t)g * q.frames_in_flight * pixels_local < want_slots || p->spp_per_frame % g)) g++;
+        while (g < p->spp_per_frame && (g * q.frames_in_flight < 16u || p->spp_per_frame % g)) g++;
         q.sample_groups = g;
     }
 }

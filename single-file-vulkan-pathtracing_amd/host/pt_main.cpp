@@ -5,7 +5,7 @@
 //
 //   pt_main [--obj assets/CornellBox-Original.obj] [--width 1024] [--height 1024]
 //           [--frames 1] [--spp 32] [--depth 8] [--device 0] [--batch N]
-//           [--ppm out.ppm] [--pfm out.pfm]
+//           [--ppm out.ppm] [--pfm out.pfm] [--pipeline wavefront|fused|nee]
 //           [--ranks N [--devices 0,1,...]]
 // --ranks N renders with N GPUs: one host thread and one context per GPU, the 8x8 pixel tiles interleaved over the
 // ranks (pt_params.rank/world), and ONE RCCL gather of the packed tiles to rank 0 per presented image
@@ -36,6 +36,7 @@ struct Options {
     std::string obj = "assets/CornellBox-Original.obj", ppm, pfm;
     uint32_t width = 1024, height = 1024, frames = 1, spp = 32, depth = 8, batch = 0;
     int device = 0;
+    uint32_t pipeline = PT_PIPELINE_WAVEFRONT;
     uint32_t ranks = 1;          // --ranks N: one host thread + one GPU per rank, tiles interleaved, RCCL gather to rank 0
     std::vector<int> devices;    // --devices a,b,...: HIP ordinals of the ranks (default 0..N-1)
 };
@@ -97,6 +98,7 @@ void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_uni
         pt_params_default(&p);
         p.width = o.width; p.height = o.height; p.spp_per_frame = o.spp; p.max_depth = o.depth;
         p.frames_in_flight = o.batch;
+        p.pipeline = o.pipeline;
         p.rank = rank; p.world = o.ranks;
         // the reference dispatches one frame per loop iteration (main.cpp:647-685); frames are
         // independent until the blend, so they are handed over in one call and batched on the device
@@ -160,6 +162,10 @@ int main(int argc, char **argv)
                 o.devices.push_back(std::atoi(v.substr(b, e - b).c_str()));
                 b = e + 1;
             }
+        }
+        else if (a == "--pipeline") {  // same image from wavefront and fused (fused: scenes that fit LDS); nee is another estimator
+            const std::string v = val();
+            o.pipeline = v == "fused" ? PT_PIPELINE_FUSED : v == "nee" ? PT_PIPELINE_WAVEFRONT_NEE : PT_PIPELINE_WAVEFRONT;
         }
         else if (a == "--ppm") o.ppm = val();
         else if (a == "--pfm") o.pfm = val();
