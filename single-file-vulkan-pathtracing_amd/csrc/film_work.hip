@@ -84,7 +84,10 @@ pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t la
     // on the cheapest guess there is -- a camera looks at its subject: in the reference's view the outer ring of the image misses
     // the box after one ray, 32 rays per slot against ~130 inside), which cuts the ~3 ms drain of a launch to the length of a
     // border slot.  Results cannot depend on it (slot -> pixel goes through this table everywhere).
-    const uint32_t order = queues ? 0u : 1u;
+    // (one sample group only: with many short slots per pixel the whole chip reaches the cheap border ring at the same time and
+    // every wave wants a new batch of slots every few microseconds -- more than the one counter word takes: one blocking 1080p
+    // frame of 16 groups went from 6.8 to 10.9 ms; short slots have no drain worth ordering for anyway)
+    const uint32_t order = (!queues && groups == 1u) ? 1u : 0u;
     if (!w.d_tiles || w.rank != rank || w.world != world || w.tile_order != order) {
         (void)hipFree(w.d_tiles);
         w.d_tiles = nullptr;
@@ -283,12 +286,13 @@ RenderShape ptw_choose_shape(const pt_film *f, const pt_params *p, int launch_cl
     sh.term_cap = worst;
     sh.term_pcap = std::min(worst, sh.group_size + 2u);  // ~1 term per sample is typical (the miss that ends it)
     if (sh.groups > 1 && can_redo) {
-        // overflow log within a budget (16 GB, a quarter of the free memory) instead of the worst case (136 GB for
-        // 16 frames x 4 groups at 1080p); a slot that fills it raises a flag and the batch is redone with groups == 1
+        // overflow log within a budget (2 GB -- 16 GB until round 4: the Cornell frame renders as fast with none at all and never
+        // overflows the shared pool, profiles/r04h_overflow_log.txt -- and a quarter of the free memory) instead of the worst case
+        // (136 GB for 16 frames x 4 groups at 1080p); a slot that fills it and the pool raises a flag and the batch is redone with groups == 1
         const uint64_t n_slots = (uint64_t)lanes * sh.groups * pixels_local;
         const uint64_t room = avail > planned(lanes, sh.groups) ? avail - planned(lanes, sh.groups) : 0;
         // (the fused pipeline is there to run in a small workspace: 1 GB of overflow log; the shared pool and the redo cover the rest)
-        const uint64_t budget = std::min<uint64_t>(std::min<uint64_t>(launch_class == 3 ? 1ull << 30 : 16ull << 30, (have_log + free_b) / 4), room);
+        const uint64_t budget = std::min<uint64_t>(std::min<uint64_t>(launch_class == 3 ? 1ull << 30 : 2ull << 30, (have_log + free_b) / 4), room);
         uint64_t ocap = std::min<uint64_t>(worst - sh.term_pcap, budget / std::max<uint64_t>(n_slots * sizeof(float4), 1));
         if (f->ctx->tune.term_ocap >= 0) ocap = std::min<uint64_t>(ocap, (uint64_t)f->ctx->tune.term_ocap);  // tests
         sh.term_cap = sh.term_pcap + (uint32_t)ocap;
