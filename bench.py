@@ -64,7 +64,7 @@ BYTES_PER_PATH = 96.0
 _MODEL = os.path.join(REPO, "profiles", "isa_valu_model.json")
 ISA_VALU_MODEL = json.load(open(_MODEL)) if os.path.exists(_MODEL) else None
 # which PMC record (scripts/make_pmc_json.py) carries the HBM-side traffic of a config's traversal kernel
-PMC_RECORD = "r03_pmc_extend_{config}.json"
+PMC_RECORD = "r04_pmc_extend_{config}.json"
 PMC_RECORD_SHADE = "r04_pmc_shade_{config}.json"
 
 

@@ -22,7 +22,7 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     }
     fp.lds_stack = pl.lds_stack;
     fp.smem = (size_t)pl.lds_stack * FTB * sizeof(uint32_t) + (pl.smem - (size_t)pl.lds_stack * TB * sizeof(uint32_t)) + tables +
-              sizeof(uint32_t) * FS_FIELDS * FTB + sizeof(uint32_t) * (FTB / 64) * (PT_FUSED_BATCH / 64);
+              sizeof(uint32_t) * FS_FIELDS * FTB + sizeof(uint32_t) * (FTB / 64) * PT_FUSED_WTILES;
     for (const void *fn : { reinterpret_cast<const void *>(k_fused<false>), reinterpret_cast<const void *>(k_fused<true>) })
         if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
     int per_cu = 0;

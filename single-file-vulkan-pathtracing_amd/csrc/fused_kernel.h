@@ -38,8 +38,15 @@
 constexpr int FTB = PT_FUSED_TB;
 
 #ifndef PT_FUSED_BATCH
-#define PT_FUSED_BATCH 256  // most slots a wave draws per atomic (a multiple of 64: 64 consecutive slots are one 8x8 tile)
+#define PT_FUSED_BATCH 256  // most slots a wave draws per atomic with one sample group (a multiple of 64: 64 consecutive slots are one 8x8 tile)
 #endif
+#ifndef PT_FUSED_GSCALE
+#define PT_FUSED_GSCALE 8   // ... times min(sample groups, this)
+#endif
+#ifndef PT_FUSED_GUIDED
+#define PT_FUSED_GUIDED 1
+#endif
+#define PT_FUSED_WTILES (PT_FUSED_BATCH / 64 * PT_FUSED_GSCALE)  // tile words a wave keeps in LDS for its current batch
 
 // path state in LDS, [field][thread]
 enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS_B, FS_C, FS_FIELDS };
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
-    lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * (PT_FUSED_BATCH / 64);
+    lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * PT_FUSED_WTILES;
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
     uint32_t ax = 0, ay = 0, az = 0, tri_base = 0;
@@ -212,10 +219,18 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     // (a rank of world 8 at config C3's size lost 23 % of a perfect split to that tail, 11 % of world 4)
                     uint32_t base = 0, size = 0;
                     if (lane == 0) {
+#if PT_FUSED_GUIDED
                         const uint32_t seen = __atomic_load_n(next_slot, __ATOMIC_RELAXED);
                         const uint32_t left = seen < n_slots ? n_slots - seen : 0u;
+#else
+                        const uint32_t left = 0xFFFFFFFFu;
+#endif
                         const uint32_t share = left / (2u * gridDim.x * (uint32_t)(FTB / 64));
-                        size = min((uint32_t)PT_FUSED_BATCH, max(64u, share & ~63u));
+                        // (with G sample groups a slot is 1/G as long: batches G times as large, up to 8x, keep the counter at the same
+                        // rate -- one blocking 1080p frame of 16 groups asked for ~150 batches per microsecond at 256 slots each, the
+                        // word takes ~88: 10.7 ms instead of 6.8)
+                        const uint32_t gs = GROUPED ? min(rc.groups, (uint32_t)PT_FUSED_GSCALE) : 1u;
+                        size = min((uint32_t)PT_FUSED_BATCH * gs, max(64u * gs, share & ~63u));
                         base = atomicAdd(next_slot, size);
                     }
                     base = __builtin_amdgcn_readfirstlane(base);

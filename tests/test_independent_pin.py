@@ -17,7 +17,7 @@ A path whose hit decision flips on such an ulp continues elsewhere, so the toler
         traceRayEXT counts on >= 99.9 % of the pixels;
   (iii) 64 samples per pixel (two launches of the shader's own 32): image relMSE <= 1e-3.
 
-Measured values are written into BASELINE.md section 7.  The CPU tests hold the oracle to this, the GPU tests
+Measured values are written into BASELINE.md section 8.  The CPU tests hold the oracle to this, the GPU tests
 (`-m gpu`) the HIP path through the C-ABI.
 """
 import os
