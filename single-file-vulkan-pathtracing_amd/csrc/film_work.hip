@@ -116,7 +116,7 @@ pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t la
         ctx->err = "too many path slots (frames_in_flight x sample_groups x pixels >= 2^31)";
         return PT_ERR_INVALID_ARG;
     }
-    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * 2 * PT_MAX_PIPES));  // queue sizes, 2 per pipeline
+    if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * PTW_COUNT_WORDS));  // queue sizes, 2 per pipeline | the fused kernel's slot counters
     const WorkNeed need = work_need(n_slots64, groups, term_cap, term_pcap, queues);
     const size_t ns = need.slots;
     const size_t limit = ctx->mem_budget;

@@ -14,9 +14,9 @@
 //     (`refill`), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
 //     raygen.rgen:76-83, the next sample's camera ray (raygen.rgen:45-60), or the first sample of a NEW slot -- and set up
 //     their next ray; the same operations in the same order as k_shade, so the film is the wavefront pipeline's bit for bit;
-//   * slots (frame, sample group, pixel) are handed out in order by one device-scope counter, PT_FUSED_BATCH at a time per
-//     wave (one atomic per ~27 000 rays: the counter sees ~1 atomic per microsecond, the chip sustains ~88 on one word),
-//     so a wave that drew cheap border pixels simply takes more of them -- no tail beyond the last batch's own length;
+//   * slots (frame, sample group, pixel) are handed out in order by device-scope counters -- eight, one per XCD's share of the
+//     workgroups, with work stealing between them -- PT_FUSED_BATCH at a time per wave, so a wave that drew cheap border
+//     pixels simply takes more of them: no tail beyond the last batch's own length;
 //   * path state that only the shade block touches (slot, sample | depth, seed, weight, pixel, the slot's colour or its
 //     term count) lives in LDS, [field][thread]: the traversal loop keeps the registers it has in k_extend_lds7p.
 //
@@ -38,15 +38,11 @@
 constexpr int FTB = PT_FUSED_TB;
 
 #ifndef PT_FUSED_BATCH
-#define PT_FUSED_BATCH 256  // most slots a wave draws per atomic with one sample group (a multiple of 64: 64 consecutive slots are one 8x8 tile)
+#define PT_FUSED_BATCH 256  // most slots a wave draws per atomic (a multiple of 64: 64 consecutive slots are one 8x8 tile)
 #endif
-#ifndef PT_FUSED_GSCALE
-#define PT_FUSED_GSCALE 8   // ... times min(sample groups, this)
-#endif
-#ifndef PT_FUSED_GUIDED
-#define PT_FUSED_GUIDED 1
-#endif
-#define PT_FUSED_WTILES (PT_FUSED_BATCH / 64 * PT_FUSED_GSCALE)  // tile words a wave keeps in LDS for its current batch
+#define PT_FUSED_WTILES (PT_FUSED_BATCH / 64)  // tile words a wave keeps in LDS for its current batch
+#define PT_FUSED_PARTS 8          // slot counters (one per XCD's share of the workgroups)
+#define PT_FUSED_PART_STRIDE 32   // ... in dwords: one 128-B line each
 
 // path state in LDS, [field][thread]
 enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS_B, FS_C, FS_FIELDS };
@@ -101,6 +97,8 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
+    uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;  // ... the part of the slot range it draws from, parts found empty
+    const uint32_t part_len = ((n_slots + PT_FUSED_PARTS - 1) / PT_FUSED_PARTS + 63u) & ~63u;
     lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * PT_FUSED_WTILES;
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
@@ -213,36 +211,42 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             const unsigned long long m_want = __ballot(in_blk && !path);
             if (m_want && !out_of_slots) {
                 if (w_next >= w_end) {
-                    // guided self-scheduling: PT_FUSED_BATCH slots while plenty are left, then -- from a (possibly stale) look at
-                    // the counter -- no more than what is left / (2 x the grid's waves), down to one tile: the last batches
-                    // handed out run alone at the end of the launch, and 256 slots of 32 samples are ~3 ms of a wave's time
-                    // (a rank of world 8 at config C3's size lost 23 % of a perfect split to that tail, 11 % of world 4)
-                    uint32_t base = 0, size = 0;
-                    if (lane == 0) {
-#if PT_FUSED_GUIDED
-                        const uint32_t seen = __atomic_load_n(next_slot, __ATOMIC_RELAXED);
-                        const uint32_t left = seen < n_slots ? n_slots - seen : 0u;
-#else
-                        const uint32_t left = 0xFFFFFFFFu;
-#endif
-                        const uint32_t share = left / (2u * gridDim.x * (uint32_t)(FTB / 64));
-                        // (with G sample groups a slot is 1/G as long: batches G times as large, up to 8x, keep the counter at the same
-                        // rate -- one blocking 1080p frame of 16 groups asked for ~150 batches per microsecond at 256 slots each, the
-                        // word takes ~88: 10.7 ms instead of 6.8)
-                        const uint32_t gs = GROUPED ? min(rc.groups, (uint32_t)PT_FUSED_GSCALE) : 1u;
-                        size = min((uint32_t)PT_FUSED_BATCH * gs, max(64u * gs, share & ~63u));
-                        base = atomicAdd(next_slot, size);
+                    // The slots are cut into PT_FUSED_PARTS contiguous parts with a counter each, 128 B apart; a wave starts on part
+                    // blockIdx % 8 -- workgroups go to the eight XCDs round-robin, so the waves of one XCD share a word -- and moves
+                    // on to the next part when its own is exhausted (work stealing, in ring order) until all eight are.  One word takes
+                    // ~88 atomics per microsecond on this chip; shapes with many short slots (several sample groups) ask for more.
+                    // One group: guided self-scheduling on top -- PT_FUSED_BATCH slots while plenty are left in the part, then, from
+                    // a look at its counter, no more than what is left / (2 x the waves that share it), down to one tile: the last
+                    // batches handed out run alone at the end of the launch, and 256 slots of 32 samples are ~3 ms of a wave's time
+                    // (a rank of world 8 at config C3's size: 28.6 -> 25.1 ms).  Several groups: always PT_FUSED_BATCH
+                    // (profiles/r04j_fused_batch_policy.log).
+                    for (;;) {
+                        const uint32_t part_begin = w_part * part_len, part_end = min(part_begin + part_len, n_slots);
+                        uint32_t rel = 0, size = 0;
+                        if (lane == 0) {
+                            uint32_t *cnt = next_slot + w_part * (uint32_t)PT_FUSED_PART_STRIDE;
+                            size = (uint32_t)PT_FUSED_BATCH;
+                            if (!GROUPED) {
+                                const uint32_t seen = __atomic_load_n(cnt, __ATOMIC_RELAXED);
+                                const uint32_t left = part_begin + seen < part_end ? part_end - part_begin - seen : 0u;
+                                const uint32_t share = left / max(2u * gridDim.x * (uint32_t)(FTB / 64) / (uint32_t)PT_FUSED_PARTS, 1u);
+                                size = min((uint32_t)PT_FUSED_BATCH, max(64u, share & ~63u));
+                            }
+                            rel = atomicAdd(cnt, size);
+                        }
+                        rel = __builtin_amdgcn_readfirstlane(rel);
+                        size = __builtin_amdgcn_readfirstlane(size);
+                        if (part_begin < part_end && rel < part_end - part_begin) {
+                            w_base = w_next = part_begin + rel;
+                            w_end = min(w_next + size, part_end);
+                            break;
+                        }
+                        w_part = (w_part + 1u) % (uint32_t)PT_FUSED_PARTS;
+                        if (++w_tried >= (uint32_t)PT_FUSED_PARTS) { out_of_slots = true; w_end = w_next; break; }
                     }
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    size = __builtin_amdgcn_readfirstlane(size);
-                    w_base = w_next = base;
-                    w_end = min(base + size, n_slots);
-                    if (base >= n_slots) { out_of_slots = true; w_end = w_next; }
-                    else if ((uint32_t)lane < size / 64u) {
-                        const uint32_t c = slot_base + base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
-                        uint32_t word = 0u;
-                        if (base + 64u * (uint32_t)lane < n_slots) word = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
-                        s_wtile[lane] = word;
+                    if (!out_of_slots && (uint32_t)lane < (w_end - w_base + 63u) / 64u) {
+                        const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
+                        s_wtile[lane] = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
                     }
                     __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order: the reads below see these words)
                 }

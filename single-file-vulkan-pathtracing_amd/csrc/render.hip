@@ -478,10 +478,12 @@ pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const Ex
 
 // ---- PT_PIPELINE_FUSED (fused.hip, fused_kernel.h) ---------------------------------------------------------------------------
 // The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches); sample groups only
-// where a batch would otherwise hold too few slots to balance: frames x groups >= 16.  (Groups cost the fused kernel ~10 % -- a
-// scattered 16-B store per radiance term instead of an add in LDS -- so they are not used to shorten the drain of a launch: a
-// rule that gave every lane >= 64 slots per batch was slower at world 4 and equal at world 8, profiles/r04g_fused_shards_by_shape.txt;
-// the centre-first tile order of film_work.hip does that.)  Explicit frames_in_flight / sample_groups are taken as given.
+// where a batch holds so few frames that its drain shows -- the last slots handed out run alone at the end of the launch, and a
+// slot of 32 samples is up to 256 rays = ~3 ms of a lane's time against ~6 ms for a frame.  Measured at 1080p, ms per frame by
+// (frames, groups), profiles/r04k_fused_groups_by_frames.log: 1 frame 8.40 / 7.22 / 6.73 / 6.55 with 1 / 8 / 16 / 32 groups; 2 frames
+// 7.75 / 6.55 / 6.37 / 6.31; 4 frames 6.49 / 6.26 / 6.17 / 6.18; 8 frames 6.01 / 6.11 / 6.09 / 6.13 -- and two groups are worse than
+// one everywhere (groups cost the kernel ~10 %: a scattered 16-B store per radiance term instead of an add in LDS).  So: one group
+// from 8 frames on, else frames x groups >= 32.  Explicit frames_in_flight / sample_groups are taken as given.
 void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &, pt_params &q)
 {
     q = *p;
@@ -493,7 +495,8 @@ void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &
     q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
     if (q.sample_groups == 0) {
         uint32_t g = 1;
-        while (g < p->spp_per_frame && (g * q.frames_in_flight < 16u || p->spp_per_frame % g)) g++;
+        if (q.frames_in_flight < 8u)
+            while (g < p->spp_per_frame && (g * q.frames_in_flight < 32u || p->spp_per_frame % g)) g++;
         q.sample_groups = g;
     }
 }
@@ -542,7 +545,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
             PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
             PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
         }
-        PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t), st));  // the slot counter
+        PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * PTW_COUNT_WORDS, st));  // the slot counters (fused_kernel.h: eight, 128 B apart)
         const uint32_t n_slots = rc.lanes_active * sh.groups * rc.slots_per_lane;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) {

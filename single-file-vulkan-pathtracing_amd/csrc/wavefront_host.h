@@ -75,6 +75,8 @@ void ptw_launch_resolve(const ptw::RenderConst &rc, const uint32_t *tiles, const
 void ptw_launch_hits_to_api(const float4 *hit, const float4 *tri4, const uint32_t *hit_inst, const uint32_t *inst_id, uint32_t n, pt_hit *out,
                             hipStream_t st);
 
+constexpr size_t PTW_COUNT_WORDS = 8 * 32;  // pt_film::Work::d_count: the wavefront's queue sizes (2 per pipeline) | eight slot counters of the fused kernel, one 128-B line each
+
 // ---- fused.hip ---------------------------------------------------------------------------------------------------------
 struct FusedPlan { size_t smem = 0; int grid = 0, block = 0, lds_stack = 0, refill = 40; };
 pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp);
