@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_API_VERSION 3
+#define PT_API_VERSION 4  /* 4: PT_PIPELINE_FUSED; pt_tuning.tlas_ploc / ploc_adopt_pct / fail_rebuild (taken from `reserved`: same size) */
 
 typedef enum pt_status {
     PT_OK = 0,

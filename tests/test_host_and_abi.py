@@ -148,14 +148,15 @@ def test_struct_layouts_match_header(pt, tmp_path):
     import shutil
     import subprocess
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %d\\n",'
-                   'sizeof(pt_params), sizeof(pt_stats), sizeof(pt_scene_info), offsetof(pt_params, sample_groups),'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\\n",'
+                   'sizeof(pt_tuning), sizeof(pt_params), sizeof(pt_stats), sizeof(pt_scene_info), offsetof(pt_params, sample_groups),'
                    'offsetof(pt_stats, workspace_bytes), offsetof(pt_stats, wave_refills), offsetof(pt_scene_info, tree_area_ploc), PT_API_VERSION);return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call([shutil.which("gcc") or "gcc", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
-    assert got == [C.sizeof(pt.Params), C.sizeof(pt.Stats), C.sizeof(pt.SceneInfo), pt.Params.sample_groups.offset,
-                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.tree_area_ploc.offset, 3], got
+    assert got == [C.sizeof(pt.Tuning), C.sizeof(pt.Params), C.sizeof(pt.Stats), C.sizeof(pt.SceneInfo), pt.Params.sample_groups.offset,
+                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.tree_area_ploc.offset, 4], got
+    assert C.sizeof(pt.Tuning) == 4 * 32 and pt.PIPELINE_FUSED == 2
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
     p = pt.default_params()
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
