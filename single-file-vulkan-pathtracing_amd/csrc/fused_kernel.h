@@ -97,11 +97,8 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
-    // (eight parts for whole-image jobs; a small job -- a rank's share of a sharded image -- keeps ONE counter: its drain is what
-    // costs it, and the guided batches see all that is left: rank 0 of world 8 at C3's size 25.5 ms with one, 26.3 with eight)
-    const uint32_t plog = n_slots >= (16u << 20) ? 3u : 0u, n_parts = 1u << plog;   // (PT_FUSED_PARTS = 8)
-    uint32_t w_part = blockIdx.x & (n_parts - 1u), w_tried = 0;  // ... the part of the slot range it draws from, parts found empty
-    const uint32_t part_len = (((n_slots + n_parts - 1u) >> plog) + 63u) & ~63u;
+    uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;  // ... the part of the slot range it draws from, parts found empty
+    const uint32_t part_len = ((n_slots + PT_FUSED_PARTS - 1) / PT_FUSED_PARTS + 63u) & ~63u;
     lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * PT_FUSED_WTILES;
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
@@ -232,7 +229,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                             if (!GROUPED) {
                                 const uint32_t seen = __atomic_load_n(cnt, __ATOMIC_RELAXED);
                                 const uint32_t left = part_begin + seen < part_end ? part_end - part_begin - seen : 0u;
-                                const uint32_t share = left / max((2u * gridDim.x * (uint32_t)(FTB / 64)) >> plog, 1u);
+                                const uint32_t share = left / max(2u * gridDim.x * (uint32_t)(FTB / 64) / (uint32_t)PT_FUSED_PARTS, 1u);
                                 size = min((uint32_t)PT_FUSED_BATCH, max(64u, share & ~63u));
                             }
                             rel = atomicAdd(cnt, size);
@@ -244,8 +241,8 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                             w_end = min(w_next + size, part_end);
                             break;
                         }
-                        w_part = (w_part + 1u) & (n_parts - 1u);
-                        if (++w_tried >= n_parts) { out_of_slots = true; w_end = w_next; break; }
+                        w_part = (w_part + 1u) % (uint32_t)PT_FUSED_PARTS;
+                        if (++w_tried >= (uint32_t)PT_FUSED_PARTS) { out_of_slots = true; w_end = w_next; break; }
                     }
                     if (!out_of_slots && (uint32_t)lane < (w_end - w_base + 63u) / 64u) {
                         const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
