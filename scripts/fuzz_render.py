@@ -1,5 +1,5 @@
 """dev tool: randomized render parity -- random film sizes (ragged), spp, depth, frame ranges, frames in flight,
-sample groups, rank/world splits, extend variants, cameras -- GPU film vs the oracle's, bit for bit."""
+sample groups, rank/world splits, extend variants, both pipelines, cameras -- GPU film vs the oracle's, bit for bit."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,6 +36,8 @@ for k in range(N):
         film = pt.Film(ctx, w, h)
         gk = dict(kw, rank=rank, world=world, frames_in_flight=int(rng.choice([0, 1, 2, 5])), sample_groups=int(rng.choice([0, 1, 2, 3, spp])),
                   extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_FLAT])))
+        if rng.random() < 0.4:   # the fused single-kernel pipeline (LDS scenes; it walks its own copy of the compact pair-leaf tree)
+            gk.update(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_AUTO)
         if f0:
             pt.render(sc, film, pt.default_params(frame=0, frame_count=f0, **gk))
         pt.render(sc, film, pt.default_params(frame=f0, frame_count=nf, **gk))

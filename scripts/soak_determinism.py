@@ -3,10 +3,13 @@ two-pipeline scheduling, lane refill, compaction atomics and term logs)."""
 import hashlib, importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
-ctx = pt.Context(0); sc = pt.Scene.from_obj(ctx); film = pt.Film(ctx, 1920, 1080)
+ctx = pt.Context(0); sc = pt.Scene(ctx, *pt.load_obj(pt.ASSET_CORNELL)); film = pt.Film(ctx, 1920, 1080)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cases = [dict(frame_count=8), dict(frame_count=8, sample_groups=4, frames_in_flight=2), dict(frame_count=3, rank=1, world=3),
-         dict(frame_count=5, frames_in_flight=1, sample_groups=1)]
+         dict(frame_count=5, frames_in_flight=1, sample_groups=1),
+         # the fused single-kernel pipeline: dynamic slot hand-out, work stealing between the eight counters, term logs
+         dict(frame_count=8, pipeline=pt.PIPELINE_FUSED), dict(frame_count=2, pipeline=pt.PIPELINE_FUSED),
+         dict(frame_count=3, rank=1, world=3, pipeline=pt.PIPELINE_FUSED), dict(frame_count=1, sample_groups=32, pipeline=pt.PIPELINE_FUSED)]
 t0 = time.time()
 for c in cases:
     hashes = set(); rays = set()
