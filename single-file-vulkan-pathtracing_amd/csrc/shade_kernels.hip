@@ -133,7 +133,8 @@ __global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad,
 // instead of one per item).  Alone on the chip (one pipeline) k_shade gets 13 % faster with it at 5 waves (91 VGPRs, no
 // spills: 104 -> 90 ms per 16 C2 frames); next to the other pipeline's traversal kernel, which is how it runs, nothing
 // changes (three interleaved repetitions, profiles/r02_shade_preload.txt) -- the frame is bound by the VALU work of both
-// kernels, not by k_shade's latency -- so the simpler code stays the default.
+// kernels, not by k_shade's latency -- so the simpler code stays the default.  Round 4, at 7 waves, all four configs: C5 / C5x / C4
+// within 0.3 %, C2 -1.1 % (profiles/r04o_ab_shade_preload_*.log).
 #ifndef PT_SHADE_PRELOAD
 #define PT_SHADE_PRELOAD 0
 #endif
@@ -248,6 +249,13 @@ __global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE
                 if (LDS_TABLES) {
                     s0 = shade4[3 * pos + 0]; s1 = shade4[3 * pos + 1]; s2 = shade4[3 * pos + 2];
                 } else {
+                    // the three vertex rows of the same 64-B record are requested WITH its fourth row, not after the emission test that
+                    // waits for it: one gather round trip per hit instead of two (the second one short -- the line is on its way --
+                    // but still a full wait of the wave); a path that ends here does not need them and does not ask.  k_shade -5 %,
+                    // C5 +0.8 %, C5x +0.7 %, three of three rounds each (profiles/r04p_ab_shade_hoist_*.log)
+                    if (depth + 1u < rc.max_depth) {
+                        a = shade64[4 * (size_t)pos + 0]; b = shade64[4 * (size_t)pos + 1]; c = shade64[4 * (size_t)pos + 2];
+                    }
                     const float4 r3 = shade64[4 * (size_t)pos + 3];
                     const float4 ke = r3.w != 0.f ? ke4[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
                     s0 = make_float4(0.f, 0.f, 0.f, r3.x); s1 = make_float4(r3.y, r3.z, ke.x, ke.y); s2 = make_float4(ke.z, 0.f, 0.f, 0.f);
@@ -266,7 +274,6 @@ __global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE
                     if (LDS_TABLES) {
                         a = tri4[3 * pos + 0]; b = tri4[3 * pos + 1]; c = tri4[3 * pos + 2];
                     } else {
-                        a = shade64[4 * (size_t)pos + 0]; b = shade64[4 * (size_t)pos + 1]; c = shade64[4 * (size_t)pos + 2];
                         s0.x = a.w; s0.y = b.w; s0.z = c.w;
                     }
                     // closesthit.rchit:56-57: position from barycentrics, (v0*b0 + v1*b1) + v2*b2
