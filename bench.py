@@ -367,6 +367,24 @@ def extra_leg(pt, ctx, W, H, config, frames, rank):
         out["ingest"] = ingest
     if config == "c4":
         out["bvh"].update({"instances": info.n_instances, "tlas_nodes": info.n_tlas_nodes, "tlas_build_wall_ms": round(tlas_ms, 3)})
+        try:   # the same frames through PT_PIPELINE_FUSED's two-level kernel (csrc/fused_inst_kernel.h), opt-in like c2_fused
+            fp = pt.default_params(frame=0, frame_count=frames, pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_PROFILE, width=W, height=H,
+                                   spp_per_frame=sh["spp"], max_depth=sh["depth"])
+            f2 = pt.Film(ctx, W, H)
+            pt.render(scene, f2, fp)
+            f2.clear()
+            ctx.reset_stats()
+            t1 = time.perf_counter()
+            pt.render(scene, f2, fp)
+            d1 = time.perf_counter() - t1
+            s2 = ctx.stats()
+            out["fused"] = {"pipeline": "PT_PIPELINE_FUSED (k_fused_inst)", "mrays_per_s": round(s2.rays / d1 / 1e6, 2), "ms_per_frame": round(d1 * 1e3 / frames, 3),
+                            "rays_equal_wavefront": s2.rays == st.rays, "film_equals_wavefront": bool(f2.read_f32().tobytes() == film.read_f32().tobytes()),
+                            "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups, "workspace_bytes": s2.workspace_bytes,
+                            "kernel_ms": round(s2.ms_extend, 3)}
+            f2.close()
+        except Exception as e:
+            out["fused"] = {"error": repr(e)}
     out.update(r)
     film.close()
     scene.close()

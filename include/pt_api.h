@@ -186,9 +186,10 @@ enum {
     PT_PIPELINE_WAVEFRONT_NEE = 1,
     /* The reference's estimator, bit for bit, as ONE persistent kernel -- the shape of the reference's own raygen shader
      * (raygen.rgen:41-91: one invocation owns its path): traversal and shading in the same lane, path state in LDS, no
-     * queues in HBM; the workspace is the per-slot radiance only (16 B per slot instead of ~150).  Only for single-level
-     * scenes that fit LDS (the Cornell-box class; PT_ERR_UNSUPPORTED otherwise), blocking calls only.  Same films, same
-     * ray counts as PT_PIPELINE_WAVEFRONT.                                                                              */
+     * queues in HBM; the workspace is the per-slot radiance only (16 B per slot instead of ~150).  For scenes whose
+     * triangles fit LDS: single-level ones (the Cornell-box class) and instanced ones of 2 .. 32767 instances over such a
+     * BLAS (the TLAS stays in L2); PT_ERR_UNSUPPORTED otherwise, tmin > 0, blocking calls only.  Same films, same ray
+     * counts as PT_PIPELINE_WAVEFRONT.                                                                                   */
     PT_PIPELINE_FUSED = 2
 };
 enum {

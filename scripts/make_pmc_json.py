@@ -42,7 +42,7 @@ rec = {
               f"(scripts/gpu_profile.sh) on `python bench.py {cfg} --warmup 0 --no-cpu-baseline`",
     "launches": kt["calls"], "rays_per_launch_in_profile_run": rays_per_launch,
     "rocprof_avg_launch_us": avg_us,
-    "bench_hipext_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"] if prefix in ("k_extend", "k_fused") else bench["roofline"]["shade_ms"] * 1e3 / bench["roofline"]["launches"],
+    "bench_hipext_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"] if prefix.startswith(("k_extend", "k_fused")) else bench["roofline"]["shade_ms"] * 1e3 / bench["roofline"]["launches"],
     "fetch_size_kib_per_launch": pl("FETCH_SIZE"), "write_size_kib_per_launch": pl("WRITE_SIZE"),
     "hbm_read_bytes_per_launch_x2_gfx950": e["hbm_read_bytes_per_launch_gfx950_x2"],
     "hbm_write_bytes_per_launch": e["hbm_write_bytes_per_launch"], "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],

@@ -5,17 +5,67 @@
 
 #define PT_EXTEND_TEMPLATES_ONLY
 #include "extend_kernel.h"  // the LDS node / stack helpers the fused kernel shares with k_extend_lds7p
+#include "extend_inst16.h"  // the two-level walk's node codes and register barrier (k_extend_inst16 itself is a template: not instantiated here)
 
 namespace {
 using namespace ptw;
 #include "fused_kernel.h"
+#include "fused_inst_kernel.h"
+
+// two-level scenes: k_extend_inst16's class (extend_launch.hip: both levels in 15-bit child codes, BLAS in LDS, pair leaves)
+pt_status plan_fused_inst(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp)
+{
+    pt_ctx *ctx = s->ctx;
+    const size_t tables = sizeof(float4) * 3 * (size_t)s->n_tris;  // shade4 (the vertices are the kz = 2 triangle copy)
+    if (!pl.inst16 || !s->pair_leaves || !(tmin > 0.f) || tables > 16 * 1024) {
+        ctx->err = "PT_PIPELINE_FUSED takes instanced scenes of the fp16 two-level kernel's class: < 32768 instances, a BLAS of <= 2047 "
+                   "triangles with pair leaves that fits LDS, tmin > 0";
+        return PT_ERR_UNSUPPORTED;
+    }
+    fp.inst = true;
+    fp.lds_stack = pl.lds_stack;
+    // TLAS nodes staged in LDS: the wavefront kernel keeps 8 KB of them because the other pipeline's k_shade needs LDS beside it
+    // (extend_launch.hip); this kernel has the CU to itself
+    const size_t tlas_lds_bytes = (size_t)pt_tuned(ctx->tune.tlas_lds_kb, PT_FUSEDI_TLAS_KB, 0, 96) * 1024;
+    fp.n_tlas_lds = (uint32_t)std::min<size_t>(s->n_tlas16, tlas_lds_bytes / (sizeof(uint32_t) * I16_NODE_DW));
+    fp.smem = (size_t)fp.lds_stack * FITB * sizeof(uint32_t) + sizeof(uint32_t) * I16_NODE_DW * ((size_t)s->n_wide + fp.n_tlas_lds) +
+              sizeof(float4) * 9 * (size_t)s->n_tris + tables + sizeof(uint32_t) * FS_FIELDS * FITB + sizeof(uint32_t) * (FITB / 64) * PT_FUSED_WTILES;
+    if (fp.smem > 160 * 1024) { ctx->err = "PT_PIPELINE_FUSED: the two-level kernel's LDS plan exceeds 160 KB (pt_tuning lds_stack / tlas_lds_kb)"; return PT_ERR_UNSUPPORTED; }
+    for (const void *fn : { reinterpret_cast<const void *>(k_fused_inst<false>), reinterpret_cast<const void *>(k_fused_inst<true>) })
+        if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
+    int per_cu = 0;
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fused_inst<false>), FITB, fp.smem));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
+    fp.grid = ctx->num_cus * per_cu;
+    fp.block = FITB;
+    fp.refill = pt_tuned(ctx->tune.refill, 48, 1, 64);
+    // stack entries beyond the LDS ones: one dword each, [level][thread], in the context's spill area (sized by ptw_plan_extend for
+    // the wavefront kernels' grids; grown here if this grid asks for more)
+    const size_t need = (size_t)std::max(pl.spill_levels, 1u) * (size_t)fp.grid * FITB * sizeof(uint32_t);
+    if (need > ctx->spill_bytes) {
+        (void)hipFree(ctx->d_spill);
+        ctx->d_spill = nullptr;
+        ctx->spill_bytes = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_spill, need));
+        ctx->spill_bytes = need;
+    }
+    fp.spill = reinterpret_cast<uint32_t *>(ctx->d_spill);
+    if (ctx->tune.inst_frames != 0) {
+        const pt_status rcf = ptb_ensure_inst_frames(s);
+        if (rcf != PT_OK) return rcf;
+        fp.inst_frame = s->d_inst_frame;
+    }
+    return PT_OK;
+}
 }  // namespace
 
 pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp)
 {
     pt_ctx *ctx = s->ctx;
+    if (s->n_inst) return plan_fused_inst(s, pl, tmin, fp);
     const size_t tables = sizeof(float4) * 5 * (size_t)s->n_tris;  // shade4 + tangent frames (the vertices are the kz = 2 triangle copy)
-    if (s->n_inst || pl.variant != PT_EXTEND_LDS || pl.spill || !pl.pairs || !(tmin > 0.f) || tables > 16 * 1024) {
+    if (pl.variant != PT_EXTEND_LDS || pl.spill || !pl.pairs || !(tmin > 0.f) || tables > 16 * 1024) {
         ctx->err = "PT_PIPELINE_FUSED is for single-level scenes whose BVH4, triangles and shading tables fit LDS (the compact pair-leaf "
                    "kernel's class: <= 2047 triangles in <= 24 KB, stack bound <= 16, tmin > 0)";
         return PT_ERR_UNSUPPORTED;
@@ -42,6 +92,22 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
                       const pt_scene *s, uint32_t n_slots, uint32_t *next_slot, unsigned long long *stats, float tmin, float tmax,
                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
+    if (fp.inst) {
+        const NormBox nbt = { s->tlas_norm_c[0], s->tlas_norm_c[1], s->tlas_norm_c[2], s->tlas_norm_s[0], s->tlas_norm_s[1], s->tlas_norm_s[2],
+                              s->tlas_norm_rs[0], s->tlas_norm_rs[1], s->tlas_norm_rs[2] };
+        const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
+        // the waiting rules of k_extend_inst16 (extend_launch.hip has the measurements)
+        const int enter_min = pt_tuned(s->ctx->tune.enter_min, 16, 1, 64), leaf_min = pt_tuned(s->ctx->tune.leaf_min, 8, 1, 64);
+        const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
+#define PT_LAUNCH_FUSED_INST(G)                                                                                                       \
+    hipExtLaunchKernelGGL((k_fused_inst<G>), dim3(fp.grid), dim3(FITB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_tlas16, nbt, \
+                          reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->d_shade4, s->n_wide, s->n_tris, s->d_inst6,       \
+                          s->d_tlas_prim_of, fp.inst_frame, 0u, n_slots, next_slot, stats, fp.spill, (uint32_t)fp.grid * FITB, fp.refill, \
+                          tmin, tmax, fp.lds_stack, enter_min, leaf_min, node_yield, fp.n_tlas_lds)
+        if (grouped) PT_LAUNCH_FUSED_INST(true); else PT_LAUNCH_FUSED_INST(false);
+#undef PT_LAUNCH_FUSED_INST
+        return;
+    }
     if (grouped)
         hipExtLaunchKernelGGL((k_fused<true>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
                               s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack);

@@ -78,7 +78,14 @@ void ptw_launch_hits_to_api(const float4 *hit, const float4 *tri4, const uint32_
 constexpr size_t PTW_COUNT_WORDS = 8 * 32;  // pt_film::Work::d_count: the wavefront's queue sizes (2 per pipeline) | eight slot counters of the fused kernel, one 128-B line each
 
 // ---- fused.hip ---------------------------------------------------------------------------------------------------------
-struct FusedPlan { size_t smem = 0; int grid = 0, block = 0, lds_stack = 0, refill = 40; };
+struct FusedPlan {
+    size_t smem = 0;
+    int grid = 0, block = 0, lds_stack = 0, refill = 40;
+    bool inst = false;                   // two-level scene: k_fused_inst (fused_inst_kernel.h) around k_extend_inst16's walk
+    uint32_t n_tlas_lds = 0;             // ... its TLAS nodes staged in LDS
+    uint32_t *spill = nullptr;           // ... its stack entries beyond lds_stack: [levels][grid * block] dwords of the context's spill area
+    const float4 *inst_frame = nullptr;  // ... the (instance, triangle) normal + tangent table, or null
+};
 pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp);
 void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst &rc, const uint32_t *tiles, const ptw::Radiance &rad,
                       const pt_scene *s, uint32_t n_slots, uint32_t *next_slot, unsigned long long *stats, float tmin, float tmax,

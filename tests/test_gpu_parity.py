@@ -1962,6 +1962,8 @@ def test_full_size_frames_equal_the_oracle_known_answers(pt, gpu_ctx, config):
     variants = [dict(), dict(frames_in_flight=1, sample_groups=1), dict(frames_in_flight=1, sample_groups=8)]
     if config == "c2":
         variants += [dict(extend=pt.EXTEND_HBM), dict(extend=pt.EXTEND_HBM8)]
+    if config == "c4":   # the fused pipeline's two-level kernel (k_fused_inst), one accumulator per slot and the term logs
+        variants += [dict(pipeline=pt.PIPELINE_FUSED, frames_in_flight=1, sample_groups=1), dict(pipeline=pt.PIPELINE_FUSED)]
     if config == "c5":
         variants += [dict(flags=pt.FLAG_SORT_RAYS), dict(extend=pt.EXTEND_HBM8)]
     for kw in variants:
@@ -2088,10 +2090,62 @@ def test_fused_pipeline_bit_exact_vs_oracle_and_wavefront(pt, orc, gpu_ctx, corn
         film.close()
 
 
+def test_fused_pipeline_on_instanced_scenes(pt, orc, gpu_ctx, cornell_arrays):
+    """PT_PIPELINE_FUSED on two-level scenes (k_fused_inst: the walk of k_extend_inst16 and k_shade<INST>'s hit shading in one
+    lane): film, rgba8 image and ray count equal the oracle's bit for bit on rotated + scaled instance sets and on a corner of
+    config C4's grid seen from close by -- one accumulator per slot and the term logs, several frames in flight, shards -- and
+    under every knob of the kernel: TLAS nodes in LDS (none, all), an LDS stack so short that entries spill to HBM, the
+    waiting rules of the leaf phase, the shade block's fill, the per-hit normal transform instead of the table."""
+    import importlib
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    grid = pt.cornell_grid_instances().reshape(100, 100, 3, 4)[:12, :12].reshape(-1, 3, 4)
+    close = dict(cam_origin=(-0.88, -1.9, 0.5), cam_target=(-0.88, -1.9, 0.0))
+    for inst, cam, (w, h, spp, depth, frames) in ((_random_instances(5, 3), {}, (80, 64, 3, 6, 2)), (_random_instances(60, 4), {}, (101, 37, 8, 8, 2)),
+                                                   (_random_instances(1500, 5), {}, (64, 48, 4, 13, 1)), (grid, close, (96, 64, 8, 8, 3))):
+        gs, osc = pt.Scene(gpu_ctx, *cornell_arrays), orc.Scene(*cornell_arrays)
+        gs.set_instances(inst)
+        osc.set_instances(inst)
+        kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=depth, **cam)
+        ofilm, obgra, orays = _render_oracle(orc, osc, frames, **kw)
+        assert (ofilm > 0).any()
+        for shape in (dict(), dict(frames_in_flight=1, sample_groups=1), dict(sample_groups=spp), dict(frames_in_flight=frames, sample_groups=2 if spp % 2 == 0 else 1)):
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=frames, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
+            st = gpu_ctx.stats()
+            assert st.rays == orays, (len(inst), shape, st.rays, orays)
+            assert film.read_f32().tobytes() == ofilm.tobytes(), (len(inst), shape)
+            assert film.read_bgra8().tobytes() == obgra.tobytes(), (len(inst), shape)
+            film.close()
+        for knobs in (dict(tlas_lds_kb=0), dict(tlas_lds_kb=64, lds_stack=8), dict(lds_stack=2), dict(enter_min=1, leaf_min=1, node_yield=0),
+                      dict(enter_min=64, leaf_min=64, node_yield=2), dict(refill=1), dict(refill=64), dict(inst_frames=0), dict(extend_blocks=1)):
+            old = gpu_ctx.set_tuning(**knobs)
+            try:
+                film = pt.Film(gpu_ctx, w, h)
+                gpu_ctx.reset_stats()
+                pt.render(gs, film, pt.default_params(frame=0, frame_count=frames, pipeline=pt.PIPELINE_FUSED, **kw))
+                assert film.read_f32().tobytes() == ofilm.tobytes() and gpu_ctx.stats().rays == orays, (len(inst), knobs)
+                film.close()
+            finally:
+                gpu_ctx.set_tuning(**old)
+        acc, rays = np.zeros_like(ofilm), 0
+        for rank in range(3):
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=frames, rank=rank, world=3, pipeline=pt.PIPELINE_FUSED, **kw))
+            rays += gpu_ctx.stats().rays
+            part = film.read_f32()
+            assert (part[~d.owned_mask(w, h, rank, 3)] == 0).all()
+            acc += part
+            film.close()
+        assert acc.tobytes() == ofilm.tobytes() and rays == orays
+        gs.close()
+
+
 def test_fused_pipeline_shards_term_log_tiers_and_refusals(pt, orc, gpu_ctx, cornell_gpu):
     """Fused renders of (rank, world) shards add up to the single-device film; the three tiers of the term log (primary,
     overflow, shared pool) and the redo of a batch whose pool overflowed give the same bits; the tuning knobs change no bit;
-    what the kernel is not built for is refused with PT_ERR_UNSUPPORTED (instanced scenes, scenes beyond LDS, NEE, async)."""
+    what the kernel is not built for is refused with PT_ERR_UNSUPPORTED (one-instance scenes, scenes beyond LDS, tmin <= 0, async)."""
     import importlib
     d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
     w, h = 200, 120
@@ -2134,9 +2188,12 @@ def test_fused_pipeline_shards_term_log_tiers_and_refusals(pt, orc, gpu_ctx, cor
             pt.render(cornell_gpu, film, pt.default_params(**{**kw, **bad}))
         assert e.value.status == 5, bad                                                     # PT_ERR_UNSUPPORTED
     inst = pt.Scene(gpu_ctx, *pt.load_obj(pt.ASSET_CORNELL))
-    inst.set_instances(pt.cornell_grid_instances()[:16])
+    inst.set_instances(pt.cornell_grid_instances()[:1])       # one instance: no fp16 TLAS, the general two-level kernel's scene
     with pytest.raises(pt.PtError):
         pt.render(inst, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, **kw))
+    inst.set_instances(pt.cornell_grid_instances()[:16])      # (k_fused_inst's class: test_fused_pipeline_on_instanced_scenes)
+    with pytest.raises(pt.PtError):
+        pt.render(inst, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, **{**kw, "tmin": 0.0}))
     inst.close()
     v, i, f = _soup(3000, 5)
     big = pt.Scene(gpu_ctx, v, i, f)
