@@ -23,6 +23,17 @@ for k in range(N):
     if rng.random() < 0.3:
         kw.update(cam_origin=tuple(float(x) for x in rng.uniform(-0.5, 0.5, 3) + np.array([0, -1, 4.0])),
                   env=tuple(float(x) for x in rng.uniform(0, 1, 3)))
+    # a third of the configurations: a two-level scene (2 .. 40 rotated + scaled instances of the box; both pipelines have a kernel for it)
+    n_inst = int(rng.integers(2, 41)) if rng.random() < 0.33 else 0
+    inst = np.zeros((n_inst, 3, 4), np.float32)
+    for i in range(n_inst):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        inst[i, :, :3] = (q * rng.uniform(0.2, 0.6)).astype(np.float32)
+        inst[i, :, 3] = rng.uniform(-1.5, 1.5, 3).astype(np.float32) + np.float32([0, -1, 0])
+    sc.set_instances(inst)
+    osc.set_instances(inst)
     # oracle: frames f0 .. f0+nf-1 blended onto a film that already holds frames 0 .. f0-1
     film_o = None
     for fr in range(0, f0 + nf):
@@ -36,7 +47,9 @@ for k in range(N):
         film = pt.Film(ctx, w, h)
         gk = dict(kw, rank=rank, world=world, frames_in_flight=int(rng.choice([0, 1, 2, 5])), sample_groups=int(rng.choice([0, 1, 2, 3, spp])),
                   extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_FLAT])))
-        if rng.random() < 0.4:   # the fused single-kernel pipeline (LDS scenes; it walks its own copy of the compact pair-leaf tree)
+        if n_inst:
+            gk.update(extend=pt.EXTEND_AUTO)   # (one two-level kernel per scene class)
+        if rng.random() < 0.4:   # the fused single-kernel pipeline (LDS scenes; it walks its own copy of the compact pair-leaf tree / of the two-level one)
             gk.update(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_AUTO)
         if f0:
             pt.render(sc, film, pt.default_params(frame=0, frame_count=f0, **gk))
@@ -45,6 +58,6 @@ for k in range(N):
         film.close()
     if total.tobytes() != film_o.tobytes():
         bad += 1
-        print("MISMATCH", k, kw, "world", world, "max abs diff", float(np.abs(total - film_o).max()))
+        print("MISMATCH", k, kw, "instances", n_inst, "world", world, "max abs diff", float(np.abs(total - film_o).max()))
 print(f"render fuzz: {N} configurations, mismatches: {bad}; {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
