@@ -12,6 +12,7 @@ SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = pt.Context(0)
 bad = 0
 ndeg = 0
+n_refused = 0
 t0 = time.time()
 def rot(rng):
     q = rng.normal(size=4); q /= np.linalg.norm(q); a, b, c, d = q
@@ -58,6 +59,30 @@ for k in range(N):
         bad += 1
         dd = np.nonzero(~ok)[0]
         print("MISMATCH", k, "n", n, "instances", ni, len(dd), "rays; first", got[dd[:2]], want[dd[:2]])
+    # the same scene through both render pipelines (k_shade<INST> / k_fused_inst) against the oracle's film: camera on instance 0
+    if tmin > 0.0:
+        c0 = xf[0, :, 3].astype(np.float64)
+        eye = c0 + rng.normal(size=3) * float(np.abs(xf[0, :, :3]).max()) * 3.0
+        kw = dict(width=48, height=32, spp_per_frame=2, max_depth=5, tmin=tmin, tmax=tmax, cam_origin=tuple(float(x) for x in eye),
+                  cam_target=tuple(float(x) for x in c0))
+        ofilm = None
+        for fr in range(2):
+            img, _, _, _ = osc.render_frame(orc.default_params(frame=fr, **kw))
+            if ofilm is None:
+                ofilm = np.zeros_like(img)
+            orc.accumulate_f32(ofilm, img, fr)
+        for pipe in (pt.PIPELINE_WAVEFRONT, pt.PIPELINE_FUSED):
+            film = pt.Film(ctx, 48, 32)
+            try:
+                pt.render(gs, film, pt.default_params(frame=0, frame_count=2, pipeline=pipe, **kw))
+                if film.read_f32().tobytes() != ofilm.tobytes():
+                    bad += 1
+                    print("RENDER MISMATCH", k, "pipeline", pipe, "n", n, "instances", ni)
+            except pt.PtError as e:   # (the fused pipeline takes the fp16 two-level kernel's scenes only)
+                assert pipe == pt.PIPELINE_FUSED and e.status == 5, str(e)
+                n_refused += 1
+            film.close()
     gs.close()
+print(f"fused refusals (scene outside k_fused_inst's class): {n_refused}")
 print(f"instance fuzz: {N} scenes, mismatching scenes: {bad}; rays where oracle brute force and TLAS walk differ: {ndeg}; {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
