@@ -17,9 +17,9 @@ pt_status plan_fused_inst(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPl
 {
     pt_ctx *ctx = s->ctx;
     const size_t tables = sizeof(float4) * 3 * (size_t)s->n_tris;  // shade4 (the vertices are the kz = 2 triangle copy)
-    if (!pl.inst16 || !s->pair_leaves || !(tmin > 0.f) || tables > 16 * 1024) {
-        ctx->err = "PT_PIPELINE_FUSED takes instanced scenes of the fp16 two-level kernel's class: < 32768 instances, a BLAS of <= 2047 "
-                   "triangles with pair leaves that fits LDS, tmin > 0";
+    if (!pl.inst16 || !(tmin > 0.f) || tables > 16 * 1024) {
+        ctx->err = "PT_PIPELINE_FUSED takes instanced scenes of the fp16 two-level kernel's class: 2 .. 32767 instances, a BLAS of <= 2047 "
+                   "triangles that fits LDS, tmin > 0";
         return PT_ERR_UNSUPPORTED;
     }
     fp.inst = true;
@@ -31,10 +31,11 @@ pt_status plan_fused_inst(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPl
     fp.smem = (size_t)fp.lds_stack * FITB * sizeof(uint32_t) + sizeof(uint32_t) * I16_NODE_DW * ((size_t)s->n_wide + fp.n_tlas_lds) +
               sizeof(float4) * 9 * (size_t)s->n_tris + tables + sizeof(uint32_t) * FS_FIELDS * FITB + sizeof(uint32_t) * (FITB / 64) * PT_FUSED_WTILES;
     if (fp.smem > 160 * 1024) { ctx->err = "PT_PIPELINE_FUSED: the two-level kernel's LDS plan exceeds 160 KB (pt_tuning lds_stack / tlas_lds_kb)"; return PT_ERR_UNSUPPORTED; }
-    for (const void *fn : { reinterpret_cast<const void *>(k_fused_inst<false>), reinterpret_cast<const void *>(k_fused_inst<true>) })
+    for (const void *fn : { reinterpret_cast<const void *>(k_fused_inst<false, true>), reinterpret_cast<const void *>(k_fused_inst<true, true>),
+                             reinterpret_cast<const void *>(k_fused_inst<false, false>), reinterpret_cast<const void *>(k_fused_inst<true, false>) })
         if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
     int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fused_inst<false>), FITB, fp.smem));
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->pair_leaves ? reinterpret_cast<const void *>(k_fused_inst<false, true>) : reinterpret_cast<const void *>(k_fused_inst<false, false>), FITB, fp.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
     per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
     fp.grid = ctx->num_cus * per_cu;
@@ -65,18 +66,20 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     pt_ctx *ctx = s->ctx;
     if (s->n_inst) return plan_fused_inst(s, pl, tmin, fp);
     const size_t tables = sizeof(float4) * 5 * (size_t)s->n_tris;  // shade4 + tangent frames (the vertices are the kz = 2 triangle copy)
-    if (pl.variant != PT_EXTEND_LDS || pl.spill || !pl.pairs || !(tmin > 0.f) || tables > 16 * 1024) {
-        ctx->err = "PT_PIPELINE_FUSED is for single-level scenes whose BVH4, triangles and shading tables fit LDS (the compact pair-leaf "
-                   "kernel's class: <= 2047 triangles in <= 24 KB, stack bound <= 16, tmin > 0)";
+    if (pl.variant != PT_EXTEND_LDS || pl.spill || !(tmin > 0.f) || tables > 16 * 1024) {
+        ctx->err = "PT_PIPELINE_FUSED is for single-level scenes whose BVH4, triangles and shading tables fit LDS (the compact "
+                   "kernels' class: <= 2047 triangles in <= 24 KB, stack bound <= 16, tmin > 0)";
         return PT_ERR_UNSUPPORTED;
     }
     fp.lds_stack = pl.lds_stack;
     fp.smem = (size_t)pl.lds_stack * FTB * sizeof(uint32_t) + (pl.smem - (size_t)pl.lds_stack * TB * sizeof(uint32_t)) + tables +
               sizeof(uint32_t) * FS_FIELDS * FTB + sizeof(uint32_t) * (FTB / 64) * PT_FUSED_WTILES;
-    for (const void *fn : { reinterpret_cast<const void *>(k_fused<false>), reinterpret_cast<const void *>(k_fused<true>) })
+    fp.pairs = pl.pairs;
+    for (const void *fn : { reinterpret_cast<const void *>(k_fused<false, true>), reinterpret_cast<const void *>(k_fused<true, true>),
+                             reinterpret_cast<const void *>(k_fused<false, false>), reinterpret_cast<const void *>(k_fused<true, false>) })
         if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
     int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fused<false>), FTB, fp.smem));
+    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.pairs ? reinterpret_cast<const void *>(k_fused<false, true>) : reinterpret_cast<const void *>(k_fused<false, false>), FTB, fp.smem));
     per_cu = std::max(1, std::min(per_cu, 8));
     per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
     fp.grid = ctx->num_cus * per_cu;
@@ -99,19 +102,20 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
         // the waiting rules of k_extend_inst16 (extend_launch.hip has the measurements)
         const int enter_min = pt_tuned(s->ctx->tune.enter_min, 16, 1, 64), leaf_min = pt_tuned(s->ctx->tune.leaf_min, 8, 1, 64);
         const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
-#define PT_LAUNCH_FUSED_INST(G)                                                                                                       \
-    hipExtLaunchKernelGGL((k_fused_inst<G>), dim3(fp.grid), dim3(FITB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_tlas16, nbt, \
+#define PT_LAUNCH_FUSED_INST(G, P)                                                                                                     \
+    hipExtLaunchKernelGGL((k_fused_inst<G, P>), dim3(fp.grid), dim3(FITB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_tlas16, nbt, \
                           reinterpret_cast<const uint4 *>(s->d_wide16), nbb, s->d_tri4, s->d_shade4, s->n_wide, s->n_tris, s->d_inst6,       \
                           s->d_tlas_prim_of, fp.inst_frame, 0u, n_slots, next_slot, stats, fp.spill, (uint32_t)fp.grid * FITB, fp.refill, \
                           tmin, tmax, fp.lds_stack, enter_min, leaf_min, node_yield, fp.n_tlas_lds)
-        if (grouped) PT_LAUNCH_FUSED_INST(true); else PT_LAUNCH_FUSED_INST(false);
+        if (s->pair_leaves) { if (grouped) PT_LAUNCH_FUSED_INST(true, true); else PT_LAUNCH_FUSED_INST(false, true); }
+        else { if (grouped) PT_LAUNCH_FUSED_INST(true, false); else PT_LAUNCH_FUSED_INST(false, false); }
 #undef PT_LAUNCH_FUSED_INST
         return;
     }
-    if (grouped)
-        hipExtLaunchKernelGGL((k_fused<true>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
-                              s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack);
-    else
-        hipExtLaunchKernelGGL((k_fused<false>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,
-                              s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack);
+#define PT_LAUNCH_FUSED(G, P)                                                                                                              \
+    hipExtLaunchKernelGGL((k_fused<G, P>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4, \
+                          s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack)
+    if (fp.pairs) { if (grouped) PT_LAUNCH_FUSED(true, true); else PT_LAUNCH_FUSED(false, true); }
+    else { if (grouped) PT_LAUNCH_FUSED(true, false); else PT_LAUNCH_FUSED(false, false); }
+#undef PT_LAUNCH_FUSED
 }

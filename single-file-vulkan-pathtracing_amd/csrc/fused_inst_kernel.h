@@ -5,7 +5,7 @@
 // and runs the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, raygen.rgen:76-83, the next sample's camera ray
 // (raygen.rgen:45-60), or the first sample of a new slot -- once enough of the wave's lanes wait with a finished ray; slots
 // come from the same eight counters.  What differs is the walk between two shade blocks:
-//   * traversal: k_extend_inst16<false, PAIRS = true> (extend_inst16.h) restated operation for operation -- 64-B fp16 nodes on
+//   * traversal: k_extend_inst16<false, PAIRS> (extend_inst16.h) restated operation for operation -- 64-B fp16 nodes on
 //     both levels (TLAS from L2 with its top levels in LDS, BLAS in LDS), one-dword stack entries with the spill area
 //     behind them, instance entry / exit with the waiting rules `enter_min` / `leaf_min` / `node_yield`;
 //   * shading of a hit: k_shade<INST> -- position to world space by the instance's matrix (48 B from L2 per hit), normal and
@@ -25,7 +25,8 @@
 #endif
 constexpr int FITB = PT_FUSEDI_TB;
 
-template <bool GROUPED>
+// PAIRS: every BLAS leaf is one triangle or one fan pair (tested with shared vertex work); else leaves of up to four triangles
+template <bool GROUPED, bool PAIRS>
 __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
     RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad, const uint4 *__restrict__ tlas16, NormBox nbt,
     const uint4 *__restrict__ g_blas16, NormBox nbb, const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
@@ -385,42 +386,53 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                         best_ipos = cur_ipos; best_iid = cur_iid;
                     }
                 };
-                const size_t ti = (size_t)tri_base + 3 * (size_t)first;
-                const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
-                const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
-                const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
-                const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
-                const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
-                const float pAC = Ax * Cy, qAC = Ay * Cx;
-                auto inside = [](float U, float V, float W) {
-                    return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
-                };
-                auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
-                    const float det = (U + V) + W;
-                    const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
-                    const float t = ptm::fdiv(T, det);
-                    if (!(t > tmin && t < tmax)) return;
-                    accept(t, V, W, det, pos, prim);
-                };
-                const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
-                const bool inA = inside(UA, VA, WA);
-                float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
-                uint32_t primB = 0u;
-                bool inB = false;
-                if (cnt == 2u) {
-                    const float4 d = s_tri[ti + 5];
-                    Dz_ = d.z - orgp.z;
-                    const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
-                    UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
-                    primB = __float_as_uint(d.w);
-                    inB = inside(UB, VB, WB);
+                if (PAIRS) {
+                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
+                    const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
+                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
+                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
+                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
+                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
+                    const float pAC = Ax * Cy, qAC = Ay * Cx;
+                    auto inside = [](float U, float V, float W) {
+                        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
+                    };
+                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
+                        const float det = (U + V) + W;
+                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
+                        const float t = ptm::fdiv(T, det);
+                        if (!(t > tmin && t < tmax)) return;
+                        accept(t, V, W, det, pos, prim);
+                    };
+                    const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
+                    const bool inA = inside(UA, VA, WA);
+                    float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
+                    uint32_t primB = 0u;
+                    bool inB = false;
+                    if (cnt == 2u) {
+                        const float4 d = s_tri[ti + 5];
+                        Dz_ = d.z - orgp.z;
+                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
+                        UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
+                        primB = __float_as_uint(d.w);
+                        inB = inside(UB, VB, WB);
+                    }
+                    if (inA || inB) {
+                        const bool sb = !inA;
+                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first,
+                               sb ? primB : __float_as_uint(a.w));
+                    }
+                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u, primB);
+                } else {
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const uint32_t pos = first + k;
+                        const size_t ti = (size_t)tri_base + 3 * (size_t)pos;
+                        const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
+                        float t, V, W, det;
+                        if (ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, nullptr))
+                            accept(t, V, W, det, pos, __float_as_uint(a.w));
+                    }
                 }
-                if (inA || inB) {
-                    const bool sb = !inA;
-                    finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first,
-                           sb ? primB : __float_as_uint(a.w));
-                }
-                if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u, primB);
                 cur = pop_and_restore();
             } else if (at_leaf && !in_blas && do_enter) {
                 // TLAS leaf: one instance.  The ray goes to object space un-normalised (t is the same parameter)

@@ -7,7 +7,7 @@
 // dozen triangles needs none of it: nodes, triangles and the shading tables fit LDS, so here a lane keeps its path from
 // bounce to bounce and HBM sees the radiance of a slot only (16 B per slot, or 16 B per logged term with sample groups).
 //
-//   * traversal: the compact pair-leaf walk of extend_kernel.h (`extend_body<true, false, false, true>`: one-dword stack
+//   * traversal: the compact walk of extend_kernel.h (`extend_body<true, false, false, PAIRS>`; pair leaves: one-dword stack
 //     entries in LDS, key-sorted children, fan pairs tested together), restated here operation for operation -- the hot
 //     instantiation of that template is register-allocated to the last VGPR and must not grow a second use;
 //   * a lane whose ray is finished WAITS with its hit in registers until a quarter of the wave's live lanes wait too
@@ -48,7 +48,8 @@ constexpr int FTB = PT_FUSED_TB;
 enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS_B, FS_C, FS_FIELDS };
 // FS_A..C: the slot's colour (one sample group) | FS_A: its term count (several groups)
 
-template <bool GROUPED>
+// PAIRS: every leaf is one triangle or one fan pair (k_extend_lds7p's trees); else leaves of up to four triangles (k_extend_lds7's)
+template <bool GROUPED, bool PAIRS>
 __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
                                                               const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
                                                               const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
@@ -344,45 +345,61 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
         if (have) {
             if (cur != DONE && (cur & LEAF_BIT)) {
-                const uint32_t first = cur & 0x7FFu;
-                const bool two = ((cur >> 11) & 3u) != 0u;
-                const size_t ti = (size_t)tri_base + 3 * (size_t)first;
-                const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
-                const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
-                const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
-                const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
-                const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
-                const float pAC = Ax * Cy, qAC = Ay * Cx;
-                auto inside = [](float U, float V, float W) {
-                    return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
-                };
-                auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos) {
-                    const float det = (U + V) + W;
-                    const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
-                    const float t = ptm::fdiv(T, det);
-                    if (!(t > tmin && t < tmax)) return;
-                    bool closer = t < best_t;
-                    if (!closer && t == best_t)
-                        closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
-                                                            __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
-                    if (closer) { best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; }
-                };
-                const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
-                const bool inA = inside(UA, VA, WA);
-                float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
-                bool inB = false;
-                if (two) {
-                    const float4 d = tri4[ti + 5];
-                    Dz_ = d.z - orgp.z;
-                    const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
-                    UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
-                    inB = inside(UB, VB, WB);
+                if (PAIRS) {
+                    const uint32_t first = cur & 0x7FFu;
+                    const bool two = ((cur >> 11) & 3u) != 0u;
+                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
+                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
+                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
+                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
+                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
+                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
+                    const float pAC = Ax * Cy, qAC = Ay * Cx;
+                    auto inside = [](float U, float V, float W) {
+                        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
+                    };
+                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos) {
+                        const float det = (U + V) + W;
+                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
+                        const float t = ptm::fdiv(T, det);
+                        if (!(t > tmin && t < tmax)) return;
+                        bool closer = t < best_t;
+                        if (!closer && t == best_t)
+                            closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
+                                                                __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
+                        if (closer) { best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; }
+                    };
+                    const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
+                    const bool inA = inside(UA, VA, WA);
+                    float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
+                    bool inB = false;
+                    if (two) {
+                        const float4 d = tri4[ti + 5];
+                        Dz_ = d.z - orgp.z;
+                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
+                        UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
+                        inB = inside(UB, VB, WB);
+                    }
+                    if (inA || inB) {
+                        const bool sb = !inA;
+                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first);
+                    }
+                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u);
+                } else {
+                    const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const uint32_t pos = first + k;
+                        const size_t ti = (size_t)tri_base + 3 * (size_t)pos;
+                        const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
+                        float t, V, W, det;
+                        if (ptm::tri_test_perm(pre, orgp, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det, nullptr)) {
+                            bool closer = t < best_t;  // closest t; equal t -> lowest gl_PrimitiveID (the first vertex of a record carries it)
+                            if (!closer && t == best_t)
+                                closer = best_pos == PT_MISS || __float_as_uint(a.w) < __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos].w);
+                            if (closer) { best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; }
+                        }
+                    }
                 }
-                if (inA || inB) {
-                    const bool sb = !inA;
-                    finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first);
-                }
-                if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u);
                 cur = pop();
             }
             if (cur == DONE) have = false;  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block

@@ -2090,6 +2090,28 @@ def test_fused_pipeline_bit_exact_vs_oracle_and_wavefront(pt, orc, gpu_ctx, corn
         film.close()
 
 
+def test_fused_pipeline_on_trees_without_pair_leaves(pt, orc, gpu_ctx, cornell_arrays):
+    """k_fused's second instantiation -- leaves of up to four independent triangles, the trees k_extend_lds7 walks: the box built
+    with pt_tuning.pair_leaves = 0, and small soups, which have no fan pairs to find -- against the oracle, both radiance forms."""
+    for arrays, pair in ((cornell_arrays, 0), (_soup(100, 5, spread=0.3), 1), (_soup(37, 6, spread=0.5), 1)):
+        old = gpu_ctx.set_tuning(pair_leaves=pair)
+        try:
+            gs = pt.Scene(gpu_ctx, *arrays)
+        finally:
+            gpu_ctx.set_tuning(**old)
+        osc = orc.Scene(*arrays)
+        kw = dict(width=90, height=50, spp_per_frame=4, max_depth=7)
+        ofilm, obgra, orays = _render_oracle(orc, osc, 2, **kw)
+        for shape in (dict(), dict(sample_groups=4), dict(frames_in_flight=1, sample_groups=2)):
+            film = pt.Film(gpu_ctx, 90, 50)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
+            assert gpu_ctx.stats().rays == orays and film.read_f32().tobytes() == ofilm.tobytes(), (pair, shape)
+            assert film.read_bgra8().tobytes() == obgra.tobytes()
+            film.close()
+        gs.close()
+
+
 def test_fused_pipeline_on_instanced_scenes(pt, orc, gpu_ctx, cornell_arrays):
     """PT_PIPELINE_FUSED on two-level scenes (k_fused_inst: the walk of k_extend_inst16 and k_shade<INST>'s hit shading in one
     lane): film, rgba8 image and ray count equal the oracle's bit for bit on rotated + scaled instance sets and on a corner of
@@ -2139,6 +2161,28 @@ def test_fused_pipeline_on_instanced_scenes(pt, orc, gpu_ctx, cornell_arrays):
             acc += part
             film.close()
         assert acc.tobytes() == ofilm.tobytes() and rays == orays
+        gs.close()
+    # BLAS leaves of up to four independent triangles instead of fan pairs (the kernel's other instantiation): the box built with
+    # pt_tuning.pair_leaves = 0, and a 100-triangle soup, which has no pairs to find
+    inst = _random_instances(9, 11)
+    for arrays, pair in ((cornell_arrays, 0), (_soup(100, 5, spread=0.3), 1)):
+        old = gpu_ctx.set_tuning(pair_leaves=pair)
+        try:
+            gs = pt.Scene(gpu_ctx, *arrays)
+        finally:
+            gpu_ctx.set_tuning(**old)
+        osc = orc.Scene(*arrays)
+        gs.set_instances(inst)
+        osc.set_instances(inst)
+        kw = dict(width=72, height=40, spp_per_frame=4, max_depth=6)
+        ofilm, obgra, orays = _render_oracle(orc, osc, 2, **kw)
+        for shape in (dict(), dict(sample_groups=4)):
+            film = pt.Film(gpu_ctx, 72, 40)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
+            assert gpu_ctx.stats().rays == orays and film.read_f32().tobytes() == ofilm.tobytes(), (pair, shape)
+            assert film.read_bgra8().tobytes() == obgra.tobytes()
+            film.close()
         gs.close()
 
 
