@@ -5,12 +5,12 @@
 // orders, cost area(L) n(L) + area(R) n(R) in binary64, first minimum in (cost, axis, position) order, median split below
 // depth 24; then the BVH4 by opening the internal child of largest area, rows in the same format and order.
 //
-// One workgroup builds it (scenes of <= 2048 triangles; the Cornell box has 18 primitives).  No sorting: for a node
+// Scenes of <= 2048 triangles; the Cornell box has 18 primitives.  No sorting: for a node
 // of m primitives each of the 3m candidates (axis a, primitive j) is "everything whose (centroid_a, id) key is <= j's
 // goes left" -- exactly the split positions of the sorted sweep -- and a thread evaluates it by one pass over the
 // node's primitives that grows the two boxes and counts the left side; that count minus one IS j's position in the sorted
 // order along a, so the winning axis' positions re-order the node's primitives for its children for free.  O(m^2) per
-// node, ~5 ms for 2048 triangles, tens of microseconds for the Cornell box.
+// node: one big workgroup for the nodes at the top, one small workgroup per subtree below (k_sah_top / k_sah_sub).
 #include "pt_internal.h"
 #include "pt_math.h"
 
@@ -57,75 +57,79 @@ __global__ void k_sah_prims(const float *__restrict__ tlo, const float *__restri
     ids[p] = p;
 }
 
-// the binary tree: ONE block; nodes are processed depth first from an explicit stack
-__global__ __launch_bounds__(TBD) void k_sah_tree(uint32_t np, uint32_t leaf_max, const double *__restrict__ plo,
-                                                  const double *__restrict__ phi, uint32_t *__restrict__ ids,
-                                                  uint32_t *__restrict__ ids_tmp, uint32_t *__restrict__ cand_pos /* [3][np] */,
-                                                  SahNode *__restrict__ nodes, uint32_t *__restrict__ n_nodes_out,
-                                                  uint2 *__restrict__ todo /* {node, depth} */)
+// The binary tree, in two launches.  k_sah_top: ONE workgroup of 1024 threads walks the nodes of more than SAH_SUB primitives depth
+// first -- their O(m^2) candidate passes are what the build's time is made of, and sixteen waves hide the LDS latency of the inner
+// loop that four could not -- and hands every child of <= SAH_SUB primitives to a list; k_sah_sub: one workgroup of 256 threads PER
+// listed subtree builds it out of its own LDS, all of them at once.  Node records are numbered by a global counter (the BVH4
+// emission follows the left / right links, not the numbers).  A node step reads LDS only -- every primitive's box (24 B), the order
+// array, the stack of pending nodes; range, depth and box travel in the stack entry / in registers -- and leaves (one
+// primitive) are written by their parent.  Scene build, before -> after (one 256-thread workgroup for everything, its working set in
+// global memory): Cornell box 1.9 -> 1.25 ms, 1024 triangles 25.5 -> 6.8, 2047 triangles 46.7 -> 16.0 (k_sah_top 9.8, the
+// single-thread BVH4 emission 3.0, k_sah_sub 0.75: profiles/r04z_build_small.log, r04aa_sah_build_ms.log).
+struct SahJob { uint32_t node, first, count, depth; };
+constexpr int SAH_STACK = 160;  // pending nodes: <= 1 per level of a depth-first walk + 1; the tree is <= 24 + log2(2048) + 1 levels deep
+constexpr uint32_t SAH_SUB = 128;  // subtrees of <= this many primitives are built by k_sah_sub
+
+// NT threads build the subtree of `root` (a range of the order array).  Primitives are addressed by SLOT: the top kernel's slot is the
+// primitive id (cap = np, gid = identity); a subtree kernel's slot is the position its range had when it was loaded (cap = SAH_SUB),
+// gid[slot] = primitive id, which ties between equal centroids are broken by.  DEFER: children of <= SAH_SUB primitives go to `roots`.
+template <int NT, bool DEFER>
+__device__ __forceinline__ void sah_build(const SahJob root, uint32_t cap, uint32_t leaf_max, const float *g_box, const uint32_t *s_gid, uint32_t *s_ids,
+                                          uint32_t *s_id, uint32_t *s_idg, float *s_box, uint32_t *s_pos, SahNode *__restrict__ nodes,
+                                          uint32_t *__restrict__ n_nodes, SahJob *__restrict__ roots, uint32_t *__restrict__ n_roots)
 {
-    extern __shared__ __attribute__((aligned(16))) char sah_smem[];  // the node's primitives: ids[np], boxes[6 np] (floats)
-    uint32_t *s_id = reinterpret_cast<uint32_t *>(sah_smem);
-    float *s_box = reinterpret_cast<float *>(sah_smem) + np;
-    __shared__ Best s_best[TBD / 64];
-    __shared__ double s_lo[TBD / 64][3], s_hi[TBD / 64][3];
-    __shared__ uint32_t s_n_nodes, s_sp;
+    __shared__ Best s_best[NT / 64];
+    __shared__ double s_lo[NT / 64][3], s_hi[NT / 64][3];
+    __shared__ uint32_t s_sp;
     __shared__ int s_axis;
     __shared__ uint32_t s_k;
     __shared__ int s_split;
+    __shared__ SahJob s_todo[SAH_STACK];
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        nodes[0].first = 0; nodes[0].count = np; nodes[0].left = nodes[0].right = -1;
-        s_n_nodes = 1; s_sp = 1;
-        todo[0] = make_uint2(0u, 0u);
-    }
-    __syncthreads();
+    if (tid == 0) { s_sp = 1; s_todo[0] = root; }
     const double INF = __builtin_inf();
-    while (s_sp > 0) {
-        __syncthreads();
-        const uint2 job = todo[s_sp - 1];
+    for (;;) {
+        __syncthreads();  // the stack as thread 0 left it; everybody is done with the previous node's LDS
+        if (s_sp == 0) break;
+        const SahJob job = s_todo[s_sp - 1];
         __syncthreads();
         if (tid == 0) s_sp--;
-        const uint32_t me = job.x, depth = job.y;
-        const uint32_t first = nodes[me].first, m = nodes[me].count;
-        // node box
+        const uint32_t me = job.node, first = job.first, m = job.count, depth = job.depth;
+        // the node's primitives side by side (slots, ids, boxes), and its box on the way
         double lo[3] = { INF, INF, INF }, hi[3] = { -INF, -INF, -INF };
-        for (uint32_t i = tid; i < m; i += TBD) {
-            const uint32_t p = ids[first + i];
-            for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], plo[3 * (size_t)p + k]); hi[k] = fmax(hi[k], phi[3 * (size_t)p + k]); }
+        for (uint32_t i = tid; i < m; i += NT) {
+            const uint32_t sl = s_ids[first - root.first + i];
+            s_id[i] = sl;
+            s_idg[i] = s_gid[sl];
+            for (int k = 0; k < 3; k++) {
+                const float a = g_box[6 * sl + k], b = g_box[6 * sl + 3 + k];
+                s_box[6 * i + k] = a; s_box[6 * i + 3 + k] = b;
+                lo[k] = fmin(lo[k], (double)a); hi[k] = fmax(hi[k], (double)b);
+            }
         }
         for (int o = 32; o > 0; o >>= 1)
             for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], o, 64)); }
         if ((tid & 63) == 0)
             for (int k = 0; k < 3; k++) { s_lo[tid >> 6][k] = lo[k]; s_hi[tid >> 6][k] = hi[k]; }
         __syncthreads();
-        if (tid == 0) {
-            for (int t = 1; t < TBD / 64; t++)
-                for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], s_lo[t][k]); hi[k] = fmax(hi[k], s_hi[t][k]); }
+        for (int k = 0; k < 3; k++) { lo[k] = s_lo[0][k]; hi[k] = s_hi[0][k]; }
+        for (int t = 1; t < NT / 64; t++)
+            for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], s_lo[t][k]); hi[k] = fmax(hi[k], s_hi[t][k]); }
+        if (tid == 0)
             for (int k = 0; k < 3; k++) { nodes[me].lo[k] = lo[k]; nodes[me].hi[k] = hi[k]; }
-        }
-        __syncthreads();
-        if (m <= 1) continue;  // leaf (uniform: m comes from global memory written before the barrier)
-        // the node's primitives go to LDS (boxes as the floats they were made from: the conversion to binary64 is exact),
-        // where the inner loop below reads them as broadcasts
-        for (uint32_t i = tid; i < m; i += TBD) {
-            const uint32_t p = ids[first + i];
-            s_id[i] = p;
-            for (int k = 0; k < 3; k++) { s_box[6 * i + k] = (float)plo[3 * (size_t)p + k]; s_box[6 * i + 3 + k] = (float)phi[3 * (size_t)p + k]; }
-        }
-        __syncthreads();
+        if (m <= 1) continue;  // (only a one-primitive scene's root comes here as a leaf)
         // every candidate (axis, primitive j): left = keys <= j's key
         Best best = { INF, 0, 0u };
-        for (uint32_t c = tid; c < 3u * m; c += TBD) {
+        for (uint32_t c = tid; c < 3u * m; c += NT) {
             const int ax = (int)(c / m);
             const uint32_t jj = c - (uint32_t)ax * m;
-            const uint32_t j = s_id[jj];
+            const uint32_t j = s_idg[jj];
             const double cj = (double)s_box[6 * jj + ax] + (double)s_box[6 * jj + 3 + ax];
             float llo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, lhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
             float rlo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, rhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
             uint32_t nl = 0;
             for (uint32_t i = 0; i < m; i++) {
-                const uint32_t p = s_id[i];
+                const uint32_t p = s_idg[i];
                 const double cp = (double)s_box[6 * i + ax] + (double)s_box[6 * i + 3 + ax];
                 const bool left = cp < cj || (cp == cj && p <= j);
                 if (left) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(TBD) void k_sah_tree(uint32_t np, uint32_t leaf_max
                     for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], s_box[6 * i + k]); rhi[k] = fmaxf(rhi[k], s_box[6 * i + 3 + k]); }
                 }
             }
-            cand_pos[(size_t)ax * np + jj] = nl - 1u;  // j's position in the sorted order along ax
+            s_pos[(size_t)ax * cap + jj] = nl - 1u;  // j's position in the sorted order along ax
             if (nl < m) {
                 const double dl[3] = { llo[0], llo[1], llo[2] }, dh[3] = { lhi[0], lhi[1], lhi[2] };
                 const double el[3] = { rlo[0], rlo[1], rlo[2] }, eh[3] = { rhi[0], rhi[1], rhi[2] };
@@ -150,9 +154,9 @@ __global__ __launch_bounds__(TBD) void k_sah_tree(uint32_t np, uint32_t leaf_max
         if ((tid & 63) == 0) s_best[tid >> 6] = best;
         __syncthreads();
         if (tid == 0) {
-            for (int t = 1; t < TBD / 64; t++)
+            for (int t = 1; t < NT / 64; t++)
                 if (better(s_best[t], best)) best = s_best[t];
-            const double a_node = box_area_d(nodes[me].lo, nodes[me].hi);
+            const double a_node = box_area_d(lo, hi);
             // a node of <= leaf_max primitives stays a leaf when splitting does not pay (node step : primitive = 1 : 0.6)
             const bool leaf = m <= leaf_max && 0.6 * (double)m * a_node <= 1.0 * a_node + 0.6 * best.cost;
             s_split = leaf ? 0 : 1;
@@ -162,20 +166,72 @@ __global__ __launch_bounds__(TBD) void k_sah_tree(uint32_t np, uint32_t leaf_max
         __syncthreads();
         if (!s_split) continue;
         const int ax = s_axis;
-        for (uint32_t i = tid; i < m; i += TBD) ids[first + cand_pos[(size_t)ax * np + i]] = s_id[i];
+        for (uint32_t i = tid; i < m; i += NT) s_ids[first - root.first + s_pos[(size_t)ax * cap + i]] = s_id[i];
         __syncthreads();
         if (tid == 0) {
-            const uint32_t l = s_n_nodes, r = s_n_nodes + 1u;
-            s_n_nodes += 2u;
+            const uint32_t l = atomicAdd(n_nodes, 2u), r = l + 1u;
             nodes[me].left = (int)l; nodes[me].right = (int)r;
-            nodes[l].first = first; nodes[l].count = s_k + 1u; nodes[l].left = nodes[l].right = -1;
-            nodes[r].first = first + s_k + 1u; nodes[r].count = m - s_k - 1u; nodes[r].left = nodes[r].right = -1;
-            todo[s_sp++] = make_uint2(r, depth + 1u);  // left first
-            todo[s_sp++] = make_uint2(l, depth + 1u);
+            const uint32_t nl = s_k + 1u;
+            auto child = [&](uint32_t c, uint32_t c_first, uint32_t c_count) {
+                nodes[c].first = c_first; nodes[c].count = c_count; nodes[c].left = nodes[c].right = -1;
+                if (c_count == 1u) {  // a leaf: its box is its primitive's
+                    const uint32_t sl = s_ids[c_first - root.first];
+                    for (int k = 0; k < 3; k++) { nodes[c].lo[k] = (double)g_box[6 * sl + k]; nodes[c].hi[k] = (double)g_box[6 * sl + 3 + k]; }
+                } else if (DEFER && c_count <= SAH_SUB) {
+                    roots[atomicAdd(n_roots, 1u)] = { c, c_first, c_count, depth + 1u };
+                } else {
+                    s_todo[s_sp++] = { c, c_first, c_count, depth + 1u };
+                }
+            };
+            child(r, first + nl, m - nl);  // left first
+            child(l, first, nl);
         }
-        __syncthreads();
     }
-    if (tid == 0) *n_nodes_out = s_n_nodes;
+}
+
+constexpr int TBT = 1024;
+__global__ __launch_bounds__(TBT) void k_sah_top(uint32_t np, uint32_t leaf_max, const double *__restrict__ plo, const double *__restrict__ phi,
+                                                 uint32_t *__restrict__ ids, SahNode *__restrict__ nodes, uint32_t *__restrict__ n_nodes,
+                                                 SahJob *__restrict__ roots, uint32_t *__restrict__ n_roots)
+{
+    extern __shared__ __attribute__((aligned(16))) char sah_smem[];
+    float *g_box = reinterpret_cast<float *>(sah_smem);                       // [np][6]: every primitive's box, by primitive id
+    uint32_t *s_gid = reinterpret_cast<uint32_t *>(g_box + 6 * (size_t)np);       // [np]: identity here
+    uint32_t *s_ids = s_gid + np;                                             // [np]: the order array (a node = a range of it)
+    uint32_t *s_id = s_ids + np, *s_idg = s_id + np;                          // [m]: the current node's slots and primitive ids ...
+    float *s_box = reinterpret_cast<float *>(s_idg + np);                     // [m][6]: ... and their boxes, read as broadcasts
+    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_box + 6 * (size_t)np);       // [3][np]: a candidate's position in its axis' sorted order
+    for (uint32_t i = threadIdx.x; i < np; i += TBT) {
+        for (int k = 0; k < 3; k++) { g_box[6 * i + k] = (float)plo[3 * (size_t)i + k]; g_box[6 * i + 3 + k] = (float)phi[3 * (size_t)i + k]; }  // (exact: made from floats)
+        s_gid[i] = i;
+        s_ids[i] = i;
+    }
+    const SahJob root = { 0u, 0u, np, 0u };
+    if (threadIdx.x == 0) { nodes[0].first = 0; nodes[0].count = np; nodes[0].left = nodes[0].right = -1; }
+    if (np <= SAH_SUB) {  // the whole scene is one subtree: k_sah_sub's work (uniform)
+        if (threadIdx.x == 0) { roots[0] = root; *n_roots = 1u; }
+        return;
+    }
+    sah_build<TBT, true>(root, np, leaf_max, g_box, s_gid, s_ids, s_id, s_idg, s_box, s_pos, nodes, n_nodes, roots, n_roots);
+    for (uint32_t i = threadIdx.x; i < np; i += TBT) ids[i] = s_ids[i];  // (the subtree kernels read their ranges from here)
+}
+
+__global__ __launch_bounds__(TBD) void k_sah_sub(uint32_t leaf_max, const double *__restrict__ plo, const double *__restrict__ phi,
+                                                 uint32_t *__restrict__ ids, SahNode *__restrict__ nodes, uint32_t *__restrict__ n_nodes,
+                                                 const SahJob *__restrict__ roots, const uint32_t *__restrict__ n_roots)
+{
+    if (blockIdx.x >= *n_roots) return;
+    __shared__ float g_box[6 * SAH_SUB], s_box[6 * SAH_SUB];
+    __shared__ uint32_t s_gid[SAH_SUB], s_ids[SAH_SUB], s_id[SAH_SUB], s_idg[SAH_SUB], s_pos[3 * SAH_SUB];
+    const SahJob root = roots[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < root.count; i += TBD) {
+        const uint32_t p = ids[root.first + i];
+        for (int k = 0; k < 3; k++) { g_box[6 * i + k] = (float)plo[3 * (size_t)p + k]; g_box[6 * i + 3 + k] = (float)phi[3 * (size_t)p + k]; }
+        s_gid[i] = p;
+        s_ids[i] = i;
+    }
+    sah_build<TBD, false>(root, SAH_SUB, leaf_max, g_box, s_gid, s_ids, s_id, s_idg, s_box, s_pos, nodes, n_nodes, nullptr, nullptr);
+    for (uint32_t i = threadIdx.x; i < root.count; i += TBD) ids[root.first + i] = s_gid[s_ids[i]];
 }
 
 // per binary node, in parallel: the padded float box of its triangles (what a BVH4 slot holds) and its area
@@ -296,14 +352,14 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
     }
     const uint32_t np = (uint32_t)prim_first.size();
     Buf<float> d_tlo, d_thi;
-    Buf<uint32_t> d_first, d_ids, d_tmp, d_pos, d_nn, d_rows, d_order, d_counts;
+    Buf<uint32_t> d_first, d_ids, d_nn, d_rows, d_order, d_counts;
     Buf<uint8_t> d_tris;
     Buf<double> d_plo, d_phi;
     Buf<SahNode> d_nodes;
     Buf<uint2> d_todo;
     PT_HIP(ctx, d_tlo.alloc(3 * (size_t)n)); PT_HIP(ctx, d_thi.alloc(3 * (size_t)n));
-    PT_HIP(ctx, d_first.alloc(np)); PT_HIP(ctx, d_tris.alloc(np)); PT_HIP(ctx, d_ids.alloc(np)); PT_HIP(ctx, d_tmp.alloc(np));
-    PT_HIP(ctx, d_pos.alloc(3 * (size_t)np)); PT_HIP(ctx, d_nn.alloc(1)); PT_HIP(ctx, d_plo.alloc(3 * (size_t)np)); PT_HIP(ctx, d_phi.alloc(3 * (size_t)np));
+    PT_HIP(ctx, d_first.alloc(np)); PT_HIP(ctx, d_tris.alloc(np)); PT_HIP(ctx, d_ids.alloc(np));
+    PT_HIP(ctx, d_nn.alloc(1)); PT_HIP(ctx, d_plo.alloc(3 * (size_t)np)); PT_HIP(ctx, d_phi.alloc(3 * (size_t)np));
     PT_HIP(ctx, d_nodes.alloc(2 * (size_t)np + 1)); PT_HIP(ctx, d_todo.alloc(2 * (size_t)np + 8));
     PT_HIP(ctx, d_rows.alloc(32 * (size_t)(2 * np + 1))); PT_HIP(ctx, d_order.alloc(n)); PT_HIP(ctx, d_counts.alloc(2));
     PT_HIP(ctx, hipMemcpyAsync(d_tlo.p, tlo, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -311,10 +367,19 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
     PT_HIP(ctx, hipMemcpyAsync(d_first.p, prim_first.data(), sizeof(uint32_t) * np, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d_tris.p, prim_tris.data(), np, hipMemcpyHostToDevice, st));
     k_sah_prims<<<(np + TBD - 1) / TBD, TBD, 0, st>>>(d_tlo.p, d_thi.p, d_first.p, d_tris.p, np, d_plo.p, d_phi.p, d_ids.p);
-    const size_t tree_smem = sizeof(uint32_t) * 7 * (size_t)np;  // <= 56 KB for 2048 primitives
-    if (tree_smem > 48 * 1024)
-        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sah_tree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_smem));
-    k_sah_tree<<<1, TBD, tree_smem, st>>>(np, leaf_max > 0 ? leaf_max : 1u, d_plo.p, d_phi.p, d_ids.p, d_tmp.p, d_pos.p, d_nodes.p, d_nn.p, d_todo.p);
+    // (d_nn: the node counter, one node -- the root -- taken; d_nroots: subtrees handed to k_sah_sub)
+    Buf<SahJob> d_roots;
+    Buf<uint32_t> d_nroots;
+    PT_HIP(ctx, d_roots.alloc(np + 1)); PT_HIP(ctx, d_nroots.alloc(1));
+    const uint32_t one = 1u;
+    PT_HIP(ctx, hipMemcpyAsync(d_nn.p, &one, sizeof(one), hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemsetAsync(d_nroots.p, 0, sizeof(uint32_t), st));
+    const size_t top_smem = sizeof(uint32_t) * 19 * (size_t)np;  // boxes 6 + ids 1 + order 1 + the node's copy 8 + positions 3: <= 152 KB for 2048 primitives
+    if (top_smem > 48 * 1024)
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sah_top), hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_smem));
+    k_sah_top<<<1, TBT, top_smem, st>>>(np, leaf_max > 0 ? leaf_max : 1u, d_plo.p, d_phi.p, d_ids.p, d_nodes.p, d_nn.p, d_roots.p, d_nroots.p);
+    // (a child handed over has >= 2 primitives and the ranges are disjoint: <= np / 2 subtrees)
+    k_sah_sub<<<std::max(1u, np / 2u), TBD, 0, st>>>(leaf_max > 0 ? leaf_max : 1u, d_plo.p, d_phi.p, d_ids.p, d_nodes.p, d_nn.p, d_roots.p, d_nroots.p);
     Buf<float> d_nbox;
     Buf<double> d_narea;
     Buf<uint32_t> d_ntris;
