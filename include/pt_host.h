@@ -38,7 +38,9 @@ int  pth_load_obj(const char *obj_path, const char *mtl_dir, pth_scene *out, cha
  * and empty in the checkout, so which rule it was built with is unknown).  On the Cornell box both rules give the
  * same surfaces and, within the stated tolerance, the same image; only gl_PrimitiveID numbering and the last bits of
  * hit positions differ.  pth_load_obj = flags 0 = fan, which all fixtures use.                          */
-enum { PTH_QUAD_SHORTER_DIAGONAL = 1u };
+enum { PTH_QUAD_SHORTER_DIAGONAL = 1u,
+       PTH_SMALL_CHUNKS = 2u /* test hook: the text is read by up to 64 threads in chunks of ~256 bytes (the loader cuts big files into one
+                                chunk per hardware thread; this makes short files cross chunk boundaries).  Same result. */ };
 int  pth_load_obj_ex(const char *obj_path, const char *mtl_dir, uint32_t flags, pth_scene *out, char *err, size_t err_len);
 void pth_free_scene(pth_scene *s);
 

@@ -199,6 +199,7 @@ def lib_host():
 
 # ---- host side: scene ingest / image output ---------------------------------------------------
 QUAD_SHORTER_DIAGONAL = 1
+SMALL_CHUNKS = 2  # test hook of the loader (include/pt_host.h)
 
 
 def load_obj(path, mtl_dir=None, flags=0):

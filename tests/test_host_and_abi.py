@@ -68,6 +68,79 @@ def test_loader_quad_rules(pt, tmp_path, orc):
     assert (d <= 1e-4).mean() >= 0.99 and abs(ra - rb) <= 0.002 * ra
 
 
+def _random_obj_text(rng, n_lines, error=None):
+    """OBJ text with everything the loader reads: comments, blank lines, CRLF ends, `v` in several number formats, faces of 3..6
+    vertices with absolute / relative indices and the v/vt/vn forms, `usemtl` of known, unknown and later-overridden names,
+    `mtllib` lines in the middle.  error: (kind, line) plants one bad line."""
+    out, nv = [], 0
+    names = ["a", "b", "c", "nosuch", "late"]
+    fmt = [lambda x: "%.9g" % x, lambda x: "%+.9g" % x, lambda x: "%.8e" % x, lambda x: repr(float(x))]
+    for no in range(1, n_lines + 1):
+        r = rng.random()
+        if error and no == error[1]:
+            kind = error[0]
+            line = {"vertex": "v 1 2", "vertex_text": "v 0.5 x 1", "face": "f 1 zz 3", "zero": "f 1 0 2", "range": f"f 1 2 {nv + 5}",
+                    "range_neg": f"f -1 -2 -{nv + 3}", "short": "f 1 2", "range_before_bad": f"f {nv + 9} qq 1", "range_in_short": f"f {nv + 2} 1"}[kind]
+            out.append(line)
+            continue
+        if nv < 3 or r < 0.45:
+            x = np.float32(rng.uniform(-3, 3, 3))
+            f = fmt[int(rng.integers(len(fmt)))]
+            out.append("v " + " ".join(f(c) for c in x) + ("  # corner" if rng.random() < 0.1 else ""))
+            nv += 1
+        elif r < 0.8:
+            k = int(rng.choice([3, 3, 3, 4, 4, 5, 6]))
+            toks = []
+            for _ in range(k):
+                a = int(rng.integers(1, nv + 1))
+                i = a if rng.random() < 0.5 else a - nv - 1
+                form = int(rng.integers(4))
+                toks.append([f"{i}", f"{i}/7", f"{i}//2", f"{i}/3/4"][form])
+            out.append(("f " if rng.random() < 0.9 else "f\t") + " ".join(toks))
+        elif r < 0.9:
+            out.append("usemtl " + names[int(rng.integers(len(names)))])
+        elif r < 0.93:
+            out.append("mtllib " + str(rng.choice(["m1.mtl", "m2.mtl", "missing.mtl"])))
+        elif r < 0.97:
+            out.append(str(rng.choice(["", "# a comment", "g group", "vn 0 1 0", "s off", "   "])))
+        else:
+            out.append("usemtl")
+    eol = "\r\n" if rng.random() < 0.3 else "\n"
+    return eol.join(out) + (eol if rng.random() < 0.7 else "")
+
+
+def test_loader_chunked_text_equals_one_reader(pt, tmp_path):
+    """The loader reads big files with one thread per chunk of text; PTH_SMALL_CHUNKS makes that happen on short ones (chunks of
+    ~256 bytes, so relative indices, materials and the quad rule reach across chunk boundaries).  Arrays -- and for a broken file
+    the message and its line number -- equal a line-by-line reader's (tests/obj_ref.py load_obj_strict), with and without chunks."""
+    (tmp_path / "m1.mtl").write_text("newmtl a\nKd 0.1 0.2 0.3\nKe 1 2 3\nnewmtl b\nKd 0.5\n")
+    (tmp_path / "m2.mtl").write_text("newmtl late\nKd 0.9 0.8 0.7\nnewmtl a\nKd 0.25 0.5 0.75\nKe 4 5 6\n")
+    rng = np.random.default_rng(12)
+    kinds = [None, None, "vertex", "vertex_text", "face", "zero", "range", "range_neg", "short", "range_before_bad", "range_in_short"]
+    for case in range(60):
+        n_lines = int(rng.integers(5, 400))
+        kind = kinds[case % len(kinds)]
+        err = (kind, int(rng.integers(4, n_lines + 1))) if kind else None
+        obj = tmp_path / f"r{case}.obj"
+        with open(obj, "w", newline="") as f:
+            f.write(_random_obj_text(rng, n_lines, err))
+        for quad in (False, True):
+            try:
+                want = obj_ref.load_obj_strict(str(obj), quad)
+            except obj_ref.ObjError as e:
+                want = str(e)
+            for flags in (0, pt.SMALL_CHUNKS):
+                try:
+                    got = pt.load_obj(str(obj), flags=flags | (pt.QUAD_SHORTER_DIAGONAL if quad else 0))
+                except RuntimeError as e:
+                    got = str(e).split(": ", 1)[1]
+                if isinstance(want, str):
+                    assert got == want, (case, kind, flags)
+                else:
+                    assert not isinstance(got, str), (case, got)
+                    assert all(x.tobytes() == y.tobytes() for x, y in zip(got, want)), (case, flags, quad)
+
+
 def test_make_soup_equals_the_obj_round_trip(pt, tmp_path):
     path = str(tmp_path / "s.obj")
     pt.write_soup_obj(path, 3000, 7)
