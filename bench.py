@@ -25,6 +25,8 @@ Beside the headline the default single-GPU run appends, OUTSIDE the timed region
   * `c2_exact`            K = 2 (= 64 spp, exactly BASELINE config C2) in one call;
   * `latency_ms_1frame`   the reference's own dispatch shape: one blocking pt_render per frame (main.cpp:647-685);
   * `roofline.valu_*`     the VALU-issue side of the Cornell traversal kernel from LIVE block counters;
+  * `roofline.traffic`    HBM-side bytes per launch of that kernel, counted: the same frames twice more in a child process under
+                          `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (`traffic_live`; --no-live-pmc: the committed record);
   * `roofline_c5`         the traversal kernel on the 1M-triangle soup (BASELINE config C5), the one config whose
                           scene does not fit LDS/L2: algorithmic bytes per ray x rays per launch / average launch
                           time / 8 TB/s, every factor measured in this run (`--config c5` runs it as the headline,
@@ -255,6 +257,54 @@ def roofline_block(pt, st, cst, info, config, note):
                            "source": "live wave-level block counts (PT_FLAG_COUNT_VISITS) x VALU instructions per block of the shipped ISA "
                                      "(profiles/isa_valu_model.json, scripts/isa_blocks.py)"}
     return r
+
+
+def live_traffic(argv_child, kernel_prefix, timeout_s=240):
+    """HBM-side bytes per ray of the dominant kernel MEASURED for this build on this box: the same command, short, twice under
+    `rocprofv3 --kernel-trace --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes, nothing but the kernel trace beside them,
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- corrected as calibrated (2 x FETCH_SIZE KiB + WRITE_SIZE KiB:
+    profiles/r03_fetch_size_calibration.json).  -> dict or None (no rocprofv3, a pass failed or timed out: the caller keeps the
+    committed record and says so)."""
+    import csv, glob, re, shutil, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations
+    kib, disp, child = {}, {}, None
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pt_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv_child,
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout_s, env=dict(os.environ, TMPDIR="/tmp"))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+            if r.returncode != 0 or not lines:
+                return None
+            child = json.loads(lines[-1])
+            tot, ids = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+                    if row["Counter_Name"] == ctr and k.startswith(kernel_prefix) and not counting.match(k):
+                        tot += float(row["Counter_Value"])
+                        ids.add(row["Dispatch_Id"])
+            if not ids:
+                return None
+            kib[ctr], disp[ctr] = tot, len(ids)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # both passes ran the same launches; the child's own line says how many rays they carried
+    launches = child["roofline"]["launches"] if "roofline" in child and child["roofline"].get("launches") else None
+    if not launches:
+        return None
+    rays_per_launch = child["rays"] / launches
+    rd = 2.0 * 1024.0 * kib["FETCH_SIZE"] / disp["FETCH_SIZE"]
+    wr = 1024.0 * kib["WRITE_SIZE"] / disp["WRITE_SIZE"]
+    return {"hbm_bytes_per_ray": (rd + wr) / rays_per_launch, "hbm_read_bytes_per_ray": rd / rays_per_launch, "hbm_write_bytes_per_ray": wr / rays_per_launch,
+            "launches_profiled": disp["FETCH_SIZE"], "rays_per_launch_profiled": round(rays_per_launch, 1), "seconds": round(time.perf_counter() - t0, 1),
+            "source": "live: this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) on this box"}
 
 
 def roofline_shade_block(st, config):
@@ -499,6 +549,8 @@ def main():
                     help="per-round device sort of the extend queue by (origin cell, octant); auto = scenes beyond the Infinity Cache")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record instead of two nested rocprofv3 passes of this command")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the nested run of live_traffic()
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c4 / _c5 / _c5x legs")
     ap.add_argument("--c5-frames", type=int, default=4, help="frames of the roofline_c5 leg")
     ap.add_argument("--c4-frames", type=int, default=8, help="frames of the roofline_c4 leg")
@@ -708,6 +760,24 @@ def main():
             out["roofline"]["pipelines"] = st.pipelines
             out["roofline"]["frac_all_launches_over_device_time"] = round(bytes_extend * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             out["roofline_shade"] = roofline_shade_block(st, scene_config)
+            if world == 1 and not (args.no_extra_legs or args.no_live_pmc or args.pmc_child):
+                # roofline.traffic measured, not looked up: the same frames twice more in a child process under rocprofv3's counters
+                child = ["--pmc-child", "--config", args.config, "--steps", str(args.steps), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
+                         "--width", str(W), "--height", str(H), "--spp", str(args.spp), "--depth", str(args.depth), "--extend", args.extend,
+                         "--frames-in-flight", str(args.frames_in_flight), "--sample-groups", str(args.sample_groups), "--sort-rays", args.sort_rays,
+                         "--bvh-quality", args.bvh_quality] + (["--soup-tris", str(args.soup_tris)] if args.soup_tris else [])
+                lt = None
+                try:
+                    lt = live_traffic(child, "k_extend")
+                except Exception:
+                    lt = None
+                r_ = out["roofline"]
+                if lt:
+                    r_["traffic"] = round(lt["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
+                    r_["frac_counted"] = round(lt["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                    r_["traffic_live"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in lt.items()}
+                else:
+                    r_["traffic_live"] = {"source": "not measured in this run (no rocprofv3, or a pass failed): `traffic` is the committed record's bytes per ray x this run's rays"}
         if world == 1 and not args.no_extra_legs and args.config in ("c2", "c3"):
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()
