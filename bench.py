@@ -259,18 +259,20 @@ def roofline_block(pt, st, cst, info, config, note):
     return r
 
 
-def live_traffic(argv_child, kernel_prefix, timeout_s=240):
-    """HBM-side bytes per ray of the dominant kernel MEASURED for this build on this box: the same command, short, twice under
+def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=300):
+    """HBM-side bytes per ray of the frame's kernels MEASURED for this build on this box: the same command, short, twice under
     `rocprofv3 --kernel-trace --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes, nothing but the kernel trace beside them,
     as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- corrected as calibrated (2 x FETCH_SIZE KiB + WRITE_SIZE KiB:
-    profiles/r03_fetch_size_calibration.json).  -> dict or None (no rocprofv3, a pass failed or timed out: the caller keeps the
-    committed record and says so)."""
+    profiles/r03_fetch_size_calibration.json).  -> {kernel prefix: record} or None (no rocprofv3, a pass failed or timed out: the
+    caller keeps the committed record and says so)."""
     import csv, glob, re, shutil, tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None
     counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations
-    kib, disp, child = {}, {}, None
+    kib = {p: {} for p in prefixes}
+    disp = {p: {} for p in prefixes}
+    child = None
     t0 = time.perf_counter()
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pt_pmc_", dir="/tmp")
@@ -281,30 +283,50 @@ def live_traffic(argv_child, kernel_prefix, timeout_s=240):
             if r.returncode != 0 or not lines:
                 return None
             child = json.loads(lines[-1])
-            tot, ids = 0.0, set()
+            tot = {p: 0.0 for p in prefixes}
+            ids = {p: set() for p in prefixes}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != ctr:
+                        continue
                     k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
-                    if row["Counter_Name"] == ctr and k.startswith(kernel_prefix) and not counting.match(k):
-                        tot += float(row["Counter_Value"])
-                        ids.add(row["Dispatch_Id"])
-            if not ids:
-                return None
-            kib[ctr], disp[ctr] = tot, len(ids)
+                    for p in prefixes:
+                        if k.startswith(p) and not counting.match(k):
+                            tot[p] += float(row["Counter_Value"])
+                            ids[p].add(row["Dispatch_Id"])
+            for p in prefixes:
+                kib[p][ctr], disp[p][ctr] = tot[p], len(ids[p])
         except Exception:
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    # both passes ran the same launches; the child's own line says how many rays they carried
+    # both passes ran the same launches; the child's own line says how many rays they carried (a shade launch handles the rays of
+    # the extend launch before it)
     launches = child["roofline"]["launches"] if "roofline" in child and child["roofline"].get("launches") else None
     if not launches:
         return None
     rays_per_launch = child["rays"] / launches
-    rd = 2.0 * 1024.0 * kib["FETCH_SIZE"] / disp["FETCH_SIZE"]
-    wr = 1024.0 * kib["WRITE_SIZE"] / disp["WRITE_SIZE"]
-    return {"hbm_bytes_per_ray": (rd + wr) / rays_per_launch, "hbm_read_bytes_per_ray": rd / rays_per_launch, "hbm_write_bytes_per_ray": wr / rays_per_launch,
-            "launches_profiled": disp["FETCH_SIZE"], "rays_per_launch_profiled": round(rays_per_launch, 1), "seconds": round(time.perf_counter() - t0, 1),
-            "source": "live: this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) on this box"}
+    out = {}
+    for p in prefixes:
+        if not disp[p].get("FETCH_SIZE") or not disp[p].get("WRITE_SIZE"):
+            continue
+        rd = 2.0 * 1024.0 * kib[p]["FETCH_SIZE"] / disp[p]["FETCH_SIZE"]
+        wr = 1024.0 * kib[p]["WRITE_SIZE"] / disp[p]["WRITE_SIZE"]
+        out[p] = {"hbm_bytes_per_ray": (rd + wr) / rays_per_launch, "hbm_read_bytes_per_ray": rd / rays_per_launch, "hbm_write_bytes_per_ray": wr / rays_per_launch,
+                  "launches_profiled": disp[p]["FETCH_SIZE"], "rays_per_launch_profiled": round(rays_per_launch, 1), "seconds": round(time.perf_counter() - t0, 1),
+                  "source": "live: this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) on this box"}
+    return out or None
+
+
+def apply_live_traffic(r_, lt, st, ms_kernel, launches):
+    """`traffic` / `frac_counted` of a roofline block from a live_traffic() record (or the note that there is none)."""
+    if lt:
+        r_["traffic"] = round(lt["hbm_bytes_per_ray"] * st.rays / max(launches, 1), 1)
+        if ms_kernel:
+            r_["frac_counted"] = round(lt["hbm_bytes_per_ray"] * st.rays / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        r_["traffic_live"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in lt.items()}
+    else:
+        r_["traffic_live"] = {"source": "not measured in this run (no rocprofv3, or a pass failed): `traffic` is the committed record's bytes per ray x this run's rays"}
 
 
 def roofline_shade_block(st, config):
@@ -385,7 +407,7 @@ NOTES["c3"] = NOTES["c2"]
 LEG_SHAPE = {"c4": dict(spp=32, depth=8, tris=0), "c5": dict(spp=16, depth=16, tris=1000000), "c5x": dict(spp=16, depth=16, tris=8000000)}
 
 
-def extra_leg(pt, ctx, W, H, config, frames, rank):
+def extra_leg(pt, ctx, W, H, config, frames, rank, live=False):
     """The traversal kernel of another BASELINE config (C4 / C5 / C5x) in the default line: `frames` warm-up frames, then the
     same `frames` frames timed with per-launch events (identical launches, so rocprofv3's average over the whole process
     equals this leg's), then the same frames through the instrumented kernel for the visit and block counts."""
@@ -435,6 +457,14 @@ def extra_leg(pt, ctx, W, H, config, frames, rank):
             f2.close()
         except Exception as e:
             out["fused"] = {"error": repr(e)}
+    if live:   # the leg's traffic counted like the headline's: the same frames in a child process under rocprofv3's counters
+        lt = None
+        try:
+            lt = live_traffic(["--pmc-child", "--config", config, "--steps", str(frames), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
+                               "--width", str(W), "--height", str(H)], prefixes=("k_extend",))
+        except Exception:
+            lt = None
+        apply_live_traffic(r["roofline"] if "roofline" in r else r, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
     out.update(r)
     film.close()
     scene.close()
@@ -768,16 +798,11 @@ def main():
                          "--bvh-quality", args.bvh_quality] + (["--soup-tris", str(args.soup_tris)] if args.soup_tris else [])
                 lt = None
                 try:
-                    lt = live_traffic(child, "k_extend")
+                    lt = live_traffic(child)
                 except Exception:
                     lt = None
-                r_ = out["roofline"]
-                if lt:
-                    r_["traffic"] = round(lt["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
-                    r_["frac_counted"] = round(lt["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                    r_["traffic_live"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in lt.items()}
-                else:
-                    r_["traffic_live"] = {"source": "not measured in this run (no rocprofv3, or a pass failed): `traffic` is the committed record's bytes per ray x this run's rays"}
+                apply_live_traffic(out["roofline"], (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
+                apply_live_traffic(out["roofline_shade"], (lt or {}).get("k_shade"), st, st.ms_shade, st.launches_extend)
         if world == 1 and not args.no_extra_legs and args.config in ("c2", "c3"):
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()
@@ -822,7 +847,7 @@ def main():
             for leg, frames in (("c4", args.c4_frames), ("c5", args.c5_frames), ("c5x", args.c5x_frames)):
                 film.clear()
                 try:
-                    out["roofline_" + leg] = extra_leg(pt, ctx, W, H, leg, frames, rank) if frames > 0 else None
+                    out["roofline_" + leg] = extra_leg(pt, ctx, W, H, leg, frames, rank, live=not (args.no_live_pmc or args.pmc_child)) if frames > 0 else None
                 except Exception as e:
                     out["roofline_" + leg] = {"error": repr(e)}
         base = None
