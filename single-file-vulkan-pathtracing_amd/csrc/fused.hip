@@ -112,9 +112,11 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
 #undef PT_LAUNCH_FUSED_INST
         return;
     }
+    FastDiv div_frames;  // one group: the hand-out order is tile-major (fused_kernel.h), chunk -> (tile, frame) by this
+    div_frames.init(std::max(rc.lanes_active, 1u));
 #define PT_LAUNCH_FUSED(G, P)                                                                                                              \
     hipExtLaunchKernelGGL((k_fused<G, P>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4, \
-                          s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack)
+                          s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack, div_frames)
     if (fp.pairs) { if (grouped) PT_LAUNCH_FUSED(true, true); else PT_LAUNCH_FUSED(false, true); }
     else { if (grouped) PT_LAUNCH_FUSED(true, false); else PT_LAUNCH_FUSED(false, false); }
 #undef PT_LAUNCH_FUSED

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                                                               const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
                                                               uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
                                                               uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
-                                                              float tmax, int lds_stack)
+                                                              float tmax, int lds_stack, FastDiv div_frames)
 {
     constexpr uint32_t LEAF_BIT = 0x2000u, DONE = 0x3FFFu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,7 +99,13 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
     uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;  // ... the part of the slot range it draws from, parts found empty
-    const uint32_t part_len = ((n_slots + PT_FUSED_PARTS - 1) / PT_FUSED_PARTS + 63u) & ~63u;
+    // several groups: the slot range is cut into PT_FUSED_PARTS contiguous parts.  One group: part p is every PT_FUSED_PARTS-th 64-slot chunk
+    // of the HAND-OUT order -- tile-major, all frames of a tile before the next tile (chunk q = tile q / frames, frame q % frames) -- so every part,
+    // like the whole launch, runs from the image's centre to its border (film_work.hip numbers the tiles that way) and ENDS with border pixels of
+    // all frames: slots of 32 rays where an interior one has a hundred and more.  What runs alone at the end of a launch is then short: a rank of
+    // world 8 is not helped (its loss is elsewhere), 16 frames on one device are: 39.76 -> 40.8 Grays/s, two of two rounds; K = 8 +-0, K = 4 +2 %; the two-level
+    // kernel loses 1 % with it and keeps the frame-major order (profiles/r04ag_ab_fused_tilemajor.log).  (Slot numbers, and with them the radiance arrays, are frame-major as before.)
+    const uint32_t part_len = ((n_slots + PT_FUSED_PARTS - 1) / PT_FUSED_PARTS + 63u) & ~63u;  // (several groups)
     lds_u32 *s_wtile = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (threadIdx.x >> 6) * PT_FUSED_WTILES;
     ptm::f3 inv{}, invf{}, on{}, of{}, orgp{};
     ptm::RayPre pre{};
@@ -222,7 +228,10 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     // (a rank of world 8 at config C3's size: 28.6 -> 25.1 ms).  Several groups: always PT_FUSED_BATCH
                     // (profiles/r04j_fused_batch_policy.log).
                     for (;;) {
-                        const uint32_t part_begin = w_part * part_len, part_end = min(part_begin + part_len, n_slots);
+                        // (one group: w_base / w_next / w_end count within the part)
+                        const uint32_t part_begin = GROUPED ? w_part * part_len : 0u,
+                                       part_end = GROUPED ? min(part_begin + part_len, n_slots)
+                                                          : (((n_slots >> 6) + (uint32_t)PT_FUSED_PARTS - 1u - w_part) / (uint32_t)PT_FUSED_PARTS) << 6;
                         uint32_t rel = 0, size = 0;
                         if (lane == 0) {
                             uint32_t *cnt = next_slot + w_part * (uint32_t)PT_FUSED_PART_STRIDE;
@@ -246,8 +255,12 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                         if (++w_tried >= (uint32_t)PT_FUSED_PARTS) { out_of_slots = true; w_end = w_next; break; }
                     }
                     if (!out_of_slots && (uint32_t)lane < (w_end - w_base + 63u) / 64u) {
-                        const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
-                        s_wtile[lane] = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
+                        if (GROUPED) {
+                            const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
+                            s_wtile[lane] = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
+                        } else {
+                            s_wtile[lane] = tiles[div_frames.div(((w_base >> 6) + (uint32_t)lane) * (uint32_t)PT_FUSED_PARTS + w_part)];
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order: the reads below see these words)
                 }
@@ -255,10 +268,19 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
                 if (in_blk && !path && rank < take) {
                     const uint32_t mine = w_next + rank;
-                    slot = slot_base + mine;
-                    const uint32_t lane_slot = rc.div_spl.div(slot);
-                    const uint32_t f = rc.div_groups.div(lane_slot), g = lane_slot - f * rc.groups;
-                    const uint32_t local = slot - lane_slot * rc.slots_per_lane;
+                    uint32_t f, g, local;
+                    if (GROUPED) {
+                        slot = slot_base + mine;
+                        const uint32_t lane_slot = rc.div_spl.div(slot);
+                        f = rc.div_groups.div(lane_slot); g = lane_slot - f * rc.groups;
+                        local = slot - lane_slot * rc.slots_per_lane;
+                    } else {  // hand-out order -> slot: chunk q of the order is (tile q / frames, frame q % frames)
+                        const uint32_t q = (mine >> 6) * (uint32_t)PT_FUSED_PARTS + w_part;
+                        const uint32_t t = div_frames.div(q);
+                        f = q - t * rc.lanes_active; g = 0u;
+                        local = t * 64u + (mine & 63u);
+                        slot = slot_base + f * rc.slots_per_lane + local;
+                    }
                     const uint32_t tw = s_wtile[(mine - w_base) >> 6];
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
                     const uint32_t sample0 = g * rc.group_size;
