@@ -267,8 +267,8 @@ def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=300):
     caller keeps the committed record and says so)."""
     import csv, glob, re, shutil, tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not exe:
-        return None
+    if not exe or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", ""):
+        return None   # (no profiler, or this process is itself being profiled: no profiler inside a profiler)
     counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations
     kib = {p: {} for p in prefixes}
     disp = {p: {} for p in prefixes}
