@@ -64,8 +64,9 @@ __global__ void k_sah_prims(const float *__restrict__ tlo, const float *__restri
 // emission follows the left / right links, not the numbers).  A node step reads LDS only -- every primitive's box (24 B), the order
 // array, the stack of pending nodes; range, depth and box travel in the stack entry / in registers -- and leaves (one
 // primitive) are written by their parent.  Scene build, before -> after (one 256-thread workgroup for everything, its working set in
-// global memory): Cornell box 1.9 -> 1.25 ms, 1024 triangles 25.5 -> 6.8, 2047 triangles 46.7 -> 16.0 (k_sah_top 9.8, the
-// single-thread BVH4 emission 3.0, k_sah_sub 0.75: profiles/r04z_build_small.log, r04aa_sah_build_ms.log).
+// global memory): Cornell box 1.9 -> 1.25 ms, 1024 triangles 25.5 -> 5.6, 2047 triangles 46.7 -> 10.2 (16.0 while the top nodes still
+// ran the quadratic pass with its boxes; what is left is mostly the single-thread BVH4 emission, 3.0 ms: profiles/r04z_build_small.log,
+// r04aa_sah_build_ms.log, r04ai_times.txt).
 struct SahJob { uint32_t node, first, count, depth; };
 constexpr int SAH_STACK = 160;  // pending nodes: <= 1 per level of a depth-first walk + 1; the tree is <= 24 + log2(2048) + 1 levels deep
 constexpr uint32_t SAH_SUB = 128;  // subtrees of <= this many primitives are built by k_sah_sub
@@ -190,30 +191,190 @@ __device__ __forceinline__ void sah_build(const SahJob root, uint32_t cap, uint3
 }
 
 constexpr int TBT = 1024;
+
+// ---- the top of the tree: nodes of more than SAH_SUB primitives -------------------------------------------------------------
+// Same candidates, same costs, same winner as sah_build, found differently: per axis the candidates are RANKED (a pass over the
+// node per candidate that only compares keys -- the part of the old pass that is quadratic, now a few instructions per step), the
+// boxes are put in that order and two scans over it -- suffix, then prefix -- give every split position its right and left box:
+// min and max are exact, so the boxes, their binary64 areas and the costs are the old pass's bit for bit.  The node's primitives
+// come from global memory each time (a top node is visited once; there are a few dozen of them).
+__device__ __forceinline__ void box_join(float *a, const float *b)
+{
+    for (int k = 0; k < 3; k++) { a[k] = fminf(a[k], b[k]); a[3 + k] = fmaxf(a[3 + k], b[3 + k]); }
+}
+
+// in-place inclusive scan (FWD: prefix, else suffix) of S[m][6] under box_join; every thread of the block calls it
+template <bool FWD>
+__device__ __forceinline__ void scan_boxes(float *S, uint32_t m, float (*s_wt)[6])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t C = (m + TBT - 1) / TBT;  // elements per thread (<= 2 for 2048 primitives)
+    const float inf = __builtin_inff();
+    float tot[6] = { inf, inf, inf, -inf, -inf, -inf };
+    const uint32_t e0 = (uint32_t)tid * C, e1 = min(m, e0 + C);
+    if (FWD) {
+        for (uint32_t e = e0; e < e1; e++) { box_join(tot, S + 6 * e); for (int k = 0; k < 6; k++) S[6 * e + k] = tot[k]; }
+    } else {
+        for (uint32_t e = e1; e > e0; e--) { box_join(tot, S + 6 * (e - 1)); for (int k = 0; k < 6; k++) S[6 * (e - 1) + k] = tot[k]; }
+    }
+    // the threads' totals: inclusive scan inside the wave, then the waves' totals
+    float inc[6];
+    for (int k = 0; k < 6; k++) inc[k] = tot[k];
+    for (int o = 1; o < 64; o <<= 1) {
+        float t[6];
+        for (int k = 0; k < 6; k++) t[k] = FWD ? __shfl_up(inc[k], o, 64) : __shfl_down(inc[k], o, 64);
+        if (FWD ? lane >= o : lane + o < 64) box_join(inc, t);
+    }
+    float exc[6];  // what lies before (FWD) / behind this thread's elements inside its wave
+    for (int k = 0; k < 6; k++) {
+        const float t = FWD ? __shfl_up(inc[k], 1, 64) : __shfl_down(inc[k], 1, 64);
+        exc[k] = (FWD ? lane == 0 : lane == 63) ? (k < 3 ? inf : -inf) : t;
+    }
+    if (FWD ? lane == 63 : lane == 0)
+        for (int k = 0; k < 6; k++) s_wt[wave][k] = inc[k];
+    __syncthreads();
+    if (FWD) { for (int w = 0; w < wave; w++) box_join(exc, s_wt[w]); }
+    else { for (int w = wave + 1; w < TBT / 64; w++) box_join(exc, s_wt[w]); }
+    for (uint32_t e = e0; e < e1; e++) box_join(S + 6 * e, exc);
+    __syncthreads();  // S is complete, s_wt free again
+}
+
 __global__ __launch_bounds__(TBT) void k_sah_top(uint32_t np, uint32_t leaf_max, const double *__restrict__ plo, const double *__restrict__ phi,
                                                  uint32_t *__restrict__ ids, SahNode *__restrict__ nodes, uint32_t *__restrict__ n_nodes,
                                                  SahJob *__restrict__ roots, uint32_t *__restrict__ n_roots)
 {
     extern __shared__ __attribute__((aligned(16))) char sah_smem[];
-    float *g_box = reinterpret_cast<float *>(sah_smem);                       // [np][6]: every primitive's box, by primitive id
-    uint32_t *s_gid = reinterpret_cast<uint32_t *>(g_box + 6 * (size_t)np);       // [np]: identity here
-    uint32_t *s_ids = s_gid + np;                                             // [np]: the order array (a node = a range of it)
-    uint32_t *s_id = s_ids + np, *s_idg = s_id + np;                          // [m]: the current node's slots and primitive ids ...
-    float *s_box = reinterpret_cast<float *>(s_idg + np);                     // [m][6]: ... and their boxes, read as broadcasts
-    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_box + 6 * (size_t)np);       // [3][np]: a candidate's position in its axis' sorted order
-    for (uint32_t i = threadIdx.x; i < np; i += TBT) {
-        for (int k = 0; k < 3; k++) { g_box[6 * i + k] = (float)plo[3 * (size_t)i + k]; g_box[6 * i + 3 + k] = (float)phi[3 * (size_t)i + k]; }  // (exact: made from floats)
-        s_gid[i] = i;
-        s_ids[i] = i;
-    }
+    double *s_key = reinterpret_cast<double *>(sah_smem);                     // [m]: the axis' centroid keys, then the right-hand areas by split position
+    float *s_box = reinterpret_cast<float *>(s_key + np);                     // [m][6]: the node's boxes ...
+    float *S = s_box + 6 * (size_t)np;                                        // [m][6]: ... in the axis' sorted order, scanned in place
+    uint32_t *s_ids = reinterpret_cast<uint32_t *>(S + 6 * (size_t)np);       // [np]: the order array (a node = a range of it)
+    uint32_t *s_id = s_ids + np;                                              // [m]: the node's primitive ids
+    uint32_t *s_pos = s_id + np;                                              // [3][np]: a candidate's position in its axis' sorted order
+    __shared__ Best s_best[TBT / 64];
+    __shared__ double s_lo[TBT / 64][3], s_hi[TBT / 64][3];
+    __shared__ float s_wt[TBT / 64][6];
+    __shared__ uint32_t s_sp;
+    __shared__ int s_axis;
+    __shared__ uint32_t s_k;
+    __shared__ SahJob s_todo[SAH_STACK];
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < np; i += TBT) s_ids[i] = i;
     const SahJob root = { 0u, 0u, np, 0u };
-    if (threadIdx.x == 0) { nodes[0].first = 0; nodes[0].count = np; nodes[0].left = nodes[0].right = -1; }
+    if (tid == 0) { nodes[0].first = 0; nodes[0].count = np; nodes[0].left = nodes[0].right = -1; s_sp = 1; s_todo[0] = root; }
     if (np <= SAH_SUB) {  // the whole scene is one subtree: k_sah_sub's work (uniform)
-        if (threadIdx.x == 0) { roots[0] = root; *n_roots = 1u; }
+        if (tid == 0) { roots[0] = root; *n_roots = 1u; }
         return;
     }
-    sah_build<TBT, true>(root, np, leaf_max, g_box, s_gid, s_ids, s_id, s_idg, s_box, s_pos, nodes, n_nodes, roots, n_roots);
-    for (uint32_t i = threadIdx.x; i < np; i += TBT) ids[i] = s_ids[i];  // (the subtree kernels read their ranges from here)
+    const double INF = __builtin_inf();
+    for (;;) {
+        __syncthreads();
+        if (s_sp == 0) break;
+        const SahJob job = s_todo[s_sp - 1];
+        __syncthreads();
+        if (tid == 0) s_sp--;
+        const uint32_t me = job.node, first = job.first, m = job.count, depth = job.depth;  // m > SAH_SUB
+        double lo[3] = { INF, INF, INF }, hi[3] = { -INF, -INF, -INF };
+        for (uint32_t i = tid; i < m; i += TBT) {
+            const uint32_t p = s_ids[first + i];
+            s_id[i] = p;
+            for (int k = 0; k < 3; k++) {
+                const double a = plo[3 * (size_t)p + k], b = phi[3 * (size_t)p + k];
+                s_box[6 * i + k] = (float)a; s_box[6 * i + 3 + k] = (float)b;  // (exact: made from floats)
+                lo[k] = fmin(lo[k], a); hi[k] = fmax(hi[k], b);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1)
+            for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], o, 64)); }
+        if ((tid & 63) == 0)
+            for (int k = 0; k < 3; k++) { s_lo[tid >> 6][k] = lo[k]; s_hi[tid >> 6][k] = hi[k]; }
+        __syncthreads();
+        for (int k = 0; k < 3; k++) { lo[k] = s_lo[0][k]; hi[k] = s_hi[0][k]; }
+        for (int t = 1; t < TBT / 64; t++)
+            for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], s_lo[t][k]); hi[k] = fmax(hi[k], s_hi[t][k]); }
+        if (tid == 0)
+            for (int k = 0; k < 3; k++) { nodes[me].lo[k] = lo[k]; nodes[me].hi[k] = hi[k]; }
+        Best best = { INF, 0, 0u };
+        for (int ax = 0; ax < 3; ax++) {
+            for (uint32_t i = tid; i < m; i += TBT) s_key[i] = (double)s_box[6 * i + ax] + (double)s_box[6 * i + 3 + ax];
+            __syncthreads();
+            // rank: j's position in the (centroid, id) order = how many keys are <= j's, minus one
+            for (uint32_t jj = tid; jj < m; jj += TBT) {
+                const double cj = s_key[jj];
+                const uint32_t j = s_id[jj];
+                uint32_t nl = 0;
+                for (uint32_t i = 0; i < m; i++) {
+                    const double cp = s_key[i];
+                    nl += (cp < cj || (cp == cj && s_id[i] <= j)) ? 1u : 0u;
+                }
+                s_pos[(size_t)ax * np + jj] = nl - 1u;
+            }
+            __syncthreads();
+            // right-hand boxes: suffix scan of the sorted boxes; the area right of split position k (left = positions 0 .. k) is that of k + 1
+            for (uint32_t i = tid; i < m; i += TBT) {
+                const uint32_t q = s_pos[(size_t)ax * np + i];
+                for (int k = 0; k < 6; k++) S[6 * q + k] = s_box[6 * i + k];
+            }
+            __syncthreads();
+            scan_boxes<false>(S, m, s_wt);
+            for (uint32_t k = tid; k + 1 < m; k += TBT) {
+                const float *b = S + 6 * (k + 1);
+                const double el[3] = { b[0], b[1], b[2] }, eh[3] = { b[3], b[4], b[5] };
+                s_key[k] = box_area_d(el, eh);
+            }
+            __syncthreads();
+            // left-hand boxes: prefix scan; cost of every split position
+            for (uint32_t i = tid; i < m; i += TBT) {
+                const uint32_t q = s_pos[(size_t)ax * np + i];
+                for (int k = 0; k < 6; k++) S[6 * q + k] = s_box[6 * i + k];
+            }
+            __syncthreads();
+            scan_boxes<true>(S, m, s_wt);
+            for (uint32_t k = tid; k + 1 < m; k += TBT) {
+                const float *b = S + 6 * k;
+                const double dl[3] = { b[0], b[1], b[2] }, dh[3] = { b[3], b[4], b[5] };
+                const uint32_t nl = k + 1u;
+                const Best c = { box_area_d(dl, dh) * (double)nl + s_key[k] * (double)(m - nl), ax, k };
+                if (better(c, best)) best = c;
+            }
+            __syncthreads();  // s_key, S are rewritten for the next axis
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const Best other = { __shfl_xor(best.cost, o, 64), __shfl_xor(best.axis, o, 64), __shfl_xor(best.k, o, 64) };
+            if (better(other, best)) best = other;
+        }
+        if ((tid & 63) == 0) s_best[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            for (int t = 1; t < TBT / 64; t++)
+                if (better(s_best[t], best)) best = s_best[t];
+            // (a node of m > SAH_SUB >= leaf_max primitives is always split)
+            s_axis = best.axis;
+            s_k = depth >= (uint32_t)SAH_MAX_DEPTH ? m / 2u - 1u : best.k;
+        }
+        __syncthreads();
+        const int ax = s_axis;
+        for (uint32_t i = tid; i < m; i += TBT) s_ids[first + s_pos[(size_t)ax * np + i]] = s_id[i];
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t l = atomicAdd(n_nodes, 2u), r = l + 1u;
+            nodes[me].left = (int)l; nodes[me].right = (int)r;
+            const uint32_t nl = s_k + 1u;
+            auto child = [&](uint32_t c, uint32_t c_first, uint32_t c_count) {
+                nodes[c].first = c_first; nodes[c].count = c_count; nodes[c].left = nodes[c].right = -1;
+                if (c_count == 1u) {  // a leaf: its box is its primitive's
+                    const uint32_t p = s_ids[c_first];
+                    for (int k = 0; k < 3; k++) { nodes[c].lo[k] = plo[3 * (size_t)p + k]; nodes[c].hi[k] = phi[3 * (size_t)p + k]; }
+                } else if (c_count <= SAH_SUB) {
+                    roots[atomicAdd(n_roots, 1u)] = { c, c_first, c_count, depth + 1u };
+                } else {
+                    s_todo[s_sp++] = { c, c_first, c_count, depth + 1u };
+                }
+            };
+            child(r, first + nl, m - nl);  // left first
+            child(l, first, nl);
+        }
+    }
+    for (uint32_t i = tid; i < np; i += TBT) ids[i] = s_ids[i];  // (the subtree kernels read their ranges from here)
 }
 
 __global__ __launch_bounds__(TBD) void k_sah_sub(uint32_t leaf_max, const double *__restrict__ plo, const double *__restrict__ phi,
@@ -374,7 +535,7 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
     const uint32_t one = 1u;
     PT_HIP(ctx, hipMemcpyAsync(d_nn.p, &one, sizeof(one), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemsetAsync(d_nroots.p, 0, sizeof(uint32_t), st));
-    const size_t top_smem = sizeof(uint32_t) * 19 * (size_t)np;  // boxes 6 + ids 1 + order 1 + the node's copy 8 + positions 3: <= 152 KB for 2048 primitives
+    const size_t top_smem = sizeof(uint32_t) * 19 * (size_t)np;  // keys / areas 2 + the node's boxes 6 + their sorted copy 6 + order 1 + ids 1 + positions 3: <= 152 KB for 2048 primitives
     if (top_smem > 48 * 1024)
         PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sah_top), hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_smem));
     k_sah_top<<<1, TBT, top_smem, st>>>(np, leaf_max > 0 ? leaf_max : 1u, d_plo.p, d_phi.p, d_ids.p, d_nodes.p, d_nn.p, d_roots.p, d_nroots.p);
