@@ -64,8 +64,8 @@ __global__ void k_sah_prims(const float *__restrict__ tlo, const float *__restri
 // emission follows the left / right links, not the numbers).  A node step reads LDS only -- every primitive's box (24 B), the order
 // array, the stack of pending nodes; range, depth and box travel in the stack entry / in registers -- and leaves (one
 // primitive) are written by their parent.  Scene build, before -> after (one 256-thread workgroup for everything, its working set in
-// global memory): Cornell box 1.9 -> 1.25 ms, 1024 triangles 25.5 -> 5.6, 2047 triangles 46.7 -> 10.2 (16.0 while the top nodes still
-// ran the quadratic pass with its boxes; what is left is mostly the single-thread BVH4 emission, 3.0 ms: profiles/r04z_build_small.log,
+// global memory): Cornell box 1.9 -> 1.25 ms, 1024 triangles 25.5 -> 5.6, 2047 triangles 46.7 -> 8.6 (16.0 while the top nodes still
+// ran the quadratic pass with its boxes, 10.2 while the BVH4 emission read global memory: profiles/r04z_build_small.log,
 // r04aa_sah_build_ms.log, r04ai_times.txt).
 struct SahJob { uint32_t node, first, count, depth; };
 constexpr int SAH_STACK = 160;  // pending nodes: <= 1 per level of a depth-first walk + 1; the tree is <= 24 + log2(2048) + 1 levels deep
@@ -423,68 +423,99 @@ __global__ __launch_bounds__(TBD) void k_sah_node_boxes(const SahNode *__restric
     ntris[i] = n_tri;
 }
 
-// BVH4 rows + leaf order from the binary tree: one thread opens, per wide node, the internal child of largest area
-__global__ void k_sah_emit(const SahNode *__restrict__ nodes, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ prim_first,
-                           const uint8_t *__restrict__ prim_tris, const float *__restrict__ nbox, const double *__restrict__ narea,
-                           const uint32_t *__restrict__ ntris, uint32_t *__restrict__ rows, uint32_t *__restrict__ order, uint32_t *__restrict__ counts /* {n_rows, n_order} */,
-                           uint2 *__restrict__ todo /* {binary node, row} */)
+// BVH4 rows + leaf order from the binary tree: one thread opens, per wide node, the internal child of largest area.  The walk is a
+// chain of dependent reads, so everything it BRANCHES on -- links, ranges, areas, triangle counts, the primitives -- is staged in LDS by
+// the whole workgroup first (<= 96 KB for 2048 primitives), and all it writes per row is which binary node sits in which slot and the slot's
+// child word: k_sah_rows then fills the 128-B rows (boxes, words, padding) in parallel.  2047 triangles: scene build 10.3 -> 8.6 ms (profiles/r04aj_times.txt).
+constexpr uint32_t ROW_EMPTY = 0xFFFFFFFFu;
+__global__ __launch_bounds__(TBD) void k_sah_emit(const SahNode *__restrict__ nodes, const uint32_t *__restrict__ n_nodes, const uint32_t *__restrict__ ids,
+                                                  const uint32_t *__restrict__ prim_first, const uint8_t *__restrict__ prim_tris, uint32_t np,
+                                                  const double *__restrict__ narea, const uint32_t *__restrict__ ntris, uint32_t *__restrict__ row_kid,
+                                                  uint32_t *__restrict__ row_word, uint32_t *__restrict__ order, uint32_t *__restrict__ counts /* {n_rows, n_order} */)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const float inf = __builtin_inff();
+    extern __shared__ __attribute__((aligned(16))) char emit_smem[];
+    const uint32_t nn = *n_nodes;
+    double *s_area = reinterpret_cast<double *>(emit_smem);                 // [nn]
+    uint32_t *s_lr = reinterpret_cast<uint32_t *>(s_area + nn);             // [nn]: left | right << 16 (0xFFFF: leaf)
+    uint32_t *s_fc = s_lr + nn;                                             // [nn]: first | count << 16
+    uint32_t *s_nt = s_fc + nn;                                             // [nn]: triangles below the node
+    uint32_t *s_prim = s_nt + nn;                                           // [np]: first triangle | triangles << 16 of the primitive at that place of the order
+    __shared__ uint2 s_todo[SAH_STACK * 3];                                 // {binary node, row}: <= 3 pushed per level
+    for (uint32_t i = threadIdx.x; i < nn; i += TBD) {
+        const SahNode &k = nodes[i];
+        s_area[i] = narea[i];
+        s_lr[i] = k.left < 0 ? 0xFFFFu : ((uint32_t)k.left | ((uint32_t)k.right << 16));
+        s_fc[i] = k.first | (k.count << 16);
+        s_nt[i] = ntris[i];
+    }
+    for (uint32_t i = threadIdx.x; i < np; i += TBD) {
+        const uint32_t prim = ids[i];
+        s_prim[i] = prim_first[prim] | ((uint32_t)prim_tris[prim] << 16);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     uint32_t n_rows = 0, n_order = 0, sp = 0;
-    auto new_row = [&]() -> uint32_t {
-        const uint32_t r = n_rows++;
-        float *f = reinterpret_cast<float *>(rows + 32 * (size_t)r);
-        for (int k = 0; k < 24; k++) f[k] = inf;  // empty slot: lo = hi = +inf
-        for (int k = 24; k < 28; k++) rows[32 * (size_t)r + k] = 0xFFFFFFFFu;
-        for (int k = 28; k < 32; k++) rows[32 * (size_t)r + k] = 0u;
-        return r;
-    };
-    todo[sp++] = make_uint2(0u, new_row());
+    auto is_leaf = [&](uint32_t n) { return (s_lr[n] & 0xFFFFu) == 0xFFFFu; };
+    s_todo[sp++] = make_uint2(0u, n_rows++);
     while (sp > 0) {
-        const uint2 it = todo[--sp];
-        int kids[4];
+        const uint2 it = s_todo[--sp];
+        uint32_t kids[4];
         int m = 0;
-        const SahNode &root = nodes[it.x];
-        if (root.left < 0) kids[m++] = (int)it.x;  // the whole scene is one leaf
-        else { kids[m++] = root.left; kids[m++] = root.right; }
+        if (is_leaf(it.x)) kids[m++] = it.x;  // the whole scene is one leaf
+        else { kids[m++] = s_lr[it.x] & 0xFFFFu; kids[m++] = s_lr[it.x] >> 16; }
         while (m < 4) {
             int pick = -1;
             double pa = -1.0;
             for (int j = 0; j < m; j++) {
-                if (nodes[kids[j]].left < 0) continue;
-                const double a = narea[kids[j]];
+                if (is_leaf(kids[j])) continue;
+                const double a = s_area[kids[j]];
                 if (a > pa) { pa = a; pick = j; }
             }
             if (pick < 0) break;
-            const SahNode &k = nodes[kids[pick]];
+            const uint32_t lr = s_lr[kids[pick]];
             for (int j = m; j > pick + 1; j--) kids[j] = kids[j - 1];
-            kids[pick] = k.left; kids[pick + 1] = k.right;
+            kids[pick] = lr & 0xFFFFu; kids[pick + 1] = lr >> 16;
             m++;
         }
-        for (int j = 0; j < m; j++) {
-            const SahNode &k = nodes[kids[j]];
-            const float *nb = nbox + 6 * (size_t)kids[j];
-            const float lo[3] = { nb[0], nb[1], nb[2] }, hi[3] = { nb[3], nb[4], nb[5] };
-            const uint32_t n_tri = ntris[kids[j]];
-            uint32_t word;
-            if (k.left < 0) {
-                word = PT_LEAF | ((n_tri - 1u) << 28) | n_order;
-                for (uint32_t t = 0; t < k.count; t++) {
-                    const uint32_t prim = ids[k.first + t];
-                    for (uint32_t h = 0; h < prim_tris[prim]; h++) order[n_order++] = prim_first[prim] + h;
+        for (int j = 0; j < 4; j++) {
+            uint32_t kid = ROW_EMPTY, word = ROW_EMPTY;
+            if (j < m) {
+                kid = kids[j];
+                if (is_leaf(kid)) {
+                    word = PT_LEAF | ((s_nt[kid] - 1u) << 28) | n_order;
+                    const uint32_t first = s_fc[kid] & 0xFFFFu, count = s_fc[kid] >> 16;
+                    for (uint32_t t = 0; t < count; t++) {
+                        const uint32_t pr = s_prim[first + t];
+                        for (uint32_t h = 0; h < (pr >> 16); h++) order[n_order++] = (pr & 0xFFFFu) + h;
+                    }
+                } else {
+                    word = n_rows++;
+                    s_todo[sp++] = make_uint2(kid, word);
                 }
-            } else {
-                word = new_row();
-                todo[sp++] = make_uint2((uint32_t)kids[j], word);
             }
-            float *f = reinterpret_cast<float *>(rows + 32 * (size_t)it.y);
-            for (int c = 0; c < 3; c++) { f[4 * c + j] = lo[c]; f[12 + 4 * c + j] = hi[c]; }
-            rows[32 * (size_t)it.y + 24 + j] = word;
+            row_kid[4 * (size_t)it.y + j] = kid;
+            row_word[4 * (size_t)it.y + j] = word;
         }
     }
     counts[0] = n_rows;
     counts[1] = n_order;
+}
+
+// one thread per (row, slot): the slot's padded box (+inf where empty), its child word, the row's padding
+__global__ __launch_bounds__(TBD) void k_sah_rows(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ row_kid, const uint32_t *__restrict__ row_word,
+                                                  const float *__restrict__ nbox, uint32_t *__restrict__ rows)
+{
+    const uint32_t i = blockIdx.x * TBD + threadIdx.x;
+    if (i >= 4u * counts[0]) return;
+    const uint32_t r = i >> 2, j = i & 3u, kid = row_kid[i];
+    float *f = reinterpret_cast<float *>(rows + 32 * (size_t)r);
+    const float inf = __builtin_inff();
+    for (int c = 0; c < 3; c++) {
+        f[4 * c + j] = kid == ROW_EMPTY ? inf : nbox[6 * (size_t)kid + c];
+        f[12 + 4 * c + j] = kid == ROW_EMPTY ? inf : nbox[6 * (size_t)kid + 3 + c];  // (an empty slot: lo = hi = +inf)
+    }
+    rows[32 * (size_t)r + 24 + j] = row_word[i];
+    rows[32 * (size_t)r + 28 + j] = 0u;
 }
 
 template <typename T>
@@ -517,11 +548,10 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
     Buf<uint8_t> d_tris;
     Buf<double> d_plo, d_phi;
     Buf<SahNode> d_nodes;
-    Buf<uint2> d_todo;
     PT_HIP(ctx, d_tlo.alloc(3 * (size_t)n)); PT_HIP(ctx, d_thi.alloc(3 * (size_t)n));
     PT_HIP(ctx, d_first.alloc(np)); PT_HIP(ctx, d_tris.alloc(np)); PT_HIP(ctx, d_ids.alloc(np));
     PT_HIP(ctx, d_nn.alloc(1)); PT_HIP(ctx, d_plo.alloc(3 * (size_t)np)); PT_HIP(ctx, d_phi.alloc(3 * (size_t)np));
-    PT_HIP(ctx, d_nodes.alloc(2 * (size_t)np + 1)); PT_HIP(ctx, d_todo.alloc(2 * (size_t)np + 8));
+    PT_HIP(ctx, d_nodes.alloc(2 * (size_t)np + 1));
     PT_HIP(ctx, d_rows.alloc(32 * (size_t)(2 * np + 1))); PT_HIP(ctx, d_order.alloc(n)); PT_HIP(ctx, d_counts.alloc(2));
     PT_HIP(ctx, hipMemcpyAsync(d_tlo.p, tlo, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d_thi.p, thi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -547,7 +577,13 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
     PT_HIP(ctx, d_nbox.alloc(6 * (2 * (size_t)np + 1))); PT_HIP(ctx, d_narea.alloc(2 * (size_t)np + 1)); PT_HIP(ctx, d_ntris.alloc(2 * (size_t)np + 1));
     k_sah_node_boxes<<<(2 * np + 1 + TBD - 1) / TBD, TBD, 0, st>>>(d_nodes.p, d_nn.p, d_ids.p, d_first.p, d_tris.p, d_tlo.p, d_thi.p, pad, d_nbox.p,
                                                                    d_narea.p, d_ntris.p);
-    k_sah_emit<<<1, 1, 0, st>>>(d_nodes.p, d_ids.p, d_first.p, d_tris.p, d_nbox.p, d_narea.p, d_ntris.p, d_rows.p, d_order.p, d_counts.p, d_todo.p);
+    Buf<uint32_t> d_row_kid, d_row_word;
+    PT_HIP(ctx, d_row_kid.alloc(4 * (2 * (size_t)np + 1))); PT_HIP(ctx, d_row_word.alloc(4 * (2 * (size_t)np + 1)));
+    const size_t emit_smem = (sizeof(double) + 3 * sizeof(uint32_t)) * (2 * (size_t)np + 1) + sizeof(uint32_t) * (size_t)np;  // <= 88 KB for 2048 primitives
+    if (emit_smem > 48 * 1024)
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sah_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_smem));
+    k_sah_emit<<<1, TBD, emit_smem, st>>>(d_nodes.p, d_nn.p, d_ids.p, d_first.p, d_tris.p, np, d_narea.p, d_ntris.p, d_row_kid.p, d_row_word.p, d_order.p, d_counts.p);
+    k_sah_rows<<<(4 * (2 * np + 1) + TBD - 1) / TBD, TBD, 0, st>>>(d_counts.p, d_row_kid.p, d_row_word.p, d_nbox.p, d_rows.p);
     uint32_t counts[2] = { 0, 0 };
     PT_HIP(ctx, hipMemcpyAsync(counts, d_counts.p, sizeof(counts), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipStreamSynchronize(st));
