@@ -1,6 +1,8 @@
 """dev model (CPU, on a box with a GPU only because the 8-wide tree is built on the device): node visits per ray of the byte-plane tree under
 several pending-children policies, on paths of config C5's kind (camera rays + uniform-hemisphere bounces through the 1 M-triangle soup).
   kernel    what k_extend8 does: children in octant order, the rest of a node pending as ONE entry culled by the smallest entry distance of the node's hits
+  all8      ... of ALL eight slots' entry distances, hit or not (no select per child in the kernel)
+  none      no bound at all: every pending child is visited
   int_min   ... of the node's INTERNAL hits (its leaf triangles were tested at the visit and are not pending)
   rest_fix  ... of the internal hits except the one visited first, fixed when the entry is made
   m12       ... the cheap form of rest_fix: the two smallest entry distances m1 <= m2 of ALL the node's hits (leaves included) and whose m1 is:
@@ -105,6 +107,10 @@ def trace(o, d, policy, tmin=1e-3, tmax=1e4):
                 g = gmin_all
                 if policy == "int_min":
                     g = min(min(k[1] for k in kids), _)
+                if policy == "all8":
+                    g = float(tn[((int(imask[n]) | int(lmask[n])) >> np.arange(8)) & 1 > 0].min())
+                if policy == "none":
+                    g = -np.inf
                 if policy == "rest_fix":
                     g = min(k[1] for k in kids)
                 if policy == "m12":
@@ -117,7 +123,7 @@ def trace(o, d, policy, tmin=1e-3, tmax=1e4):
                 stack.pop(); continue
             if policy == "rest_min" and min(k[1] for k in ks) > best_t:
                 stack.pop(); continue
-            if policy in ("int_min", "rest_fix", "m12") and gmin > best_t:
+            if policy in ("int_min", "rest_fix", "m12", "all8", "none") and gmin > best_t:
                 stack.pop(); continue
             s, t = ks.pop(0)
             if not ks:
@@ -131,7 +137,7 @@ def trace(o, d, policy, tmin=1e-3, tmax=1e4):
 
 rng = np.random.default_rng(5)
 W, H = 1920, 1080
-policies = ["kernel", "int_min", "rest_fix", "m12", "rest_min", "per_child", "sorted", "global"]
+policies = ["kernel", "all8", "none", "int_min", "rest_fix", "m12", "rest_min", "per_child", "sorted", "global"]
 tot = {p: [0, 0] for p in policies}
 n_rays = 0
 t_start = time.time()

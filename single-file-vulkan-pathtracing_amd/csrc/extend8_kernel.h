@@ -27,7 +27,13 @@ namespace {
 
 // SPILL = false: the tree's levels fit the LDS stack entries (every tree up to 8^12 leaves does with the default 12), so the
 // address arithmetic of the HBM spill column leaves the push and the pop loop
-template <bool COUNT, bool SPILL>
+// BOUND: a pending group carries the smallest entry distance of its node's hits and is dropped on the pop when that lies behind the best hit.
+// A model of the walk (scripts/sim_bvh8_policies.py, which reproduces the kernel's node visits per ray to 0.2 %) says this bound NEVER culls
+// -- it is nearly always the entry distance of the child visited first, whose subtree cannot hold a hit in front of it -- and the kernel
+// without it visits exactly as many nodes (27.65 per ray on C5, 24.19 on C5x) with 22 VALU instructions less per node step.  Measured, same box,
+// three rounds each: scenes walked out of HBM (C5x) +3.3 % at 6 waves and +2.8 % at 7; the cache-resident C5 -1.1 % at either
+// (profiles/r04ao_*, r04ap_*).  So the instantiation for scenes beyond the Infinity Cache (WAVES = 7) goes without, the other keeps it.
+template <bool COUNT, bool SPILL, bool BOUND>
 __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
                                              const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
                                              float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
@@ -188,7 +194,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
            step loses 7 instructions of 240, C5 -1 %, C5x -20 % (6 dwords spilled at 72 VGPRs): profiles/r04g_ab_node8_perm_*)  */ \
         const bool hk = tn <= tf;                                                                                 \
         h |= hk ? (1u << (K)) : 0u;                                                                               \
-        gmin = hk ? min_raw(tn, gmin) : gmin;                                                                     \
+        if constexpr (BOUND) gmin = hk ? min_raw(tn, gmin) : gmin;                                                \
     }
                 PT_SLAB8(0) PT_SLAB8(1) PT_SLAB8(2) PT_SLAB8(3) PT_SLAB8(4) PT_SLAB8(5) PT_SLAB8(6) PT_SLAB8(7)
 #undef PT_SLAB8
@@ -203,7 +209,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 // entry distance of the group, rounded DOWN to 16 bits (negative values -- only with a negative tmin --
                 // away from zero)
                 const uint32_t gb = __float_as_uint(gmin);
-                const uint32_t g16 = (gb + ((uint32_t)((int32_t)gb >> 31) & 0xFFFFu)) & 0xFFFF0000u;
+                const uint32_t g16 = BOUND ? (gb + ((uint32_t)((int32_t)gb >> 31) & 0xFFFFu)) & 0xFFFF0000u : 0u;
                 ng_base = hd.z & 0x00FFFFFFu;
                 ng_meta = hi_ | (nim << 8) | g16;
                 tg_base = hd.w & 0x00FFFFFFu;
@@ -249,7 +255,7 @@ __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, N
                 if (!SPILL || sp < lds_stack) e = my_stack[sp * TB];
                 else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
                 const uint32_t meta = (uint32_t)(e >> 32);
-                if (__uint_as_float(meta & 0xFFFF0000u) <= best_t) {
+                if (!BOUND || __uint_as_float(meta & 0xFFFF0000u) <= best_t) {
                     ng_base = (uint32_t)e;
                     ng_meta = meta;
                     got = true;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(TB, WAVES) void k_extend8(const uint4 *__restrict__
                                                 uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
                                                 int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
-    extend8_body<COUNT, SPILL>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
+    extend8_body<COUNT, SPILL, WAVES != 7>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
                         tmax, lds_stack, raw_hit, perm, ray_tmax);
 }
 
