@@ -259,7 +259,10 @@ def roofline_block(pt, st, cst, info, config, note):
     return r
 
 
-def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=300):
+_LIVE_PMC_FAILED = [False]   # a pass that failed or timed out once is not tried again in this run (the legs would each wait for it)
+
+
+def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=150):
     """HBM-side bytes per ray of the frame's kernels MEASURED for this build on this box: the same command, short, twice under
     `rocprofv3 --kernel-trace --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes, nothing but the kernel trace beside them,
     as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- corrected as calibrated (2 x FETCH_SIZE KiB + WRITE_SIZE KiB:
@@ -267,8 +270,9 @@ def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=300):
     caller keeps the committed record and says so)."""
     import csv, glob, re, shutil, tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not exe or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", ""):
+    if not exe or _LIVE_PMC_FAILED[0] or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", ""):
         return None   # (no profiler, or this process is itself being profiled: no profiler inside a profiler)
+    _LIVE_PMC_FAILED[0] = True   # until both passes have come back
     counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations
     kib = {p: {} for p in prefixes}
     disp = {p: {} for p in prefixes}
@@ -315,6 +319,7 @@ def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=300):
         out[p] = {"hbm_bytes_per_ray": (rd + wr) / rays_per_launch, "hbm_read_bytes_per_ray": rd / rays_per_launch, "hbm_write_bytes_per_ray": wr / rays_per_launch,
                   "launches_profiled": disp[p]["FETCH_SIZE"], "rays_per_launch_profiled": round(rays_per_launch, 1), "seconds": round(time.perf_counter() - t0, 1),
                   "source": "live: this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) on this box"}
+    _LIVE_PMC_FAILED[0] = not out
     return out or None
 
 
