@@ -58,8 +58,8 @@ __global__ void k_sah_prims(const float *__restrict__ tlo, const float *__restri
 }
 
 // The binary tree, in two launches.  k_sah_top: ONE workgroup of 1024 threads walks the nodes of more than SAH_SUB primitives depth
-// first -- their O(m^2) candidate passes are what the build's time is made of, and sixteen waves hide the LDS latency of the inner
-// loop that four could not -- and hands every child of <= SAH_SUB primitives to a list; k_sah_sub: one workgroup of 256 threads PER
+// first -- the candidate passes of those nodes were what the build's time was made of; it ranks the candidates and scans boxes instead
+// (below) -- and hands every child of <= SAH_SUB primitives to a list; k_sah_sub: one workgroup of 256 threads PER
 // listed subtree builds it out of its own LDS, all of them at once.  Node records are numbered by a global counter (the BVH4
 // emission follows the left / right links, not the numbers).  A node step reads LDS only -- every primitive's box (24 B), the order
 // array, the stack of pending nodes; range, depth and box travel in the stack entry / in registers -- and leaves (one
@@ -71,13 +71,12 @@ struct SahJob { uint32_t node, first, count, depth; };
 constexpr int SAH_STACK = 160;  // pending nodes: <= 1 per level of a depth-first walk + 1; the tree is <= 24 + log2(2048) + 1 levels deep
 constexpr uint32_t SAH_SUB = 128;  // subtrees of <= this many primitives are built by k_sah_sub
 
-// NT threads build the subtree of `root` (a range of the order array).  Primitives are addressed by SLOT: the top kernel's slot is the
-// primitive id (cap = np, gid = identity); a subtree kernel's slot is the position its range had when it was loaded (cap = SAH_SUB),
-// gid[slot] = primitive id, which ties between equal centroids are broken by.  DEFER: children of <= SAH_SUB primitives go to `roots`.
-template <int NT, bool DEFER>
+// NT threads build the subtree of `root` (a range of the order array) with the quadratic candidate pass.  Primitives are addressed by SLOT: the
+// position the subtree's range had when it was loaded (cap = SAH_SUB), gid[slot] = primitive id, which ties between equal centroids are broken by.  (k_sah_top has its own loop for nodes above SAH_SUB.)
+template <int NT>
 __device__ __forceinline__ void sah_build(const SahJob root, uint32_t cap, uint32_t leaf_max, const float *g_box, const uint32_t *s_gid, uint32_t *s_ids,
                                           uint32_t *s_id, uint32_t *s_idg, float *s_box, uint32_t *s_pos, SahNode *__restrict__ nodes,
-                                          uint32_t *__restrict__ n_nodes, SahJob *__restrict__ roots, uint32_t *__restrict__ n_roots)
+                                          uint32_t *__restrict__ n_nodes)
 {
     __shared__ Best s_best[NT / 64];
     __shared__ double s_lo[NT / 64][3], s_hi[NT / 64][3];
@@ -178,8 +177,6 @@ __device__ __forceinline__ void sah_build(const SahJob root, uint32_t cap, uint3
                 if (c_count == 1u) {  // a leaf: its box is its primitive's
                     const uint32_t sl = s_ids[c_first - root.first];
                     for (int k = 0; k < 3; k++) { nodes[c].lo[k] = (double)g_box[6 * sl + k]; nodes[c].hi[k] = (double)g_box[6 * sl + 3 + k]; }
-                } else if (DEFER && c_count <= SAH_SUB) {
-                    roots[atomicAdd(n_roots, 1u)] = { c, c_first, c_count, depth + 1u };
                 } else {
                     s_todo[s_sp++] = { c, c_first, c_count, depth + 1u };
                 }
@@ -391,7 +388,7 @@ __global__ __launch_bounds__(TBD) void k_sah_sub(uint32_t leaf_max, const double
         s_gid[i] = p;
         s_ids[i] = i;
     }
-    sah_build<TBD, false>(root, SAH_SUB, leaf_max, g_box, s_gid, s_ids, s_id, s_idg, s_box, s_pos, nodes, n_nodes, nullptr, nullptr);
+    sah_build<TBD>(root, SAH_SUB, leaf_max, g_box, s_gid, s_ids, s_id, s_idg, s_box, s_pos, nodes, n_nodes);
     for (uint32_t i = threadIdx.x; i < root.count; i += TBD) ids[root.first + i] = s_gid[s_ids[i]];
 }
 
