@@ -165,7 +165,8 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                         else {
                             const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
                             if (idx < rad.spill_cap) {
-                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(rad.spill_head[slot]));
+                                // (the slot's first pool entry ends its chain: no per-slot initialisation of the heads)
+                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rad.spill_head[slot]));
                                 rad.spill_head[slot] = (uint32_t)idx;
                             } else {
                                 *rad.overflow = 1ull;
@@ -277,7 +278,6 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     const uint32_t tw = s_wtile[(mine - w_base) >> 6];
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
                     const uint32_t sample0 = g * rc.group_size;
-                    if (GROUPED) rad.spill_head[slot] = SPILL_NONE;
                     if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
                         pxy = px | (py << 16);
                         ctr = sample0;
