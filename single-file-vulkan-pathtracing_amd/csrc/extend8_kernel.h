@@ -22,6 +22,10 @@
 #pragma once
 #include "extend_kernel.h"
 
+#ifndef PT_E8_BOUND6
+#define PT_E8_BOUND6 1  // 0: the 6-wave instantiation, too, without the pending-group bound (C5 -1.1 %: see extend8_body)
+#endif
+
 
 namespace {
 
@@ -32,7 +36,9 @@ namespace {
 // -- it is nearly always the entry distance of the child visited first, whose subtree cannot hold a hit in front of it -- and the kernel
 // without it visits exactly as many nodes (27.65 per ray on C5, 24.19 on C5x) with 22 VALU instructions less per node step.  Measured, same box,
 // three rounds each: scenes walked out of HBM (C5x) +3.3 % at 6 waves and +2.8 % at 7; the cache-resident C5 -1.1 % at either
-// (profiles/r04ao_*, r04ap_*).  So the instantiation for scenes beyond the Infinity Cache (WAVES = 7) goes without, the other keeps it.
+// (profiles/r04ao_*, r04ap_*).  So the instantiation for scenes beyond the Infinity Cache (WAVES = 7) goes without, the other keeps it:
+// alone on the chip (one pipeline) the 6-wave kernel without the bound is 3.3 % faster on C5 as well, in the two-pipeline frame it is
+// 0.9 % slower, and no refill / vote / stack setting changes that (PT_E8_BOUND6 = 0 builds it: profiles/r04ax_*, r04ay_*).
 template <bool COUNT, bool SPILL, bool BOUND>
 __device__ __forceinline__ void extend8_body(const uint4 *__restrict__ nodes8, NormBox nb, const float4 *__restrict__ tri4, const float4 *__restrict__ rec64,
                                              const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(TB, WAVES) void k_extend8(const uint4 *__restrict__
                                                 uint32_t spill_stride, int refill_min_idle, float tmin, float tmax, int lds_stack,
                                                 int raw_hit, const uint32_t *__restrict__ perm, const float *__restrict__ ray_tmax)
 {
-    extend8_body<COUNT, SPILL, WAVES != 7>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
+    extend8_body<COUNT, SPILL, (WAVES != 7) && PT_E8_BOUND6 != 0>(nodes8, nb, tri4, rec64, rayA, rayB, hit, count_in, count_zero, stats, spill, spill_stride, refill_min_idle, tmin,
                         tmax, lds_stack, raw_hit, perm, ray_tmax);
 }
 
