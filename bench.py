@@ -259,6 +259,25 @@ def roofline_block(pt, st, cst, info, config, note):
     return r
 
 
+def sum_counter_csvs(directory, ctr, prefixes):
+    """rocprofv3 `*counter_collection.csv` files under `directory` -> ({prefix: sum of `ctr` over the dispatches of kernels whose short name starts with
+    it}, {prefix: number of those dispatches}); the instrumented instantiations (PT_FLAG_COUNT_VISITS frames of the same run) do not count."""
+    import csv, glob, re
+    counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")
+    tot = {p: 0.0 for p in prefixes}
+    ids = {p: set() for p in prefixes}
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != ctr:
+                continue
+            k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+            for p in prefixes:
+                if k.startswith(p) and not counting.match(k):
+                    tot[p] += float(row["Counter_Value"])
+                    ids[p].add(row["Dispatch_Id"])
+    return tot, {p: len(v) for p, v in ids.items()}
+
+
 _LIVE_PMC_FAILED = [False]   # a pass that failed or timed out once is not tried again in this run (the legs would each wait for it)
 
 
@@ -268,12 +287,11 @@ def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=150):
     as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- corrected as calibrated (2 x FETCH_SIZE KiB + WRITE_SIZE KiB:
     profiles/r03_fetch_size_calibration.json).  -> {kernel prefix: record} or None (no rocprofv3, a pass failed or timed out: the
     caller keeps the committed record and says so)."""
-    import csv, glob, re, shutil, tempfile
+    import shutil, tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe or _LIVE_PMC_FAILED[0] or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", ""):
         return None   # (no profiler, or this process is itself being profiled: no profiler inside a profiler)
     _LIVE_PMC_FAILED[0] = True   # until both passes have come back
-    counting = re.compile(r"k_extend<\w+, true|k_extend_inst(16)?<true|k_extend8<true")   # the instrumented instantiations
     kib = {p: {} for p in prefixes}
     disp = {p: {} for p in prefixes}
     child = None
@@ -287,19 +305,9 @@ def live_traffic(argv_child, prefixes=("k_extend", "k_shade"), timeout_s=150):
             if r.returncode != 0 or not lines:
                 return None
             child = json.loads(lines[-1])
-            tot = {p: 0.0 for p in prefixes}
-            ids = {p: set() for p in prefixes}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] != ctr:
-                        continue
-                    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
-                    for p in prefixes:
-                        if k.startswith(p) and not counting.match(k):
-                            tot[p] += float(row["Counter_Value"])
-                            ids[p].add(row["Dispatch_Id"])
+            tot, n = sum_counter_csvs(d, ctr, prefixes)
             for p in prefixes:
-                kib[p][ctr], disp[p][ctr] = tot[p], len(ids[p])
+                kib[p][ctr], disp[p][ctr] = tot[p], n[p]
         except Exception:
             return None
         finally:

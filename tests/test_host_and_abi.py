@@ -335,3 +335,37 @@ def test_fast_division_by_the_pdf_is_proven_for_every_float(tmp_path):
     out = subprocess.run([str(exe), str(min(os.cpu_count() or 1, 16))], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches 0" in out.stdout and "tried 3690987522" in out.stdout
+
+
+def test_bench_counter_csv_sums_and_the_fallback(tmp_path, monkeypatch):
+    """bench.py measures `roofline.traffic` itself: the same frames under `rocprofv3 --pmc` in a child process.  What can be checked without
+    a GPU: the sum over rocprofv3's counter CSVs (kernels by short-name prefix, the instrumented instantiations left out, dispatches
+    counted once), and that a run which is itself being profiled, or whose first pass failed, does not start (more) passes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    d = tmp_path / "pass" / "host" / "1234"
+    d.mkdir(parents=True)
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value",
+            '1,1,0,"(anonymous namespace)::k_extend_lds7p(HIP_vector_type<float, 4u> const*, int)",FETCH_SIZE,100',
+            '2,2,0,"(anonymous namespace)::k_extend_lds7p(HIP_vector_type<float, 4u> const*, int)",FETCH_SIZE,140',
+            '2,2,0,"(anonymous namespace)::k_extend_lds7p(HIP_vector_type<float, 4u> const*, int)",FETCH_SIZE,60',     # a second row of the same dispatch (another XCD)
+            '3,3,0,"void (anonymous namespace)::k_extend<true, true, false, true, false>(HIP_vector_type<float, 4u> const*)",FETCH_SIZE,999',   # the counting instantiation
+            '4,4,0,"void (anonymous namespace)::k_shade<2, true, false, false>(ptw::RenderConst, unsigned int const*)",FETCH_SIZE,50',
+            '5,5,0,"void (anonymous namespace)::k_extend8<false, false, 7>(HIP_vector_type<unsigned int, 4u> const*)",WRITE_SIZE,7',
+            '6,6,0,"(anonymous namespace)::k_resolve(ptw::RenderConst)",FETCH_SIZE,5']
+    (d / "p_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    tot, n = b.sum_counter_csvs(str(tmp_path / "pass"), "FETCH_SIZE", ("k_extend", "k_shade"))
+    assert tot == {"k_extend": 300.0, "k_shade": 50.0} and n == {"k_extend": 2, "k_shade": 1}
+    tot, n = b.sum_counter_csvs(str(tmp_path / "pass"), "WRITE_SIZE", ("k_extend",))
+    assert tot == {"k_extend": 7.0} and n == {"k_extend": 1}
+    # no profiler inside a profiler; and no second try after a failure
+    monkeypatch.setenv("ROCPROFILER_LIBRARY_CTOR", "1")
+    assert b.live_traffic(["--pmc-child"]) is None and b._LIVE_PMC_FAILED[0] is False
+    monkeypatch.delenv("ROCPROFILER_LIBRARY_CTOR")
+    b._LIVE_PMC_FAILED[0] = True
+    assert b.live_traffic(["--pmc-child"]) is None
+    r = {}
+    b.apply_live_traffic(r, None, None, 1.0, 1)
+    assert "not measured" in r["traffic_live"]["source"]
