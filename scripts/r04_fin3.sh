@@ -3,7 +3,7 @@
 # round 4 final measurements (GPU box, repo root): the GPU suite, the default bench line (+ cpu baseline), rocprofv3 kernel stats
 # of the very same command, bench lines of C3 (one GPU) / C4 / C5 / C5x and of the fused pipeline, PMC passes (one run per counter
 # set) for the traversal kernel of every config, for k_shade and for k_fused, the C3 shard probes.
-TAG=${1:-r04fin3}; O=gpurun_out; mkdir -p $O
+TAG=${1:-r04fin4}; O=gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/${TAG}_pytest.log | tail -1
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/${TAG}_smoke.log
