@@ -124,7 +124,8 @@ def build(verbose=False):
 def lib_amd():
     global _amd
     if _amd is None:
-        path = os.path.join(_HERE, "libpt_amd.so")
+        # PT_LIB_AMD: a development build of the same library (scripts/: timeline instrumentation, an older revision for an A/B)
+        path = os.environ.get("PT_LIB_AMD") or os.path.join(_HERE, "libpt_amd.so")
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                               "there is no CPU fallback")

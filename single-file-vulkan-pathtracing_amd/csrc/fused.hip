@@ -7,6 +7,14 @@
 #include "extend_kernel.h"  // the LDS node / stack helpers the fused kernel shares with k_extend_lds7p
 #include "extend_inst16.h"  // the two-level walk's node codes and register barrier (k_extend_inst16 itself is a template: not instantiated here)
 
+#ifdef PT_FUSED_TIMELINE
+__device__ unsigned long long *g_fused_timeline = nullptr;
+extern "C" int pt_debug_fused_timeline(void *device_u64x4_per_wave)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_timeline), &device_u64x4_per_wave, sizeof(void *));
+}
+#endif
+
 namespace {
 using namespace ptw;
 #include "fused_kernel.h"

@@ -93,6 +93,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
 
+#ifdef PT_FUSED_TIMELINE  // dev build (scripts/probe_fused_timeline.py): per wave {start, out of slots, end, rays} in device clock ticks
+    unsigned long long tl_start = wall_clock64(), tl_oos = 0ull;
+#endif
     bool have = false;          // the lane traces a ray
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
@@ -255,6 +258,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                         w_part = (w_part + 1u) % (uint32_t)PT_FUSED_PARTS;
                         if (++w_tried >= (uint32_t)PT_FUSED_PARTS) { out_of_slots = true; w_end = w_next; break; }
                     }
+#ifdef PT_FUSED_TIMELINE
+                    if (out_of_slots) tl_oos = wall_clock64();
+#endif
                     if (!out_of_slots && (uint32_t)lane < (w_end - w_base + 63u) / 64u) {
                         if (GROUPED) {
                             const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
@@ -428,4 +434,10 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         }
     }
     if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);
+#ifdef PT_FUSED_TIMELINE
+    if (lane == 0 && g_fused_timeline) {
+        unsigned long long *o = g_fused_timeline + 4 * (size_t)(blockIdx.x * (FTB / 64) + (threadIdx.x >> 6));
+        o[0] = tl_start; o[1] = tl_oos; o[2] = wall_clock64(); o[3] = n_rays_wave;
+    }
+#endif
 }
