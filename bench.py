@@ -125,14 +125,15 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
     # single thread: every 16th 16x16 tile of the WHOLE image (row-major tile index % 16 == 0 -- 510 of the 8 160 tiles of a
     # 1080p frame: 120 tiles per row, so the subset walks down the columns 0, 16, 32 ... 112 of tiles and takes border and
     # centre in the image's own proportion): the same ray population as the all-core run, so `scaling_efficiency` compares
-    # like with like and cannot exceed 1 by construction (round 3 timed the single thread on the central crop, which has none
-    # of the cheap border pixels, and read 1.18)
-    stride = 16
+    # like with like (round 3 timed the single thread on the central crop, which has none of the cheap border pixels, and read 1.18)
+    stride = max(16, cores)   # (more cores than 16: a thinner subset, so this leg takes about as long as the all-core one)
     p1 = orc.default_params(width=width, height=height, spp_per_frame=1, max_depth=depth)
     t0 = time.perf_counter()
     _, r1 = orc.render_tile_subset(osc, p1, stride, 0, mode=1, nthreads=1)
     d1 = time.perf_counter() - t0
-    spp1 = int(max(1, min(spp_max, budget_s / 4 / max(d1, 1e-3))))
+    # the SAME samples per pixel as the all-core leg (round 4 gave the single thread a quarter of the budget: 15 spp against 32, and read
+    # an "efficiency" of 1.02): on `cores` = 16 threads this leg then takes about as long as the all-core one
+    spp1 = spp
     if spp1 > 1:
         p1 = orc.default_params(width=width, height=height, spp_per_frame=spp1, max_depth=depth)
         t0 = time.perf_counter()
@@ -141,8 +142,13 @@ def cpu_baseline(arrays, name, width, height, spp_max, depth, budget_s=10.0, ins
     all_mrays, one_mrays = rays / dt / 1e6, r1 / d1 / 1e6
     base = {"value": round(all_mrays, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "_rays": rays, "_spp": spp, "_img": img,
             "cpu_model": cpu_model(), "cores_available": cores_how, "single_thread_mrays": round(one_mrays, 4),
-            # all threads against `cores` x the single thread on the same ray population (every 16th tile of the same image)
+            # all threads against `cores` x the single thread on the same ray population (every 16th tile of the same image, the same
+            # samples); a core that runs alone clocks higher than sixteen together, so this is a lower bound of the software's scaling
             "scaling_efficiency": round(all_mrays / (cores * one_mrays), 4),
+            # SURVEY 8d's gather term as written there: the instrumented ORACLE's walk of its own binary LBVH (32-B nodes, 36-B triangles)
+            "oracle_walk": {"nodes_visited_per_ray": round(cnt.nodes_visited / max(rays, 1), 3), "tris_tested_per_ray": round(cnt.tris_tested / max(rays, 1), 3),
+                            "gather_bytes_per_ray_8d": round((cnt.nodes_visited * 32.0 + cnt.tris_tested * 36.0) / max(rays, 1), 1),
+                            "source": "oracle/pt_oracle.c counters of the all-core render above (binary LBVH, one primitive per leaf)"},
             "sample": f"{name} {width}x{height}, {spp} spp (frame 0), depth {depth}: {rays} rays in "
                       f"{dt:.2f} s; oracle/pt_oracle.c, software LBVH, gcc -O3 -march=native -ffp-contract=off, {cores} threads "
                       f"pulling 16x16 tiles from one counter; single thread: every {stride}th 16x16 tile of the same image, {spp1} spp, "
@@ -376,6 +382,101 @@ def roofline_shade_block(st, config):
     return r
 
 
+def wavefront_roofline_blocks(pt, st, cst, info, config, note, mean_len):
+    """(`roofline` of the traversal kernel, `roofline_shade`) of a timed wavefront render: every factor from that render's per-launch events."""
+    r = roofline_block(pt, st, cst, info, config, note)
+    bytes_extend = r["algorithmic_bytes_per_ray"]
+    pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
+    r["pipeline_algorithmic_GBps"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2)
+    # SURVEY 8d's canonical whole-pipeline figure: (extend + 104 shade + 96 per path / mean length) B per ray over the
+    # device time of the timed region, of the HBM peak
+    r["pipeline_frac"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    # `frac` prices ONE launch against its own duration, and the launches of the concurrent pipelines share the chip:
+    # with three pipelines a launch carries a third of the rays and lasts about as long as one of two did.  The same
+    # algorithmic bytes over the device time of the timed region do not depend on how the work is cut into launches
+    r["pipelines"] = st.pipelines
+    r["frac_all_launches_over_device_time"] = round(bytes_extend * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    return r, roofline_shade_block(st, config)
+
+
+PMC_RECORD_FUSED = {"k_fused": "r05_pmc_fused_c2.json", "k_fused_inst": "r05_pmc_fused_c4.json"}
+
+
+def fused_roofline_block(st, mean_len, config, kernel):
+    """`roofline` of the fused kernel (PT_PIPELINE_FUSED / what PT_PIPELINE_AUTO runs for scenes that live in LDS).  By the contract ("a fused
+    variant that keeps path state in registers moves fewer bytes -- still divide by the ALGORITHMIC bytes so designs are comparable, and say which
+    variant ran") `achieved` / `frac` price the kernel by the wavefront design's algorithmic bytes per ray over its launch time; they are a comparison
+    device, not traffic: `traffic` / `frac_counted` are what HBM really sees (live counters), and the bound that binds this kernel is VALU issue
+    (`binding_bound`: wave-instructions per 64 rays of the committed SQ_INSTS_VALU pass x this run's ray rate / the chip's 2-cycle issue peak)."""
+    bytes_ray = BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len
+    launches = max(st.launches_extend, 1)
+    gbs = bytes_ray * st.rays / (st.ms_extend * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "variant": "fused: traversal and shading in one persistent kernel, path state in LDS / registers; HBM sees 16 B per slot (or per logged term)",
+         "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+         "launches": st.launches_extend, "rays_per_launch": round(st.rays / launches, 1), "avg_launch_us": round(st.ms_extend * 1e3 / launches, 3),
+         "algorithmic_bytes_per_ray": round(bytes_ray, 1), "algorithmic_bytes_per_launch": round(bytes_ray * st.rays / launches, 1),
+         "note": "SURVEY 8d prices a fused variant by the wavefront design's algorithmic bytes (40 extend + 104 shade + 96 per path / mean path length) so that designs "
+                 "compare: the kernel moves none of them -- see traffic / frac_counted for what HBM sees and binding_bound for the bound that binds (VALU issue)"}
+    prof = os.path.join(REPO, "profiles", PMC_RECORD_FUSED.get(kernel, ""))
+    if not os.path.isfile(prof):
+        prof = prof.replace("r05_", "r04fin4_")
+    if os.path.isfile(prof):
+        try:
+            pmc = json.load(open(prof))
+            per64 = pmc["valu_wave_instr_per_64_rays"]
+            rays_per_s = st.rays / (st.ms_extend * 1e-3)
+            r["binding_bound"] = {"kind": "valu_issue", "valu_wave_instr_per_64_rays": round(per64, 1),
+                                  "valu_active_lanes_per_instr": round(pmc.get("valu_active_lanes_per_instr", 0.0), 1),
+                                  "wave_instr_per_s": round(per64 / 64.0 * rays_per_s, 1), "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
+                                  "frac": round(per64 / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4),
+                                  "source": f"SQ_INSTS_VALU per ray of {os.path.relpath(prof, REPO)} x this run's rays per second / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op)"}
+            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * st.rays / launches, 1)
+            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+        except Exception:
+            pass
+    return r
+
+
+def wavefront_leg(pt, ctx, scene, info, W, H, args, config, note, child_argv):
+    """The same K frames through PT_PIPELINE_WAVEFRONT (the north star's queue-per-bounce design) when the timed region ran the fused kernel:
+    its rate and workspace, and the full roofline blocks of its two kernels from per-launch events of THIS run (+ live counter passes)."""
+    import statistics
+    kw = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, pipeline=pt.PIPELINE_WAVEFRONT)
+    film = pt.Film(ctx, W, H)
+    timed = pt.default_params(frame=0, frame_count=args.steps, flags=pt.FLAG_PROFILE, **kw)
+    pt.render_prepare(scene, film, timed)
+    shape = ctx.stats()
+    kw.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups)
+    timed = pt.default_params(frame=0, frame_count=args.steps, flags=pt.FLAG_PROFILE, **kw)
+    pt.render(scene, film, pt.default_params(frame=0, frame_count=max(args.warmup, 1), **kw))
+    reps = []
+    for _ in range(3):
+        film.clear()
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        pt.render(scene, film, timed)
+        reps.append((time.perf_counter() - t0, ctx.stats()))
+    reps.sort(key=lambda r: r[0])
+    dt, st = reps[len(reps) // 2]
+    film.close()
+    cst, _, _ = count_visits(pt, ctx, scene, W, H, kw, args.steps)
+    mean_len = st.rays / max(st.paths, 1)
+    r, rs = wavefront_roofline_blocks(pt, st, cst, info, config, note, mean_len)
+    if child_argv is not None:
+        lt = None
+        try:
+            lt = live_traffic(child_argv + ["--pipeline", "wavefront"])
+        except Exception:
+            lt = None
+        apply_live_traffic(r, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
+        if rs:
+            apply_live_traffic(rs, (lt or {}).get("k_shade"), st, st.ms_shade, st.launches_shade)
+    return {"pipeline": "PT_PIPELINE_WAVEFRONT (generate / extend / shade queues, compacted per bounce)", "frames": args.steps,
+            "mrays_per_s": round(st.rays / dt / 1e6, 2), "values": [round(st.rays / x[0] / 1e6, 2) for x in reps], "ms_per_frame": round(dt * 1e3 / args.steps, 4),
+            "rays": st.rays, "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "pipelines": st.pipelines,
+            "workspace_bytes": st.workspace_bytes, "rounds": st.rounds, "roofline": r, "roofline_shade": rs}
+
+
 def build_scene(pt, ctx, config, soup_tris, rank, bvh_quality):
     ingest = tlas_ms = None
     if config in ("c5", "c5x"):
@@ -420,7 +521,7 @@ NOTES["c3"] = NOTES["c2"]
 LEG_SHAPE = {"c4": dict(spp=32, depth=8, tris=0), "c5": dict(spp=16, depth=16, tris=1000000), "c5x": dict(spp=16, depth=16, tris=8000000)}
 
 
-def extra_leg(pt, ctx, W, H, config, frames, rank, live=False):
+def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False):
     """The traversal kernel of another BASELINE config (C4 / C5 / C5x) in the default line: `frames` warm-up frames, then the
     same `frames` frames timed with per-launch events (identical launches, so rocprofv3's average over the whole process
     equals this leg's), then the same frames through the instrumented kernel for the visit and block counts."""
@@ -428,7 +529,8 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False):
     scene, arrays, name, ingest, tlas_ms = build_scene(pt, ctx, config, sh["tris"], rank, "fast_trace")
     info = scene.info()
     film = pt.Film(ctx, W, H)
-    common = dict(width=W, height=H, spp_per_frame=sh["spp"], max_depth=sh["depth"])
+    # (the wavefront pipeline explicitly: the leg is about its traversal kernel; what PT_PIPELINE_AUTO gives a caller of C4 is the `fused` block)
+    common = dict(width=W, height=H, spp_per_frame=sh["spp"], max_depth=sh["depth"], pipeline=pt.PIPELINE_WAVEFRONT)
     timed = pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_PROFILE, **common)
     pt.render_prepare(scene, film, timed)
     shape = ctx.stats()
@@ -463,7 +565,7 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False):
             pt.render(scene, f2, fp)
             d1 = time.perf_counter() - t1
             s2 = ctx.stats()
-            out["fused"] = {"pipeline": "PT_PIPELINE_FUSED (k_fused_inst)", "mrays_per_s": round(s2.rays / d1 / 1e6, 2), "ms_per_frame": round(d1 * 1e3 / frames, 3),
+            out["fused"] = {"pipeline": "PT_PIPELINE_FUSED (k_fused_inst): what PT_PIPELINE_AUTO runs for this scene", "mrays_per_s": round(s2.rays / d1 / 1e6, 2), "ms_per_frame": round(d1 * 1e3 / frames, 3),
                             "rays_equal_wavefront": s2.rays == st.rays, "film_equals_wavefront": bool(f2.read_f32().tobytes() == film.read_f32().tobytes()),
                             "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups, "workspace_bytes": s2.workspace_bytes,
                             "kernel_ms": round(s2.ms_extend, 3)}
@@ -474,10 +576,31 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False):
         lt = None
         try:
             lt = live_traffic(["--pmc-child", "--config", config, "--steps", str(frames), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
-                               "--width", str(W), "--height", str(H)], prefixes=("k_extend",))
+                               "--width", str(W), "--height", str(H), "--pipeline", "wavefront"], prefixes=("k_extend",))
         except Exception:
             lt = None
         apply_live_traffic(r["roofline"] if "roofline" in r else r, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
+    if oracle_walk:
+        # SURVEY 8d's gather term to the letter -- "sum over rays of nodesVisited x 32 B + trisTested x 36 B with counts taken from the instrumented
+        # oracle traversing the same LBVH": the oracle's binary LBVH of the same triangles, walked by the oracle on every 64th 16x16 tile of the
+        # same image at 1 spp (checker only, outside every timed region).  It prices a BINARY tree with one primitive per leaf, so it counts more
+        # and smaller nodes than the 8-wide tree the kernel walks; both figures are given, the kernel's own tree stays the one in `frac`.
+        try:
+            from oracle import pt_oracle as orc
+            t0 = time.perf_counter()
+            osc = orc.Scene(*arrays)
+            cores, _ = effective_cores()
+            p1 = orc.default_params(width=W, height=H, spp_per_frame=1, max_depth=sh["depth"])
+            orays, cnt = orc.render_tile_subset_counted(osc, p1, 64, 0, mode=1, nthreads=cores)
+            g8d = (cnt.nodes_visited * 32.0 + cnt.tris_tested * 36.0) / max(orays, 1)
+            gbs = (BYTES_EXTEND + g8d) * st.rays / (st.ms_extend * 1e-3) / 1e9
+            r["gather_8d_literal"] = {"oracle_nodes_visited_per_ray": round(cnt.nodes_visited / max(orays, 1), 2), "oracle_tris_tested_per_ray": round(cnt.tris_tested / max(orays, 1), 2),
+                                      "bytes_per_ray": round(g8d, 1), "algorithmic_bytes_per_ray": round(BYTES_EXTEND + g8d, 1), "achieved_GBps": round(gbs, 2),
+                                      "frac": round(gbs / HBM_PEAK_GBS, 5), "oracle_rays_sampled": orays, "seconds": round(time.perf_counter() - t0, 2),
+                                      "source": "oracle/pt_oracle.c counters, binary LBVH (32-B nodes, one triangle per leaf), every 64th 16x16 tile of the same image at 1 spp"}
+            del osc
+        except Exception as e:
+            r["gather_8d_literal"] = {"error": repr(e)}
     out.update(r)
     film.close()
     scene.close()
@@ -583,9 +706,10 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--sample-groups", type=int, default=0)
     ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm", "hbm8"], default="auto", help="closest-hit kernel variant")
-    ap.add_argument("--pipeline", choices=["wavefront", "fused"], default="wavefront",
-                    help="wavefront = generate / extend / shade queues (the default, the north star's design); fused = PT_PIPELINE_FUSED, "
-                         "the whole loop as one persistent kernel (scenes in LDS only: c2 / c3)")
+    ap.add_argument("--pipeline", choices=["auto", "wavefront", "fused"], default="auto",
+                    help="auto = PT_PIPELINE_AUTO, what pt_params_default gives a caller: the fused kernel where the scene lives in LDS (c2 / c3 / c4), the "
+                         "wavefront queues otherwise (c5 / c5x); wavefront = generate / extend / shade queues (the north star's design); fused = "
+                         "PT_PIPELINE_FUSED, the whole loop as one persistent kernel")
     ap.add_argument("--bvh-quality", choices=["fast_trace", "fast_build"], default="fast_trace",
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--sort-rays", choices=["auto", "on", "off"], default="auto",
@@ -659,7 +783,7 @@ def main():
     flags |= sort_flag
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
                   frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
-                  pipeline={"wavefront": pt.PIPELINE_WAVEFRONT, "fused": pt.PIPELINE_FUSED}[args.pipeline],
+                  pipeline={"auto": pt.PIPELINE_AUTO, "wavefront": pt.PIPELINE_WAVEFRONT, "fused": pt.PIPELINE_FUSED}[args.pipeline],
                   extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM, "hbm8": pt.EXTEND_HBM8}[args.extend])
 
     def barrier():
@@ -671,7 +795,8 @@ def main():
     timed = pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common)
     pt.render_prepare(scene, film, timed)
     shape = ctx.stats()
-    common.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups)
+    ran = pt.PIPELINE_NAMES.get(shape.pipeline, str(shape.pipeline))     # what PT_PIPELINE_AUTO resolved to for this scene and call
+    common.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups, pipeline=shape.pipeline)
     timed = pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common)
     # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
@@ -740,7 +865,8 @@ def main():
                      + (", written as OBJ+MTL and parsed by the host loader" if args.config == "c5" else ""))
                     + "; rays are generated on device",
             "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {args.spp} spp/frame x {args.steps} frames, "
-                                   f"{args.depth} bounces, {args.pipeline} pipeline; step = 1 frame",
+                                   f"{args.depth} bounces, {ran} pipeline" + (" (the library default, PT_PIPELINE_AUTO)" if args.pipeline == "auto" else "") + "; step = 1 frame",
+                       "pipeline": ran, "pipeline_requested": args.pipeline,
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
                        "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "pipelines": st.pipelines,
@@ -771,51 +897,59 @@ def main():
         # BVH4 (untimed extra frames): feeds the scene-gather term of the algorithmic bytes and the VALU model
         frame0_rays_gpu = frame0_film_gpu = None
         cst = None
-        if args.pipeline == "fused":   # (no instrumented form: frame 0 alone for the film / ray-count comparison)
+        live = world == 1 and not (args.no_extra_legs or args.no_live_pmc or args.pmc_child)
+        child_common = ["--pmc-child", "--config", args.config, "--steps", str(args.steps), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
+                        "--width", str(W), "--height", str(H), "--spp", str(args.spp), "--depth", str(args.depth), "--extend", args.extend,
+                        "--frames-in-flight", str(args.frames_in_flight), "--sample-groups", str(args.sample_groups), "--sort-rays", args.sort_rays,
+                        "--bvh-quality", args.bvh_quality] + (["--soup-tris", str(args.soup_tris)] if args.soup_tris else [])
+        if ran == "fused":   # (no instrumented form: frame 0 alone for the film / ray-count comparison)
             if not args.no_cpu_baseline and world == 1:
                 scratch = pt.Film(ctx, W, H)
                 ctx.reset_stats()
                 pt.render(scene, scratch, pt.default_params(frame=0, frame_count=1, **common))
                 frame0_rays_gpu, frame0_film_gpu = ctx.stats().rays, scratch.read_f32()
                 scratch.close()
-            pipeline_bytes = (BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
-            out["roofline"] = {"bound": "hbm", "kernel": "k_fused", "variant": "fused: path state stays in LDS / registers, HBM sees 16 B per slot or logged term",
-                               # a fused variant is still priced by the wavefront's algorithmic bytes so that designs compare
-                               "achieved": round(pipeline_bytes / (st.ms_extend * 1e-3) / 1e9, 2) if st.ms_extend else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(pipeline_bytes / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st.ms_extend else None, "traffic": None,
-                               "launches": st.launches_extend, "rays_per_launch": round(st.rays / max(st.launches_extend, 1), 1),
-                               "avg_launch_us": round(st.ms_extend * 1e3 / max(st.launches_extend, 1), 3),
-                               "algorithmic_bytes_per_ray": round(BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len, 1),
-                               "note": "the kernel moves none of these bytes: it is VALU-issue bound like k_extend_lds7p"}
+            if st.launches_extend and st.ms_extend > 0:
+                kname = "k_fused_inst" if info.n_instances else "k_fused"
+                out["roofline"] = fused_roofline_block(st, mean_len, scene_config, kname)
+                if live:
+                    lt = None
+                    try:
+                        lt = live_traffic(child_common + ["--pipeline", "fused"], prefixes=(kname,))
+                    except Exception:
+                        lt = None
+                    apply_live_traffic(out["roofline"], (lt or {}).get(kname), st, st.ms_extend, st.launches_extend)
+                    if out["roofline"].get("frac_counted") is not None:
+                        out["roofline"]["frac_counted_note"] = "counted HBM-side bytes of the kernel over its launch time, of the 8 TB/s peak: what the fused kernel really moves"
+            # the north star's own design beside it: the same frames through the wavefront queues, with the roofline blocks of ITS two kernels
+            if world == 1 and not args.no_extra_legs and flags:
+                try:
+                    wl = wavefront_leg(pt, ctx, scene, info, W, H, args, scene_config, NOTES[args.config], child_common if live else None)
+                    out["roofline_wavefront"] = wl.pop("roofline")
+                    out["roofline_shade"] = wl.pop("roofline_shade")
+                    out["wavefront"] = wl
+                except Exception as e:
+                    out["wavefront"] = {"error": repr(e)}
         elif st.extend_variant != pt.EXTEND_FLAT:
             cst, frame0_film_gpu, frame0_rays_gpu = count_visits(pt, ctx, scene, W, H, common, args.steps, frame0=not args.no_cpu_baseline and world == 1)   # (rank 0's shard when N > 1)
-        if flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
-            out["roofline"] = roofline_block(pt, st, cst, info, scene_config, NOTES[args.config])
-            bytes_extend = out["roofline"]["algorithmic_bytes_per_ray"]
-            pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
-            out["roofline"]["pipeline_algorithmic_GBps"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2)
-            # SURVEY 8d's canonical whole-pipeline figure: (extend + 104 shade + 96 per path / mean length) B per ray over the
-            # device time of the timed region, of the HBM peak
-            out["roofline"]["pipeline_frac"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            # `frac` prices ONE launch against its own duration, and the launches of the concurrent pipelines share the chip:
-            # with three pipelines a launch carries a third of the rays and lasts about as long as one of two did.  The same
-            # algorithmic bytes over the device time of the timed region do not depend on how the work is cut into launches
-            out["roofline"]["pipelines"] = st.pipelines
-            out["roofline"]["frac_all_launches_over_device_time"] = round(bytes_extend * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            out["roofline_shade"] = roofline_shade_block(st, scene_config)
-            if world == 1 and not (args.no_extra_legs or args.no_live_pmc or args.pmc_child):
+        if ran != "fused" and flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
+            out["roofline"], out["roofline_shade"] = wavefront_roofline_blocks(pt, st, cst, info, scene_config, NOTES[args.config], mean_len)
+            # `roofline` is the kernel with the most time in the timed region; the other one keeps its block beside it
+            if out["roofline_shade"] and st.ms_shade > st.ms_extend:
+                out["roofline"], out["roofline_extend"] = dict(out["roofline_shade"], note_dominant="k_shade has the most kernel time of the timed region "
+                                                               f"({st.ms_shade:.1f} ms of launches against the traversal kernel's {st.ms_extend:.1f}); the traversal kernel is in roofline_extend"), out["roofline"]
+            if live:
                 # roofline.traffic measured, not looked up: the same frames twice more in a child process under rocprofv3's counters
-                child = ["--pmc-child", "--config", args.config, "--steps", str(args.steps), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
-                         "--width", str(W), "--height", str(H), "--spp", str(args.spp), "--depth", str(args.depth), "--extend", args.extend,
-                         "--frames-in-flight", str(args.frames_in_flight), "--sample-groups", str(args.sample_groups), "--sort-rays", args.sort_rays,
-                         "--bvh-quality", args.bvh_quality] + (["--soup-tris", str(args.soup_tris)] if args.soup_tris else [])
                 lt = None
                 try:
-                    lt = live_traffic(child)
+                    lt = live_traffic(child_common + ["--pipeline", "wavefront"])
                 except Exception:
                     lt = None
-                apply_live_traffic(out["roofline"], (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
-                apply_live_traffic(out["roofline_shade"], (lt or {}).get("k_shade"), st, st.ms_shade, st.launches_extend)
+                ext = out.get("roofline_extend") or out["roofline"]
+                apply_live_traffic(ext, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
+                shd = out["roofline"] if "roofline_extend" in out else out.get("roofline_shade")
+                if shd:
+                    apply_live_traffic(shd, (lt or {}).get("k_shade"), st, st.ms_shade, st.launches_shade)
         if world == 1 and not args.no_extra_legs and args.config in ("c2", "c3"):
             # ---- the reference's own dispatch shapes (outside the timed region) --------------------------------
             ctx.reset_stats()
@@ -832,7 +966,8 @@ def main():
             s2 = ctx.stats()
             out["c2_exact"] = {"workload": f"BASELINE config C2 exactly: {W}x{H}, 64 spp = 2 frames x 32, {args.depth} bounces, one pt_render",
                                "mrays_per_s": round(s2.rays / d2 / 1e6, 2), "ms_total": round(d2 * 1e3, 3), "ms_per_frame": round(d2 * 1e3 / 2, 3),
-                               "rays": s2.rays, "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups}
+                               "rays": s2.rays, "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups,
+                               "pipeline": pt.PIPELINE_NAMES.get(s2.pipeline) + " (PT_PIPELINE_AUTO, what pt_params_default gives a caller)"}
             one = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, frame_count=1)
             pt.render_prepare(scene, film, pt.default_params(frame=0, **one))
             film.clear()
@@ -848,9 +983,10 @@ def main():
             out["latency_ms_1frame"] = round(lat[len(lat) // 2], 3)
             out["latency_1frame"] = {"median_ms": round(lat[len(lat) // 2], 3), "min_ms": round(lat[0], 3), "max_ms": round(lat[-1], 3),
                                      "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 2), "frames": len(lat),
-                                     "sample_groups": s1.sample_groups,
+                                     "sample_groups": s1.sample_groups, "workspace_bytes": s1.workspace_bytes,
+                                     "pipeline": pt.PIPELINE_NAMES.get(s1.pipeline) + " (PT_PIPELINE_AUTO, what pt_params_default gives a caller)",
                                      "shape": "K = 1: one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle, main.cpp:656-683)"}
-            if args.pipeline == "wavefront":
+            if ran == "wavefront" and scene_config == "c2":
                 try:
                     out["c2_fused"] = fused_leg(pt, ctx, scene, film, W, H, args.spp, args.depth, args.steps, st.rays / dt / 1e6)
                 except Exception as e:
@@ -860,7 +996,7 @@ def main():
             for leg, frames in (("c4", args.c4_frames), ("c5", args.c5_frames), ("c5x", args.c5x_frames)):
                 film.clear()
                 try:
-                    out["roofline_" + leg] = extra_leg(pt, ctx, W, H, leg, frames, rank, live=not (args.no_live_pmc or args.pmc_child)) if frames > 0 else None
+                    out["roofline_" + leg] = extra_leg(pt, ctx, W, H, leg, frames, rank, live=not (args.no_live_pmc or args.pmc_child), oracle_walk=leg == "c5" and not args.no_cpu_baseline) if frames > 0 else None
                 except Exception as e:
                     out["roofline_" + leg] = {"error": repr(e)}
         base = None

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_API_VERSION 4  /* 4: PT_PIPELINE_FUSED; pt_tuning.tlas_ploc / ploc_adopt_pct / fail_rebuild (taken from `reserved`: same size) */
+#define PT_API_VERSION 5  /* 5: PT_PIPELINE_AUTO (what pt_params_default returns); pt_stats.pipeline (appended).  4: PT_PIPELINE_FUSED; pt_tuning.tlas_ploc / ploc_adopt_pct / fail_rebuild */
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -77,7 +77,8 @@ typedef struct pt_tuning {
                                the per-(instance, triangle) table                                                         */
     int32_t tlas_ploc;      /* 1: the TLAS of an instanced scene is rebuilt by PLOC like a big scene's binary tree (0: LBVH)   */
     int32_t ploc_adopt_pct; /* a PLOC tree is kept when its area sum is below this percentage of the LBVH's (90; 1000 = always) */
-    int32_t fail_rebuild;   /* tests: > 0 makes the next rebuilds of a scene's tree products fail after the old ones were freed */
+    int32_t fail_rebuild;   /* NOT a speed knob -- failure injection for the tests: > 0 makes the next rebuilds of a scene's tree products fail
+                               after the old ones were freed.  Only pt_ctx_set_tuning sets it; PT_TUNE refuses the name.                      */
     int32_t reserved[5];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
@@ -190,7 +191,11 @@ enum {
      * triangles fit LDS: single-level ones (the Cornell-box class) and instanced ones of 2 .. 32767 instances over such a
      * BLAS (the TLAS stays in L2); PT_ERR_UNSUPPORTED otherwise, tmin > 0, blocking calls only.  Same films, same ray
      * counts as PT_PIPELINE_WAVEFRONT.                                                                                   */
-    PT_PIPELINE_FUSED = 2
+    PT_PIPELINE_FUSED = 2,
+    /* What pt_params_default returns: the fastest pipeline that renders the reference's estimator bit for bit for THIS scene and call --
+     * PT_PIPELINE_FUSED where it applies (scenes that live in LDS, see above; blocking calls without PT_FLAG_COUNT_VISITS), else
+     * PT_PIPELINE_WAVEFRONT.  Films, rgba8 images and ray counts do not depend on the choice; pt_stats.pipeline says which one ran.  */
+    PT_PIPELINE_AUTO = 3
 };
 enum {
     PT_FLAG_PROFILE = 1u,      /* hipEvent-time every extend/shade launch (adds events to the stream)       */
@@ -230,7 +235,7 @@ typedef struct pt_params {
     uint32_t sample_groups;    /* slots per (frame, pixel) tracing disjoint sample ranges concurrently  */
                                /* (0 = auto); results do not depend on it                              */
 } pt_params;
-void pt_params_default(pt_params *p); /* the reference's compile-time constants, 1024x1024, world 1 */
+void pt_params_default(pt_params *p); /* the reference's compile-time constants, 1024x1024, world 1, PT_PIPELINE_AUTO */
 
 /* Renders frames [frame, frame+frame_count) into the film: each frame is one reference launch
  * (spp_per_frame samples/pixel, <= max_depth rays each) blended by raygen.rgen:88-90.
@@ -322,6 +327,8 @@ typedef struct pt_stats {
      * records, radiance accumulators or term logs, sort scratch and shadow queue, plus the context's traversal-stack
      * spill area (the scene and the film images themselves are not included: pt_scene_info.device_bytes, W*H*16)   */
     uint64_t workspace_bytes;
+    uint32_t pipeline;         /* (API version 5) PT_PIPELINE_* the last pt_render / pt_render_prepare ran (never PT_PIPELINE_AUTO) */
+    uint32_t reserved_;
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

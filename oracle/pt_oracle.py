@@ -240,6 +240,14 @@ def render_tile_subset(scene, params, stride, offset=0, mode=1, nthreads=1):
     return img, int(rays)
 
 
+def render_tile_subset_counted(scene, params, stride, offset=0, mode=1, nthreads=1):
+    """render_tile_subset plus the instrumented walk's counters (binary-LBVH nodes visited, triangles tested) -> (rays, Counters)"""
+    img = np.zeros((params.height, params.width, 3), dtype=np.float32)
+    cnt = Counters()
+    rays = lib().orc_render_tile_subset(scene.h, C.byref(params), mode, nthreads, stride, offset, img.ctypes.data, C.byref(cnt))
+    return int(rays), cnt
+
+
 def primary_ray(params, px, py, seed_value):
     s = C.c_uint32(seed_value)
     o = (C.c_float * 3)()

@@ -28,6 +28,8 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "
 PIPELINE_WAVEFRONT = 0
 PIPELINE_WAVEFRONT_NEE = 1
 PIPELINE_FUSED = 2
+PIPELINE_AUTO = 3
+PIPELINE_NAMES = {0: "wavefront", 1: "wavefront_nee", 2: "fused", 3: "auto"}
 FLAG_PROFILE = 1
 FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4
@@ -77,7 +79,8 @@ class Stats(C.Structure):
                 ("wave_refills", C.c_uint64), ("wave_pops", C.c_uint64), ("wave_hit_blocks", C.c_uint64),
                 ("wave_finishes", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("leaf_lanes", C.c_uint64), ("pop_lanes", C.c_uint64), ("hit_lanes", C.c_uint64),
-                ("enter_steps", C.c_uint64), ("enter_lanes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+                ("enter_steps", C.c_uint64), ("enter_lanes", C.c_uint64), ("workspace_bytes", C.c_uint64),
+                ("pipeline", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 TUNING_NAMES = ["refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves", "pair_kernel", "topdown4",

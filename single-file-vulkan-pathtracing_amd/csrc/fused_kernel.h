@@ -40,6 +40,15 @@ constexpr int FTB = PT_FUSED_TB;
 #ifndef PT_FUSED_BATCH
 #define PT_FUSED_BATCH 256  // most slots a wave draws per atomic (a multiple of 64: 64 consecutive slots are one 8x8 tile)
 #endif
+// ... with one sample group: ONE tile.  A wave hands a batch to its lanes as they finish their slots, so the last slot of a batch STARTS
+// (batch / 64 - 1) slot lengths after the batch was drawn -- with 256 and slots of 32 samples (1.5 - 2.6 ms each) interior slots drawn 6 ms
+// before the counters ran dry were still being started after it, whatever the hand-out order (the wave timeline of
+// scripts/probe_fused_timeline.py: profiles/r05b_fused_timeline.log -> r05c_fused_timeline64.log).  64 / 128 / 256, 1080p Cornell box, Grays/s:
+// K = 16 41.2 / 41.4 / 40.8; K = 4 38.8 / 37.7 / 33.8; K = 2 36.0 / 32.6 / 27.3; a rank of world 8 at 16 frames 36.1 / 33.0 / 27.2
+// (profiles/r05c_fused_batch1.log).  The guided self-scheduling the bigger batches needed at the end of a launch is gone with them.
+#ifndef PT_FUSED_BATCH1
+#define PT_FUSED_BATCH1 64
+#endif
 #define PT_FUSED_WTILES (PT_FUSED_BATCH / 64)  // tile words a wave keeps in LDS for its current batch
 #define PT_FUSED_PARTS 8          // slot counters (one per XCD's share of the workgroups)
 #define PT_FUSED_PART_STRIDE 32   // ... in dwords: one 128-B line each
@@ -95,6 +104,8 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
 
 #ifdef PT_FUSED_TIMELINE  // dev build (scripts/probe_fused_timeline.py): per wave {start, out of slots, end, rays} in device clock ticks
     unsigned long long tl_start = wall_clock64(), tl_oos = 0ull;
+    unsigned long long tl_slot_t0 = 0ull, tl_last_t0 = 0ull, tl_last_t1 = 0ull;  // per lane: when its current slot began; its last completed slot
+    uint32_t tl_last_slot = 0xFFFFFFFFu, tl_n_slots = 0u;
 #endif
     bool have = false;          // the lane traces a ray
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
@@ -168,6 +179,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                         my_state[FS_C * FTB] = __float_as_uint(__uint_as_float(my_state[FS_C * FTB]) + eb);
                     } else {  // the ordered term log of add_radiance (wavefront_types.h), the count kept in LDS
                         const uint32_t k = my_state[FS_A * FTB];
+#ifdef PT_DBG_NO_TERMS  // timing experiment only (wrong images): what the term log's stores cost
+                        if (k == 0xFFFFFFFFu)
+#endif
                         if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
                         else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
                         else {
@@ -210,8 +224,13 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     } else {  // the slot is complete
                         if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FTB]), __uint_as_float(my_state[FS_B * FTB]),
                                                                    __uint_as_float(my_state[FS_C * FTB]), 0.f);
+#ifndef PT_DBG_NO_NTERM
                         else rad.nterm[slot] = my_state[FS_A * FTB];
+#endif
                         path = false;
+#ifdef PT_FUSED_TIMELINE
+                        tl_last_slot = slot; tl_last_t0 = tl_slot_t0; tl_last_t1 = wall_clock64(); tl_n_slots++;
+#endif
                     }
                 }
                 ctr = sample | (depth << 16);
@@ -226,11 +245,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     // blockIdx % 8 -- workgroups go to the eight XCDs round-robin, so the waves of one XCD share a word -- and moves
                     // on to the next part when its own is exhausted (work stealing, in ring order) until all eight are.  One word takes
                     // ~88 atomics per microsecond on this chip; shapes with many short slots (several sample groups) ask for more.
-                    // One group: guided self-scheduling on top -- PT_FUSED_BATCH slots while plenty are left in the part, then, from
-                    // a look at its counter, no more than what is left / (2 x the waves that share it), down to one tile: the last
-                    // batches handed out run alone at the end of the launch, and 256 slots of 32 samples are ~3 ms of a wave's time
-                    // (a rank of world 8 at config C3's size: 28.6 -> 25.1 ms).  Several groups: always PT_FUSED_BATCH
-                    // (profiles/r04j_fused_batch_policy.log).
+                    // One group: PT_FUSED_BATCH1 = one tile per draw (see there).  Several groups: always PT_FUSED_BATCH.
                     for (;;) {
                         // (one group: w_base / w_next / w_end count within the part)
                         const uint32_t part_begin = GROUPED ? w_part * part_len : 0u,
@@ -239,13 +254,15 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                         uint32_t rel = 0, size = 0;
                         if (lane == 0) {
                             uint32_t *cnt = next_slot + w_part * (uint32_t)PT_FUSED_PART_STRIDE;
-                            size = (uint32_t)PT_FUSED_BATCH;
+                            size = (uint32_t)(GROUPED ? PT_FUSED_BATCH : PT_FUSED_BATCH1);
+#if PT_FUSED_BATCH1 > 64  // (guided self-scheduling of bigger one-group batches: what is left / (2 x the waves that share the part), down to one tile)
                             if (!GROUPED) {
                                 const uint32_t seen = __atomic_load_n(cnt, __ATOMIC_RELAXED);
                                 const uint32_t left = part_begin + seen < part_end ? part_end - part_begin - seen : 0u;
                                 const uint32_t share = left / max(2u * gridDim.x * (uint32_t)(FTB / 64) / (uint32_t)PT_FUSED_PARTS, 1u);
-                                size = min((uint32_t)PT_FUSED_BATCH, max(64u, share & ~63u));
+                                size = min((uint32_t)PT_FUSED_BATCH1, max(64u, share & ~63u));
                             }
+#endif
                             rel = atomicAdd(cnt, size);
                         }
                         rel = __builtin_amdgcn_readfirstlane(rel);
@@ -298,6 +315,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                         if (!GROUPED) { my_state[FS_B * FTB] = 0u; my_state[FS_C * FTB] = 0u; }
                         path = true;
                         need_primary = true;
+#ifdef PT_FUSED_TIMELINE
+                        tl_slot_t0 = wall_clock64();
+#endif
                     } else if (GROUPED) {
                         rad.nterm[slot] = 0u;  // (a slot outside the image or the batch: k_resolve never reads it, kept defined anyway)
                     }
@@ -438,6 +458,10 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     if (lane == 0 && g_fused_timeline) {
         unsigned long long *o = g_fused_timeline + 4 * (size_t)(blockIdx.x * (FTB / 64) + (threadIdx.x >> 6));
         o[0] = tl_start; o[1] = tl_oos; o[2] = wall_clock64(); o[3] = n_rays_wave;
+    }
+    if (g_fused_timeline) {  // per lane, after the per-wave records: {last slot | slots done << 32, its start, its end}
+        unsigned long long *o = g_fused_timeline + 4 * (size_t)(gridDim.x * (FTB / 64)) + 3 * (size_t)(blockIdx.x * FTB + threadIdx.x);
+        o[0] = (unsigned long long)tl_last_slot | ((unsigned long long)tl_n_slots << 32); o[1] = tl_last_t0; o[2] = tl_last_t1;
     }
 #endif
 }

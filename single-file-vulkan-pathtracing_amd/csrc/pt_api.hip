@@ -63,6 +63,7 @@ static bool tuning_parse(const char *text, pt_tuning *t, std::string &err)
                 if (pair.compare(0, eq, k_tune_names[k]) == 0) idx = k;
         char *end = nullptr;
         const long v = eq != std::string::npos ? std::strtol(pair.c_str() + eq + 1, &end, 10) : 0;
+        if (idx == k_tune_count - 1) idx = -1;  // fail_rebuild is failure injection for the tests, not a knob: never from the environment
         if (idx < 0 || !end || *end != 0 || end == pair.c_str() + eq + 1 || v < INT32_MIN || v > INT32_MAX) { err = "PT_TUNE: cannot use '" + pair + "'"; return false; }
         f[idx] = (int32_t)v;
     }
@@ -351,7 +352,7 @@ void pt_params_default(pt_params *p)
     p->cam_target[0] = 0.f; p->cam_target[1] = -1.f; p->cam_target[2] = 2.f;  // raygen.rgen:56
     p->env[0] = 0.7f; p->env[1] = 0.6f; p->env[2] = 0.5f;                     // miss.rmiss:10
     p->rank = 0; p->world = 1;
-    p->pipeline = PT_PIPELINE_WAVEFRONT;
+    p->pipeline = PT_PIPELINE_AUTO;
     p->frames_in_flight = 0;
     p->flags = 0;
     p->extend = PT_EXTEND_AUTO;

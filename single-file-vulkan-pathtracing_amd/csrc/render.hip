@@ -28,7 +28,7 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
         return PT_ERR_INVALID_ARG;
     }
     if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
-    if (p->pipeline > PT_PIPELINE_FUSED) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
+    if (p->pipeline > PT_PIPELINE_AUTO) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
     if (p->pipeline == PT_PIPELINE_FUSED && (p->flags & (PT_FLAG_ASYNC | PT_FLAG_COUNT_VISITS))) {
         ctx->err = "the fused pipeline has no asynchronous and no instrumented form";
         return PT_ERR_UNSUPPORTED;
@@ -477,13 +477,13 @@ pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const Ex
 }
 
 // ---- PT_PIPELINE_FUSED (fused.hip, fused_kernel.h) ---------------------------------------------------------------------------
-// The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches); sample groups only
-// where a batch holds so few frames that its drain shows -- the last slots handed out run alone at the end of the launch, and a
-// slot of 32 samples is up to 256 rays = ~3 ms of a lane's time against ~6 ms for a frame.  Measured at 1080p, ms per frame by
-// (frames, groups), profiles/r04k_fused_groups_by_frames.log: 1 frame 8.40 / 7.22 / 6.73 / 6.55 with 1 / 8 / 16 / 32 groups; 2 frames
-// 7.75 / 6.55 / 6.37 / 6.31; 4 frames 6.49 / 6.26 / 6.17 / 6.18; 8 frames 6.01 / 6.11 / 6.09 / 6.13 -- and two groups are worse than
-// one everywhere (groups cost the kernel ~10 %: a scattered 16-B store per radiance term instead of an add in LDS).  So: one group
-// from 8 frames on, else frames x groups >= 32.  Explicit frames_in_flight / sample_groups are taken as given.
+// The shape of a fused render: frames in flight as the wavefront pipeline batches them (<= 32, equal batches), and ONE sample group from
+// two frames per launch on; a single frame is cut into 32 groups (one-sample slots at the reference's 32 spp).  What decides is the drain of a launch -- the slots
+// handed out last run alone, and a slot of 32 samples is up to 256 rays = ~2.5 ms of a lane's time against ~5.5 ms for a frame -- against
+// what groups cost (a 16-B store per radiance term and a log k_resolve replays: ~10 % of a frame).  1080p Cornell box, ms per frame, with
+// one-tile batches (fused_kernel.h PT_FUSED_BATCH1): 1 frame 7.2 / 6.9 / 6.4 with 1 / 8 / 32 groups; 2 frames 6.21 / 6.27 with 1 / 16;
+// 4 frames 5.78 / 6.15 with 1 / 8 (profiles/r05c_fused_batch1.log, r05d_grouped_cost.log; with the 256-slot batches of round 4 groups
+// paid up to 8 frames: r04k_fused_groups_by_frames.log).  Explicit frames_in_flight / sample_groups are taken as given.
 void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &, pt_params &q)
 {
     q = *p;
@@ -495,8 +495,8 @@ void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &
     q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
     if (q.sample_groups == 0) {
         uint32_t g = 1;
-        if (q.frames_in_flight < 8u)
-            while (g < p->spp_per_frame && (g * q.frames_in_flight < 32u || p->spp_per_frame % g)) g++;
+        if (q.frames_in_flight < 2u)  // the smallest divisor of spp that is >= 32 (or spp itself)
+            while (g < p->spp_per_frame && (g < 32u || p->spp_per_frame % g)) g++;
         q.sample_groups = g;
     }
 }
@@ -516,7 +516,21 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     fused_shape_defaults(f, p_in, fp, q);
     const pt_params *p = &q;
     RenderShape sh;
-    rc_ = ptw_shape_and_work(f, p, sh, 3, false);
+    for (;;) {
+        rc_ = ptw_shape_and_work(f, p, sh, 3, false);
+        if (rc_ != PT_ERR_OOM) break;
+        // a shape this function chose (the caller passed 0) and that does not fit is planned again smaller, like the wavefront's AUTO
+        // shapes: first fewer sample groups (the next smaller divisor of spp), then fewer frames in flight
+        if (p_in->sample_groups == 0 && q.sample_groups > 1) {
+            uint32_t g = q.sample_groups - 1;
+            while (g > 1 && p_in->spp_per_frame % g) g--;
+            q.sample_groups = g;
+        } else if (p_in->frames_in_flight == 0 && q.frames_in_flight > 1) {
+            q.frames_in_flight = (q.frames_in_flight + 1) / 2;
+        } else {
+            break;
+        }
+    }
     if (!nested) {
         ctx->stats.frames_in_flight = sh.lanes;
         ctx->stats.sample_groups = sh.groups;
@@ -598,17 +612,40 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     return PT_OK;
 }
 
+// PT_PIPELINE_AUTO (what pt_params_default returns): the reference's raygen shader is one invocation per pixel that owns its path
+// (raygen.rgen:41-91) and its host issues one blocking dispatch per frame (main.cpp:656-683) -- the fused kernel is that shape, and
+// wherever it applies it is the faster bit-exact pipeline at every call shape measured (1080p Cornell box, K = 16 / 2 / 1 frames per call:
+// 41.2 / 36.0 / 34.9 Grays/s against the wavefront's 28 / 27.5 / 26; a rank of world 8 at 16 frames 36 against 25; the 10 000-instance grid
+// 14.9 against 13.9: profiles/r05c_fused_batch1.log) in a workspace of 16 B per slot.  So: fused for the scenes fused.hip plans (they live in
+// LDS) when the call is one it can serve (blocking, not instrumented, tmin > 0, image <= 65535^2, the closest-hit kernel left to AUTO);
+// the wavefront pipeline for everything else -- big scenes need its queues, sorting and long launches.
+uint32_t resolve_pipeline(pt_scene *s, const pt_params *p, const ExtendPlan &pl)
+{
+    if (p->pipeline != PT_PIPELINE_AUTO) return p->pipeline;
+    if ((p->flags & (PT_FLAG_ASYNC | PT_FLAG_COUNT_VISITS)) || p->extend != PT_EXTEND_AUTO || p->width > 0xFFFFu || p->height > 0xFFFFu)
+        return PT_PIPELINE_WAVEFRONT;
+    FusedPlan fp;
+    const std::string keep = s->ctx->err;
+    const pt_status rc = ptw_plan_fused(s, pl, p->tmin, fp);
+    if (rc != PT_OK) s->ctx->err = keep;  // (not an error of this call: the scene is simply not the fused kernel's)
+    return rc == PT_OK ? PT_PIPELINE_FUSED : PT_PIPELINE_WAVEFRONT;
+}
+
 }  // namespace
 
 // pt_render_prepare: exactly the shape and workspace pt_render would pick, and the one-time objects of its schedule
-pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
+pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p_in)
 {
     pt_ctx *ctx = s->ctx;
-    pt_status rc_ = check_params(s, f, p);
+    pt_status rc_ = check_params(s, f, p_in);
     if (rc_ != PT_OK) return rc_;
     ExtendPlan pl;
-    rc_ = ptw_plan_extend(s, p->extend, pl);
+    rc_ = ptw_plan_extend(s, p_in->extend, pl);
     if (rc_ != PT_OK) return rc_;
+    pt_params p_res = *p_in;
+    p_res.pipeline = resolve_pipeline(s, p_in, pl);
+    const pt_params *p = &p_res;
+    ctx->stats.pipeline = p->pipeline;
     if (p->pipeline == PT_PIPELINE_FUSED) return render_fused(s, f, p, pl, false, true);
     RenderShape sh;
     rc_ = ptw_shape_and_work(f, p, sh, launch_class(s, pl));
@@ -626,13 +663,17 @@ pt_status ptw_prepare(pt_scene *s, pt_film *f, const pt_params *p)
     return PT_OK;
 }
 
-pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p)
+pt_status ptw_render(pt_scene *s, pt_film *f, const pt_params *p_in)
 {
-    pt_status rc_ = check_params(s, f, p);
+    pt_status rc_ = check_params(s, f, p_in);
     if (rc_ != PT_OK) return rc_;
     ExtendPlan pl;
-    rc_ = ptw_plan_extend(s, p->extend, pl);
+    rc_ = ptw_plan_extend(s, p_in->extend, pl);
     if (rc_ != PT_OK) return rc_;
+    pt_params p_res = *p_in;
+    p_res.pipeline = resolve_pipeline(s, p_in, pl);
+    const pt_params *p = &p_res;
+    s->ctx->stats.pipeline = p->pipeline;
     if (p->pipeline == PT_PIPELINE_FUSED) return render_fused(s, f, p, pl, false, false);
     return render_wavefront(s, f, p, pl, false);
 }

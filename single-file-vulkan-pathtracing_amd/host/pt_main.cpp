@@ -5,7 +5,7 @@
 //
 //   pt_main [--obj assets/CornellBox-Original.obj] [--width 1024] [--height 1024]
 //           [--frames 1] [--spp 32] [--depth 8] [--device 0] [--batch N]
-//           [--ppm out.ppm] [--pfm out.pfm] [--pipeline wavefront|fused|nee]
+//           [--ppm out.ppm] [--pfm out.pfm] [--pipeline auto|wavefront|fused|nee]
 //           [--ranks N [--devices 0,1,...]]
 // --ranks N renders with N GPUs: one host thread and one context per GPU, the 8x8 pixel tiles interleaved over the
 // ranks (pt_params.rank/world), and ONE RCCL gather of the packed tiles to rank 0 per presented image
@@ -36,7 +36,7 @@ struct Options {
     std::string obj = "assets/CornellBox-Original.obj", ppm, pfm;
     uint32_t width = 1024, height = 1024, frames = 1, spp = 32, depth = 8, batch = 0;
     int device = 0;
-    uint32_t pipeline = PT_PIPELINE_WAVEFRONT;
+    uint32_t pipeline = PT_PIPELINE_AUTO;
     uint32_t ranks = 1;          // --ranks N: one host thread + one GPU per rank, tiles interleaved, RCCL gather to rank 0
     std::vector<int> devices;    // --devices a,b,...: HIP ordinals of the ranks (default 0..N-1)
 };
@@ -165,7 +165,11 @@ int main(int argc, char **argv)
         }
         else if (a == "--pipeline") {  // same image from wavefront and fused (fused: scenes that fit LDS); nee is another estimator
             const std::string v = val();
-            o.pipeline = v == "fused" ? PT_PIPELINE_FUSED : v == "nee" ? PT_PIPELINE_WAVEFRONT_NEE : PT_PIPELINE_WAVEFRONT;
+            if (v == "auto") o.pipeline = PT_PIPELINE_AUTO;  // the library's choice: fused where the scene lives in LDS, else wavefront
+            else if (v == "wavefront") o.pipeline = PT_PIPELINE_WAVEFRONT;
+            else if (v == "fused") o.pipeline = PT_PIPELINE_FUSED;
+            else if (v == "nee") o.pipeline = PT_PIPELINE_WAVEFRONT_NEE;
+            else die("unknown pipeline " + v + " (auto, wavefront, fused, nee)");
         }
         else if (a == "--ppm") o.ppm = val();
         else if (a == "--pfm") o.pfm = val();

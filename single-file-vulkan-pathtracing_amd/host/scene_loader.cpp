@@ -179,7 +179,8 @@ void parse_chunk(Chunk &c)
                 if (t.empty()) break;
                 char *end = nullptr;
                 const long i = std::strtol(t.data(), &end, 10);  // "a", "a/b", "a//c", "a/b/c": vertex index first
-                if (end == t.data()) { note(c.err, c.lines, n, 3, "bad face"); break; }
+                // (the index ends the token or is followed by '/': "1x" is not index 1)
+                if (end == t.data() || (end != t.data() + t.size() && *end != '/')) { note(c.err, c.lines, n, 3, "bad face"); break; }
                 if (i == 0) { note(c.err, c.lines, n, 3, "face index out of range"); break; }
                 c.idx.push_back(i);
                 n++;

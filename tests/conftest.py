@@ -36,6 +36,28 @@ def pytest_collection_modifyitems(config, items):
                 it.add_marker(pytest.mark.gpu)
 
 
+class _WavefrontByDefault:
+    """The product package as the tests see it.  Since API version 5 pt_params_default returns PT_PIPELINE_AUTO, which renders LDS-class
+    scenes (the Cornell box, the instanced grid) with the fused kernel.  This suite was written against the wavefront pipeline as the
+    default and most of its tests are ABOUT that pipeline (queues, sample groups, pipelines on streams, term logs, ray sorting), so here
+    `default_params` names PT_PIPELINE_WAVEFRONT wherever a test does not name a pipeline itself; everything else is the module's own.
+    PT_PIPELINE_AUTO has its own tests (test_auto_pipeline_*, the full-size frames through AUTO), which pass `pipeline=pt.PIPELINE_AUTO`
+    or use `pt.library_default_params`; __graft_entry__.smoke() and bench.py use the library's real default."""
+
+    def __init__(self, mod):
+        self.__dict__["_mod"] = mod
+
+    def __getattr__(self, name):
+        return getattr(self._mod, name)
+
+    def default_params(self, **kw):
+        kw.setdefault("pipeline", self._mod.PIPELINE_WAVEFRONT)
+        return self._mod.default_params(**kw)
+
+    def library_default_params(self, **kw):
+        return self._mod.default_params(**kw)
+
+
 @pytest.fixture(scope="session")
 def pt():
     """The product package (directory name has '-', hence importlib)."""
@@ -44,7 +66,7 @@ def pt():
     host = os.path.join(os.path.dirname(mod.__file__), "libpt_host.so")
     if not (os.path.exists(so) and os.path.exists(host)):
         mod.build()
-    return mod
+    return _WavefrontByDefault(mod)
 
 
 @pytest.fixture(scope="session")

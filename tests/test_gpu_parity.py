@@ -1966,10 +1966,14 @@ def test_full_size_frames_equal_the_oracle_known_answers(pt, gpu_ctx, config):
         variants += [dict(pipeline=pt.PIPELINE_FUSED, frames_in_flight=1, sample_groups=1), dict(pipeline=pt.PIPELINE_FUSED)]
     if config == "c5":
         variants += [dict(flags=pt.FLAG_SORT_RAYS), dict(extend=pt.EXTEND_HBM8)]
+    # what a caller gets from pt_params_default (PT_PIPELINE_AUTO): the fused kernels for C2 / C4, the wavefront queues for the soup
+    variants += [dict(pipeline=pt.PIPELINE_AUTO)]
     for kw in variants:
         film.clear()
         gpu_ctx.reset_stats()
         pt.render(scene, film, pt.default_params(**base, **kw))
+        if kw.get("pipeline") == pt.PIPELINE_AUTO:
+            assert gpu_ctx.stats().pipeline == (pt.PIPELINE_WAVEFRONT if config == "c5" else pt.PIPELINE_FUSED), config
         assert gpu_ctx.stats().rays == gold["rays"], (config, kw)
         got = film.read_f32()
         assert got.shape == (h, w, 3)
@@ -1987,7 +1991,8 @@ def _c3_gold():
     return gold
 
 
-def test_c3_full_size_1024spp_progressive_equals_the_oracle_known_answer(pt, gpu_ctx, cornell_gpu):
+@pytest.mark.parametrize("pipeline", ["wavefront", "auto"])
+def test_c3_full_size_1024spp_progressive_equals_the_oracle_known_answer(pt, gpu_ctx, cornell_gpu, pipeline):
     """BASELINE config C3 at its size on ONE device: the Cornell box at 1920x1080, 1024 spp = frames 0..31 of 32 spp (seed
     multipliers m = 1 .. 1024, raygen.rgen:47), depth 8, blended progressively (raygen.rgen:88-90).  The oracle's known
     answer (tests/golden/fullsize_hashes.json `c3`, tests/golden/make_fullsize_hashes.py) holds the SHA-256 of the float film
@@ -1997,7 +2002,9 @@ def test_c3_full_size_1024spp_progressive_equals_the_oracle_known_answer(pt, gpu
     import hashlib
     gold = _c3_gold()
     w, h = gold["width"], gold["height"]
-    kw = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"])
+    # (`auto` = PT_PIPELINE_AUTO, what pt_params_default gives a caller: the fused kernel for this scene)
+    kw = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"],
+              pipeline=pt.PIPELINE_AUTO if pipeline == "auto" else pt.PIPELINE_WAVEFRONT)
     film = pt.Film(gpu_ctx, w, h)
     gpu_ctx.reset_stats()
     first = 0
@@ -2015,12 +2022,14 @@ def test_c3_full_size_1024spp_progressive_equals_the_oracle_known_answer(pt, gpu
     pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=gold["frames"], **kw))
     last = gold["after_frame"][str(gold["frames"] - 1)]
     assert gpu_ctx.stats().rays == gold["rays"]
+    assert gpu_ctx.stats().pipeline == (pt.PIPELINE_FUSED if pipeline == "auto" else pt.PIPELINE_WAVEFRONT)
     assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == last["film_sha256"]
     assert hashlib.sha256(film.read_bgra8().tobytes()).hexdigest() == last["bgra8_sha256"]
     film.close()
 
 
-def test_c3_full_size_as_eight_ranks_in_sequence_assembles_the_same_image(pt, gpu_ctx, cornell_gpu):
+@pytest.mark.parametrize("pipeline", ["wavefront", "auto"])
+def test_c3_full_size_as_eight_ranks_in_sequence_assembles_the_same_image(pt, gpu_ctx, cornell_gpu, pipeline):
     """BASELINE config C3 as the 8-GPU job it is, on the one GPU there is: ranks 0..7 of world 8 render their 8x8 tiles of
     the 1920x1080 x 1024-spp image one after the other (32 frames each, one call), pt_film_pack_tiles / _unpack_tiles --
     the two kernels of pt_film_present either side of the RCCL gather -- assemble one image: the oracle's film to the bit
@@ -2032,7 +2041,8 @@ def test_c3_full_size_as_eight_ranks_in_sequence_assembles_the_same_image(pt, gp
     d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
     gold = _c3_gold()
     w, h, world = gold["width"], gold["height"], gold["world"]
-    kw = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"], frame=0, frame_count=gold["frames"])
+    kw = dict(width=w, height=h, spp_per_frame=gold["spp_per_frame"], max_depth=gold["max_depth"], frame=0, frame_count=gold["frames"],
+              pipeline=pt.PIPELINE_AUTO if pipeline == "auto" else pt.PIPELINE_WAVEFRONT)
     last = gold["after_frame"][str(gold["frames"] - 1)]
     image = pt.DeviceBuffer(gpu_ctx, w * h * 12)
     bgra = np.zeros((h, w, 4), np.uint8)
@@ -2059,6 +2069,69 @@ def test_c3_full_size_as_eight_ranks_in_sequence_assembles_the_same_image(pt, gp
     assert hashlib.sha256(got.astype("<f4").tobytes()).hexdigest() == last["film_sha256"]
     assert hashlib.sha256(bgra.tobytes()).hexdigest() == last["bgra8_sha256"]
     image.close()
+
+
+# ---- PT_PIPELINE_AUTO: what pt_params_default returns (API version 5) --------------------------------------------------
+def test_auto_pipeline_picks_fused_where_it_applies_and_wavefront_elsewhere(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    """pt_params_default names PT_PIPELINE_AUTO: the fused kernel for scenes that live in LDS when the call is one it can serve, the
+    wavefront queues otherwise -- never an error where one of the two can render, pt_stats.pipeline says which ran (also after
+    pt_render_prepare), and the bits do not depend on the choice: every case below is the oracle's film, rgba8 image and ray count."""
+    w, h = 96, 56
+    kw = dict(width=w, height=h, spp_per_frame=8, max_depth=8)
+    p = pt.library_default_params(**kw)
+    assert p.pipeline == pt.PIPELINE_AUTO == 3
+    ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 2, **kw)
+    film = pt.Film(gpu_ctx, w, h)
+    cases = [(dict(), pt.PIPELINE_FUSED), (dict(frames_in_flight=1, sample_groups=4), pt.PIPELINE_FUSED),
+             (dict(flags=pt.FLAG_COUNT_VISITS), pt.PIPELINE_WAVEFRONT),            # no instrumented fused kernel
+             (dict(flags=pt.FLAG_ASYNC), pt.PIPELINE_WAVEFRONT),                   # the fused pipeline is blocking
+             (dict(extend=pt.EXTEND_HBM), pt.PIPELINE_WAVEFRONT),                  # a named closest-hit kernel is a wavefront kernel
+             (dict(rank=1, world=3), pt.PIPELINE_FUSED)]
+    for extra, want in cases:
+        film.clear()
+        gpu_ctx.reset_stats()
+        q = pt.library_default_params(frame=0, frame_count=2, **kw, **extra)
+        pt.render_prepare(cornell_gpu, film, q)
+        assert gpu_ctx.stats().pipeline == want, extra
+        pt.render(cornell_gpu, film, q)
+        gpu_ctx.sync()
+        st = gpu_ctx.stats()
+        assert st.pipeline == want, extra
+        if "world" not in extra:
+            assert st.rays == orays, extra
+            assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes(), extra
+    # tmin <= 0 is not the fused kernel's: AUTO renders it through the queues (the explicit request is refused, tested below)
+    kz = dict(kw, tmin=0.0)
+    oz, _, rz = _render_oracle(orc, cornell_oracle, 1, **kz)
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=1, **kz))
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_WAVEFRONT and gpu_ctx.stats().rays == rz and film.read_f32().tobytes() == oz.tobytes()
+    # a scene beyond LDS: the wavefront pipeline; an instanced scene of the compact two-level kernel's class: k_fused_inst
+    v, i, f = _soup(3000, 5)
+    big, obig = pt.Scene(gpu_ctx, v, i, f), orc.Scene(v, i, f)
+    ob, _, rb = _render_oracle(orc, obig, 1, **kw)
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(big, film, pt.library_default_params(frame=0, frame_count=1, **kw))
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_WAVEFRONT and gpu_ctx.stats().rays == rb and film.read_f32().tobytes() == ob.tobytes()
+    big.close()
+    inst = pt.Scene(gpu_ctx, *pt.load_obj(pt.ASSET_CORNELL))
+    xf = pt.cornell_grid_instances()[:16]
+    inst.set_instances(xf)
+    oi = orc.Scene(*pt.load_obj(pt.ASSET_CORNELL))
+    oi.set_instances(xf)
+    of_, _, ri = _render_oracle(orc, oi, 1, **kw)
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(inst, film, pt.library_default_params(frame=0, frame_count=1, **kw))
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_FUSED and gpu_ctx.stats().rays == ri and film.read_f32().tobytes() == of_.tobytes()
+    inst.set_instances(xf[:1])      # one instance: the general two-level kernel, wavefront only
+    film.clear()
+    pt.render(inst, film, pt.library_default_params(frame=0, frame_count=1, **kw))
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_WAVEFRONT
+    inst.close()
+    film.close()
 
 
 # ---- PT_PIPELINE_FUSED: the whole loop as one persistent kernel (csrc/fused_kernel.h) ----------------------------------
@@ -2227,7 +2300,7 @@ def test_fused_pipeline_shards_term_log_tiers_and_refusals(pt, orc, gpu_ctx, cor
             gpu_ctx.set_tuning(**old)
     film = pt.Film(gpu_ctx, w, h)
     for bad in (dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_ASYNC), dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_COUNT_VISITS),
-                dict(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_HBM), dict(pipeline=pt.PIPELINE_FUSED, tmin=0.0), dict(pipeline=3)):
+                dict(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_HBM), dict(pipeline=pt.PIPELINE_FUSED, tmin=0.0), dict(pipeline=4)):
         with pytest.raises(pt.PtError) as e:
             pt.render(cornell_gpu, film, pt.default_params(**{**kw, **bad}))
         assert e.value.status == 5, bad                                                     # PT_ERR_UNSUPPORTED

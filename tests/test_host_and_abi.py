@@ -221,21 +221,22 @@ def test_struct_layouts_match_header(pt, tmp_path):
     import shutil
     import subprocess
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n",'
                    'sizeof(pt_tuning), sizeof(pt_params), sizeof(pt_stats), sizeof(pt_scene_info), offsetof(pt_params, sample_groups),'
-                   'offsetof(pt_stats, workspace_bytes), offsetof(pt_stats, wave_refills), offsetof(pt_scene_info, tree_area_ploc), PT_API_VERSION);return 0;}\n')
+                   'offsetof(pt_stats, workspace_bytes), offsetof(pt_stats, wave_refills), offsetof(pt_scene_info, tree_area_ploc), offsetof(pt_stats, pipeline), PT_API_VERSION);return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call([shutil.which("gcc") or "gcc", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert got == [C.sizeof(pt.Tuning), C.sizeof(pt.Params), C.sizeof(pt.Stats), C.sizeof(pt.SceneInfo), pt.Params.sample_groups.offset,
-                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.tree_area_ploc.offset, 4], got
-    assert C.sizeof(pt.Tuning) == 4 * 32 and pt.PIPELINE_FUSED == 2
+                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.tree_area_ploc.offset, pt.Stats.pipeline.offset, 5], got
+    assert C.sizeof(pt.Tuning) == 4 * 32 and pt.PIPELINE_FUSED == 2 and pt.PIPELINE_AUTO == 3
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
-    p = pt.default_params()
+    p = pt.library_default_params()   # (pt_params_default itself; the suite's own pt.default_params names the wavefront pipeline, conftest.py)
     assert (p.width, p.height, p.spp_per_frame, p.max_depth, p.world, p.frame_count) == (1024, 1024, 32, 8, 1, 1)
     assert list(p.cam_origin) == [0.0, -1.0, 5.0] and list(p.cam_target) == [0.0, -1.0, 2.0]
     assert [round(x, 6) for x in p.env] == [0.7, 0.6, 0.5]
     assert abs(p.tmin - 0.001) < 1e-9 and p.tmax == 10000.0
+    assert p.pipeline == pt.PIPELINE_AUTO   # what a caller who follows INTEGRATION.md gets: the fastest bit-exact pipeline for the scene
 
 
 def test_no_cpu_fallback(pt):
