@@ -35,7 +35,8 @@ for K, G in shapes:
     lanes = raw[NW * 4:].reshape(NL, 3)
     t = t[t[:, 2] > 0]
     t0 = t[:, 0].min()
-    start, oos, end, rays = [(t[:, i].astype(np.int64) - int(t0)) / 100.0 for i in range(3)] + [t[:, 3].astype(np.int64)]   # us
+    start, oos, end, rays = [(t[:, i].astype(np.int64) - int(t0)) / 100.0 for i in range(3)] + [(t[:, 3] & np.uint64((1 << 48) - 1)).astype(np.int64)]   # us
+    items = (t[:, 3] >> np.uint64(48)).astype(np.int64)   # donated items the wave created (fused_kernel.h part 2b)
     oos = np.where(t[:, 1] > 0, oos, end)
     span = end.max()
     q = lambda a, f: float(np.percentile(a, f))
@@ -43,7 +44,8 @@ for K, G in shapes:
     print(f"K {K} G {G}: k_fused {st.ms_extend:.3f} ms, {len(end)} waves, span {span/1e3:.3f} ms | first out-of-slots at {oos.min()/1e3:.3f} ms, median {q(oos,50)/1e3:.3f}, last {oos.max()/1e3:.3f} | "
           f"wave ends: 1% {q(end,1)/1e3:.3f} 10% {q(end,10)/1e3:.3f} 50% {q(end,50)/1e3:.3f} 90% {q(end,90)/1e3:.3f} 99% {q(end,99)/1e3:.3f} max {span/1e3:.3f} | "
           f"wave-time after a wave's end {100*lost:.1f} % of waves x span | rays per wave min {rays.min()} median {int(np.median(rays))} max {rays.max()} | "
-          f"{st.rays / st.ms_extend / 1e3:.0f} Mrays/s; if the launch ended at the median wave end: {st.rays / q(end,50) :.0f} Mrays/s")
+          f"{st.rays / st.ms_extend / 1e3:.0f} Mrays/s; if the launch ended at the median wave end: {st.rays / q(end,50) :.0f} Mrays/s | "
+          f"donated items: {int(items.sum())} in all, per wave median {int(np.median(items))} max {int(items.max())}, waves with none {int((items == 0).sum())}")
     if G == 1:
         ok = (lanes[:, 0] & np.uint64(0xFFFFFFFF)) != np.uint64(0xFFFFFFFF)
         ls = lanes[ok]
