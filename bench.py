@@ -248,7 +248,7 @@ def roofline_block(pt, st, cst, info, config, note):
             # algorithmic ones over the same launch time -- what "rocprof HBM GB/s against the chip's peak" reads
             r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             r["pmc_profile"] = {k: (round(pmc[k], 3) if isinstance(pmc[k], float) else pmc[k]) for k in
-                                ("hbm_bytes_per_ray", "hbm_read_requests_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays",
+                                ("hbm_bytes_per_ray", "hbm_read_requests_per_ray", "valu_issue_frac", "valu_wave_instr_per_64_rays",
                                  "valu_active_lanes_per_instr", "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "rocprof_avg_launch_us") if k in pmc}
             r["pmc_profile"]["source"] = os.path.relpath(prof, REPO)
         except Exception:
@@ -373,7 +373,7 @@ def roofline_shade_block(st, config):
             r["traffic"] = round(pmc["hbm_bytes_per_ray"] * rays_per_launch, 1)
             r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * rays_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
             r["pmc_profile"] = {k: (round(pmc[k], 4) if isinstance(pmc[k], float) else pmc[k]) for k in
-                                ("hbm_bytes_per_ray", "hbm_write_bytes_per_ray", "valu_busy_fraction", "valu_wave_instr_per_64_rays",
+                                ("hbm_bytes_per_ray", "hbm_write_bytes_per_ray", "valu_issue_frac", "valu_wave_instr_per_64_rays",
                                  "valu_active_lanes_per_instr", "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "utcl1_miss_rate",
                                  "l1_to_l2_read_latency_cycles", "l1_to_l2_write_latency_cycles", "rocprof_avg_launch_us") if k in pmc}
             r["pmc_profile"]["source"] = os.path.relpath(prof, REPO)
@@ -580,6 +580,11 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False
         except Exception:
             lt = None
         apply_live_traffic(r["roofline"] if "roofline" in r else r, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
+        # the same bytes over the DEVICE time of the leg (its pipelines' launches overlap, so the sum of launch durations exceeds it): what the
+        # fabric carried for this kernel per second of the frame, of the 8 TB/s peak
+        r["frac_all_launches_over_device_time"] = round(r["algorithmic_bytes_per_ray"] * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        if lt and lt.get("k_extend"):
+            r["frac_counted_over_device_time"] = round(lt["k_extend"]["hbm_bytes_per_ray"] * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     if oracle_walk:
         # SURVEY 8d's gather term to the letter -- "sum over rays of nodesVisited x 32 B + trisTested x 36 B with counts taken from the instrumented
         # oracle traversing the same LBVH": the oracle's binary LBVH of the same triangles, walked by the oracle on every 64th 16x16 tile of the
@@ -596,7 +601,9 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False
             gbs = (BYTES_EXTEND + g8d) * st.rays / (st.ms_extend * 1e-3) / 1e9
             r["gather_8d_literal"] = {"oracle_nodes_visited_per_ray": round(cnt.nodes_visited / max(orays, 1), 2), "oracle_tris_tested_per_ray": round(cnt.tris_tested / max(orays, 1), 2),
                                       "bytes_per_ray": round(g8d, 1), "algorithmic_bytes_per_ray": round(BYTES_EXTEND + g8d, 1), "achieved_GBps": round(gbs, 2),
-                                      "frac": round(gbs / HBM_PEAK_GBS, 5), "oracle_rays_sampled": orays, "seconds": round(time.perf_counter() - t0, 2),
+                                      "would_be_frac": round(gbs / HBM_PEAK_GBS, 5), "oracle_rays_sampled": orays, "seconds": round(time.perf_counter() - t0, 2),
+                                      "note": "not a bandwidth: the oracle walks a BINARY tree with one triangle per leaf (5x the node visits of the 8-wide tree), so pricing the "
+                                              "kernel's time with those bytes can exceed the HBM peak -- a worse tree would score higher; the kernel's own tree stays in `frac`",
                                       "source": "oracle/pt_oracle.c counters, binary LBVH (32-B nodes, one triangle per leaf), every 64th 16x16 tile of the same image at 1 spp"}
             del osc
         except Exception as e:
@@ -714,6 +721,9 @@ def main():
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--sort-rays", choices=["auto", "on", "off"], default="auto",
                     help="per-round device sort of the extend queue by (origin cell, octant); auto = scenes beyond the Infinity Cache")
+    ap.add_argument("--selftest", action="store_true",
+                    help="N > 1: before any timing, present a rank-coloured film through the run's own collective and check on rank 0 that every tile "
+                         "carries its owner's colour and that the communicator connected N ranks; the record goes into the line, a failure ends the run")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record instead of two nested rocprofv3 passes of this command")
@@ -801,8 +811,17 @@ def main():
     # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
         pt.render(scene, film, pt.default_params(frame=0, frame_count=args.warmup, flags=sort_flag, **common))
+    selftest = None
     if presenter:      # communicator set-up (the first collective of a process) is not a step: always outside the timed region
         presenter.present()
+        if args.selftest:
+            selftest = presenter.selftest(film_t)
+            verdict = torch.tensor([1 if (rank != 0 or selftest["ok"]) else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+            if not int(verdict.item()):
+                if rank == 0:
+                    print(json.dumps({"selftest": selftest, "error": "presentation self-test failed: tiles did not arrive from their owners"}), flush=True)
+                sys.exit(2)
 
     # ---- the timed region: EXACTLY `steps` frames (+ the one collective that presents the image for N > 1) between
     # barrier + synchronize, repeated; the film is cleared and the counters reset between repetitions, outside of it
@@ -887,6 +906,8 @@ def main():
             out["rccl_ranks"] = presenter.ranks_seen
             out["present_ms"] = round(present_s * 1e3, 4)     # the collective + pack / unpack, max over ranks, median repetition
             out["launcher"] = "bench.py's own (one process per GPU)" if os.environ.get("PT_BENCH_SPAWNED") else "external (torch.distributed.run)"
+            if selftest is not None:
+                out["selftest"] = selftest
         # sum of the presented image (N = 1: the film; N > 1: what the gather assembled on rank 0), order-insensitive in float64
         out["presented_checksum"] = float(presented.double().sum().item())
         if ingest:

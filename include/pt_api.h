@@ -286,11 +286,12 @@ pt_status pt_film_pack_tiles(pt_film *film, uint32_t rank, uint32_t world, float
 pt_status pt_film_unpack_tiles(pt_film *film, uint32_t rank, uint32_t world, const float *d_packed, float *d_image);
 
 /* Device memory for the buffers a caller hands to the library (pt_film_create_external, pt_film_present), for hosts
- * that do not link HIP themselves (host/pt_main.cpp is plain g++): hipMalloc / hipFree / a blocking device->host copy
+ * that do not link HIP themselves (host/pt_main.cpp is plain g++): hipMalloc / hipFree / blocking copies either way,
  * ordered after the context's stream.                                                                            */
 pt_status pt_device_alloc(pt_ctx *ctx, size_t bytes, void **out);
 pt_status pt_device_free(pt_ctx *ctx, void *device_ptr);
 pt_status pt_device_read(pt_ctx *ctx, const void *device_src, void *host_dst, size_t bytes);
+pt_status pt_device_write(pt_ctx *ctx, void *device_dst, const void *host_src, size_t bytes); /* (API version 5) blocking host->device copy */
 
 /* ---- statistics ------------------------------------------------------------------------ */
 typedef struct pt_stats {

@@ -10,7 +10,7 @@ big-scene traversal kernels do -- FETCH_SIZE = 0.97 ... 1.00 x the RECORD bytes 
 kernel that gathers 64-B records half of it is the neighbouring record nobody asked for: `hbm_read_bytes_per_ray_records64`
 (1 x FETCH_SIZE) is the figure to hold against algorithmic bytes counted in 64-B records, `hbm_bytes_per_ray` (2 x FETCH_SIZE +
 WRITE_SIZE) the one to hold against the 8 TB/s;
-VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz, rocprofv3 --stats average);
+VALU issue = SQ_INSTS_VALU per second / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction);
 wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; L2 hit = TCC_HIT / TCC_REQ."""
 import json
 import os
@@ -52,7 +52,11 @@ rec = {
     "hbm_write_bytes_per_ray": e["hbm_write_bytes_per_launch"] / rays_per_launch,
     "counter_calibration": "profiles/r03_fetch_size_calibration.json: FETCH_SIZE x2 = bytes of the 128-B lines moved (streams and gathers alike), "
                            "x1 = the 64-B records a divergent gather asked for; WRITE_SIZE x1",
-    "valu_busy_fraction": pl("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * avg_us * 2400.0),
+    # VALU issue: wave64 VALU instructions per second of this kernel over the chip's peak of one per SIMD every 2 cycles (256 CUs x 4 SIMDs x
+    # 2.4 GHz / 2: what bench.py's valu_frac uses; an fma-class op takes 4, so a kernel of fmas tops out at 0.5).  (Rounds 1-4 printed a
+    # `valu_busy_fraction` = SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles here, which exceeded 1 for the fused kernels: the counter's unit
+    # is not 4 cycles per instruction on this chip.  Dropped.)
+    "valu_issue_frac": pl("SQ_INSTS_VALU") / (avg_us * 1e-6) / (256 * 4 * 2.4e9 / 2),
     "valu_wave_instr_per_64_rays": pl("SQ_INSTS_VALU") / (rays_per_launch / 64.0),
     "valu_active_lanes_per_instr": pl("SQ_THREAD_CYCLES_VALU") / pl("SQ_INSTS_VALU"),
     "wait_any_fraction_of_wave_cycles": pl("SQ_WAIT_ANY") / pl("SQ_WAVE_CYCLES"),

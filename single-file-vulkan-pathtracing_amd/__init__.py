@@ -109,7 +109,7 @@ API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "p
                "pt_get_stats", "pt_reset_stats",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_ranks", "pt_comm_destroy", "pt_film_present",
                "pt_film_tile_count", "pt_film_pack_tiles", "pt_film_unpack_tiles",
-               "pt_device_alloc", "pt_device_free", "pt_device_read", "pt_ctx_get_tuning", "pt_ctx_set_tuning"]
+               "pt_device_alloc", "pt_device_free", "pt_device_read", "pt_device_write", "pt_ctx_get_tuning", "pt_ctx_set_tuning"]
 HOST_SYMBOLS = ["pth_load_obj", "pth_load_obj_ex", "pth_free_scene", "pth_write_ppm_bgra8", "pth_write_pfm", "pth_write_soup_obj", "pth_make_soup",
                 "pth_make_stadium"]
 

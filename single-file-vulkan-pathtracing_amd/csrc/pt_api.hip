@@ -417,6 +417,16 @@ pt_status pt_device_read(pt_ctx *ctx, const void *src, void *dst, size_t bytes)
     return PT_OK;
 }
 
+pt_status pt_device_write(pt_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!src || !dst) { ctx->err = "null argument"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
 {
     if (!ctx || !out) return PT_ERR_INVALID_ARG;

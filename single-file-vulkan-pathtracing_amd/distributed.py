@@ -85,6 +85,30 @@ def gather_present_host(film, rank, world, dst=0, group=None):
     return None
 
 
+def selftest_film(width, height, rank, world):
+    """The film of the presentation self-test: this rank's tiles carry ITS colour -- (rank + 1, 100 + rank, tile x + 1000 * tile y) -- and
+    every other pixel is zero, as after a render of its shard."""
+    ty, tx = np.meshgrid(np.arange(height) // TILE, np.arange(width) // TILE, indexing="ij")
+    film = np.zeros((height, width, 3), np.float32)
+    own = (tx + ty) % world == rank
+    film[..., 0] = np.where(own, rank + 1, 0)
+    film[..., 1] = np.where(own, 100 + rank, 0)
+    film[..., 2] = np.where(own, tx + 1000 * ty, 0)
+    return film
+
+
+def selftest_check(image, world):
+    """The presented image of the self-test on the root: every pixel must carry the colour of the rank that OWNS its tile.
+    -> {"ok", "ranks_seen", "wrong_pixels", "tiles_per_rank"}"""
+    h, w = image.shape[:2]
+    ty, tx = np.meshgrid(np.arange(h) // TILE, np.arange(w) // TILE, indexing="ij")
+    owner = (tx + ty) % world
+    good = (image[..., 0] == owner + 1) & (image[..., 1] == 100 + owner) & (image[..., 2] == tx + 1000 * ty)
+    tiles = [int(len(tile_list(w, h, r, world))) for r in range(world)]
+    seen = sorted(set(int(x) - 1 for x in np.unique(image[..., 0]) if x >= 1))
+    return {"ok": bool(good.all()), "ranks_seen": seen, "wrong_pixels": int((~good).sum()), "tiles_per_rank": tiles}
+
+
 class Presenter:
     """bench.py's glue: this rank's film -> the presented image on rank 0, once per call.
 
@@ -183,6 +207,26 @@ class Presenter:
         if self.counts[self.rank]:
             dist.send(host, dst=0)
         return None
+
+    def selftest(self, film_tensor):
+        """Before any timing: present a rank-coloured film through the very collective the run will use and check on the root that every tile
+        arrived from the rank that owns it.  `film_tensor` (this rank's accumulation film, torch-owned) is overwritten and left cleared.
+        -> the check's record on rank 0 (with how many ranks the communicator connected), None elsewhere."""
+        torch = self.torch
+        h, w = film_tensor.shape[:2]
+        film_tensor.copy_(torch.from_numpy(selftest_film(w, h, self.rank, self.world)).to(film_tensor.device))
+        torch.cuda.synchronize()
+        img = self.present()
+        torch.cuda.synchronize()
+        rec = None
+        if self.rank == 0:
+            rec = selftest_check(img.cpu().numpy(), self.world)
+            rec["rccl_ranks"] = self.ranks_seen
+            rec["ok"] = bool(rec["ok"] and self.ranks_seen == self.world and rec["ranks_seen"] == list(range(self.world)))
+            rec["path"] = self.describe()
+        film_tensor.zero_()
+        torch.cuda.synchronize()
+        return rec
 
     def close(self):
         if self.comm:

@@ -6,10 +6,11 @@
 //   pt_main [--obj assets/CornellBox-Original.obj] [--width 1024] [--height 1024]
 //           [--frames 1] [--spp 32] [--depth 8] [--device 0] [--batch N]
 //           [--ppm out.ppm] [--pfm out.pfm] [--pipeline auto|wavefront|fused|nee]
-//           [--ranks N [--devices 0,1,...]]
+//           [--ranks N [--devices 0,1,...] [--selftest]]
 // --ranks N renders with N GPUs: one host thread and one context per GPU, the 8x8 pixel tiles interleaved over the
 // ranks (pt_params.rank/world), and ONE RCCL gather of the packed tiles to rank 0 per presented image
-// (pt_film_present); the image written is the presented one.
+// (pt_film_present); the image written is the presented one.  --selftest: before rendering, every rank presents a film whose own tiles
+// carry its colour through the same collective and rank 0 checks that every tile arrived from its owner (and that RCCL connected N ranks).
 // Prints one JSON line with ray count, ms/frame and Mrays/s.
 #include <algorithm>
 #include <atomic>
@@ -39,6 +40,7 @@ struct Options {
     uint32_t pipeline = PT_PIPELINE_AUTO;
     uint32_t ranks = 1;          // --ranks N: one host thread + one GPU per rank, tiles interleaved, RCCL gather to rank 0
     std::vector<int> devices;    // --devices a,b,...: HIP ordinals of the ranks (default 0..N-1)
+    bool selftest = false;       // --selftest (with --ranks N): the presentation collective on a rank-coloured film before the render
 };
 
 // --ranks N: the ranks agree on success before every collective (ncclCommInitRank, the gather inside pt_film_present): a rank
@@ -60,6 +62,7 @@ struct RankResult {
     pt_stats st{};
     pt_scene_info info{};
     uint32_t rccl_ranks = 0;
+    long long selftest_wrong = -1;   // rank 0 after --selftest: pixels of the presented test film that did not carry their owner's colour
     double render_ms = 0.0, present_ms = 0.0;
     std::string error;
 };
@@ -94,6 +97,44 @@ void run_rank(const Options &o, const pth_scene &hs, uint32_t rank, const pt_uni
             else pt_comm_ranks(comm, &res.rccl_ranks);
         }
         if (!peers_ok(ok)) { if (ok) res.error = peer_msg; break; }
+        if (o.selftest && o.ranks > 1) {
+            // the film of distributed.py selftest_film: own tiles (rank + 1, 100 + rank, tile x + 1000 tile y), zero elsewhere -- presented
+            // through the communicator the run is about to use; rank 0 holds every pixel against the colour of the rank that owns its tile
+            const size_t np = (size_t)o.width * o.height;
+            std::vector<float> host(3 * np, 0.f);
+            for (uint32_t y = 0; y < o.height; y++)
+                for (uint32_t x = 0; x < o.width; x++)
+                    if ((x / 8 + y / 8) % o.ranks == rank) {
+                        float *c = &host[3 * ((size_t)y * o.width + x)];
+                        c[0] = (float)(rank + 1); c[1] = (float)(100 + rank); c[2] = (float)(x / 8 + 1000 * (y / 8));
+                    }
+            void *d_test = nullptr, *d_out = nullptr;
+            pt_film *tf = nullptr;
+            if (pt_device_alloc(ctx, sizeof(float) * 3 * np, &d_test) != PT_OK || pt_device_write(ctx, d_test, host.data(), sizeof(float) * 3 * np) != PT_OK ||
+                pt_film_create_external(ctx, o.width, o.height, d_test, &tf) != PT_OK ||
+                (rank == 0 && pt_device_alloc(ctx, sizeof(float) * 3 * np, &d_out) != PT_OK)) { fail("selftest set-up"); ok = false; }
+            if (peers_ok(ok)) {
+                if (pt_film_present(tf, comm, 0, (float *)d_out) != PT_OK) { fail("selftest pt_film_present"); ok = false; }
+                else if (rank == 0) {
+                    if (pt_device_read(ctx, d_out, host.data(), sizeof(float) * 3 * np) != PT_OK) { fail("selftest pt_device_read"); ok = false; }
+                    else {
+                        long long wrong = 0;
+                        for (uint32_t y = 0; y < o.height; y++)
+                            for (uint32_t x = 0; x < o.width; x++) {
+                                const uint32_t owner = (x / 8 + y / 8) % o.ranks;
+                                const float *c = &host[3 * ((size_t)y * o.width + x)];
+                                wrong += !(c[0] == (float)(owner + 1) && c[1] == (float)(100 + owner) && c[2] == (float)(x / 8 + 1000 * (y / 8)));
+                            }
+                        res.selftest_wrong = wrong;
+                        if (wrong != 0 || res.rccl_ranks != o.ranks) { res.error = "selftest: " + std::to_string(wrong) + " pixels without their owner's colour, RCCL connected " + std::to_string(res.rccl_ranks) + " ranks"; ok = false; }
+                    }
+                }
+            } else if (ok) { res.error = peer_msg; ok = false; }
+            pt_film_destroy(tf);
+            if (d_test) pt_device_free(ctx, d_test);
+            if (d_out) pt_device_free(ctx, d_out);
+            if (!peers_ok(ok)) { if (ok) res.error = peer_msg; break; }
+        }
         pt_params p;
         pt_params_default(&p);
         p.width = o.width; p.height = o.height; p.spp_per_frame = o.spp; p.max_depth = o.depth;
@@ -155,6 +196,7 @@ int main(int argc, char **argv)
         else if (a == "--device") o.device = std::atoi(val());
         else if (a == "--batch") o.batch = (uint32_t)std::atoi(val());
         else if (a == "--ranks") o.ranks = (uint32_t)std::max(1, std::atoi(val()));
+        else if (a == "--selftest") o.selftest = true;
         else if (a == "--devices") {
             std::string v = val();
             for (size_t b = 0; b <= v.size();) {
@@ -241,10 +283,10 @@ int main(int argc, char **argv)
                 "\"bvh_build_ms\": %.3f, \"width\": %u, \"height\": %u, \"frames\": %u, \"spp_per_frame\": %u, "
                 "\"max_depth\": %u, \"ranks\": %u, \"rccl_ranks\": %u, \"rays\": %llu, \"paths\": %llu, "
                 "\"rays_per_rank_min\": %llu, \"rays_per_rank_max\": %llu, \"rounds\": %u, \"ms_total\": %.3f, "
-                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f}\n",
+                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f, \"selftest_wrong_pixels\": %lld}\n",
                 o.obj.c_str(), info.n_tris, info.n_nodes, info.bvh_height, load_ms, info.build_ms, o.width, o.height, o.frames, o.spp,
                 o.depth, o.ranks, res[0].rccl_ranks, rays, paths, rays_min, rays_max, st.rounds, ms, present_ms, wall_ms,
-                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0);
+                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0, res[0].selftest_wrong);
     pth_free_scene(&hs);
     return 0;
 }

@@ -80,3 +80,38 @@ def test_gloo_world2_gather_present_is_bit_exact(orc, cornell_oracle, tmp_path, 
     red = np.load(out + ".reduced.npy")
     assert red.tobytes() == full.tobytes()
     assert list(np.load(out + ".rays.npy")) == [2001, 14]
+
+
+def _selftest_worker(rank, world, port, w, h, out):
+    sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    img = d.gather_present_host(d.selftest_film(w, h, rank, world), rank, world, dst=0)
+    if rank == 0:
+        rec = d.selftest_check(img, world)
+        # ... and the check does find a tile that came from the wrong rank
+        bad = img.copy()
+        bad[0:8, 8:16] = bad[0:8, 0:8]
+        rec["catches_a_swapped_tile"] = not d.selftest_check(bad, world)["ok"]
+        import json
+        json.dump(rec, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_presentation_selftest_over_gloo(tmp_path, world):
+    """`bench.py --gpus N --selftest` / `pt_main --ranks N --selftest` present a rank-coloured film before timing and check on the root that every
+    tile carries its owner's colour.  The same film, gather and check here over gloo with N = 2, 4, 8 processes (host mirrors of the pack /
+    unpack kernels): all ranks seen, no wrong pixel, per-rank tile counts that add up; and a swapped tile IS caught."""
+    import json
+    w, h = 200, 120
+    out = str(tmp_path / "rec.json")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_selftest_worker, args=(world, port, w, h, out), nprocs=world, join=True)
+    rec = json.load(open(out))
+    assert rec["ok"] and rec["wrong_pixels"] == 0 and rec["ranks_seen"] == list(range(world)), rec
+    assert sum(rec["tiles_per_rank"]) == ((w + 7) // 8) * ((h + 7) // 8) and rec["catches_a_swapped_tile"]
