@@ -956,9 +956,12 @@ def test_bench_gpus2_without_a_launcher_starts_its_own_ranks():
     env = {"PT_BENCH_EMULATE": "1"}
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         assert k not in os.environ, "this test must run without a launcher's environment"
-    two, j2 = _bench(["--gpus", "2"] + args, env=env)
+    two, j2 = _bench(["--gpus", "2", "--selftest"] + args, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     assert j2["n_gpus"] == 2 and j2["steps"] == 2 and j2["reps"] >= 2
+    # --selftest: a rank-coloured film went through the run's own collective before the timing and every tile carried its owner's colour
+    st = j2["selftest"]
+    assert st["ok"] and st["wrong_pixels"] == 0 and st["ranks_seen"] == [0, 1] and st["rccl_ranks"] == 2 and sum(st["tiles_per_rank"]) == 40 * 23
     assert j2["launcher"].startswith("bench.py's own")
     assert j2["rays"] == j1["rays"] and j2["paths"] == j1["paths"]
     assert abs(j2["presented_checksum"] - j1["presented_checksum"]) <= 1e-9 * abs(j1["presented_checksum"])
