@@ -162,7 +162,7 @@ def extend_kernel_name(pt, st, info, config):
     lds = "k_extend<lds>"
     if info.n_wide_nodes <= 8191 and info.n_tris <= 2047:     # the compact no-spill instantiations (plan_extend)
         lds = "k_extend_lds7p"
-    return {1: "k_extend_flat", 2: lds, 3: "k_extend<hbm>", 4: "k_extend8"}.get(st.extend_variant, "?")
+    return {2: lds, 3: "k_extend<hbm>", 4: "k_extend8"}.get(st.extend_variant, "?")
 
 
 def count_visits(pt, ctx, scene, W, H, common, frames=1, frame0=False):
@@ -712,7 +712,7 @@ def main():
     ap.add_argument("--soup-tris", type=int, default=None)
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--sample-groups", type=int, default=0)
-    ap.add_argument("--extend", choices=["auto", "flat", "lds", "hbm", "hbm8"], default="auto", help="closest-hit kernel variant")
+    ap.add_argument("--extend", choices=["auto", "lds", "hbm", "hbm8"], default="auto", help="closest-hit kernel variant")
     ap.add_argument("--pipeline", choices=["auto", "wavefront", "fused"], default="auto",
                     help="auto = PT_PIPELINE_AUTO, what pt_params_default gives a caller: the fused kernel where the scene lives in LDS (c2 / c3 / c4), the "
                          "wavefront queues otherwise (c5 / c5x); wavefront = generate / extend / shade queues (the north star's design); fused = "
@@ -794,7 +794,7 @@ def main():
     common = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, rank=rank, world=world,
                   frames_in_flight=args.frames_in_flight, sample_groups=args.sample_groups,
                   pipeline={"auto": pt.PIPELINE_AUTO, "wavefront": pt.PIPELINE_WAVEFRONT, "fused": pt.PIPELINE_FUSED}[args.pipeline],
-                  extend={"auto": pt.EXTEND_AUTO, "flat": pt.EXTEND_FLAT, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM, "hbm8": pt.EXTEND_HBM8}[args.extend])
+                  extend={"auto": pt.EXTEND_AUTO, "lds": pt.EXTEND_LDS, "hbm": pt.EXTEND_HBM, "hbm8": pt.EXTEND_HBM8}[args.extend])
 
     def barrier():
         if world > 1:
@@ -951,7 +951,7 @@ def main():
                     out["wavefront"] = wl
                 except Exception as e:
                     out["wavefront"] = {"error": repr(e)}
-        elif st.extend_variant != pt.EXTEND_FLAT:
+        else:
             cst, frame0_film_gpu, frame0_rays_gpu = count_visits(pt, ctx, scene, W, H, common, args.steps, frame0=not args.no_cpu_baseline and world == 1)   # (rank 0's shard when N > 1)
         if ran != "fused" and flags and st.launches_extend and st.ms_extend > 0 and cst is not None:
             out["roofline"], out["roofline_shade"] = wavefront_roofline_blocks(pt, st, cst, info, scene_config, NOTES[args.config], mean_len)

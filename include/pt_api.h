@@ -211,7 +211,7 @@ enum {
  * return identical bits; AUTO picks by scene size. */
 enum {
     PT_EXTEND_AUTO = 0,
-    PT_EXTEND_FLAT = 1, /* <= 1024 triangles: one wide leaf scanned wave-uniformly (SGPR stream); never AUTO  */
+    PT_EXTEND_FLAT_REMOVED = 1, /* (until API version 4: a brute-force loop over <= 1024 triangles, never AUTO; PT_ERR_UNSUPPORTED now) */
     PT_EXTEND_LDS = 2,  /* BVH4 + triangles staged in LDS (scenes <= 24 KB by AUTO), lane refill             */
     PT_EXTEND_HBM = 3,  /* BVH4 + triangles read through L1/L2/MALL from HBM, LDS short stack + HBM spill    */
     PT_EXTEND_HBM8 = 4  /* 8-wide tree: 64-B nodes with byte planes, one stack entry per node (AUTO only with pt_tuning.hbm8) */

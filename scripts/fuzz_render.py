@@ -46,7 +46,7 @@ for k in range(N):
     for rank in range(world):
         film = pt.Film(ctx, w, h)
         gk = dict(kw, rank=rank, world=world, frames_in_flight=int(rng.choice([0, 1, 2, 5])), sample_groups=int(rng.choice([0, 1, 2, 3, spp])),
-                  extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_FLAT])))
+                  extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_HBM8])))
         if n_inst:
             gk.update(extend=pt.EXTEND_AUTO)   # (one two-level kernel per scene class)
         if rng.random() < 0.4:   # the fused single-kernel pipeline (LDS scenes; it walks its own copy of the compact pair-leaf tree / of the two-level one)

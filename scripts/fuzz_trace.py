@@ -64,7 +64,7 @@ for seed in range(N):
     gs = pt.Scene(ctx, v, i, f)
     for q in (pt.BVH_PREFER_FAST_TRACE, pt.BVH_PREFER_FAST_BUILD):
         gs.set_bvh_quality(q)
-        for ext_v in (pt.EXTEND_AUTO, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_LDS, pt.EXTEND_FLAT):
+        for ext_v in (pt.EXTEND_AUTO, pt.EXTEND_HBM, pt.EXTEND_HBM8, pt.EXTEND_LDS):
             try:
                 got = gs.trace(rays, tmin=tmin, tmax=tmax, extend=ext_v)
             except pt.PtError:
@@ -72,7 +72,7 @@ for seed in range(N):
             gb = got.view(np.uint8).reshape(m, -1)
             eq_w = (gb == want.view(np.uint8).reshape(m, -1)).all(axis=1)
             eq_b = (gb == brute.view(np.uint8).reshape(m, -1)).all(axis=1)
-            ok = eq_b if ext_v == pt.EXTEND_FLAT else np.where(agree, eq_w, eq_w | eq_b)
+            ok = np.where(agree, eq_w, eq_w | eq_b)
             if not ok.all():
                 diff = np.nonzero(~ok)[0]
                 bad += 1

@@ -243,55 +243,15 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
                 if (COUNT) { c_tris += cnt; c_leaf_lanes += PAIRS ? 1u : cnt; }
                 if (PAIRS) { PT_COUNT_WAVE(c_tri_steps); }
                 auto accept = [&](float t, float V, float W, float det, uint32_t pos, uint32_t prim) {
-                    // closest t; equal t -> lowest (gl_InstanceID, gl_PrimitiveID)
-                    if (t < best_t || (t == best_t && (cur_iid < best_iid || (cur_iid == best_iid && prim < best_prim)))) {
-                        best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; best_prim = prim;
-                        best_ipos = cur_ipos; best_iid = cur_iid;
-                        if (SHADOW) sp = 0;  // any hit will do: nothing pending any more (the pop below finds the stack empty)
-                    }
+                    if (ptl::closer_instanced(t, V, W, det, pos, prim, cur_ipos, cur_iid, best_t, best_V, best_W, best_det, best_pos, best_prim, best_ipos, best_iid) && SHADOW)
+                        sp = 0;  // any hit will do: nothing pending any more (the pop below finds the stack empty)
                 };
                 if (PAIRS) {
-                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
-                    const float4 a = s_tri[ti + 0], b = s_tri[ti + 1], c = s_tri[ti + 2];
-                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
-                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
-                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
-                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
-                    const float pAC = Ax * Cy, qAC = Ay * Cx;
-                    // edge test of one half: inside (no strictly negative AND strictly positive edge function) and not edge-on
-                    auto inside = [](float U, float V, float W) {
-                        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
-                    };
-                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
-                        const float det = (U + V) + W;
-                        PT_COUNT_WAVE(c_hit_blocks);
-                        if (COUNT) c_hit_lanes++;
-                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
-                        const float t = ptm::fdiv(T, det);
-                        if (!(t > tmin && t < tmax)) return;
-                        accept(t, V, W, det, pos, prim);
-                    };
-                    const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
-                    const bool inA = inside(UA, VA, WA);
-                    float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
-                    uint32_t primB = 0u;
-                    bool inB = false;
-                    if (cnt == 2u) {
-                        const float4 d = s_tri[ti + 5];
-                        Dz_ = d.z - orgp.z;
-                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
-                        UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
-                        primB = __float_as_uint(d.w);
-                        inB = inside(UB, VB, WB);
-                    }
-                    // one divide block for the lanes inside either half (k_extend_lds7p explains); a lane inside both takes the
-                    // first half here and the second in a block of its own, in primitive order
-                    if (inA || inB) {
-                        const bool sb = !inA;
-                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first,
-                               sb ? primB : __float_as_uint(a.w));
-                    }
-                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u, primB);
+                    ptl::pair_leaf_test(s_tri, (size_t)tri_base + 3 * (size_t)first, cnt == 2u, first, pre, orgp, tmin, tmax, accept,
+                                        [&] {
+                                            PT_COUNT_WAVE(c_hit_blocks);
+                                            if (COUNT) c_hit_lanes++;
+                                        });
                 } else {
                     for (uint32_t k = 0; k < cnt; k++) {
                         PT_COUNT_WAVE(c_tri_steps);

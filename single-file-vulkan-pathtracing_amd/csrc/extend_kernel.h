@@ -7,6 +7,7 @@
 #pragma once
 #include "pt_internal.h"
 #include "pt_math.h"
+#include "pair_leaf.h"
 
 #include <hip/hip_ext.h>
 
@@ -88,6 +89,45 @@ __device__ __forceinline__ float min_raw(float a, float b)
     float r;
     asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+}
+
+// ONE source of the compact node step of the scenes that live in LDS (k_extend_lds7 / _lds7p and k_fused instantiate it with their block
+// sizes): the BVH4 node's planes through the direction-sign offsets (PT_NODE_LOAD), four slab tests (PT_SLAB4), the children ordered as
+// one-dword keys -- entry distance truncated to its top 18 bits | 14-bit child word; formed BEFORE the sort they order like the distances
+// (non-negative floats compare like their bit patterns; a miss is +inf | word, above every hit), so a compare-exchange is v_min_u32 +
+// v_max_u32 instead of a compare and four selects: 14 VALU for the network instead of 25, and the pushes store the key as it is.
+// Children closer together than 2^-9 of their distance may swap places -- the visit order is not part of the result (closest t, lowest
+// primitive id).  The host runs these kernels for tmin > 0 only (entry distances >= tmin: no -0, whose bit pattern would sort last).
+// -> the nearest child's code, or what `pop` returns when the ray misses all four.  STRIDE: threads per block (the stack is [level][thread]).
+template <int STRIDE, class Pop>
+__device__ __forceinline__ uint32_t compact_node_step(const float4 *wide, uint32_t cur, const ptm::f3 &inv, const ptm::f3 &invf, const ptm::f3 &on,
+                                                      const ptm::f3 &of, uint32_t ax, uint32_t ay, uint32_t az, float tmin, float best_t,
+                                                      lds_u32 *my_stack32, int &sp, Pop &&pop)
+{
+    const float INF = __builtin_inff();
+    float t0, t1, t2, t3;
+    // (a 24-bit multiply-add forms the node's LDS address: the child codes are below 2^14)
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wide) + __umul24(cur, 16u * LDS_NODE_F4));
+    PT_NODE_LOAD(nd)
+    const uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z), w3 = __float_as_uint(cw.w);
+    PT_SLAB4(t0, x)
+    PT_SLAB4(t1, y)
+    PT_SLAB4(t2, z)
+    PT_SLAB4(t3, w)
+    uint32_t k0 = (__float_as_uint(t0) & 0xFFFFC000u) | w0, k1 = (__float_as_uint(t1) & 0xFFFFC000u) | w1,
+             k2 = (__float_as_uint(t2) & 0xFFFFC000u) | w2, k3 = (__float_as_uint(t3) & 0xFFFFC000u) | w3;
+#define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
+    PT_KSWAP(k0, k1)
+    PT_KSWAP(k2, k3)
+    PT_KSWAP(k0, k2)
+    PT_KSWAP(k1, k3)
+    PT_KSWAP(k1, k2)
+#undef PT_KSWAP
+    constexpr uint32_t KINF = 0x7F800000u;
+    if (k3 < KINF) { my_stack32[sp * STRIDE] = k3; sp++; }  // farthest first, so the nearest pending pops first
+    if (k2 < KINF) { my_stack32[sp * STRIDE] = k2; sp++; }
+    if (k1 < KINF) { my_stack32[sp * STRIDE] = k1; sp++; }
+    return k0 < KINF ? (k0 & 0x3FFFu) : pop();
 }
 __device__ __forceinline__ void slab_setup(const ptm::f3 org, const ptm::f3 inv, ptm::f3 &invf, ptm::f3 &on, ptm::f3 &of)
 {
@@ -349,6 +389,9 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 c_nodes++;
                 if (lane == __ffsll((long long)__ballot(1)) - 1) c_node_steps++;  // one lane per wave step
             }
+            if constexpr (LDS_SCENE && COMPACT) {
+                cur = compact_node_step<TB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, pop);
+            } else {
             float t0, t1, t2, t3;
             uint32_t w0, w1, w2, w3;
             if (LDS_SCENE) {
@@ -381,29 +424,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                 PT_SLAB4H(t2, y, 0)
                 PT_SLAB4H(t3, y, 1)
             }
-            if (COMPACT) {
-                // One-dword keys (entry distance truncated to its top 18 bits | 14-bit child word) are what the stack holds
-                // anyway; formed BEFORE the sort they order like the distances (non-negative floats compare like their bit
-                // patterns; a miss is +inf | word, above every hit), so a compare-exchange is v_min_u32 + v_max_u32
-                // instead of a compare and four selects: 14 VALU for the network instead of 25, and the pushes store the
-                // key as it is.  Children closer together than 2^-9 of their distance may swap places -- the visit order
-                // is not part of the result (closest t, lowest primitive id).  The host runs this kernel for tmin > 0 only
-                // (entry distances >= tmin: no -0, whose bit pattern would sort last).
-                uint32_t k0 = (__float_as_uint(t0) & 0xFFFFC000u) | w0, k1 = (__float_as_uint(t1) & 0xFFFFC000u) | w1,
-                         k2 = (__float_as_uint(t2) & 0xFFFFC000u) | w2, k3 = (__float_as_uint(t3) & 0xFFFFC000u) | w3;
-#define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
-                PT_KSWAP(k0, k1)
-                PT_KSWAP(k2, k3)
-                PT_KSWAP(k0, k2)
-                PT_KSWAP(k1, k3)
-                PT_KSWAP(k1, k2)
-#undef PT_KSWAP
-                constexpr uint32_t KINF = 0x7F800000u;
-                if (k3 < KINF) { my_stack32[sp * TB] = k3; sp++; }  // farthest first, so the nearest pending pops first
-                if (k2 < KINF) { my_stack32[sp * TB] = k2; sp++; }
-                if (k1 < KINF) { my_stack32[sp * TB] = k1; sp++; }
-                cur = k0 < KINF ? (k0 & 0x3FFFu) : pop();
-            } else {
+            {
 #define PT_CSWAP(TA, WA, TB_, WB)                            \
     {                                                        \
         const bool sw = TB_ < TA;                            \
@@ -422,6 +443,7 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
             if (t1 < INF) push(w1, t1);
             cur = t0 < INF ? w0 : pop();
             }
+            }
             do_node = !VOTE && !(cur & LEAF_BIT);
             if (!VOTE) {
                 // fewer than 1/6 of the wave's rays still descending while the rest waits with a leaf: let the
@@ -439,59 +461,15 @@ __device__ __forceinline__ void extend_body(const float4 *__restrict__ g_wide, c
                     const bool two = ((cur >> 11) & 3u) != 0u;  // count - 1: a fan pair at positions first, first + 1
                     if (COUNT) { c_tris += two ? 2u : 1u; c_leaf_lanes++; }
                     PT_COUNT_WAVE(c_tri_steps);
-                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
-                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
-                    // the sheared vertices and the products of the edge v0-v2 serve both halves (ptm::tri_test_perm, same
-                    // operands in the same order: bit-identical numerators)
-                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
-                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
-                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
-                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
-                    const float pAC = Ax * Cy, qAC = Ay * Cx;
-                    // edge test of one half: inside (no strictly negative AND strictly positive edge function) and not edge-on
-                    auto inside = [](float U, float V, float W) {
-                        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
-                    };
-                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos) {
-                        const float det = (U + V) + W;
-                        PT_COUNT_WAVE(c_hit_blocks);
-                        if (COUNT) c_hit_lanes++;
-                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
-                        const float t = ptm::fdiv(T, det);
-                        if (!(t > tmin && t < tmax)) return;
-                        // closest t; equal t -> lowest gl_PrimitiveID (the OBJ has coincident quads).  The ids of the two rivals are
-                        // read when it happens (the third vertex of every record carries its triangle's id, k_pack), not kept
-                        bool closer = t < best_t;
-                        if (!closer && t == best_t)
-                            closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
-                                                                __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
-                        if (closer) {
-                            best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos;
-                            if (ray_tmax) sp = 0;  // any hit will do: nothing pending any more
-                        }
-                    };
-                    const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
-                    const bool inA = inside(UA, VA, WA);
-                    float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
-                    bool inB = false;
-                    if (two) {
-                        const float4 d = tri4[ti + 5];  // third vertex of the second half; .w = its primitive id (k_pack)
-                        Dz_ = d.z - orgp.z;
-                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
-                        // (v0, v2, v3): U = Dx*Cy - Dy*Cx, V = Ax*Dy - Ay*Dx, W = Cx*Ay - Cy*Ax = qAC - pAC
-                        UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
-                        inB = inside(UB, VB, WB);
-                    }
-                    // A wave nearly always holds lanes inside the first half AND lanes inside the second, so two separate
-                    // divide blocks both ran in 95 % of the steps, each for a handful of lanes.  One block now serves both:
-                    // a lane inside the second half only brings that half's operands; the lane inside BOTH (a ray through
-                    // the shared diagonal, a folded quad) takes the first half here and the second in a block of its own,
-                    // in primitive order as before.  Same operations on the same operands: same bits.
-                    if (inA || inB) {
-                        const bool sb = !inA;
-                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first);
-                    }
-                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u);
+                    ptl::pair_leaf_test(tri4, (size_t)tri_base + 3 * (size_t)first, two, first, pre, orgp, tmin, tmax,
+                                        [&](float t, float V, float W, float det, uint32_t pos, uint32_t) {
+                                            if (ptl::closer_single_level(tri4, tri_base, t, V, W, det, pos, best_t, best_V, best_W, best_det, best_pos) && ray_tmax)
+                                                sp = 0;  // any hit will do: nothing pending any more
+                                        },
+                                        [&] {
+                                            PT_COUNT_WAVE(c_hit_blocks);
+                                            if (COUNT) c_hit_lanes++;
+                                        });
                     cur = pop();
                 }
             } else

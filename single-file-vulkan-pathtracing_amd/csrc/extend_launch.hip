@@ -17,53 +17,16 @@
 
 namespace {
 
-// ---- PT_EXTEND_FLAT: brute force on the device ---------------------------------------------------
-// Every lane tests every triangle in input order: no tree, no stack, the triangle stream wave-uniform (s_load into SGPRs).
-// Never AUTO -- the LDS BVH4 with lane refill is faster even at 36 triangles (9.2 against 10.1 Grays/s when both were last
-// measured, round 1; the tree walk has gained 3x since).  It stays as the on-device reference the tree walks are tested
-// against (tests/test_gpu_parity.py: every variant returns these records; DESIGN.md section 3: on the false hits of
-// degenerate triangles this loop returns the oracle's brute-force answer).  <= 1024 triangles.
-__global__ __launch_bounds__(TB) void k_extend_flat(const float4 *__restrict__ tri4, uint32_t n_tris,
-                                                    const float4 *__restrict__ rayA, const float2 *__restrict__ rayB,
-                                                    float4 *__restrict__ hit, const uint32_t *__restrict__ count_in,
-                                                    uint32_t *count_zero, unsigned long long *stats, float tmin,
-                                                    float tmax, int raw_hit)
-{
-    const uint32_t n = *count_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (count_zero) *count_zero = 0u;
-        if (stats) atomicAdd(stats, (unsigned long long)n);
-    }
-    for (uint32_t base = blockIdx.x * TB; base < n; base += gridDim.x * TB) {
-        const uint32_t q = min(base + threadIdx.x, n - 1u);  // tail lanes redo the last ray (same value stored)
-        const float4 ra = rayA[q];
-        const float2 rb = rayB[q];
-        const ptm::RayPre pre = ptm::ray_setup({ ra.x, ra.y, ra.z }, { ra.w, rb.x, rb.y });
-        float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
-        uint32_t best_pos = PT_MISS, best_prim = PT_MISS;
-        for (uint32_t i = 0; i < n_tris; i++) {
-            const float4 a = tri4[3 * i + 0], b = tri4[3 * i + 1], c = tri4[3 * i + 2];  // uniform address
-            float t, V, W, det;
-            if (ptm::tri_test(pre, { a.x, a.y, a.z }, { b.x, b.y, b.z }, { c.x, c.y, c.z }, tmin, tmax, t, V, W, det)) {
-                const uint32_t prim = __float_as_uint(a.w);
-                if (t < best_t || (t == best_t && prim < best_prim)) {
-                    best_t = t; best_V = V; best_W = W; best_det = det; best_pos = i; best_prim = prim;
-                }
-            }
-        }
-        const bool miss = best_pos == PT_MISS;
-        hit[q] = raw_hit ? make_float4(__uint_as_float(best_pos), best_V, best_W, best_det)
-                         : make_float4(__uint_as_float(best_pos), miss ? 0.f : best_t, miss ? 0.f : ptm::fdiv(best_V, best_det),
-                                       miss ? 0.f : ptm::fdiv(best_W, best_det));
-    }
-}
-
 }  // namespace
 
 pt_status ptw_plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
 {
     pt_ctx *ctx = s->ctx;
     if (want > PT_EXTEND_HBM8) { ctx->err = "unknown extend variant"; return PT_ERR_INVALID_ARG; }
+    if (want == PT_EXTEND_FLAT_REMOVED) {
+        ctx->err = "PT_EXTEND_FLAT (the brute-force loop, never AUTO) was removed in API version 5: every tree walk returns the brute-force closest hit";
+        return PT_ERR_UNSUPPORTED;
+    }
     if (s->broken) {  // an earlier rebuild of the tree ran out of memory (lbvh_build.hip): never launch on null tables
         const pt_status rcb = ptb_repair(s);
         if (rcb != PT_OK) return rcb;
@@ -84,7 +47,7 @@ pt_status ptw_plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
     }
     if (want == PT_EXTEND_HBM8 && (s->n_inst || !s->d_wide8)) { ctx->err = "no 8-wide nodes for this scene (instanced, or <= 2048 triangles)"; return PT_ERR_UNSUPPORTED; }
     if (s->n_inst) {  // two-level scenes: one kernel variant (BVH4s read through L1/L2)
-        if (want == PT_EXTEND_FLAT || want == PT_EXTEND_LDS) { ctx->err = "instanced scenes only have the HBM extend variant"; return PT_ERR_UNSUPPORTED; }
+        if (want == PT_EXTEND_LDS) { ctx->err = "instanced scenes only have the HBM extend variant"; return PT_ERR_UNSUPPORTED; }
         pl.variant = PT_EXTEND_HBM;
         const size_t blas_bytes = 16 * LDS_NODE_F4 * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;
         pl.lds_scene = blas_bytes <= 24 * 1024;  // here: the BLAS (shared by all instances) is staged in LDS
@@ -143,15 +106,6 @@ pt_status ptw_plan_extend(pt_scene *s, uint32_t want, ExtendPlan &pl)
             PT_HIP(ctx, hipMalloc((void **)&ctx->d_spill, need_i));
             ctx->spill_bytes = need_i;
         }
-        return PT_OK;
-    }
-    if (want == PT_EXTEND_FLAT && s->n_tris > 1024) { ctx->err = "flat extend variant needs <= 1024 triangles"; return PT_ERR_UNSUPPORTED; }
-    if (want == PT_EXTEND_FLAT) {  // never chosen by AUTO: the LDS BVH4 with lane refill measured faster even at 36 triangles
-        pl.variant = PT_EXTEND_FLAT;
-        pl.smem = 0;
-        int per_cu = 0;
-        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_extend_flat), TB, 0));
-        pl.grid = ctx->num_cus * std::max(1, std::min(per_cu, 8));
         return PT_OK;
     }
     const size_t scene_bytes = 16 * LDS_NODE_F4 * (size_t)s->n_wide + sizeof(float4) * 9 * (size_t)s->n_tris;  // 3 permuted triangle copies
@@ -298,11 +252,6 @@ void ptw_launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, co
             if (count) PT_LAUNCH_INST(true, false, false); else PT_LAUNCH_INST(false, false, false);
         }
 #undef PT_LAUNCH_INST
-        return;
-    }
-    if (pl.variant == PT_EXTEND_FLAT) {
-        hipExtLaunchKernelGGL(k_extend_flat, dim3(pl.grid), dim3(TB), 0u, st, ev0, ev1, 0u, s->d_tri4, s->n_tris, rayA, rayB, hit,
-                              count_in, count_zero, stats, tmin, tmax, raw);
         return;
     }
     uint2 *spill = reinterpret_cast<uint2 *>(s->ctx->d_spill) + spill_off;

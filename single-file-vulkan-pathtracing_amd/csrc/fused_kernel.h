@@ -99,7 +99,6 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     const float4 *verts = s_tri + 6 * (size_t)n_tris;
 
     lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
-    const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
 
 #ifdef PT_FUSED_TIMELINE  // dev build (scripts/probe_fused_timeline.py): per wave {start, out of slots, end, rays} in device clock ticks
@@ -363,29 +362,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         bool do_node = have && !(cur & LEAF_BIT);
         const int n_have = __popcll(__ballot(have));
         while (do_node) {
-            float t0, t1, t2, t3;
-            uint32_t w0, w1, w2, w3;
-            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wide) + __umul24(cur, 16u * LDS_NODE_F4));
-            PT_NODE_LOAD(nd)
-            w0 = __float_as_uint(cw.x); w1 = __float_as_uint(cw.y); w2 = __float_as_uint(cw.z); w3 = __float_as_uint(cw.w);
-            PT_SLAB4(t0, x)
-            PT_SLAB4(t1, y)
-            PT_SLAB4(t2, z)
-            PT_SLAB4(t3, w)
-            uint32_t k0 = (__float_as_uint(t0) & 0xFFFFC000u) | w0, k1 = (__float_as_uint(t1) & 0xFFFFC000u) | w1,
-                     k2 = (__float_as_uint(t2) & 0xFFFFC000u) | w2, k3 = (__float_as_uint(t3) & 0xFFFFC000u) | w3;
-#define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
-            PT_KSWAP(k0, k1)
-            PT_KSWAP(k2, k3)
-            PT_KSWAP(k0, k2)
-            PT_KSWAP(k1, k3)
-            PT_KSWAP(k1, k2)
-#undef PT_KSWAP
-            constexpr uint32_t KINF = 0x7F800000u;
-            if (k3 < KINF) { my_stack32[sp * FTB] = k3; sp++; }
-            if (k2 < KINF) { my_stack32[sp * FTB] = k2; sp++; }
-            if (k1 < KINF) { my_stack32[sp * FTB] = k1; sp++; }
-            cur = k0 < KINF ? (k0 & 0x3FFFu) : pop();
+            cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, pop);
             do_node = !(cur & LEAF_BIT);
             const int n_cont = __popcll(__ballot(do_node));
             if (n_cont * 6 < n_have) break;
@@ -395,44 +372,11 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             if (cur != DONE && (cur & LEAF_BIT)) {
                 if (PAIRS) {
                     const uint32_t first = cur & 0x7FFu;
-                    const bool two = ((cur >> 11) & 3u) != 0u;
-                    const size_t ti = (size_t)tri_base + 3 * (size_t)first;
-                    const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
-                    const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
-                    const float Ax = (a.x - orgp.x) - pre.Sx * Az_, Ay = (a.y - orgp.y) - pre.Sy * Az_;
-                    const float Bx = (b.x - orgp.x) - pre.Sx * Bz_, By = (b.y - orgp.y) - pre.Sy * Bz_;
-                    const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
-                    const float pAC = Ax * Cy, qAC = Ay * Cx;
-                    auto inside = [](float U, float V, float W) {
-                        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
-                    };
-                    auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos) {
-                        const float det = (U + V) + W;
-                        const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
-                        const float t = ptm::fdiv(T, det);
-                        if (!(t > tmin && t < tmax)) return;
-                        bool closer = t < best_t;
-                        if (!closer && t == best_t)
-                            closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
-                                                                __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
-                        if (closer) { best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; }
-                    };
-                    const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
-                    const bool inA = inside(UA, VA, WA);
-                    float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
-                    bool inB = false;
-                    if (two) {
-                        const float4 d = tri4[ti + 5];
-                        Dz_ = d.z - orgp.z;
-                        const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
-                        UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
-                        inB = inside(UB, VB, WB);
-                    }
-                    if (inA || inB) {
-                        const bool sb = !inA;
-                        finish(sb ? UB : UA, sb ? VB : VA, sb ? WB : WA, Az_, sb ? Cz_ : Bz_, sb ? Dz_ : Cz_, sb ? first + 1u : first);
-                    }
-                    if (inA && inB) finish(UB, VB, WB, Az_, Cz_, Dz_, first + 1u);
+                    ptl::pair_leaf_test(tri4, (size_t)tri_base + 3 * (size_t)first, ((cur >> 11) & 3u) != 0u, first, pre, orgp, tmin, tmax,
+                                        [&](float t, float V, float W, float det, uint32_t pos, uint32_t) {
+                                            ptl::closer_single_level(tri4, tri_base, t, V, W, det, pos, best_t, best_V, best_W, best_det, best_pos);
+                                        },
+                                        [] {});
                 } else {
                     const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
                     for (uint32_t k = 0; k < cnt; k++) {

@@ -34,7 +34,6 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
         return PT_ERR_UNSUPPORTED;
     }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT_NEE) {
-        if (p->extend == PT_EXTEND_FLAT) { ctx->err = "the NEE pipeline has no flat extend variant (shadow rays need a per-ray tmax)"; return PT_ERR_UNSUPPORTED; }
         if (p->sample_groups > 1) { ctx->err = "the NEE pipeline runs one sample group per pixel"; return PT_ERR_UNSUPPORTED; }
     }
     return PT_OK;
@@ -42,7 +41,7 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
 
 
 // 0 instanced scenes, 1 scenes walked out of L2 / MALL / HBM, 2 single-level scenes in LDS (film_work.hip ptw_choose_shape)
-int launch_class(const pt_scene *s, const ExtendPlan &pl) { return s->n_inst || pl.variant == PT_EXTEND_FLAT ? 0 : pl.lds_scene ? 2 : 1; }
+int launch_class(const pt_scene *s, const ExtendPlan &pl) { return s->n_inst ? 0 : pl.lds_scene ? 2 : 1; }
 
 // The one-time objects of a context's renders: side streams, fork / join / poll / shade events, the pinned poll words.
 pt_status ensure_schedule_objects(pt_ctx *ctx, int n_pipes)

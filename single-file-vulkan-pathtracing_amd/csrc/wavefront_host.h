@@ -15,7 +15,7 @@
 
 // ---- extend_launch.hip ---------------------------------------------------------------------------------------------
 struct ExtendPlan {
-    uint32_t variant = PT_EXTEND_LDS;  // PT_EXTEND_FLAT / _LDS / _HBM / _HBM8 that will run
+    uint32_t variant = PT_EXTEND_LDS;  // PT_EXTEND_LDS / _HBM / _HBM8 that will run
     bool lds_scene = false;
     size_t smem = 0;
     int grid = 0;

@@ -245,7 +245,7 @@ def test_trace_primary_rays_bit_exact(pt, orc, cornell_gpu, cornell_oracle):
             o, d, _ = orc.primary_ray(p, x, y, orc.seed(x, y, 0, 0))
             rays[y * 256 + x] = np.concatenate([o, d])
     ohits, _ = cornell_oracle.trace(rays, mode=0)
-    for variant in (pt.EXTEND_AUTO, pt.EXTEND_FLAT, pt.EXTEND_LDS, pt.EXTEND_HBM):
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM):
         hits = cornell_gpu.trace(rays, extend=variant)
         assert hits.tobytes() == ohits.tobytes(), variant
     prim = hits["prim"].astype(np.int64)
@@ -271,7 +271,7 @@ def test_trace_random_rays_soup_bit_exact(pt, orc, gpu_ctx):
         hits = gs.trace(rays, extend=variant)
         assert hits.tobytes() == ohits.tobytes()
     with pytest.raises(pt.PtError):
-        gs.trace(rays, extend=pt.EXTEND_FLAT)      # 20000 triangles are not "one leaf"
+        gs.trace(rays, extend=1)                   # (PT_EXTEND_FLAT, the brute-force loop: removed in API version 5)
     assert 0.2 < (hits["prim"] != pt.MISS).mean() < 1.0
     assert gs.trace(rays[:0]).size == 0  # empty batch
     gs.close()
@@ -302,7 +302,7 @@ def test_ray_setup_divides_inside_and_outside_the_short_division_guards(pt, orc,
         d[100 + j] = np.float32([0.3, -0.2, 1.0]) * e
     rays = np.concatenate([org, d], 1).astype(np.float32)
     ohits, _ = cornell_oracle.trace(rays, mode=0, tmax=1e30)
-    for variant in (pt.EXTEND_AUTO, pt.EXTEND_FLAT, pt.EXTEND_LDS, pt.EXTEND_HBM):
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM):
         hits = cornell_gpu.trace(rays, extend=variant, tmax=1e30)
         assert hits.tobytes() == ohits.tobytes(), variant
     assert (ohits["prim"] != pt.MISS).mean() > 0.3
@@ -767,7 +767,7 @@ def test_tiny_scenes_end_to_end(pt, orc, gpu_ctx, n):
     rays = np.array([np.concatenate(orc.primary_ray(p, x, y, orc.seed(x, y, 0, 0))[:2])
                      for y in range(0, 64, 2) for x in range(0, 64, 2)], np.float32)
     oh, _ = osc.trace(rays, mode=0)
-    for variant in (pt.EXTEND_AUTO, pt.EXTEND_FLAT, pt.EXTEND_LDS, pt.EXTEND_HBM):
+    for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM):
         assert gs.trace(rays, extend=variant).tobytes() == oh.tobytes()
     assert (oh["prim"] != orc.MISS).any()
     kw = dict(width=48, height=48, spp_per_frame=5, max_depth=6)
@@ -1149,7 +1149,7 @@ def test_spirv_reference_shaders_1080p_progressive(pt, gpu_ctx, cornell_gpu):
     film.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4])
 def test_spirv_reference_shaders_full_small_launch(pt, gpu_ctx, cornell_gpu, variant):
     """every invocation of a complete 120x68 launch, frames 0 and 1, every extend variant: texels and the exact
     number of traceRayEXT calls the reference's raygen made."""
@@ -1189,7 +1189,7 @@ def test_negative_tmin_takes_the_wide_stack_entries(pt, orc, gpu_ctx, cornell_gp
     rays = np.concatenate([org, d], 1).astype(np.float32)
     for tmin in (-0.75, -1e-3, 0.0):
         want, _ = cornell_oracle.trace(rays, tmin=tmin, tmax=10.0, mode=0)
-        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_FLAT):
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM):
             got = cornell_gpu.trace(rays, tmin=tmin, tmax=10.0, extend=variant)
             assert got.tobytes() == want.tobytes(), (tmin, variant)
     assert (want["t"] < 0.9).any()
@@ -1479,7 +1479,7 @@ def test_pair_leaves_fan_quads_share_work_but_not_bits(pt, orc, gpu_ctx, cornell
     assert n_pair == 44 and len(leaves) == 44 + 25 + 2    # 40 quads + 4 duplicates paired; the reversed one is two singles
     for tmin in (0.001, 0.0, -0.5):
         want, _ = osc.trace(rays, tmin=tmin, tmax=100.0, mode=0)
-        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_FLAT):
+        for variant in (pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM):
             got = gs.trace(rays, tmin=tmin, tmax=100.0, extend=variant)
             assert got.tobytes() == want.tobytes(), (tmin, variant)
     assert (want["prim"] != 0xFFFFFFFF).sum() > 5000
@@ -1694,7 +1694,7 @@ def test_nee_pipeline_equals_the_oracles_nee_mode(pt, orc, gpu_ctx, cornell_gpu,
     st = gpu_ctx.stats()
     assert st.rays == orays and st.sample_groups == 1
     assert film.read_f32().tobytes() == ofilm.tobytes()
-    for bad in (dict(extend=pt.EXTEND_FLAT), dict(sample_groups=4)):
+    for bad in (dict(extend=1), dict(sample_groups=4)):
         with pytest.raises(pt.PtError):
             pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=1, pipeline=pt.PIPELINE_WAVEFRONT_NEE, **dict(kw, **bad)))
     film.close()

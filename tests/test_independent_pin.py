@@ -110,7 +110,7 @@ def test_the_two_independent_variants_agree_with_each_other():
 
 # ---- GPU: the HIP path through the C-ABI ---------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4])
 def test_gpu_hits_within_tolerance_of_binary64_moeller_trumbore(pt, cornell_gpu, variant):
     check_hits(cornell_gpu.trace(G["e_rays6"], tmin=0.001, tmax=10000.0, extend=variant))
 
