@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
         if (OP == 47) { REP8(asm volatile("v_cvt_f32_ubyte0 %0, %1\n v_fma_f32 %2, %0, %1, %1\n v_cvt_f32_ubyte2 %3, %1\n v_fma_f32 %4, %3, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
         if (OP == 48) { REP8(asm volatile("v_bfe_u32 %0, %1, 8, 8\n v_bfe_u32 %2, %1, 16, 8\n v_bfe_u32 %3, %1, 0, 8\n v_bfe_u32 %4, %1, 24, 8" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
         if (OP == 49) { REP8(asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %1, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %1, %4, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        // round 5: sub-dword addressing (SDWA) -- a byte of a register zero-extended as an operand of a VOP2 instruction, or the result written to one byte
+        if (OP == 50) { REP8(asm volatile("v_or_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_or_b32_sdwa %2, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_or_b32_sdwa %3, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n v_or_b32_sdwa %4, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 51) { REP8(asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n v_mov_b32_sdwa %2, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n v_mov_b32_sdwa %3, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n v_mov_b32_sdwa %4, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 52) { REP8(asm volatile("v_or_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_fma_f32 %2, %0, %1, %1\n v_or_b32_sdwa %3, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n v_fma_f32 %4, %3, %1, %1" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 53) { REP8(asm volatile("v_cvt_f32_ubyte0_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n v_cvt_f32_ubyte0_sdwa %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n v_cvt_f32_ubyte0_sdwa %3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n v_cvt_f32_ubyte0_sdwa %4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
+        if (OP == 54) { REP8(asm volatile("v_mul_f32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n v_mul_f32_sdwa %2, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n v_mul_f32_sdwa %3, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n v_mul_f32_sdwa %4, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "+v"(r0), "+v"(a), "+v"(r1), "+v"(r2), "+v"(r3));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + a;
 }
@@ -88,6 +94,7 @@ int main()
   run<36>("P1 cnd32vcc,add,cnd32vcc,add", d); run<37>("P2 cnd32vcc,cnd64sgpr alternating", d); run<38>("P3 cnd32vcc,s_nop alternating (2 valu/grp)", d); run<39>("P4 4x v_addc_co (vcc carry in/out)", d); run<40>("P5 4x cnd e32 vcc, distinct srcs", d); run<41>("P6 4x cnd e64 sgpr, distinct srcs", d);
   run<42>("v_fma_f32 3 distinct srcs", d); run<43>("v_pk_fma_f32 3 srcs, op_sel broadcast", d); run<44>("v_max3/min3 3 distinct srcs", d);
   run<45>("v_cvt_f32_ubyte0..3", d); run<46>("v_cvt_f32_u32", d); run<47>("cvt_ubyte + fma alternating", d); run<48>("v_bfe_u32", d); run<49>("v_fma_mix_f32 (f16 src0)", d);
+    run<50>("v_or_b32_sdwa src1 BYTE_k", d); run<51>("v_mov_b32_sdwa dst BYTE_1 preserve", d); run<52>("or_sdwa + fma alternating", d); run<53>("v_cvt_f32_ubyte0_sdwa src BYTE_k", d); run<54>("v_mul_f32_sdwa dwords", d);
     printf("(the two cswap lines issue 5 instructions per group, not 4: multiply their figure by 4/5... i.e. cycles per GROUP = figure x 4)\n");
     return 0;
 }
