@@ -66,8 +66,8 @@ BYTES_PER_PATH = 96.0
 _MODEL = os.path.join(REPO, "profiles", "isa_valu_model.json")
 ISA_VALU_MODEL = json.load(open(_MODEL)) if os.path.exists(_MODEL) else None
 # which PMC record (scripts/make_pmc_json.py) carries the HBM-side traffic of a config's traversal kernel
-PMC_RECORD = "r04_pmc_extend_{config}.json"
-PMC_RECORD_SHADE = "r04_pmc_shade_{config}.json"
+PMC_RECORD = "r05_pmc_extend_{config}.json"
+PMC_RECORD_SHADE = "r05_pmc_shade_{config}.json"
 
 
 def cpu_model():
@@ -418,8 +418,6 @@ def fused_roofline_block(st, mean_len, config, kernel):
          "note": "SURVEY 8d prices a fused variant by the wavefront design's algorithmic bytes (40 extend + 104 shade + 96 per path / mean path length) so that designs "
                  "compare: the kernel moves none of them -- see traffic / frac_counted for what HBM sees and binding_bound for the bound that binds (VALU issue)"}
     prof = os.path.join(REPO, "profiles", PMC_RECORD_FUSED.get(kernel, ""))
-    if not os.path.isfile(prof):
-        prof = prof.replace("r05_", "r04fin4_")
     if os.path.isfile(prof):
         try:
             pmc = json.load(open(prof))

@@ -34,7 +34,10 @@ prefix = want_kernel or "k_extend"
 name = max((k for k in s["kernels"] if k.startswith(prefix) and not counting.match(k)), key=lambda k: s["kernels"][k]["total_ns"])
 e, kt = s["pmc"][name], s["kernels"][name]
 pl = lambda c: e.get(c + "_per_launch", 0.0)
-rays_per_launch = bench["rays"] / bench["roofline"]["launches"]   # (a shade launch handles the rays of the extend launch before it)
+# the bench line's block of THIS kernel (round 5: `roofline` is the kernel with the most time of the timed region, the others sit beside it)
+blocks = [bench.get(k) for k in ("roofline", "roofline_extend", "roofline_shade", "roofline_wavefront") if isinstance(bench.get(k), dict)]
+mine = next((b for b in blocks if str(b.get("kernel", "")).startswith(prefix.split("<")[0])), blocks[0])
+rays_per_launch = bench["rays"] / mine["launches"]   # (a shade launch handles the rays of the extend launch before it)
 avg_us = kt["avg_ns"] / 1e3
 rec = {
     "kernel": name, "config": cfg,
@@ -42,7 +45,7 @@ rec = {
               f"(scripts/gpu_profile.sh) on `python bench.py {cfg} --warmup 0 --no-cpu-baseline`",
     "launches": kt["calls"], "rays_per_launch_in_profile_run": rays_per_launch,
     "rocprof_avg_launch_us": avg_us,
-    "bench_hipext_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"] if prefix.startswith(("k_extend", "k_fused")) else bench["roofline"]["shade_ms"] * 1e3 / bench["roofline"]["launches"],
+    "bench_hipext_avg_launch_us_same_run": mine["avg_launch_us"],
     "fetch_size_kib_per_launch": pl("FETCH_SIZE"), "write_size_kib_per_launch": pl("WRITE_SIZE"),
     "hbm_read_bytes_per_launch_x2_gfx950": e["hbm_read_bytes_per_launch_gfx950_x2"],
     "hbm_write_bytes_per_launch": e["hbm_write_bytes_per_launch"], "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],

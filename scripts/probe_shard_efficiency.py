@@ -3,13 +3,13 @@ rank's share of the 1920x1080 image is rendered alone (no collectives; K frames 
     efficiency(N) = time(world 1) / (N x max over ranks of time(rank r of N))
 -- what an N-GPU job would reach if the ranks ran side by side, the presentation gather (3.1 MB per rank, ~30 us) aside -- with the
 per-rank ray counts (balance) and the AUTO shape each rank picked.  Writes one JSON object.
-    python scripts/probe_shard_efficiency.py [K] [wavefront|fused] > profiles/r04_shard_efficiency.json"""
+    python scripts/probe_shard_efficiency.py [K] [wavefront|fused|auto] > profiles/r04_shard_efficiency.json"""
 import importlib, json, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 pipe = sys.argv[2] if len(sys.argv) > 2 else "wavefront"
-pipeline = {"wavefront": pt.PIPELINE_WAVEFRONT, "fused": pt.PIPELINE_FUSED}[pipe]
+pipeline = {"wavefront": pt.PIPELINE_WAVEFRONT, "fused": pt.PIPELINE_FUSED, "auto": pt.PIPELINE_AUTO}[pipe]
 ctx = pt.Context(0)
 sc = pt.Scene(ctx, *pt.load_obj(pt.ASSET_CORNELL))
 out = {"workload": f"C3: CornellBox-Original.obj 1920x1080, 32 spp/frame x {K} frames, 8 bounces, {pipe} pipeline; every rank of every world rendered alone on one MI355X",
