@@ -174,6 +174,7 @@ def lib_amd():
         L.pt_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.pt_device_free.argtypes = [vp, vp]
         L.pt_device_read.argtypes = [vp, vp, vp, C.c_size_t]
+        L.pt_device_write.argtypes = [vp, vp, vp, C.c_size_t]
         L.pt_film_tile_count.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.pt_film_pack_tiles.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
         L.pt_film_unpack_tiles.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]

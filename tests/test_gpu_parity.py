@@ -1897,8 +1897,23 @@ def test_pt_tune_environment_variable_is_parsed_once_at_context_creation(pt):
         with pytest.raises(pt.PtError) as e:
             pt.Context(0)
         assert e.value.status == 1 and "no_such_knob" in str(e.value)
+        # fail_rebuild is failure injection for the tests, not a knob: a stray PT_TUNE must not be able to break a production rebuild
+        os.environ["PT_TUNE"] = "fail_rebuild=1"
+        with pytest.raises(pt.PtError) as e:
+            pt.Context(0)
+        assert e.value.status == 1 and "fail_rebuild" in str(e.value)
     finally:
         os.environ.pop("PT_TUNE", None)
+
+
+def test_device_write_read_round_trip(pt, gpu_ctx):
+    """pt_device_write / pt_device_read (API version 5): the host <-> device copies a host that does not link HIP uses (pt_main --selftest)."""
+    import ctypes as C
+    a = np.arange(1000, dtype=np.float32) * np.float32(0.5)
+    buf = pt.DeviceBuffer(gpu_ctx, a.nbytes)
+    gpu_ctx._check(pt.lib_amd().pt_device_write(gpu_ctx.h, C.c_void_p(buf.ptr), a.ctypes.data, a.nbytes))
+    assert buf.read(np.float32, a.shape).tobytes() == a.tobytes()
+    buf.close()
 
 
 def test_presenter_falls_back_to_the_process_group_when_the_library_communicator_fails(tmp_path):

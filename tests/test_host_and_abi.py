@@ -155,6 +155,21 @@ def test_loader_errors(pt, tmp_path):
     bad.write_text("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
     with pytest.raises(RuntimeError, match="out of range"):
         pt.load_obj(str(bad))
+    # a face token with trailing garbage is a bad face, as for the one-reader restatement (strtol alone would read "1x" as index 1: ADVICE r04)
+    import obj_ref
+    for tok in ("1x", "2/3x/4", "3.5", "0x2", "1/"):
+        junk = tmp_path / "junk.obj"
+        junk.write_text(f"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 {tok}\n")
+        ok_ref = True
+        try:
+            obj_ref.load_obj_strict(str(junk))
+        except obj_ref.ObjError:
+            ok_ref = False
+        if ok_ref:           # ("1/", "2/3x/4": the vertex index before the first '/' is all that either reader looks at)
+            pt.load_obj(str(junk))
+        else:
+            with pytest.raises(RuntimeError, match="bad face"):
+                pt.load_obj(str(junk))
     empty = tmp_path / "empty.obj"
     empty.write_text("v 0 0 0\n")
     with pytest.raises(RuntimeError, match="no faces"):
