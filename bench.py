@@ -719,9 +719,10 @@ def main():
                     help="fast_trace = the reference's ePreferFastTrace (main.cpp:419, default); fast_build = collapsed LBVH only")
     ap.add_argument("--sort-rays", choices=["auto", "on", "off"], default="auto",
                     help="per-round device sort of the extend queue by (origin cell, octant); auto = scenes beyond the Infinity Cache")
-    ap.add_argument("--selftest", action="store_true",
-                    help="N > 1: before any timing, present a rank-coloured film through the run's own collective and check on rank 0 that every tile "
-                         "carries its owner's colour and that the communicator connected N ranks; the record goes into the line, a failure ends the run")
+    ap.add_argument("--selftest", action="store_true", default=True,
+                    help="N > 1 (on by default): before any timing, present a rank-coloured film through the run's own collective and check on rank 0 that every "
+                         "tile carries its owner's colour and that the communicator connected N ranks; the record goes into the line, a failure ends the run")
+    ap.add_argument("--no-selftest", dest="selftest", action="store_false", help="N > 1: skip the presentation self-test")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hipEvent-time each extend/shade launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record instead of two nested rocprofv3 passes of this command")
