@@ -39,11 +39,16 @@ pt_status plan_fused_inst(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPl
     fp.smem = (size_t)fp.lds_stack * FITB * sizeof(uint32_t) + sizeof(uint32_t) * I16_NODE_DW * ((size_t)s->n_wide + fp.n_tlas_lds) +
               sizeof(float4) * 9 * (size_t)s->n_tris + tables + sizeof(uint32_t) * FS_FIELDS * FITB + sizeof(uint32_t) * (FITB / 64) * PT_FUSED_WTILES;
     if (fp.smem > 160 * 1024) { ctx->err = "PT_PIPELINE_FUSED: the two-level kernel's LDS plan exceeds 160 KB (pt_tuning lds_stack / tlas_lds_kb)"; return PT_ERR_UNSUPPORTED; }
-    for (const void *fn : { reinterpret_cast<const void *>(k_fused_inst<false, true>), reinterpret_cast<const void *>(k_fused_inst<true, true>),
-                             reinterpret_cast<const void *>(k_fused_inst<false, false>), reinterpret_cast<const void *>(k_fused_inst<true, false>) })
-        if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
-    int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->pair_leaves ? reinterpret_cast<const void *>(k_fused_inst<false, true>) : reinterpret_cast<const void *>(k_fused_inst<false, false>), FITB, fp.smem));
+    int per_cu = ctx->fused_per_cu[1];
+    const size_t key1 = (fp.smem << 1) | (s->pair_leaves ? 1u : 0u);
+    if (ctx->fused_smem[1] != key1 || per_cu <= 0) {
+        for (const void *fn : { reinterpret_cast<const void *>(k_fused_inst<false, true>), reinterpret_cast<const void *>(k_fused_inst<true, true>),
+                                 reinterpret_cast<const void *>(k_fused_inst<false, false>), reinterpret_cast<const void *>(k_fused_inst<true, false>) })
+            if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->pair_leaves ? reinterpret_cast<const void *>(k_fused_inst<false, true>) : reinterpret_cast<const void *>(k_fused_inst<false, false>), FITB, fp.smem));
+        ctx->fused_smem[1] = key1;
+        ctx->fused_per_cu[1] = per_cu;
+    }
     per_cu = std::max(1, std::min(per_cu, 8));
     per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
     fp.grid = ctx->num_cus * per_cu;
@@ -83,11 +88,16 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     fp.smem = (size_t)pl.lds_stack * FTB * sizeof(uint32_t) + (pl.smem - (size_t)pl.lds_stack * TB * sizeof(uint32_t)) + tables +
               sizeof(uint32_t) * FS_FIELDS * FTB + sizeof(uint32_t) * (FTB / 64) * PT_FUSED_WTILES;
     fp.pairs = pl.pairs;
-    for (const void *fn : { reinterpret_cast<const void *>(k_fused<false, true>), reinterpret_cast<const void *>(k_fused<true, true>),
-                             reinterpret_cast<const void *>(k_fused<false, false>), reinterpret_cast<const void *>(k_fused<true, false>) })
-        if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
-    int per_cu = 0;
-    PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.pairs ? reinterpret_cast<const void *>(k_fused<false, true>) : reinterpret_cast<const void *>(k_fused<false, false>), FTB, fp.smem));
+    int per_cu = ctx->fused_per_cu[0];
+    const size_t key0 = (fp.smem << 1) | (pl.pairs ? 1u : 0u);
+    if (ctx->fused_smem[0] != key0 || per_cu <= 0) {
+        for (const void *fn : { reinterpret_cast<const void *>(k_fused<false, true>), reinterpret_cast<const void *>(k_fused<true, true>),
+                                 reinterpret_cast<const void *>(k_fused<false, false>), reinterpret_cast<const void *>(k_fused<true, false>) })
+            if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.pairs ? reinterpret_cast<const void *>(k_fused<false, true>) : reinterpret_cast<const void *>(k_fused<false, false>), FTB, fp.smem));
+        ctx->fused_smem[0] = key0;
+        ctx->fused_per_cu[0] = per_cu;
+    }
     per_cu = std::max(1, std::min(per_cu, 8));
     per_cu = pt_tuned(ctx->tune.extend_blocks, per_cu, 1, per_cu);
     fp.grid = ctx->num_cus * per_cu;

@@ -47,6 +47,10 @@ struct pt_ctx {
     // allocator (torch), and for the out-of-memory tests.
     size_t mem_budget = 0;
     pt_tuning tune;            // include/pt_api.h: defaults (-1) + PT_TUNE, filled once by pt_ctx_create
+    // fused.hip: the launch attributes / occupancy of the fused kernels for the last LDS size planned ([0] single-level, [1] two-level):
+    // a blocking call per frame plans twice (PT_PIPELINE_AUTO's look, then the render) and should not pay five runtime calls each time
+    size_t fused_smem[2] = { 0, 0 };
+    int fused_per_cu[2] = { 0, 0 };
 };
 // a tuning field with its built-in choice and its valid range
 inline int pt_tuned(int32_t v, int dflt, int lo, int hi) { return v < 0 ? dflt : (v < lo ? lo : (v > hi ? hi : v)); }
