@@ -49,8 +49,13 @@ for k in range(N):
                   extend=int(rng.choice([pt.EXTEND_AUTO, pt.EXTEND_LDS, pt.EXTEND_HBM, pt.EXTEND_HBM8])))
         if n_inst:
             gk.update(extend=pt.EXTEND_AUTO)   # (one two-level kernel per scene class)
-        if rng.random() < 0.4:   # the fused single-kernel pipeline (LDS scenes; it walks its own copy of the compact pair-leaf tree / of the two-level one)
+        r = rng.random()
+        if r < 0.35:     # the fused single-kernel pipeline (LDS scenes; the compact pair-leaf tree / the two-level one)
             gk.update(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_AUTO)
+        elif r < 0.7:    # the wavefront queues, named
+            gk.update(pipeline=pt.PIPELINE_WAVEFRONT)
+        else:            # PT_PIPELINE_AUTO (what pt_params_default returns): fused where the call allows it, else wavefront
+            gk.update(pipeline=pt.PIPELINE_AUTO)
         if f0:
             pt.render(sc, film, pt.default_params(frame=0, frame_count=f0, **gk))
         pt.render(sc, film, pt.default_params(frame=f0, frame_count=nf, **gk))
