@@ -11,7 +11,7 @@
 #include "../../include/pt_host.h"
 
 extern "C" int pth_write_ppm_bgra8(const char *path, const uint8_t *bgra, uint32_t w, uint32_t h)
-{
+try {
     if (!path || !bgra || !w || !h) return 1;
     FILE *f = std::fopen(path, "wb");
     if (!f) return 2;
@@ -27,16 +27,20 @@ extern "C" int pth_write_ppm_bgra8(const char *path, const uint8_t *bgra, uint32
         std::fwrite(row.data(), 1, row.size(), f);
     }
     return std::fclose(f) == 0 ? 0 : 3;
+} catch (...) {
+    return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }
 
 extern "C" int pth_write_pfm(const char *path, const float *rgb, uint32_t w, uint32_t h)
-{
+try {
     if (!path || !rgb || !w || !h) return 1;
     FILE *f = std::fopen(path, "wb");
     if (!f) return 2;
     std::fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
     for (uint32_t y = h; y-- > 0;) std::fwrite(rgb + 3 * (size_t)y * w, sizeof(float), 3 * (size_t)w, f);
     return std::fclose(f) == 0 ? 0 : 3;
+} catch (...) {
+    return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }
 
 namespace {
@@ -74,7 +78,7 @@ void soup_triangle(Pcg &rng, float (&v)[3][3])
 // The same soup as pth_write_soup_obj + pth_load_obj would give, without the detour through ~140 bytes of text per
 // triangle: for the scenes larger than the Infinity Cache (bench.py --config c5x, 8 M triangles = 1.1 GB of OBJ).
 extern "C" int pth_make_soup(uint32_t n_tris, uint32_t seed, pth_scene *out)
-{
+try {
     if (!out || !n_tris || n_tris > 0x0FFFFFFFu) return 1;
     *out = pth_scene{};
     float *vert = static_cast<float *>(std::malloc(sizeof(float) * 9 * (size_t)n_tris));
@@ -100,6 +104,8 @@ extern "C" int pth_make_soup(uint32_t n_tris, uint32_t seed, pth_scene *out)
     }
     out->vertices = vert; out->n_verts = 3u * n_tris; out->indices = idx; out->n_tris = n_tris; out->faces = faces;
     return 0;
+} catch (...) {
+    return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }
 
 // ---- the "teapot in a stadium" stress scene: primitive sizes over four orders of magnitude ------------------------------
@@ -140,7 +146,7 @@ struct StadiumOut {
 }  // namespace
 
 extern "C" int pth_make_stadium(uint32_t floor_side, uint32_t sphere_seg, pth_scene *out)
-{
+try {
     if (!out || floor_side < 1u || sphere_seg < 3u || floor_side > 8192u || sphere_seg > 4096u) return 1;
     *out = pth_scene{};
     StadiumOut o;
@@ -219,6 +225,8 @@ extern "C" int pth_make_stadium(uint32_t floor_side, uint32_t sphere_seg, pth_sc
     for (size_t i = 0; i < 3 * nt; i++) idx[i] = (uint32_t)i;
     out->vertices = vert; out->n_verts = (uint32_t)(3 * nt); out->indices = idx; out->n_tris = (uint32_t)nt; out->faces = faces;
     return 0;
+} catch (...) {
+    return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }
 
 // Recipe (frozen): centre c ~ U([-1,1] x [0,2] x [-1,1]) in OBJ space (Y is negated at load, so
@@ -226,7 +234,7 @@ extern "C" int pth_make_stadium(uint32_t floor_side, uint32_t sphere_seg, pth_sc
 // three vertices are c + 0.02 * (U(-1/2,1/2))^3; triangles with |cross| < 1e-8 are re-drawn;
 // material of triangle i = palette[i mod 8], except `light` when i mod 64 == 7.
 extern "C" int pth_write_soup_obj(const char *obj_path, uint32_t n_tris, uint32_t seed)
-{
+try {
     if (!obj_path || !n_tris) return 1;
     std::string obj(obj_path);
     std::string mtl = obj.size() > 4 && obj.substr(obj.size() - 4) == ".obj" ? obj.substr(0, obj.size() - 4) + ".mtl" : obj + ".mtl";
@@ -259,4 +267,6 @@ extern "C" int pth_write_soup_obj(const char *obj_path, uint32_t n_tris, uint32_
         std::fprintf(f, "f -3 -2 -1\n");
     }
     return std::fclose(f) == 0 ? 0 : 3;
+} catch (...) {
+    return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }

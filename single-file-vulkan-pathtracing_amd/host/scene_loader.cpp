@@ -5,6 +5,10 @@
 // indices and v/vt/vn forms, fan triangulation of polygons (PTH_QUAD_SHORTER_DIAGONAL: the quad rule of
 // newer tinyobjloader releases), `mtllib`, `usemtl`, and from the MTL `newmtl`, `Kd`, `Ke`.  Shapes/groups do not matter: the reference concatenates all
 // shapes in file order (main.cpp:38-57) and material ids are per face.
+#include <sys/stat.h>
+#include <exception>
+#include <new>
+#include <stdexcept>
 #include <algorithm>
 #include <cerrno>
 #include <charconv>
@@ -35,6 +39,11 @@ bool read_file(const std::string &path, std::string &out)
 {
     std::FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) != 0 || !S_ISREG(sb.st_mode)) {  // (a directory opens for reading and "is" LONG_MAX bytes long: `mtllib` without a name)
+        std::fclose(f);
+        return false;
+    }
     bool ok = std::fseek(f, 0, SEEK_END) == 0;
     const long n = ok ? std::ftell(f) : -1;
     ok = ok && n >= 0 && std::fseek(f, 0, SEEK_SET) == 0;
@@ -204,15 +213,40 @@ template <class F>
 void for_chunks(std::vector<Chunk> &cs, F f)
 {
     if (cs.size() == 1) { f(cs[0]); return; }
+    // an exception of a worker (std::bad_alloc on a huge file) is carried to the caller: left inside the thread it would end the process
+    std::vector<std::exception_ptr> failed(cs.size());
+    auto guarded = [&cs, &f, &failed](size_t k) {
+        try { f(cs[k]); } catch (...) { failed[k] = std::current_exception(); }
+    };
     std::vector<std::thread> th;
-    for (size_t k = 1; k < cs.size(); k++) th.emplace_back([&cs, k, &f] { f(cs[k]); });
-    f(cs[0]);
+    for (size_t k = 1; k < cs.size(); k++) th.emplace_back(guarded, k);
+    guarded(0);
     for (auto &t : th) t.join();
+    for (const auto &e : failed)
+        if (e) std::rethrow_exception(e);
 }
 
 }  // namespace
 
+static int load_obj_impl(const char *obj_path, const char *mtl_dir, uint32_t flags, pth_scene *out, char *err, size_t err_len);
+
+// (nothing may leave the C-ABI as an exception -- the reference's loader throws, main.cpp:35; here it is a status and a message)
 extern "C" int pth_load_obj_ex(const char *obj_path, const char *mtl_dir, uint32_t flags, pth_scene *out, char *err, size_t err_len)
+{
+    try {
+        return load_obj_impl(obj_path, mtl_dir, flags, out, err, err_len);
+    } catch (const std::bad_alloc &) {
+        set_err(err, err_len, "out of memory");
+    } catch (const std::exception &e) {
+        set_err(err, err_len, std::string("internal error: ") + e.what());
+    } catch (...) {
+        set_err(err, err_len, "internal error");
+    }
+    if (out) pth_free_scene(out);
+    return 3;
+}
+
+static int load_obj_impl(const char *obj_path, const char *mtl_dir, uint32_t flags, pth_scene *out, char *err, size_t err_len)
 {
     if (!obj_path || !out) { set_err(err, err_len, "null argument"); return 1; }
     std::memset(out, 0, sizeof(*out));

@@ -179,6 +179,12 @@ def test_loader_errors(pt, tmp_path):
     nomtl.write_text("mtllib nothere.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl x\nf 1 2 3\n")
     _, _, f = pt.load_obj(str(nomtl))
     np.testing.assert_allclose(f, [0.6, 0.6, 0.6, 0, 0, 0])
+    # `mtllib` / `usemtl` without a name: the "library" is then the OBJ's directory, which opens for reading and reports LONG_MAX bytes -- found by
+    # tests/test_sanitizers.py as a std::bad_alloc that left the C-ABI; it is a missing library like any other
+    noname = tmp_path / "noname.obj"
+    noname.write_text("mtllib\nusemtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    _, _, f = pt.load_obj(str(noname))
+    np.testing.assert_allclose(f, [0.6, 0.6, 0.6, 0, 0, 0])
 
 
 def test_soup_generator_roundtrip(pt, tmp_path):
