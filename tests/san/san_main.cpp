@@ -58,6 +58,46 @@ int main(int argc, char **argv)
         }
     }
     CHECK(pth_load_obj((dir + "/does_not_exist.obj").c_str(), nullptr, &b, err, sizeof err) != 0);
+    // ---- mutation fuzz: the reference's OBJ with random bytes overwritten, spans deleted or duplicated, truncated -- whole and in 256-byte chunks
+    {
+        std::string base;
+        if (FILE *f = std::fopen(argv[1], "rb")) {
+            char buf[4096];
+            size_t k;
+            while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) base.append(buf, k);
+            std::fclose(f);
+        }
+        CHECK(!base.empty());
+        uint32_t fz = 2463534242u;
+        auto next = [&]() { fz ^= fz << 13; fz ^= fz >> 17; fz ^= fz << 5; return fz; };
+        const char alphabet[] = "0123456789-+.e/ \n\tvfxm#usl\r\\";
+        int loaded = 0, refused = 0;
+        for (int it = 0; it < 400; it++) {
+            std::string t = base;
+            const int edits = 1 + (int)(next() % 6);
+            for (int e = 0; e < edits && !t.empty(); e++) {
+                const size_t at = next() % t.size();
+                switch (next() % 5) {
+                case 0: t[at] = alphabet[next() % (sizeof alphabet - 1)]; break;
+                case 1: t.erase(at, next() % 40); break;
+                case 2: t.insert(at, t.substr(next() % t.size(), next() % 60)); break;
+                case 3: t.resize(at); break;
+                default: t[at] = (char)(next() & 0xFF); break;
+                }
+            }
+            const std::string path = dir + "/fuzz.obj";
+            write_file(path, t);
+            for (uint32_t flags : { 0u, (uint32_t)PTH_SMALL_CHUNKS }) {
+                pth_scene s{};
+                err[0] = 0;
+                // (the MTL next to the original: materials resolve as for the real file)
+                const std::string mdir = std::string(argv[1]).substr(0, std::string(argv[1]).find_last_of('/'));
+                if (pth_load_obj_ex(path.c_str(), mdir.c_str(), flags, &s, err, sizeof err) == 0) { loaded++; CHECK(s.n_tris > 0); pth_free_scene(&s); }
+                else { refused++; CHECK(err[0] != 0); }
+            }
+        }
+        std::printf("san_main: mutation fuzz: %d loads, %d refusals\n", loaded, refused);
+    }
     // ---- the oracle: LBVH, both closest-hit modes on a batch of rays, a small frame in every mode
     orc_scene *sc = orc_scene_create(a.vertices, a.n_verts, a.indices, a.n_tris, a.faces);
     CHECK(sc != nullptr);
