@@ -739,6 +739,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))    # no launcher: bench.py is its own
 
+    # dmabuf IPC: what RCCL needs between processes on this driver (already exported on the pool's boxes; under a foreign launcher it may not be)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
