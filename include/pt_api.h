@@ -79,7 +79,10 @@ typedef struct pt_tuning {
     int32_t ploc_adopt_pct; /* a PLOC tree is kept when its area sum is below this percentage of the LBVH's (90; 1000 = always) */
     int32_t fail_rebuild;   /* NOT a speed knob -- failure injection for the tests: > 0 makes the next rebuilds of a scene's tree products fail
                                after the old ones were freed.  Only pt_ctx_set_tuning sets it; PT_TUNE refuses the name.                      */
-    int32_t reserved[5];
+    int32_t fused_tail;     /* fused pipeline, sample_groups left at 0, single-level scenes: S of a pixel's spp samples are traced as one-sample
+                               tail slots handed out after every head slot (spp - S samples) -- a launch with few slots per lane ends with short
+                               work.  0 = never; -1: by the launch's slots per lane (render.hip fused_tail_samples); clamped to spp - 1.      */
+    int32_t reserved[4];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);
@@ -329,7 +332,7 @@ typedef struct pt_stats {
      * spill area (the scene and the film images themselves are not included: pt_scene_info.device_bytes, W*H*16)   */
     uint64_t workspace_bytes;
     uint32_t pipeline;         /* (API version 5) PT_PIPELINE_* the last pt_render / pt_render_prepare ran (never PT_PIPELINE_AUTO) */
-    uint32_t reserved_;
+    uint32_t tail_samples;     /* fused pipeline: samples per pixel and frame traced as one-sample tail slots behind a head slot (0: none) */
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

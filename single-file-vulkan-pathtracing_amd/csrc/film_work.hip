@@ -18,15 +18,19 @@ constexpr size_t SLOT_BYTES_QUEUES = 2 * (8 + 16 + 16 + 8) + 16 + 4, SLOT_BYTES_
 constexpr size_t SLOT_BYTES = SLOT_BYTES_QUEUES + SLOT_BYTES_META;
 
 struct WorkNeed { size_t slots, color, terms, terms_over, total; };
-WorkNeed work_need(uint64_t n_slots, uint32_t groups, uint32_t term_cap, uint32_t term_pcap, bool queues = true)
+// (tail > 0: n_slots head slots with an accumulator each + n_slots * tail one-sample tail slots with the logs; `slots` then counts the tail slots,
+// which are what the per-slot meta arrays and the logs hold)
+WorkNeed work_need(uint64_t n_slots, uint32_t groups, uint32_t term_cap, uint32_t term_pcap, bool queues = true, uint32_t tail = 0)
 {
     WorkNeed n{};
-    n.slots = (size_t)std::max<uint64_t>(n_slots, 1);
-    n.color = groups == 1 ? n.slots : 0;
-    n.terms = groups > 1 ? n.slots * (size_t)term_pcap : 0;
-    n.terms_over = groups > 1 ? n.slots * (size_t)(term_cap - term_pcap) : 0;
+    const size_t heads = (size_t)std::max<uint64_t>(n_slots, 1);
+    n.slots = tail ? heads * tail : heads;
+    n.color = groups == 1 ? heads : 0;
+    const bool logs = groups > 1 || tail;
+    n.terms = logs ? n.slots * (size_t)term_pcap : 0;
+    n.terms_over = logs ? n.slots * (size_t)(term_cap - term_pcap) : 0;
     n.total = n.slots * (queues ? SLOT_BYTES : SLOT_BYTES_META) + sizeof(float4) * (n.color + n.terms + n.terms_over) +
-              (groups > 1 ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0);
+              (logs ? sizeof(float4) * (size_t)SPILL_POOL_ENTRIES : 0);
     return n;
 }
 
@@ -73,7 +77,7 @@ void free_shape_buffers(pt_film::Work &w)
 // ever grow: a later call with a smaller shape reuses them (hipMalloc of tens of GB costs 100s of ms).
 // A grow that does not fit returns PT_ERR_OOM and leaves the film WITHOUT shape buffers (all freed, capacities 0).
 pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap,
-                          uint32_t term_pcap, bool queues)
+                          uint32_t term_pcap, bool queues, uint32_t tail)
 {
     // queues = false (PT_PIPELINE_FUSED): no path queues and no hit records, only the per-slot radiance arrays
     pt_ctx *ctx = f->ctx;
@@ -117,7 +121,11 @@ pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t la
         return PT_ERR_INVALID_ARG;
     }
     if (!w.d_count) PT_HIP(ctx, hipMalloc((void **)&w.d_count, sizeof(uint32_t) * PTW_COUNT_WORDS));  // queue sizes, 2 per pipeline | the fused kernel's slot counters
-    const WorkNeed need = work_need(n_slots64, groups, term_cap, term_pcap, queues);
+    if (tail && (n_slots64 * tail >= (1ull << 31) || queues || groups != 1)) {
+        ctx->err = "head + tail slots: too many tail slots, or not the fused pipeline's one-group shape";
+        return PT_ERR_INVALID_ARG;
+    }
+    const WorkNeed need = work_need(n_slots64, groups, term_cap, term_pcap, queues, tail);
     const size_t ns = need.slots;
     const size_t limit = ctx->mem_budget;
     pt_status rc = PT_OK;
@@ -175,7 +183,7 @@ pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t la
         PT_WORK_ALLOC(w.d_terms_over, sizeof(float4) * need.terms_over);
         if (rc == PT_OK) w.cap_terms_over = need.terms_over;
     }
-    if (rc == PT_OK && groups > 1 && !w.d_spill) PT_WORK_ALLOC(w.d_spill, sizeof(float4) * (size_t)SPILL_POOL_ENTRIES);
+    if (rc == PT_OK && (groups > 1 || tail) && !w.d_spill) PT_WORK_ALLOC(w.d_spill, sizeof(float4) * (size_t)SPILL_POOL_ENTRIES);
 #undef PT_WORK_ALLOC
     if (rc != PT_OK) {
         free_shape_buffers(w);
@@ -185,6 +193,7 @@ pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t la
     }
     w.lanes = lanes; w.groups = groups; w.term_cap = term_cap;
     w.n_slots = (uint32_t)n_slots64;
+    w.tail = tail;
     return PT_OK;
 }
 
@@ -335,6 +344,11 @@ ptw::RenderConst ptw_render_const(const pt_params *p, const pt_film::Work &w, co
     rc.div_spl.init(std::max(rc.slots_per_lane, 1u)); rc.div_groups.init(std::max(sh.groups, 1u));
     rc.term_pcap = sh.term_pcap;
     rc.n_slots = w.n_slots;
+    rc.tail = sh.tail;
+    rc.head_samples = p->spp_per_frame - std::min(sh.tail, p->spp_per_frame);
+    rc.n_head = sh.tail ? w.n_slots : 0u;
+    rc.n_tail = sh.tail ? w.n_slots * sh.tail : 0u;
+    rc.div_tail.init(std::max(sh.tail, 1u));
     return rc;
 }
 

@@ -91,10 +91,11 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     int per_cu = ctx->fused_per_cu[0];
     const size_t key0 = (fp.smem << 1) | (pl.pairs ? 1u : 0u);
     if (ctx->fused_smem[0] != key0 || per_cu <= 0) {
-        for (const void *fn : { reinterpret_cast<const void *>(k_fused<false, true>), reinterpret_cast<const void *>(k_fused<true, true>),
-                                 reinterpret_cast<const void *>(k_fused<false, false>), reinterpret_cast<const void *>(k_fused<true, false>) })
+        for (const void *fn : { reinterpret_cast<const void *>(k_fused<0, true>), reinterpret_cast<const void *>(k_fused<1, true>),
+                                 reinterpret_cast<const void *>(k_fused<0, false>), reinterpret_cast<const void *>(k_fused<1, false>),
+                                 reinterpret_cast<const void *>(k_fused<2, true>), reinterpret_cast<const void *>(k_fused<2, false>) })
             if (fp.smem > 48 * 1024) PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.smem));
-        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.pairs ? reinterpret_cast<const void *>(k_fused<false, true>) : reinterpret_cast<const void *>(k_fused<false, false>), FTB, fp.smem));
+        PT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.pairs ? reinterpret_cast<const void *>(k_fused<0, true>) : reinterpret_cast<const void *>(k_fused<0, false>), FTB, fp.smem));
         ctx->fused_smem[0] = key0;
         ctx->fused_per_cu[0] = per_cu;
     }
@@ -135,7 +136,8 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
 #define PT_LAUNCH_FUSED(G, P)                                                                                                              \
     hipExtLaunchKernelGGL((k_fused<G, P>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4, \
                           s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack, div_frames)
-    if (fp.pairs) { if (grouped) PT_LAUNCH_FUSED(true, true); else PT_LAUNCH_FUSED(false, true); }
-    else { if (grouped) PT_LAUNCH_FUSED(true, false); else PT_LAUNCH_FUSED(false, false); }
+    const int mode = rc.tail ? 2 : (grouped ? 1 : 0);
+    if (fp.pairs) { if (mode == 2) PT_LAUNCH_FUSED(2, true); else if (mode == 1) PT_LAUNCH_FUSED(1, true); else PT_LAUNCH_FUSED(0, true); }
+    else { if (mode == 2) PT_LAUNCH_FUSED(2, false); else if (mode == 1) PT_LAUNCH_FUSED(1, false); else PT_LAUNCH_FUSED(0, false); }
 #undef PT_LAUNCH_FUSED
 }

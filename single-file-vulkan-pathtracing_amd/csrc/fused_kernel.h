@@ -58,7 +58,10 @@ enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS
 // FS_A..C: the slot's colour (one sample group) | FS_A: its term count (several groups)
 
 // PAIRS: every leaf is one triangle or one fan pair (k_extend_lds7p's trees); else leaves of up to four triangles (k_extend_lds7's)
-template <bool GROUPED, bool PAIRS>
+// MODE 0: one sample group (a slot is a pixel's whole frame; radiance added in LDS); 1: several groups (every slot logs its radiance terms);
+// 2: HEAD + TAIL (wavefront_types.h RenderConst::tail) -- head slots like mode 0 for samples [0, head_samples), handed out first, then one-sample tail
+// slots like mode 1: what a launch of few frames ends with is short work, and only the tail's terms go through the log
+template <int MODE, bool PAIRS>
 __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
                                                               const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
                                                               const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                                                               float tmax, int lds_stack, FastDiv div_frames)
 {
     constexpr uint32_t LEAF_BIT = 0x2000u, DONE = 0x3FFFu;
+    constexpr bool GROUPED = MODE == 1, HYB = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS: stack | BVH4 nodes | three permuted triangle copies | shade4 | tangent frames | path state
     float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * FTB * sizeof(uint32_t));
@@ -112,6 +116,8 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
     uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;  // ... the part of the slot range it draws from, parts found empty
+    bool w_tails = false;       // wave-uniform, MODE 2: the head slots are all handed out, the wave draws tail slots (a second set of eight counters)
+    const uint32_t n_tail_slots = HYB ? rc.lanes_active * rc.tail * rc.slots_per_lane : 0u;  // ... of this launch (n_slots: its head slots)
     // several groups: the slot range is cut into PT_FUSED_PARTS contiguous parts.  One group: part p is every PT_FUSED_PARTS-th 64-slot chunk
     // of the HAND-OUT order -- tile-major, all frames of a tile before the next tile (chunk q = tile q / frames, frame q % frames) -- so every part,
     // like the whole launch, runs from the image's centre to its border (film_work.hip numbers the tiles that way) and ENDS with border pixels of
@@ -171,8 +177,11 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     depth++;
                     terminated = depth >= rc.max_depth;  // raygen.rgen:62
                 }
+                const bool logs = GROUPED || (HYB && slot >= rc.n_head);  // (a slot whose radiance goes through the term log)
+                const uint32_t lslot = HYB ? slot - rc.n_head : slot;     // ... its place in the log arrays
+                const uint32_t lstride = HYB ? rc.n_tail : rc.n_slots;
                 if (add) {
-                    if (!GROUPED) {
+                    if (!logs) {
                         my_state[FS_A * FTB] = __float_as_uint(__uint_as_float(my_state[FS_A * FTB]) + er);
                         my_state[FS_B * FTB] = __float_as_uint(__uint_as_float(my_state[FS_B * FTB]) + eg);
                         my_state[FS_C * FTB] = __float_as_uint(__uint_as_float(my_state[FS_C * FTB]) + eb);
@@ -181,14 +190,14 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
 #ifdef PT_DBG_NO_TERMS  // timing experiment only (wrong images): what the term log's stores cost
                         if (k == 0xFFFFFFFFu)
 #endif
-                        if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
-                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
+                        if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * lstride + lslot), make_float4(er, eg, eb, 0.f));
+                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)lslot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
                         else {
                             const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
                             if (idx < rad.spill_cap) {
                                 // (the slot's first pool entry ends its chain: no per-slot initialisation of the heads)
-                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rad.spill_head[slot]));
-                                rad.spill_head[slot] = (uint32_t)idx;
+                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rad.spill_head[lslot]));
+                                rad.spill_head[lslot] = (uint32_t)idx;
                             } else {
                                 *rad.overflow = 1ull;
                             }
@@ -216,15 +225,21 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 } else {
                     sample++;
                     depth = 0;
-                    const uint32_t lane_slot = rc.div_spl.div(slot);  // = frame lane * groups + sample group (slot_pixel)
-                    const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
-                    if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {
+                    bool more;
+                    if (HYB) {
+                        more = !logs && sample < rc.head_samples;  // (a tail slot is one sample)
+                    } else {
+                        const uint32_t lane_slot = rc.div_spl.div(slot);  // = frame lane * groups + sample group (slot_pixel)
+                        const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
+                        more = sample < min(rc.spp, (g + 1u) * rc.group_size);
+                    }
+                    if (more) {
                         need_primary = true;  // the slot's next sample: raygen.rgen:45-60
                     } else {  // the slot is complete
-                        if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FTB]), __uint_as_float(my_state[FS_B * FTB]),
+                        if (!logs) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FTB]), __uint_as_float(my_state[FS_B * FTB]),
                                                                    __uint_as_float(my_state[FS_C * FTB]), 0.f);
 #ifndef PT_DBG_NO_NTERM
-                        else rad.nterm[slot] = my_state[FS_A * FTB];
+                        else rad.nterm[lslot] = my_state[FS_A * FTB];
 #endif
                         path = false;
 #ifdef PT_FUSED_TIMELINE
@@ -247,13 +262,16 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     // One group: PT_FUSED_BATCH1 = one tile per draw (see there).  Several groups: always PT_FUSED_BATCH.
                     for (;;) {
                         // (one group: w_base / w_next / w_end count within the part)
-                        const uint32_t part_begin = GROUPED ? w_part * part_len : 0u,
-                                       part_end = GROUPED ? min(part_begin + part_len, n_slots)
-                                                          : (((n_slots >> 6) + (uint32_t)PT_FUSED_PARTS - 1u - w_part) / (uint32_t)PT_FUSED_PARTS) << 6;
+                        const bool grp = GROUPED || (HYB && w_tails);  // (contiguous parts of the slot range, as with several groups)
+                        const uint32_t ns = (HYB && w_tails) ? n_tail_slots : n_slots;
+                        const uint32_t plen = HYB ? ((ns + PT_FUSED_PARTS - 1) / PT_FUSED_PARTS + 63u) & ~63u : part_len;
+                        const uint32_t part_begin = grp ? w_part * plen : 0u,
+                                       part_end = grp ? min(part_begin + plen, ns)
+                                                      : (((ns >> 6) + (uint32_t)PT_FUSED_PARTS - 1u - w_part) / (uint32_t)PT_FUSED_PARTS) << 6;
                         uint32_t rel = 0, size = 0;
                         if (lane == 0) {
-                            uint32_t *cnt = next_slot + w_part * (uint32_t)PT_FUSED_PART_STRIDE;
-                            size = (uint32_t)(GROUPED ? PT_FUSED_BATCH : PT_FUSED_BATCH1);
+                            uint32_t *cnt = next_slot + (w_part + ((HYB && w_tails) ? (uint32_t)PT_FUSED_PARTS : 0u)) * (uint32_t)PT_FUSED_PART_STRIDE;
+                            size = (uint32_t)(grp ? PT_FUSED_BATCH : PT_FUSED_BATCH1);
 #if PT_FUSED_BATCH1 > 64  // (guided self-scheduling of bigger one-group batches: what is left / (2 x the waves that share the part), down to one tile)
                             if (!GROUPED) {
                                 const uint32_t seen = __atomic_load_n(cnt, __ATOMIC_RELAXED);
@@ -272,13 +290,23 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                             break;
                         }
                         w_part = (w_part + 1u) % (uint32_t)PT_FUSED_PARTS;
-                        if (++w_tried >= (uint32_t)PT_FUSED_PARTS) { out_of_slots = true; w_end = w_next; break; }
+                        if (++w_tried >= (uint32_t)PT_FUSED_PARTS) {
+                            if (HYB && !w_tails && n_tail_slots) {  // every head slot is handed out: on to the tail slots
+                                w_tails = true;
+                                w_tried = 0;
+                                w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS;
+                                continue;
+                            }
+                            out_of_slots = true;
+                            w_end = w_next;
+                            break;
+                        }
                     }
 #ifdef PT_FUSED_TIMELINE
                     if (out_of_slots) tl_oos = wall_clock64();
 #endif
                     if (!out_of_slots && (uint32_t)lane < (w_end - w_base + 63u) / 64u) {
-                        if (GROUPED) {
+                        if (GROUPED || (HYB && w_tails)) {
                             const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
                             s_wtile[lane] = tiles[(c - rc.div_spl.div(c) * rc.slots_per_lane) >> 6];
                         } else {
@@ -292,7 +320,12 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 if (in_blk && !path && rank < take) {
                     const uint32_t mine = w_next + rank;
                     uint32_t f, g, local;
-                    if (GROUPED) {
+                    if (HYB && w_tails) {  // tail slot `mine` of the launch: (frame lane, tail j, pixel); sample head_samples + j
+                        const uint32_t lane_slot = rc.div_spl.div(mine);
+                        f = rc.div_tail.div(lane_slot); g = lane_slot - f * rc.tail;
+                        local = mine - lane_slot * rc.slots_per_lane;
+                        slot = rc.n_head + mine;
+                    } else if (GROUPED) {
                         slot = slot_base + mine;
                         const uint32_t lane_slot = rc.div_spl.div(slot);
                         f = rc.div_groups.div(lane_slot); g = lane_slot - f * rc.groups;
@@ -306,7 +339,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     }
                     const uint32_t tw = s_wtile[(mine - w_base) >> 6];
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
-                    const uint32_t sample0 = g * rc.group_size;
+                    const uint32_t sample0 = (HYB && w_tails) ? rc.head_samples + g : g * rc.group_size;
                     if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
                         pxy = px | (py << 16);
                         ctr = sample0;
@@ -319,13 +352,15 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
 #endif
                     } else if (GROUPED) {
                         rad.nterm[slot] = 0u;  // (a slot outside the image or the batch: k_resolve never reads it, kept defined anyway)
+                    } else if (HYB && w_tails) {
+                        rad.nterm[slot - rc.n_head] = 0u;
                     }
                 }
                 w_next += take;
             }
             // (3) camera ray of a slot's next (or first) sample
             if (need_primary) {
-                const uint32_t f = rc.div_groups.div(rc.div_spl.div(slot));
+                const uint32_t f = (HYB && slot >= rc.n_head) ? rc.div_tail.div(rc.div_spl.div(slot - rc.n_head)) : rc.div_groups.div(rc.div_spl.div(slot));
                 const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
                 seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
                 ptm::primary_ray(rc.cam, px, py, seed, org, dir);

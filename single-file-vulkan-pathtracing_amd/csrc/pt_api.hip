@@ -33,9 +33,9 @@ static pt_status guarded(pt_ctx *ctx, F &&body)
 static const char *const k_tune_names[] = { "refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves",
                                             "pair_kernel", "topdown4", "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield",
                                             "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb", "hbm8", "ploc_radius", "leaf_min",
-                                            "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild" };
+                                            "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail" };
 constexpr int k_tune_count = (int)(sizeof(k_tune_names) / sizeof(k_tune_names[0]));
-static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 5), "pt_tuning: names and fields out of step");
+static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 4), "pt_tuning: names and fields out of step");
 
 static void tuning_defaults(pt_tuning *t)
 {
@@ -63,7 +63,7 @@ static bool tuning_parse(const char *text, pt_tuning *t, std::string &err)
                 if (pair.compare(0, eq, k_tune_names[k]) == 0) idx = k;
         char *end = nullptr;
         const long v = eq != std::string::npos ? std::strtol(pair.c_str() + eq + 1, &end, 10) : 0;
-        if (idx == k_tune_count - 1) idx = -1;  // fail_rebuild is failure injection for the tests, not a knob: never from the environment
+        if (idx >= 0 && std::string(k_tune_names[idx]) == "fail_rebuild") idx = -1;  // fail_rebuild is failure injection for the tests, not a knob: never from the environment
         if (idx < 0 || !end || *end != 0 || end == pair.c_str() + eq + 1 || v < INT32_MIN || v > INT32_MAX) { err = "PT_TUNE: cannot use '" + pair + "'"; return false; }
         f[idx] = (int32_t)v;
     }

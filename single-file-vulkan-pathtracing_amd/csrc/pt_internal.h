@@ -141,6 +141,7 @@ struct pt_film {
         uint32_t rank = 0, world = 0, lanes = 0;  // lanes = frames in flight
         uint32_t tile_order = 0;                  // 0: the rank's tiles row by row, 1: centre first (fused pipeline; film_work.hip)
         uint32_t groups = 0, term_cap = 0;        // sample groups per pixel, radiance-term log capacity per slot
+        uint32_t tail = 0;                        // one-sample tail slots per (frame, pixel) of the last shape (fused head + tail form)
         uint32_t n_tiles = 0;                     // local 8x8 tiles
         uint32_t n_slots = 0;                     // lanes * n_tiles * 64
         uint32_t *d_tiles = nullptr;              // local tile -> global tile id

@@ -483,7 +483,17 @@ pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const Ex
 // one-tile batches (fused_kernel.h PT_FUSED_BATCH1): 1 frame 7.2 / 6.9 / 6.4 with 1 / 8 / 32 groups; 2 frames 6.21 / 6.27 with 1 / 16;
 // 4 frames 5.78 / 6.15 with 1 / 8 (profiles/r05c_fused_batch1.log, r05d_grouped_cost.log; with the 256-slot batches of round 4 groups
 // paid up to 8 frames: r04k_fused_groups_by_frames.log).  Explicit frames_in_flight / sample_groups are taken as given.
-void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &, pt_params &q)
+// Twice the head slots (frames x owned pixels) per lane of the fused grid: what the shape rules below go by.
+uint32_t fused_slots_x2(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames)
+{
+    const uint64_t tiles = (uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8);
+    const uint64_t world = std::max(p->world, 1u);
+    const uint64_t heads = (uint64_t)frames * 64ull * ((tiles + world - 1) / world);
+    const uint64_t grid_lanes = (uint64_t)std::max(ctx->num_cus, 1) * 6ull * 256ull;  // (six 256-thread workgroups per CU: fused.hip)
+    return (uint32_t)std::min<uint64_t>(heads * 2ull / grid_lanes, 1u << 20);
+}
+
+void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan &, pt_params &q)
 {
     q = *p;
     if (q.frames_in_flight == 0) {
@@ -493,11 +503,38 @@ void fused_shape_defaults(const pt_film *, const pt_params *p, const FusedPlan &
     }
     q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
     if (q.sample_groups == 0) {
+        // every sample its own slot (the smallest divisor of spp that is >= 32, or spp itself) where the launch has fewer than two head slots
+        // per lane of the grid -- small films, whatever the frames: 256 x 256 x 4 frames 1.23 ms against 2.50 with one group -- and for a single
+        // frame up to 18 per lane (1080p: 6.43 against 7.24; 2160p, 21 per lane: 24.5 against 23.2, so not there); else one group.
+        // profiles/r05z4_tail_rule.log.  (Where fused_tail_samples below gives S > 0 the head + tail shape replaces either.)
+        const uint32_t x2 = fused_slots_x2(f->ctx, f, p, q.frames_in_flight);
         uint32_t g = 1;
-        if (q.frames_in_flight < 2u)  // the smallest divisor of spp that is >= 32 (or spp itself)
+        if (x2 < 4u || (q.frames_in_flight < 2u && x2 <= 36u))
             while (g < p->spp_per_frame && (g < 32u || p->spp_per_frame % g)) g++;
         q.sample_groups = g;
     }
+}
+
+// Tail samples per pixel of a fused launch (0: the one-group or all-groups shape above).  A launch with few slots per lane of the grid ends
+// with whole 32-sample slots still running; with S of a pixel's samples as one-sample tail slots handed out after every head the launch ends with
+// short work, and only those S samples' radiance terms go through the log.  Measured on one MI355X, spp 32, depth 8, ms per call as
+// all groups / one group / best S (profiles/r05z4_tail_rule.log; r05z_fused_tail_samples.log, r05z2_..., r05z3_... for other spp and ranks):
+//   slots x2 per lane   4 (720p x 1)  5 (540p x 2)  9 (720p x 2)  10 (1080p x 1)  21 (1080p x 2)  31 (1080p x 3)  37 (1440p x 2)  42 (2160p x 1)
+//   all / one / S       3.09 4.19     3.60 4.53     5.80 6.80     6.43 7.24       -    12.40      -    17.64      21.9 20.7      24.5 23.2
+//   best S              3.07 (S 24)   3.39 (S 20)   5.72 (S 20)   6.29 (S 16)     11.92 (S 12)    17.35 (S 8)     20.5 (S 8)     23.0 (S 4)
+// (a rank of world 8 at 16 frames, 21: 12.38 -> 12.19; of 4 at 8 frames: 12.38 -> 12.06; world 8 at 32 frames and 1080p x 8: S 0 is best.)
+// So by twice the slots per lane: under 4 -> 0 (all groups); 4..9 -> 5 spp / 8; 10..16 -> spp / 2; 17..28 -> 3 spp / 8; 29..36 -> spp / 4; above
+// -> 0 (the gain is inside the noise).  pt_tuning.fused_tail >= 0 overrides.
+uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames)
+{
+    const uint32_t spp = p->spp_per_frame;
+    if (spp < 2u) return 0u;
+    int t = ctx->tune.fused_tail;
+    if (t < 0) {
+        const uint32_t x2 = fused_slots_x2(ctx, f, p, frames);
+        t = x2 < 4u ? 0 : x2 <= 9u ? (int)(spp * 5u / 8u) : x2 <= 16u ? (int)(spp / 2u) : x2 <= 28u ? (int)(spp * 3u / 8u) : x2 <= 36u ? (int)(spp / 4u) : 0;
+    }
+    return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }
 
 pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const ExtendPlan &pl, bool nested, bool prepare_only)
@@ -515,7 +552,28 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     fused_shape_defaults(f, p_in, fp, q);
     const pt_params *p = &q;
     RenderShape sh;
-    for (;;) {
+    // HEAD + TAIL slots (fused_kernel.h MODE 2): where the library picks the groups itself and the launch holds few frames, a pixel's frame is one
+    // head slot of spp - S samples and S one-sample tail slots -- the launch ends with short work and only the tail's radiance terms go through
+    // the log (see fused_tail_samples for S).
+    const uint32_t tail = (!fp.inst && !nested && p_in->sample_groups == 0) ? fused_tail_samples(ctx, f, p_in, q.frames_in_flight) : 0u;
+    if (tail) {
+        q.sample_groups = 1;
+        sh = RenderShape{};
+        sh.lanes = q.frames_in_flight; sh.groups = 1; sh.group_size = p->spp_per_frame; sh.tail = tail;
+        const uint32_t worst = p->max_depth;                       // a tail slot is one sample: at most one term per ray
+        sh.term_pcap = std::min(worst, 3u);
+        const uint64_t n_tail = (uint64_t)sh.lanes * tail * (uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8) * 64ull / std::max(p->world, 1u) + 64;
+        uint64_t ocap = std::min<uint64_t>(worst - sh.term_pcap, (1ull << 30) / std::max<uint64_t>(n_tail * sizeof(float4), 1));
+        if (ctx->tune.term_ocap >= 0) ocap = std::min<uint64_t>(ocap, (uint64_t)ctx->tune.term_ocap);
+        sh.term_cap = sh.term_pcap + (uint32_t)ocap;
+        sh.bounded = sh.term_cap < worst;
+        rc_ = ptw_ensure_work(f, p->rank, p->world, sh.lanes, 1, sh.term_cap, sh.term_pcap, false, tail);
+        if (rc_ == PT_ERR_OOM) {  // (no room for the logs: the plain shape)
+            fused_shape_defaults(f, p_in, fp, q);
+            sh = RenderShape{};
+        }
+    }
+    for (; !sh.tail;) {
         rc_ = ptw_shape_and_work(f, p, sh, 3, false);
         if (rc_ != PT_ERR_OOM) break;
         // a shape this function chose (the caller passed 0) and that does not fit is planned again smaller, like the wavefront's AUTO
@@ -533,6 +591,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     if (!nested) {
         ctx->stats.frames_in_flight = sh.lanes;
         ctx->stats.sample_groups = sh.groups;
+        ctx->stats.tail_samples = sh.tail;
     }
     if (rc_ != PT_OK) return rc_;
     ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
@@ -559,7 +618,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
             PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
         }
         PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * PTW_COUNT_WORDS, st));  // the slot counters (fused_kernel.h: eight, 128 B apart)
-        const uint32_t n_slots = rc.lanes_active * sh.groups * rc.slots_per_lane;
+        const uint32_t n_slots = rc.lanes_active * sh.groups * rc.slots_per_lane;  // (head + tail: the launch's head slots; its tail slots follow from rc)
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) {
             rc_ = grow_event_pool(ctx, ev_used + 2);
@@ -567,7 +626,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
             e0 = ctx->ev_pool[ev_used++]; e1 = ctx->ev_pool[ev_used++];
             evs.push_back(e0); evs.push_back(e1);
         }
-        ptw_launch_fused(fp, sh.groups > 1, rc, w.d_tiles, rad, s, n_slots, w.d_count, ctx->d_stats, p->tmin, p->tmax, st, e0, e1);
+        ptw_launch_fused(fp, sh.groups > 1, rc, w.d_tiles, rad, s, n_slots, w.d_count, ctx->d_stats, p->tmin, p->tmax, st, e0, e1);  // (rc.tail != 0: the head + tail kernel)
         PT_HIP(ctx, hipGetLastError());
         ctx->stats.launches_extend++;
         ctx->stats.rounds++;
@@ -589,7 +648,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
             r.frame = rc.frame_base; r.frame_count = rc.lanes_active; r.frames_in_flight = rc.lanes_active; r.sample_groups = 1;
             rc_ = render_fused(s, f, &r, pl, true, false);
             if (rc_ != PT_OK) return rc_;
-            rc_ = ptw_ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap, false);
+            rc_ = ptw_ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap, false, sh.tail);
             if (rc_ != PT_OK) return rc_;
             rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
         }

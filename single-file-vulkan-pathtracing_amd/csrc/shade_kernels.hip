@@ -463,13 +463,16 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rc.groups == 1u) {
             c = rad.color[(size_t)f * rc.slots_per_lane + local];
-        } else {  // replay the groups' term logs in sample order: the reference's sequence of adds
-            for (uint32_t g = 0; g < rc.groups; g++) {
-                const size_t slot = ((size_t)f * rc.groups + g) * rc.slots_per_lane + local;
+        }
+        if (rc.groups > 1u || rc.tail) {  // replay the groups' (or, behind a head slot's accumulator, the one-sample tail slots') term logs in sample order: the reference's sequence of adds
+            const uint32_t n_logs = rc.tail ? rc.tail : rc.groups;
+            const size_t log_slots = rc.tail ? rc.n_tail : rc.n_slots;
+            for (uint32_t g = 0; g < n_logs; g++) {
+                const size_t slot = ((size_t)f * n_logs + g) * rc.slots_per_lane + local;
                 const uint32_t nt_all = rad.nterm[slot], nt = min(nt_all, rc.term_cap);
                 const float4 *to = rad.terms_over + slot * (rc.term_cap - rc.term_pcap);
                 for (uint32_t k = 0; k < nt; k++) {
-                    const float4 e = k < rc.term_pcap ? rad.terms[(size_t)k * rc.n_slots + slot] : to[k - rc.term_pcap];
+                    const float4 e = k < rc.term_pcap ? rad.terms[(size_t)k * log_slots + slot] : to[k - rc.term_pcap];
                     c.x = c.x + e.x;
                     c.y = c.y + e.y;
                     c.z = c.z + e.z;

@@ -75,7 +75,7 @@ void ptw_launch_resolve(const ptw::RenderConst &rc, const uint32_t *tiles, const
 void ptw_launch_hits_to_api(const float4 *hit, const float4 *tri4, const uint32_t *hit_inst, const uint32_t *inst_id, uint32_t n, pt_hit *out,
                             hipStream_t st);
 
-constexpr size_t PTW_COUNT_WORDS = 8 * 32;  // pt_film::Work::d_count: the wavefront's queue sizes (2 per pipeline) | eight slot counters of the fused kernel, one 128-B line each
+constexpr size_t PTW_COUNT_WORDS = 16 * 32;  // pt_film::Work::d_count: the wavefront's queue sizes (2 per pipeline) | eight slot counters of the fused kernel, one 128-B line each (sixteen with head + tail slots)
 
 // ---- fused.hip ---------------------------------------------------------------------------------------------------------
 struct FusedPlan {
@@ -96,11 +96,12 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
 struct RenderShape {
     uint32_t lanes = 1, groups = 1, group_size = 1, term_cap = 0, term_pcap = 0;
     bool bounded = false;  // term_cap < group_size * max_depth: a full log is detected and the batch redone ungrouped
+    uint32_t tail = 0;     // fused pipeline: one-sample tail slots per (frame, pixel) behind a head slot of spp - tail samples (groups == 1 then)
 };
 // launch_class: 0 instanced scenes, 1 scenes walked out of L2 / MALL / HBM, 2 single-level scenes in LDS, 3 the fused pipeline
 RenderShape ptw_choose_shape(const pt_film *f, const pt_params *p, int launch_class, int shrink = 0);
 pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap, uint32_t term_pcap,
-                          bool queues = true);
+                          bool queues = true, uint32_t tail = 0);
 pt_status ptw_shape_and_work(pt_film *f, const pt_params *p, RenderShape &sh, int launch_class, bool queues = true);
 uint64_t ptw_workspace_bytes(const pt_film *f);
 ptw::RenderConst ptw_render_const(const pt_params *p, const pt_film::Work &w, const RenderShape &sh);

@@ -56,6 +56,13 @@ struct RenderConst {
     uint32_t term_pcap;        // entries of it kept in the dense primary log (the rest is the overflow log)
     uint32_t n_slots;          // all slots of this render (the primary log is term-major: [term_pcap][n_slots])
     FastDiv div_spl, div_groups;  // slot -> frame lane / sample group without integer divides
+    // HEAD + TAIL slots (PT_PIPELINE_FUSED at few frames per launch, fused_kernel.h MODE 2; `tail` = 0 everywhere else).  A (frame, pixel) is ONE head
+    // slot -- samples [0, head_samples), radiance added in LDS like a one-group slot, slot number frame_lane * slots_per_lane + local < n_head -- and
+    // `tail` slots of one sample each -- sample head_samples + j, radiance terms logged like a sample group's, slot number
+    // n_head + (frame_lane * tail + j) * slots_per_lane + local; the log arrays (nterm, terms, terms_over, spill_head) are indexed by
+    // slot - n_head and hold n_tail slots.  The heads go first and are long; the tails fill the end of the launch with short work.
+    uint32_t tail, head_samples, n_head, n_tail;
+    FastDiv div_tail;
 };
 
 // Where a slot's radiance goes.  groups == 1: one accumulator per slot, added to in path order

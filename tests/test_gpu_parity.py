@@ -2181,6 +2181,165 @@ def test_fused_pipeline_bit_exact_vs_oracle_and_wavefront(pt, orc, gpu_ctx, corn
         film.close()
 
 
+def test_fused_head_and_tail_slots_bit_exact(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle, cornell_arrays):
+    """k_fused's HEAD + TAIL shape (fused_kernel.h MODE 2; pt_tuning.fused_tail = S, or the library's own rule on launches with few slots
+    per lane): a pixel's frame is one head slot of spp - S samples summed in LDS and S one-sample tail slots whose radiance terms go through the
+    log and are replayed after the head's sum in sample order.  Film, rgba8 image and ray count equal the oracle's for every S (1, a middle
+    one, spp - 1, beyond spp), ragged images, several frames in flight and batches of frames, shards, the log's three tiers and the redo of
+    an overflowed launch, and on trees without pair leaves; explicit sample_groups never take the shape; pt_stats.tail_samples reports it."""
+    import importlib
+    d = importlib.import_module("single-file-vulkan-pathtracing_amd.distributed")
+    for (w, h, spp, depth, frames) in ((64, 64, 4, 8, 3), (100, 37, 8, 5, 2), (120, 68, 32, 8, 2), (1, 1, 2, 3, 1), (33, 9, 5, 13, 4)):
+        kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=depth)
+        ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, frames, **kw)
+        for S in sorted({1, spp // 2, spp - 1, spp + 7}):
+            for shape in (dict(), dict(frames_in_flight=1), dict(frames_in_flight=frames)):
+                old = gpu_ctx.set_tuning(fused_tail=S)
+                try:
+                    film = pt.Film(gpu_ctx, w, h)
+                    gpu_ctx.reset_stats()
+                    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=frames, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
+                    st = gpu_ctx.stats()
+                    assert st.tail_samples == min(S, spp - 1) and st.sample_groups == 1, (S, st.tail_samples)
+                    assert st.rays == orays, (w, h, S, shape, st.rays, orays)
+                    assert film.read_f32().tobytes() == ofilm.tobytes(), (w, h, S, shape)
+                    assert film.read_bgra8().tobytes() == obgra.tobytes(), (w, h, S, shape)
+                    film.close()
+                finally:
+                    gpu_ctx.set_tuning(**old)
+    w, h, spp, frames = 200, 120, 8, 2
+    kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=8)
+    ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, frames, **kw)
+    # explicit groups are taken as given; fused_tail = 0 is the plain shape
+    for knobs, shape, tail in ((dict(fused_tail=3), dict(sample_groups=2), 0), (dict(fused_tail=3), dict(sample_groups=1), 0), (dict(fused_tail=0), dict(), 0),
+                               (dict(fused_tail=3), dict(pipeline=pt.PIPELINE_AUTO), 3)):
+        old = gpu_ctx.set_tuning(**knobs)
+        try:
+            film = pt.Film(gpu_ctx, w, h)
+            pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=frames, **{**dict(pipeline=pt.PIPELINE_FUSED), **kw, **shape}))
+            assert gpu_ctx.stats().tail_samples == tail and film.read_f32().tobytes() == ofilm.tobytes(), (knobs, shape)
+            film.close()
+        finally:
+            gpu_ctx.set_tuning(**old)
+    # the log's tiers (primary only + pool, a pool of three entries: the launch is done again with the plain shape) and the shade block's fill
+    for knobs in (dict(term_ocap=0, term_spill=1 << 20), dict(term_ocap=1, term_spill=1 << 20), dict(term_ocap=0, term_spill=3), dict(refill=1), dict(refill=64)):
+        old = gpu_ctx.set_tuning(fused_tail=5, **knobs)
+        try:
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=frames, pipeline=pt.PIPELINE_FUSED, **kw))
+            st = gpu_ctx.stats()
+            assert film.read_f32().tobytes() == ofilm.tobytes() and st.rays == orays and st.tail_samples == 5, knobs
+            film.close()
+        finally:
+            gpu_ctx.set_tuning(**old)
+    # every surface emits, so a tail slot's one sample logs a term per ray: past the three primary entries into the overflow log and the pool,
+    # and with a pool of three entries the launch is done again with the plain shape (redone_batches)
+    v, i, f = cornell_arrays
+    f = f.reshape(-1, 6).copy()
+    f[:, 3:] = np.float32(0.25) + f[:, :3] * np.float32(0.5)
+    gs, osc = pt.Scene(gpu_ctx, v, i, f.reshape(-1)), orc.Scene(v, i, f.reshape(-1))
+    ke = dict(width=64, height=40, spp_per_frame=6, max_depth=12)
+    of3, ob3, or3 = _render_oracle(orc, osc, 3, **ke)
+    for knobs in (dict(), dict(term_ocap=0, term_spill=1 << 20), dict(term_ocap=2, term_spill=1 << 20), dict(term_ocap=0, term_spill=3), dict(term_ocap=1, term_spill=0)):
+        old = gpu_ctx.set_tuning(fused_tail=4, **knobs)
+        try:
+            film = pt.Film(gpu_ctx, 64, 40)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=3, frames_in_flight=2, pipeline=pt.PIPELINE_FUSED, **ke))
+            st = gpu_ctx.stats()
+            assert film.read_f32().tobytes() == of3.tobytes() and film.read_bgra8().tobytes() == ob3.tobytes() and st.rays == or3, knobs
+            if knobs.get("term_spill") in (0, 3):
+                assert st.redone_batches >= 1, knobs
+            film.close()
+        finally:
+            gpu_ctx.set_tuning(**old)
+    gs.close()
+    # shards add up; a rank's film is zero outside its tiles
+    old = gpu_ctx.set_tuning(fused_tail=4)
+    try:
+        for world in (3, 8):
+            acc, rays = np.zeros_like(ofilm), 0
+            for rank in range(world):
+                film = pt.Film(gpu_ctx, w, h)
+                gpu_ctx.reset_stats()
+                pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=frames, rank=rank, world=world, pipeline=pt.PIPELINE_FUSED, **kw))
+                rays += gpu_ctx.stats().rays
+                part = film.read_f32()
+                assert (part[~d.owned_mask(w, h, rank, world)] == 0).all()
+                acc += part
+                film.close()
+            assert acc.tobytes() == ofilm.tobytes() and rays == orays
+        # progressive: frames 0..1 then 2..4 onto the same film, against five oracle frames
+        o5, b5, r5 = _render_oracle(orc, cornell_oracle, 5, **kw)
+        film = pt.Film(gpu_ctx, w, h)
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_FUSED, **kw))
+        pt.render(cornell_gpu, film, pt.default_params(frame=2, frame_count=3, frames_in_flight=2, pipeline=pt.PIPELINE_FUSED, **kw))
+        assert film.read_f32().tobytes() == o5.tobytes() and film.read_bgra8().tobytes() == b5.tobytes() and gpu_ctx.stats().rays == r5
+        film.close()
+    finally:
+        gpu_ctx.set_tuning(**old)
+    # the kernel's other instantiation (leaves of independent triangles)
+    for arrays, pair in ((cornell_arrays, 0), (_soup(100, 5, spread=0.3), 1)):
+        old = gpu_ctx.set_tuning(pair_leaves=pair)
+        try:
+            gs = pt.Scene(gpu_ctx, *arrays)
+        finally:
+            gpu_ctx.set_tuning(**old)
+        osc = orc.Scene(*arrays)
+        k2 = dict(width=90, height=50, spp_per_frame=6, max_depth=7)
+        of2, ob2, or2 = _render_oracle(orc, osc, 2, **k2)
+        old = gpu_ctx.set_tuning(fused_tail=2)
+        try:
+            film = pt.Film(gpu_ctx, 90, 50)
+            gpu_ctx.reset_stats()
+            pt.render(gs, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_FUSED, **k2))
+            assert gpu_ctx.stats().rays == or2 and film.read_f32().tobytes() == of2.tobytes() and gpu_ctx.stats().tail_samples == 2, pair
+            assert film.read_bgra8().tobytes() == ob2.tobytes()
+            film.close()
+        finally:
+            gpu_ctx.set_tuning(**old)
+        gs.close()
+
+
+def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cornell_gpu):
+    """The library's own head + tail rule (render.hip fused_tail_samples: by head slots per lane of the grid) at 1920x1080, 32 spp: one frame
+    per call takes spp / 2 tail samples, two frames 3 spp / 8, four frames none -- and each call's film is the oracle's known answer
+    (tests/golden/fullsize_hashes.json: C2's frame 0, C3 after frames 1 and 3) whatever the shape."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(HERE, "golden", "fullsize_hashes.json")))
+    g2, g3 = gold["c2"], gold.get("c3")
+    w, h, spp = g2["width"], g2["height"], g2["spp_per_frame"]
+    kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=g2["max_depth"])
+    film = pt.Film(gpu_ctx, w, h)
+    gpu_ctx.reset_stats()
+    pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=1, **kw))
+    st = gpu_ctx.stats()
+    assert st.pipeline == pt.PIPELINE_FUSED and st.tail_samples == spp // 2 and st.rays == g2["rays"]
+    assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == g2["film_sha256"]
+    if g3 is not None and "1" in g3["after_frame"]:
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=2, **kw))
+        st, m = gpu_ctx.stats(), g3["after_frame"]["1"]
+        assert st.tail_samples == spp * 3 // 8 and st.frames_in_flight == 2 and st.rays == m["rays_so_far"]
+        assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
+    if g3 is not None:
+        film.clear()
+        gpu_ctx.reset_stats()
+        pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=4, **kw))
+        st, m = gpu_ctx.stats(), g3["after_frame"]["3"]
+        assert st.tail_samples == 0 and st.rays == m["rays_so_far"]
+        assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
+        # a rank of world 8 with 16 frames in flight holds as many slots as two whole frames: the same rule
+        film.clear()
+        pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=16, rank=3, world=8, **kw))
+        assert gpu_ctx.stats().tail_samples == spp * 3 // 8
+    film.close()
+
+
 def test_fused_pipeline_on_trees_without_pair_leaves(pt, orc, gpu_ctx, cornell_arrays):
     """k_fused's second instantiation -- leaves of up to four independent triangles, the trees k_extend_lds7 walks: the box built
     with pt_tuning.pair_leaves = 0, and small soups, which have no fan pairs to find -- against the oracle, both radiance forms."""
