@@ -502,7 +502,7 @@ class Comm:
 
 
 class DeviceBuffer:
-    """hipMalloc'ed memory through the C-ABI (for callers without torch): .ptr, .read(dtype, shape)"""
+    """hipMalloc'ed memory through the C-ABI (for callers without torch): .ptr, .read(dtype, shape), .write(array)"""
 
     def __init__(self, ctx, nbytes):
         self.ctx, self.nbytes = ctx, nbytes
@@ -515,6 +515,11 @@ class DeviceBuffer:
         assert a.nbytes <= self.nbytes
         self.ctx._check(lib_amd().pt_device_read(self.ctx.h, C.c_void_p(self.ptr), a.ctypes.data, a.nbytes))
         return a
+
+    def write(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        self.ctx._check(lib_amd().pt_device_write(self.ctx.h, C.c_void_p(self.ptr), a.ctypes.data, a.nbytes))
 
     def close(self):
         if self.ptr:

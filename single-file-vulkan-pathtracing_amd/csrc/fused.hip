@@ -15,6 +15,14 @@ extern "C" int pt_debug_fused_timeline(void *device_u64x4_per_wave)
 }
 #endif
 
+#ifdef PT_FUSED_HIST
+__device__ uint32_t *g_fused_hist = nullptr;
+extern "C" int pt_debug_fused_hist(void *device_u32_2x8192x16)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_hist), &device_u32_2x8192x16, sizeof(void *));
+}
+#endif
+
 namespace {
 using namespace ptw;
 #include "fused_kernel.h"

@@ -110,6 +110,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     unsigned long long tl_slot_t0 = 0ull, tl_last_t0 = 0ull, tl_last_t1 = 0ull;  // per lane: when its current slot began; its last completed slot
     uint32_t tl_last_slot = 0xFFFFFFFFu, tl_n_slots = 0u;
 #endif
+#ifdef PT_FUSED_HIST
+    uint32_t tl_hb = 0xFFFFFFFFu, tl_hn = 0u, tl_ht = 0u, tl_pass = 0u;  // the histogram bucket being counted, rays started in it (all / on tail slots)
+#endif
     bool have = false;          // the lane traces a ray
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
@@ -387,6 +390,25 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 have = true;
             }
             n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));  // (wave-uniform control flow here: every lane keeps the same count)
+#ifdef PT_FUSED_HIST
+            {   // dev build (scripts/probe_fused_hist.py): rays started per 50 us of device clock (100 MHz), [bucket][16 words by block]; the second
+                // half: those of waves drawing tail slots.  Counted in registers; the clock is read on every 8th pass only (a scalar memory read the
+                // wave waits for) and a bucket's count is flushed when the bucket changes: one atomic per wave and bucket, spread over 16 words
+                const uint32_t tl_n = (uint32_t)__popcll(__ballot(got_ray));
+                if ((tl_pass++ & 7u) == 0u) {
+                    const uint32_t b = (uint32_t)(wall_clock64() / 5000ull) & 8191u;
+                    if (b != tl_hb) {
+                        if (lane == 0 && g_fused_hist && tl_hn) {
+                            atomicAdd(g_fused_hist + tl_hb * 16u + (blockIdx.x & 15u), tl_hn);
+                            if (tl_ht) atomicAdd(g_fused_hist + (8192u + tl_hb) * 16u + (blockIdx.x & 15u), tl_ht);
+                        }
+                        tl_hb = b; tl_hn = 0u; tl_ht = 0u;
+                    }
+                }
+                tl_hn += tl_n;
+                if (HYB && w_tails) tl_ht += tl_n;
+            }
+#endif
         }
         if (__ballot(have) == 0ull) {
             if (__ballot(path) == 0ull && out_of_slots) break;
@@ -433,6 +455,12 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         }
     }
     if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);
+#ifdef PT_FUSED_HIST
+    if (lane == 0 && g_fused_hist && tl_hn) {
+        atomicAdd(g_fused_hist + (tl_hb & 8191u) * 16u + (blockIdx.x & 15u), tl_hn);
+        if (tl_ht) atomicAdd(g_fused_hist + (8192u + (tl_hb & 8191u)) * 16u + (blockIdx.x & 15u), tl_ht);
+    }
+#endif
 #ifdef PT_FUSED_TIMELINE
     if (lane == 0 && g_fused_timeline) {
         unsigned long long *o = g_fused_timeline + 4 * (size_t)(blockIdx.x * (FTB / 64) + (threadIdx.x >> 6));

@@ -611,10 +611,13 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     for (uint32_t done = 0; w.n_slots > 0 && done < p->frame_count; done += sh.lanes) {
         rc.frame_base = p->frame + (int32_t)done;
         rc.lanes_active = std::min(sh.lanes, p->frame_count - done);
-        unsigned long long rays_before = 0;
+        // A launch whose term logs are bounded can overflow them (scenes where most surfaces emit): k_fused raises d_overflow, k_resolve then
+        // leaves the film alone, and the host -- which looks at the flag once the stream is idle anyway: after the call's last launch, or
+        // before the next launch of a longer call, whose blend must follow this one's -- renders the same frames again with one group.
+        // Nothing here waits for the device before the launch: the ray counter to restore is kept in a spare device word.
+        unsigned long long *const d_rays_before = ctx->d_stats + 18;
         if (sh.bounded) {
-            PT_HIP(ctx, hipStreamSynchronize(st));
-            PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
+            PT_HIP(ctx, hipMemcpyAsync(d_rays_before, ctx->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
             PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
         }
         PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * PTW_COUNT_WORDS, st));  // the slot counters (fused_kernel.h: eight, 128 B apart)
@@ -630,18 +633,17 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
         PT_HIP(ctx, hipGetLastError());
         ctx->stats.launches_extend++;
         ctx->stats.rounds++;
+        ptw_launch_resolve(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra, st, sh.bounded ? d_overflow : nullptr);
+        ctx->stats.launches_other++;
         bool redo = false;
         if (sh.bounded) {
             unsigned long long flag = 0;
-            PT_HIP(ctx, hipStreamSynchronize(st));
+            PT_HIP(ctx, hipStreamSynchronize(st));  // (the last launch of a blocking call: the wait the call ends with)
             PT_HIP(ctx, hipMemcpy(&flag, d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
             redo = flag != 0ull;
         }
-        if (!redo) {
-            ptw_launch_resolve(rc, w.d_tiles, rad, f->d_rgb, f->d_bgra, st);
-            ctx->stats.launches_other++;
-        } else {  // a slot filled its term log (scenes where most surfaces emit): the same frames once more with one group
-            PT_HIP(ctx, hipMemcpy(ctx->d_stats, &rays_before, sizeof(rays_before), hipMemcpyHostToDevice));
+        if (redo) {  // a slot filled its term log: the same frames once more with one group
+            PT_HIP(ctx, hipMemcpy(ctx->d_stats, d_rays_before, sizeof(unsigned long long), hipMemcpyDeviceToDevice));
             PT_HIP(ctx, hipMemset(d_overflow, 0, sizeof(unsigned long long)));
             ctx->stats.redone_batches++;
             pt_params r = *p;

@@ -448,10 +448,11 @@ __device__ __forceinline__ uint8_t to_unorm8(float c)
 }
 
 __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
-                                                float *__restrict__ film, uint8_t *__restrict__ bgra)
+                                                float *__restrict__ film, uint8_t *__restrict__ bgra, const unsigned long long *__restrict__ skip_if_set)
 {
     const uint32_t local = blockIdx.x * TB + threadIdx.x;
     if (local >= rc.slots_per_lane) return;
+    if (skip_if_set && *skip_if_set != 0ull) return;  // (a term log overflowed in the launch before: the host renders these frames again)
     uint32_t f0, g0, px, py;
     slot_pixel(rc, tiles, local, f0, g0, px, py);
     if (px >= rc.width || py >= rc.height) return;
@@ -571,9 +572,10 @@ void ptw_launch_shadow_add(const ptw::RenderConst &rc, const ptw::Radiance &rad,
     k_shadow_add<<<grid, TB, 0, st>>>(rc, rad, sq_hit, contrib, slot, count);
 }
 
-void ptw_launch_resolve(const ptw::RenderConst &rc, const uint32_t *tiles, const ptw::Radiance &rad, float *film, uint8_t *bgra, hipStream_t st)
+void ptw_launch_resolve(const ptw::RenderConst &rc, const uint32_t *tiles, const ptw::Radiance &rad, float *film, uint8_t *bgra, hipStream_t st,
+                        const unsigned long long *skip_if_set)
 {
-    k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, tiles, rad, film, bgra);
+    k_resolve<<<(rc.slots_per_lane + TB - 1) / TB, TB, 0, st>>>(rc, tiles, rad, film, bgra, skip_if_set);
 }
 
 void ptw_launch_hits_to_api(const float4 *hit, const float4 *tri4, const uint32_t *hit_inst, const uint32_t *inst_id, uint32_t n, pt_hit *out,

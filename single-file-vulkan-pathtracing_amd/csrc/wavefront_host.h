@@ -71,7 +71,9 @@ void ptw_launch_generate(const ptw::RenderConst &rc, const uint32_t *tiles, uint
                          const ptw::QueueView &out, uint32_t *count_out, int num_cus, hipStream_t st);
 void ptw_launch_shadow_add(const ptw::RenderConst &rc, const ptw::Radiance &rad, const float4 *sq_hit, const float4 *contrib,
                            const uint32_t *slot, const uint32_t *count, int grid, hipStream_t st);
-void ptw_launch_resolve(const ptw::RenderConst &rc, const uint32_t *tiles, const ptw::Radiance &rad, float *film, uint8_t *bgra, hipStream_t st);
+// (skip_if_set: a device word; the kernel leaves the film alone when it is non-zero -- the fused pipeline's overflow flag, read by the host afterwards)
+void ptw_launch_resolve(const ptw::RenderConst &rc, const uint32_t *tiles, const ptw::Radiance &rad, float *film, uint8_t *bgra, hipStream_t st,
+                        const unsigned long long *skip_if_set = nullptr);
 void ptw_launch_hits_to_api(const float4 *hit, const float4 *tri4, const uint32_t *hit_inst, const uint32_t *inst_id, uint32_t n, pt_hit *out,
                             hipStream_t st);
 
