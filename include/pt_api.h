@@ -82,7 +82,8 @@ typedef struct pt_tuning {
     int32_t fused_tail;     /* fused pipeline, sample_groups left at 0, single-level scenes: S of a pixel's spp samples are traced as one-sample
                                tail slots handed out after every head slot (spp - S samples) -- a launch with few slots per lane ends with short
                                work.  0 = never; -1: by the launch's slots per lane (render.hip fused_tail_samples); clamped to spp - 1.      */
-    int32_t reserved[4];
+    int32_t fused_subject;  /* fused pipeline: 0 = hand the tiles out centre first only; -1 / 1: the tiles the scene's box projects to first (render.hip) */
+    int32_t reserved[3];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
 pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in);

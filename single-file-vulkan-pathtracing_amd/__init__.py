@@ -85,12 +85,12 @@ class Stats(C.Structure):
 
 TUNING_NAMES = ["refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves", "pair_kernel", "topdown4",
                 "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield", "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb",
-                "hbm8", "ploc_radius", "leaf_min", "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail"]
+                "hbm8", "ploc_radius", "leaf_min", "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail", "fused_subject"]
 
 
 class Tuning(C.Structure):
     """include/pt_api.h pt_tuning: speed knobs of a context, -1 = the built-in choice; never changes a result."""
-    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 4)]
+    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 3)]
 
 
 class HostScene(C.Structure):

@@ -111,6 +111,8 @@ pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t la
         w.tile_order = order;
         w.rank = rank; w.world = world;
         w.n_tiles = (uint32_t)tiles.size();
+        w.tile_rect[0] = w.tile_rect[1] = 0; w.tile_rect[2] = w.tile_rect[3] = -1;
+        if (order == 1u) w.h_tiles = tiles; else w.h_tiles.clear();
         PT_HIP(ctx, hipMalloc((void **)&w.d_tiles, sizeof(uint32_t) * std::max<size_t>(tiles.size(), 1)));
         if (!tiles.empty())
             PT_HIP(ctx, hipMemcpy(w.d_tiles, tiles.data(), sizeof(uint32_t) * tiles.size(), hipMemcpyHostToDevice));
@@ -314,6 +316,37 @@ RenderShape ptw_choose_shape(const pt_film *f, const pt_params *p, int launch_cl
 // The shape of a render and its workspace.  An AUTO shape that does not fit after all (another allocator took the
 // memory between hipMemGetInfo and hipMalloc) is planned again for half the memory, down to one frame and one group;
 // an explicit shape that does not fit is PT_ERR_OOM.  Either way a failure leaves the film usable.
+// The fused pipeline's hand-out order, second key.  Centre first is a guess about where the subject is; the camera and the scene's box say where
+// it is NOT: a pixel whose primary rays pass outside the box's projection costs one ray per sample (32 rays a slot against ~170 inside the
+// Cornell box), and whatever is handed out last runs alone at the end of the launch.  So the tiles that touch the pixel rectangle `rect`
+// {x0, y0, x1, y1} (render.hip: the projection of the scene's box) go first, centre first among themselves, and the others after them: the
+// launch ends with the cheapest slots there are.  x1 < x0: no rectangle, the centre-first list as built.  Order only -- slot -> pixel goes through
+// the table everywhere, results cannot depend on it.  Costs a pass over the host list and a 130 KB copy when the rectangle changes, else nothing.
+pt_status ptw_tiles_subject_first(pt_film *f, const int32_t rect[4], hipStream_t st)
+{
+    pt_film::Work &w = f->work;
+    pt_ctx *ctx = f->ctx;
+    if (w.tile_order != 1u || w.h_tiles.empty() || !w.d_tiles) return PT_OK;
+    const bool none = rect[2] < rect[0] || rect[3] < rect[1], had_none = w.tile_rect[2] < w.tile_rect[0] || w.tile_rect[3] < w.tile_rect[1];
+    if ((none && had_none) || (!none && !had_none && std::equal(rect, rect + 4, w.tile_rect))) return PT_OK;
+    std::vector<uint32_t> out;
+    out.reserve(w.h_tiles.size());
+    if (none) {
+        out = w.h_tiles;
+    } else {
+        auto touches = [&](uint32_t t) {
+            const int32_t x = (int32_t)(t & 0xFFFFu) * 8, y = (int32_t)(t >> 16) * 8;
+            return x <= rect[2] && x + 7 >= rect[0] && y <= rect[3] && y + 7 >= rect[1];
+        };
+        for (uint32_t t : w.h_tiles) if (touches(t)) out.push_back(t);
+        for (uint32_t t : w.h_tiles) if (!touches(t)) out.push_back(t);
+    }
+    PT_HIP(ctx, hipStreamSynchronize(st));  // (nothing of this film is in flight when a blocking render begins; kept for callers that come later)
+    PT_HIP(ctx, hipMemcpy(w.d_tiles, out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice));
+    std::copy(rect, rect + 4, w.tile_rect);
+    return PT_OK;
+}
+
 pt_status ptw_shape_and_work(pt_film *f, const pt_params *p_in, RenderShape &sh, int launch_class, bool queues)
 {
     pt_status rc = PT_OK;

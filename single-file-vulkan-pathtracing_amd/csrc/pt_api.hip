@@ -33,9 +33,10 @@ static pt_status guarded(pt_ctx *ctx, F &&body)
 static const char *const k_tune_names[] = { "refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves",
                                             "pair_kernel", "topdown4", "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield",
                                             "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb", "hbm8", "ploc_radius", "leaf_min",
-                                            "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail" };
+                                            "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail",
+                                            "fused_subject" };
 constexpr int k_tune_count = (int)(sizeof(k_tune_names) / sizeof(k_tune_names[0]));
-static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 4), "pt_tuning: names and fields out of step");
+static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 3), "pt_tuning: names and fields out of step");
 
 static void tuning_defaults(pt_tuning *t)
 {

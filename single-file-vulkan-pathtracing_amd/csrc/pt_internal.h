@@ -145,6 +145,8 @@ struct pt_film {
         uint32_t n_tiles = 0;                     // local 8x8 tiles
         uint32_t n_slots = 0;                     // lanes * n_tiles * 64
         uint32_t *d_tiles = nullptr;              // local tile -> global tile id
+        std::vector<uint32_t> h_tiles;            // tile_order 1: the centre-first list as built (ptw_tiles_subject_first re-orders d_tiles from it)
+        int32_t tile_rect[4] = { 0, 0, -1, -1 };  // ... the pixel rectangle {x0, y0, x1, y1} whose tiles currently go first in d_tiles (x1 < x0: none)
         float4 *d_color = nullptr;                // per slot: frame colour accumulator rgb + pad (groups == 1)
         float4 *d_terms = nullptr;                // per slot: ordered radiance terms, dense primary log   (groups > 1)
         float4 *d_terms_over = nullptr;           // per slot: overflow of the primary log (worst-case sized)

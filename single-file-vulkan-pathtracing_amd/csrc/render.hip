@@ -537,6 +537,38 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
     return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }
 
+// The pixel rectangle the scene's box projects to (film_work.hip ptw_tiles_subject_first: its tiles are handed out first).  The camera of
+// raygen.rgen:51-57 shoots from cam_origin through (target.x + dx, target.y + dy, target.z), dx, dy in [-1, 1] across the image: a point P in
+// front of the origin lands at dx = o.x + (P.x - o.x) (t.z - o.z) / (P.z - o.z) - t.x.  A box is convex, so its image lies inside the bounding
+// rectangle of its corners' images.  No rectangle (x1 < x0) when a corner is not in front of the origin (the camera is inside or beside the
+// box), for two-level scenes (no world box kept), or when pt_tuning.fused_subject = 0.  A guess about cost, not about results.
+void fused_subject_rect(const pt_scene *s, const pt_params *p, const FusedPlan &fp, int32_t rect[4])
+{
+    rect[0] = rect[1] = 0; rect[2] = rect[3] = -1;
+    if (fp.inst || s->n_inst || s->ctx->tune.fused_subject == 0) return;
+    const float den = p->cam_target[2] - p->cam_origin[2];
+    if (!(std::fabs(den) > 0.f)) return;
+    float lo[2] = { 3.0e38f, 3.0e38f }, hi[2] = { -3.0e38f, -3.0e38f };
+    for (int c = 0; c < 8; c++) {
+        const float P[3] = { (c & 1) ? s->bmax[0] : s->bmin[0], (c & 2) ? s->bmax[1] : s->bmin[1], (c & 4) ? s->bmax[2] : s->bmin[2] };
+        const float a = (P[2] - p->cam_origin[2]) / den;  // how far along the view axis the corner is, in units of the image plane's distance
+        if (!(a > 1.0e-4f)) return;
+        for (int k = 0; k < 2; k++) {
+            const float d = p->cam_origin[k] + (P[k] - p->cam_origin[k]) / a - p->cam_target[k];
+            lo[k] = std::min(lo[k], d); hi[k] = std::max(hi[k], d);
+        }
+    }
+    const float size[2] = { (float)p->width, (float)p->height };
+    int32_t r[4];
+    for (int k = 0; k < 2; k++) {  // dx -> pixel (raygen.rgen:52-53 inverted), one pixel of slack, clamped to the image
+        const float a = (lo[k] + 1.0f) * 0.5f * size[k] - 1.0f, b = (hi[k] + 1.0f) * 0.5f * size[k] + 1.0f;
+        if (!(a == a) || !(b == b) || b < 0.f || a > size[k]) return;  // (NaN, or the box is off the image: no subject to put first)
+        r[k] = (int32_t)std::max(a, 0.f);
+        r[k + 2] = (int32_t)std::min(b, size[k] - 1.0f);
+    }
+    std::copy(r, r + 4, rect);
+}
+
 pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const ExtendPlan &pl, bool nested, bool prepare_only)
 {
     pt_ctx *ctx = s->ctx;
@@ -596,6 +628,12 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     if (rc_ != PT_OK) return rc_;
     ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
     if (prepare_only) return PT_OK;
+    if (!nested) {
+        int32_t rect[4];
+        fused_subject_rect(s, p, fp, rect);
+        rc_ = ptw_tiles_subject_first(f, rect, st);
+        if (rc_ != PT_OK) return rc_;
+    }
     pt_film::Work &w = f->work;
     unsigned long long *const d_overflow = ctx->d_stats + 6, *const d_spill_count = ctx->d_stats + 7;
     uint32_t spill_cap = sh.bounded ? SPILL_POOL_ENTRIES : 0u;

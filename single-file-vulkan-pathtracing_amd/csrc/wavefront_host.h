@@ -105,6 +105,7 @@ RenderShape ptw_choose_shape(const pt_film *f, const pt_params *p, int launch_cl
 pt_status ptw_ensure_work(pt_film *f, uint32_t rank, uint32_t world, uint32_t lanes, uint32_t groups, uint32_t term_cap, uint32_t term_pcap,
                           bool queues = true, uint32_t tail = 0);
 pt_status ptw_shape_and_work(pt_film *f, const pt_params *p, RenderShape &sh, int launch_class, bool queues = true);
+pt_status ptw_tiles_subject_first(pt_film *f, const int32_t rect[4], hipStream_t st);  // fused pipeline: tiles that can see the scene first (film_work.hip)
 uint64_t ptw_workspace_bytes(const pt_film *f);
 ptw::RenderConst ptw_render_const(const pt_params *p, const pt_film::Work &w, const RenderShape &sh);
 uint64_t ptw_valid_local_pixels(const pt_film *f, const pt_params *p);

@@ -2303,6 +2303,34 @@ def test_fused_head_and_tail_slots_bit_exact(pt, orc, gpu_ctx, cornell_gpu, corn
         gs.close()
 
 
+def test_fused_subject_first_order_changes_no_bit(pt, orc, gpu_ctx, cornell_gpu, cornell_oracle):
+    """The fused pipeline hands out first the tiles the scene's box projects to (render.hip fused_subject_rect, film_work.hip
+    ptw_tiles_subject_first; pt_tuning.fused_subject = 0: centre first only).  Order only: for views with the box pushed to a side or a corner,
+    far away, off the image, and with the camera inside or behind the box (no rectangle), the film, the rgba8 image and the ray count are the
+    oracle's with and without it, for the plain, the all-groups and the head + tail shape, and when the view changes between calls on one film."""
+    w, h, spp = 136, 72, 4
+    views = [dict(), dict(cam_origin=(1.1, -1.0, 5.0), cam_target=(1.1, -1.0, 2.0)), dict(cam_origin=(1.0, -0.2, 5.0), cam_target=(1.0, -0.2, 2.0)),
+             dict(cam_origin=(0.0, -1.0, 9.0), cam_target=(0.0, -1.0, 6.0)), dict(cam_origin=(3.5, -1.0, 5.0), cam_target=(3.5, -1.0, 2.0)),
+             dict(cam_origin=(0.0, -1.0, 0.5), cam_target=(0.0, -1.0, -2.5)), dict(cam_origin=(0.0, -1.0, -5.0), cam_target=(0.0, -1.0, -8.0)),
+             dict(cam_origin=(0.0, -1.0, 5.0), cam_target=(0.0, -1.0, 8.0))]
+    film = pt.Film(gpu_ctx, w, h)        # one film for every view: the tile table is re-ordered when the rectangle changes
+    for cam in views:
+        kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=6, **cam)
+        ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 2, **kw)
+        for subject in (1, 0, -1):
+            for knobs, shape in ((dict(fused_tail=0), dict(sample_groups=1)), (dict(fused_tail=0), dict(sample_groups=spp)), (dict(fused_tail=2), dict())):
+                old = gpu_ctx.set_tuning(fused_subject=subject, **knobs)
+                try:
+                    film.clear()
+                    gpu_ctx.reset_stats()
+                    pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
+                    assert gpu_ctx.stats().rays == orays, (cam, subject, shape)
+                    assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes(), (cam, subject, shape)
+                finally:
+                    gpu_ctx.set_tuning(**old)
+    film.close()
+
+
 def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cornell_gpu):
     """The library's own head + tail rule (render.hip fused_tail_samples: by head slots per lane of the grid) at 1920x1080, 32 spp: one frame
     per call takes spp / 2 tail samples, two frames 3 spp / 8, four frames none -- and each call's film is the oracle's known answer
