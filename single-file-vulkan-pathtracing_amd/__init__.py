@@ -80,17 +80,17 @@ class Stats(C.Structure):
                 ("wave_finishes", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("leaf_lanes", C.c_uint64), ("pop_lanes", C.c_uint64), ("hit_lanes", C.c_uint64),
                 ("enter_steps", C.c_uint64), ("enter_lanes", C.c_uint64), ("workspace_bytes", C.c_uint64),
-                ("pipeline", C.c_uint32), ("tail_samples", C.c_uint32)]
+                ("pipeline", C.c_uint32), ("tail_samples", C.c_uint32), ("rays_culled", C.c_uint64)]
 
 
 TUNING_NAMES = ["refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves", "pair_kernel", "topdown4",
                 "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield", "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb",
-                "hbm8", "ploc_radius", "leaf_min", "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail", "fused_subject"]
+                "hbm8", "ploc_radius", "leaf_min", "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail", "fused_subject", "fused_cull"]
 
 
 class Tuning(C.Structure):
     """include/pt_api.h pt_tuning: speed knobs of a context, -1 = the built-in choice; never changes a result."""
-    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 3)]
+    _fields_ = [(n, C.c_int32) for n in TUNING_NAMES] + [("reserved", C.c_int32 * 2)]
 
 
 class HostScene(C.Structure):

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
+    uint32_t n_cull_wave = 0;   // ... of them camera rays of pixels that cannot see the scene, resolved without a walk
     uint32_t w_next = 0, w_end = 0, w_base = 0;  // wave-uniform: what is left of the wave's current batch of slots, and where it began
     uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;  // ... the part of the slot range it draws from, parts found empty
     bool w_tails = false;       // wave-uniform, MODE 2: the head slots are all handed out, the wave draws tail slots (a second set of eight counters)
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 }
                 const uint32_t take = min((uint32_t)__popcll(m_want), w_end - w_next);
                 const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
+                uint32_t cull_n = 0u;  // samples of a slot that is finished here: its pixel cannot see the scene (RenderConst::cull)
                 if (in_blk && !path && rank < take) {
                     const uint32_t mine = w_next + rank;
                     uint32_t f, g, local;
@@ -343,7 +345,20 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     const uint32_t tw = s_wtile[(mine - w_base) >> 6];
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
                     const uint32_t sample0 = (HYB && w_tails) ? rc.head_samples + g : g * rc.group_size;
-                    if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
+                    const bool in_image = px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp;
+                    if (in_image && rc.cull_on && ((int32_t)px < rc.cull[0] || (int32_t)px > rc.cull[2] || (int32_t)py < rc.cull[1] || (int32_t)py > rc.cull[3])) {
+                        // every sample of the slot: one camera ray, a miss, color += 1 * env -- without the walk that would find nothing
+                        const float4 e = make_float4(rc.env[0], rc.env[1], rc.env[2], 0.f);
+                        if (GROUPED || (HYB && w_tails)) {
+                            const uint32_t lslot = HYB ? slot - rc.n_head : slot, lstride = HYB ? rc.n_tail : rc.n_slots;
+                            cull_n = HYB ? 1u : min(rc.spp, (g + 1u) * rc.group_size) - sample0;
+                            for (uint32_t k = 0; k < cull_n; k++) ptm::st_stream<true>(rad.terms + ((size_t)k * lstride + lslot), e);  // (cull_n <= group_size <= term_pcap)
+                            rad.nterm[lslot] = cull_n;
+                        } else {
+                            cull_n = HYB ? rc.head_samples : rc.spp;
+                            rad.color[slot] = make_float4(rc.cull_sum[0], rc.cull_sum[1], rc.cull_sum[2], 0.f);
+                        }
+                    } else if (in_image) {
                         pxy = px | (py << 16);
                         ctr = sample0;
                         my_state[FS_A * FTB] = 0u;  // colour.r = +0.0f | term count = 0
@@ -360,6 +375,13 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     }
                 }
                 w_next += take;
+                if (rc.cull_on) {  // (wave-uniform: the rays of the slots finished above, counted as the rays they are)
+                    const uint32_t n_a = HYB ? (w_tails ? 1u : rc.head_samples) : rc.group_size;
+                    uint32_t n_c = (uint32_t)__popcll(__ballot(cull_n == n_a)) * n_a;
+                    if (GROUPED) n_c += (uint32_t)__popcll(__ballot(cull_n != 0u && cull_n != n_a)) * (rc.spp - (rc.groups - 1u) * rc.group_size);
+                    n_rays_wave += n_c;
+                    n_cull_wave += n_c;
+                }
             }
             // (3) camera ray of a slot's next (or first) sample
             if (need_primary) {
@@ -455,6 +477,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         }
     }
     if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);
+    if (lane == 0 && n_cull_wave) atomicAdd(stats + 19, (unsigned long long)n_cull_wave);  // (pt_stats.rays_culled)
 #ifdef PT_FUSED_HIST
     if (lane == 0 && g_fused_hist && tl_hn) {
         atomicAdd(g_fused_hist + (tl_hb & 8191u) * 16u + (blockIdx.x & 15u), tl_hn);

@@ -483,17 +483,20 @@ pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const Ex
 // one-tile batches (fused_kernel.h PT_FUSED_BATCH1): 1 frame 7.2 / 6.9 / 6.4 with 1 / 8 / 32 groups; 2 frames 6.21 / 6.27 with 1 / 16;
 // 4 frames 5.78 / 6.15 with 1 / 8 (profiles/r05c_fused_batch1.log, r05d_grouped_cost.log; with the 256-slot batches of round 4 groups
 // paid up to 8 frames: r04k_fused_groups_by_frames.log).  Explicit frames_in_flight / sample_groups are taken as given.
-// Twice the head slots (frames x owned pixels) per lane of the fused grid: what the shape rules below go by.
-uint32_t fused_slots_x2(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames)
+// 32 x the head slots that are WALKED (frames x owned pixels that can see the scene: the tiles of the cull rectangle, or all of them where there
+// is none) per lane of the fused grid: what the shape rules below go by.
+uint32_t fused_slots_x32(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames, const int32_t rect[4])
 {
-    const uint64_t tiles = (uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8);
+    uint64_t tiles = (uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8);
+    if (rect[2] >= rect[0] && rect[3] >= rect[1] && ctx->tune.fused_cull != 0)
+        tiles = (uint64_t)(rect[2] / 8 - rect[0] / 8 + 1) * (uint64_t)(rect[3] / 8 - rect[1] / 8 + 1);
     const uint64_t world = std::max(p->world, 1u);
     const uint64_t heads = (uint64_t)frames * 64ull * ((tiles + world - 1) / world);
     const uint64_t grid_lanes = (uint64_t)std::max(ctx->num_cus, 1) * 6ull * 256ull;  // (six 256-thread workgroups per CU: fused.hip)
-    return (uint32_t)std::min<uint64_t>(heads * 2ull / grid_lanes, 1u << 20);
+    return (uint32_t)std::min<uint64_t>(heads * 32ull / grid_lanes, 1u << 24);
 }
 
-void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan &, pt_params &q)
+void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan &, const int32_t rect[4], pt_params &q)
 {
     q = *p;
     if (q.frames_in_flight == 0) {
@@ -503,13 +506,13 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
     }
     q.frames_in_flight = std::max(1u, std::min(q.frames_in_flight, p->frame_count));
     if (q.sample_groups == 0) {
-        // every sample its own slot (the smallest divisor of spp that is >= 32, or spp itself) where the launch has fewer than two head slots
-        // per lane of the grid -- small films, whatever the frames: 256 x 256 x 4 frames 1.23 ms against 2.50 with one group -- and for a single
-        // frame up to 18 per lane (1080p: 6.43 against 7.24; 2160p, 21 per lane: 24.5 against 23.2, so not there); else one group.
-        // profiles/r05z4_tail_rule.log.  (Where fused_tail_samples below gives S > 0 the head + tail shape replaces either.)
-        const uint32_t x2 = fused_slots_x2(f->ctx, f, p, q.frames_in_flight);
+        // every sample its own slot (the smallest divisor of spp that is >= 32, or spp itself) where the launch has little more than one walked
+        // slot per lane of the grid -- small films, whatever the frames: 256 x 256 x 4 frames 1.23 ms against 2.50 with one group -- and for a
+        // single frame up to 10 per lane (1080p, 3 per lane: 6.43 against 7.24; 2160p, 12 per lane: 24.5 against 23.2, so not there); else one
+        // group.  profiles/r05z4_tail_rule.log.  (Where fused_tail_samples below gives S > 0 the head + tail shape replaces either.)
+        const uint32_t x32 = fused_slots_x32(f->ctx, f, p, q.frames_in_flight, rect);
         uint32_t g = 1;
-        if (x2 < 4u || (q.frames_in_flight < 2u && x2 <= 36u))
+        if (x32 < 36u || (q.frames_in_flight < 2u && x32 <= 324u))
             while (g < p->spp_per_frame && (g < 32u || p->spp_per_frame % g)) g++;
         q.sample_groups = g;
     }
@@ -517,22 +520,25 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
 
 // Tail samples per pixel of a fused launch (0: the one-group or all-groups shape above).  A launch with few slots per lane of the grid ends
 // with whole 32-sample slots still running; with S of a pixel's samples as one-sample tail slots handed out after every head the launch ends with
-// short work, and only those S samples' radiance terms go through the log.  Measured on one MI355X, spp 32, depth 8, ms per call as
-// all groups / one group / best S (profiles/r05z4_tail_rule.log; r05z_fused_tail_samples.log, r05z2_..., r05z3_... for other spp and ranks):
-//   slots x2 per lane   4 (720p x 1)  5 (540p x 2)  9 (720p x 2)  10 (1080p x 1)  21 (1080p x 2)  31 (1080p x 3)  37 (1440p x 2)  42 (2160p x 1)
-//   all / one / S       3.09 4.19     3.60 4.53     5.80 6.80     6.43 7.24       -    12.40      -    17.64      21.9 20.7      24.5 23.2
-//   best S              3.07 (S 24)   3.39 (S 20)   5.72 (S 20)   6.29 (S 16)     11.92 (S 12)    17.35 (S 8)     20.5 (S 8)     23.0 (S 4)
-// (a rank of world 8 at 16 frames, 21: 12.38 -> 12.19; of 4 at 8 frames: 12.38 -> 12.06; world 8 at 32 frames and 1080p x 8: S 0 is best.)
-// So by twice the slots per lane: under 4 -> 0 (all groups); 4..9 -> 5 spp / 8; 10..16 -> spp / 2; 17..28 -> 3 spp / 8; 29..36 -> spp / 4; above
-// -> 0 (the gain is inside the noise).  pt_tuning.fused_tail >= 0 overrides.
-uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames)
+// short work, and only those S samples' radiance terms go through the log.  Measured on one MI355X, the Cornell box (58 % of the tiles can see
+// it: 3.05 walked slots per lane and 1080p frame), spp 32, depth 8, ms per call as all groups / one group / best S
+// (profiles/r05z4_tail_rule.log, r05z_fused_tail_samples.log, r05z2_..., r05z3_... before the cull; r05zf_cull.log with it):
+//   walked slots per lane  1.3 (720p x 1)  1.5 (540p x 2)  2.7 (720p x 2)  3.0 (1080p x 1)  6.1 (1080p x 2)  9.1 (1080p x 3)  12.2 (1080p x 4)
+//   all / one              3.09 4.19       3.60 4.53       5.80 6.80       6.43 7.24        -    12.40       -    17.64       -     23.0
+//   best S                 3.07 (S 24)     3.39 (S 20)     5.72 (S 20)     6.29 (S 16)      11.92 (S 12)     17.35 (S 8)      22.9 (S 4)
+//   with the cull          .               .               .               7.11 / 6.15 (16) 12.37 / 11.67 (12) 17.39 / 16.94 (8) 22.70 / 22.32 (4)
+// (a rank of world 8 at 16 frames, 6.1: 12.38 -> 12.19; of 4 at 8 frames: 12.38 -> 12.06; 8 and 16 frames: S 2 .. 4 within 0.3 % of none.)
+// So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 3 spp / 8; to 10.1 -> spp / 4; to
+// 13.5 -> spp / 8; above -> 0.  pt_tuning.fused_tail >= 0 overrides.
+uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames, const int32_t rect[4])
 {
     const uint32_t spp = p->spp_per_frame;
     if (spp < 2u) return 0u;
     int t = ctx->tune.fused_tail;
     if (t < 0) {
-        const uint32_t x2 = fused_slots_x2(ctx, f, p, frames);
-        t = x2 < 4u ? 0 : x2 <= 9u ? (int)(spp * 5u / 8u) : x2 <= 16u ? (int)(spp / 2u) : x2 <= 28u ? (int)(spp * 3u / 8u) : x2 <= 36u ? (int)(spp / 4u) : 0;
+        const uint32_t x = fused_slots_x32(ctx, f, p, frames, rect);
+        t = x < 36u ? 0 : x <= 81u ? (int)(spp * 5u / 8u) : x <= 144u ? (int)(spp / 2u) : x <= 252u ? (int)(spp * 3u / 8u) : x <= 324u ? (int)(spp / 4u)
+                                   : x <= 432u ? (int)(spp / 8u) : 0;
     }
     return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }
@@ -541,11 +547,12 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
 // raygen.rgen:51-57 shoots from cam_origin through (target.x + dx, target.y + dy, target.z), dx, dy in [-1, 1] across the image: a point P in
 // front of the origin lands at dx = o.x + (P.x - o.x) (t.z - o.z) / (P.z - o.z) - t.x.  A box is convex, so its image lies inside the bounding
 // rectangle of its corners' images.  No rectangle (x1 < x0) when a corner is not in front of the origin (the camera is inside or beside the
-// box), for two-level scenes (no world box kept), or when pt_tuning.fused_subject = 0.  A guess about cost, not about results.
+// box) and for two-level scenes (no world box kept).  Used twice: as a guess about cost (the hand-out order) and as a proof (the cull below):
+// the pixel of slack on every side is far above the rounding of this projection and of raygen's own.
 void fused_subject_rect(const pt_scene *s, const pt_params *p, const FusedPlan &fp, int32_t rect[4])
 {
     rect[0] = rect[1] = 0; rect[2] = rect[3] = -1;
-    if (fp.inst || s->n_inst || s->ctx->tune.fused_subject == 0) return;
+    if (fp.inst || s->n_inst) return;
     const float den = p->cam_target[2] - p->cam_origin[2];
     if (!(std::fabs(den) > 0.f)) return;
     float lo[2] = { 3.0e38f, 3.0e38f }, hi[2] = { -3.0e38f, -3.0e38f };
@@ -580,14 +587,17 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     FusedPlan fp;
     pt_status rc_ = ptw_plan_fused(s, pl, p_in->tmin, fp);
     if (rc_ != PT_OK) return rc_;
+    int32_t rect[4];
+    fused_subject_rect(s, p_in, fp, rect);
+    const bool have_rect = rect[2] >= rect[0] && rect[3] >= rect[1];
     pt_params q;
-    fused_shape_defaults(f, p_in, fp, q);
+    fused_shape_defaults(f, p_in, fp, rect, q);
     const pt_params *p = &q;
     RenderShape sh;
     // HEAD + TAIL slots (fused_kernel.h MODE 2): where the library picks the groups itself and the launch holds few frames, a pixel's frame is one
     // head slot of spp - S samples and S one-sample tail slots -- the launch ends with short work and only the tail's radiance terms go through
     // the log (see fused_tail_samples for S).
-    const uint32_t tail = (!fp.inst && !nested && p_in->sample_groups == 0) ? fused_tail_samples(ctx, f, p_in, q.frames_in_flight) : 0u;
+    const uint32_t tail = (!fp.inst && !nested && p_in->sample_groups == 0) ? fused_tail_samples(ctx, f, p_in, q.frames_in_flight, rect) : 0u;
     if (tail) {
         q.sample_groups = 1;
         sh = RenderShape{};
@@ -601,7 +611,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
         sh.bounded = sh.term_cap < worst;
         rc_ = ptw_ensure_work(f, p->rank, p->world, sh.lanes, 1, sh.term_cap, sh.term_pcap, false, tail);
         if (rc_ == PT_ERR_OOM) {  // (no room for the logs: the plain shape)
-            fused_shape_defaults(f, p_in, fp, q);
+            fused_shape_defaults(f, p_in, fp, rect, q);
             sh = RenderShape{};
         }
     }
@@ -628,10 +638,9 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     if (rc_ != PT_OK) return rc_;
     ctx->stats.workspace_bytes = ptw_workspace_bytes(f);
     if (prepare_only) return PT_OK;
-    if (!nested) {
-        int32_t rect[4];
-        fused_subject_rect(s, p, fp, rect);
-        rc_ = ptw_tiles_subject_first(f, rect, st);
+    {
+        const int32_t none[4] = { 0, 0, -1, -1 };
+        rc_ = ptw_tiles_subject_first(f, ctx->tune.fused_subject == 0 ? none : rect, st);
         if (rc_ != PT_OK) return rc_;
     }
     pt_film::Work &w = f->work;
@@ -640,6 +649,18 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);
     Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
     RenderConst rc = ptw_render_const(p, w, sh);
+    // Pixels outside the rectangle cannot see the scene: their slots are finished where they are handed out (wavefront_types.h RenderConst::cull;
+    // pt_tuning.fused_cull = 0: every camera ray is walked).  The sum a slot without a log stores is the reference's sequence of adds, done here.
+    if (have_rect && ctx->tune.fused_cull != 0 && std::isfinite(p->env[0]) && std::isfinite(p->env[1]) && std::isfinite(p->env[2])) {
+        rc.cull_on = 1u;
+        std::copy(rect, rect + 4, rc.cull);
+        const uint32_t n = sh.tail ? rc.head_samples : p->spp_per_frame;
+        for (int k = 0; k < 3; k++) {
+            volatile float c = 0.0f;  // (volatile: one rounded float add per sample, nothing folded)
+            for (uint32_t i = 0; i < n; i++) c = c + 1.0f * p->env[k];
+            rc.cull_sum[k] = c;
+        }
+    }
     const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;
     ctx->stats.extend_variant = pl.variant;
     ctx->stats.pipelines = 1;

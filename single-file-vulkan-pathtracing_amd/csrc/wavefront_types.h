@@ -63,6 +63,13 @@ struct RenderConst {
     // slot - n_head and hold n_tail slots.  The heads go first and are long; the tails fill the end of the launch with short work.
     uint32_t tail, head_samples, n_head, n_tail;
     FastDiv div_tail;
+    // PT_PIPELINE_FUSED, single-level scenes: camera rays that cannot reach the scene.  cull_on: every primary ray of a pixel OUTSIDE the pixel
+    // rectangle cull = {x0, y0, x1, y1} (the projection of the scene's box, a pixel of slack: render.hip fused_subject_rect) misses the box and
+    // with it every triangle, so such a slot is finished where it is handed out: each of its samples is one ray (counted) whose miss adds
+    // 1 * env (raygen.rgen:59, 76; miss.rmiss:10) -- cull_sum = that add done head_samples (head + tail) or spp times, what a slot without a log stores.
+    uint32_t cull_on;
+    int32_t cull[4];
+    float cull_sum[3];
 };
 
 // Where a slot's radiance goes.  groups == 1: one accumulator per slot, added to in path order

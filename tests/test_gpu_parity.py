@@ -2307,33 +2307,48 @@ def test_fused_subject_first_order_changes_no_bit(pt, orc, gpu_ctx, cornell_gpu,
     """The fused pipeline hands out first the tiles the scene's box projects to (render.hip fused_subject_rect, film_work.hip
     ptw_tiles_subject_first; pt_tuning.fused_subject = 0: centre first only).  Order only: for views with the box pushed to a side or a corner,
     far away, off the image, and with the camera inside or behind the box (no rectangle), the film, the rgba8 image and the ray count are the
-    oracle's with and without it, for the plain, the all-groups and the head + tail shape, and when the view changes between calls on one film."""
+    oracle's with and without it, for the plain, the all-groups and the head + tail shape, and when the view changes between calls on one film.
+    The same rectangle is a proof: a pixel outside it (by a pixel of slack) cannot see the scene, and the kernel finishes its slots where it hands
+    them out -- every sample one counted ray whose miss adds the environment (pt_tuning.fused_cull, pt_stats.rays_culled).  Same bits, same rays."""
     w, h, spp = 136, 72, 4
     views = [dict(), dict(cam_origin=(1.1, -1.0, 5.0), cam_target=(1.1, -1.0, 2.0)), dict(cam_origin=(1.0, -0.2, 5.0), cam_target=(1.0, -0.2, 2.0)),
              dict(cam_origin=(0.0, -1.0, 9.0), cam_target=(0.0, -1.0, 6.0)), dict(cam_origin=(3.5, -1.0, 5.0), cam_target=(3.5, -1.0, 2.0)),
              dict(cam_origin=(0.0, -1.0, 0.5), cam_target=(0.0, -1.0, -2.5)), dict(cam_origin=(0.0, -1.0, -5.0), cam_target=(0.0, -1.0, -8.0)),
              dict(cam_origin=(0.0, -1.0, 5.0), cam_target=(0.0, -1.0, 8.0))]
     film = pt.Film(gpu_ctx, w, h)        # one film for every view: the tile table is re-ordered when the rectangle changes
+    n_culled = []
     for cam in views:
         kw = dict(width=w, height=h, spp_per_frame=spp, max_depth=6, **cam)
         ofilm, obgra, orays = _render_oracle(orc, cornell_oracle, 2, **kw)
-        for subject in (1, 0, -1):
-            for knobs, shape in ((dict(fused_tail=0), dict(sample_groups=1)), (dict(fused_tail=0), dict(sample_groups=spp)), (dict(fused_tail=2), dict())):
-                old = gpu_ctx.set_tuning(fused_subject=subject, **knobs)
+        culled = set()
+        for subject, cull in ((1, 1), (0, 1), (-1, -1), (1, 0), (0, 0)):
+            for knobs, shape in ((dict(fused_tail=0), dict(sample_groups=1)), (dict(fused_tail=0), dict(sample_groups=spp)), (dict(fused_tail=0), dict(sample_groups=3)),
+                                 (dict(fused_tail=2), dict())):
+                old = gpu_ctx.set_tuning(fused_subject=subject, fused_cull=cull, **knobs)
                 try:
                     film.clear()
                     gpu_ctx.reset_stats()
                     pt.render(cornell_gpu, film, pt.default_params(frame=0, frame_count=2, pipeline=pt.PIPELINE_FUSED, **kw, **shape))
-                    assert gpu_ctx.stats().rays == orays, (cam, subject, shape)
-                    assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes(), (cam, subject, shape)
+                    st = gpu_ctx.stats()
+                    assert st.rays == orays, (cam, subject, cull, shape)
+                    assert film.read_f32().tobytes() == ofilm.tobytes() and film.read_bgra8().tobytes() == obgra.tobytes(), (cam, subject, cull, shape)
+                    # pt_stats.rays_culled: camera rays finished without a walk -- whole pixels' worth, the same for every shape, none with the knob off
+                    assert st.rays_culled % (2 * spp) == 0 and st.rays_culled <= w * h * spp * 2 and (cull != 0 or st.rays_culled == 0)
+                    if cull != 0:
+                        culled.add(st.rays_culled)
                 finally:
                     gpu_ctx.set_tuning(**old)
+        assert len(culled) == 1, (cam, culled)
+        n_culled.append(culled.pop())
     film.close()
+    # the reference's view leaves a quarter of this small image's pixels outside the box's projection; the far box most of them; a camera inside
+    # the box, behind it or looking away has no rectangle to cull by
+    assert 0 < n_culled[0] < n_culled[3] and n_culled[5] == n_culled[6] == n_culled[7] == 0, n_culled
 
 
 def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cornell_gpu):
     """The library's own head + tail rule (render.hip fused_tail_samples: by head slots per lane of the grid) at 1920x1080, 32 spp: one frame
-    per call takes spp / 2 tail samples, two frames 3 spp / 8, four frames none -- and each call's film is the oracle's known answer
+    per call takes spp / 2 tail samples, two frames 3 spp / 8, four frames spp / 8 -- and each call's film is the oracle's known answer
     (tests/golden/fullsize_hashes.json: C2's frame 0, C3 after frames 1 and 3) whatever the shape."""
     import hashlib
     import json
@@ -2347,6 +2362,8 @@ def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cor
     st = gpu_ctx.stats()
     assert st.pipeline == pt.PIPELINE_FUSED and st.tail_samples == spp // 2 and st.rays == g2["rays"]
     assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == g2["film_sha256"]
+    # 44 % of the reference's image lies outside the box's projection (raygen.rgen:52-53 has no aspect correction): 901 676 pixels' camera rays
+    assert st.rays_culled == 901676 * spp
     if g3 is not None and "1" in g3["after_frame"]:
         film.clear()
         gpu_ctx.reset_stats()
@@ -2359,7 +2376,7 @@ def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cor
         gpu_ctx.reset_stats()
         pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=4, **kw))
         st, m = gpu_ctx.stats(), g3["after_frame"]["3"]
-        assert st.tail_samples == 0 and st.rays == m["rays_so_far"]
+        assert st.tail_samples == spp // 8 and st.rays == m["rays_so_far"] and st.rays_culled == 4 * 901676 * spp
         assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
         # a rank of world 8 with 16 frames in flight holds as many slots as two whole frames: the same rule
         film.clear()
