@@ -410,26 +410,32 @@ def fused_roofline_block(st, mean_len, config, kernel):
     (`binding_bound`: wave-instructions per 64 rays of the committed SQ_INSTS_VALU pass x this run's ray rate / the chip's 2-cycle issue peak)."""
     bytes_ray = BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len
     launches = max(st.launches_extend, 1)
-    gbs = bytes_ray * st.rays / (st.ms_extend * 1e-3) / 1e9
+    # rays the kernel WALKS: camera rays of pixels outside the scene box's projection are finished where their slot is handed out (pt_stats.rays_culled;
+    # counted in `value` because the reference traces them, raygen.rgen:62) -- they gather no node and are priced at no byte and no instruction here
+    culled = int(getattr(st, "rays_culled", 0))
+    walked = st.rays - culled
+    gbs = bytes_ray * walked / (st.ms_extend * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": kernel, "variant": "fused: traversal and shading in one persistent kernel, path state in LDS / registers; HBM sees 16 B per slot (or per logged term)",
          "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
-         "launches": st.launches_extend, "rays_per_launch": round(st.rays / launches, 1), "avg_launch_us": round(st.ms_extend * 1e3 / launches, 3),
-         "algorithmic_bytes_per_ray": round(bytes_ray, 1), "algorithmic_bytes_per_launch": round(bytes_ray * st.rays / launches, 1),
+         "launches": st.launches_extend, "rays_per_launch": round(st.rays / launches, 1), "rays_walked_per_launch": round(walked / launches, 1),
+         "rays_culled_per_launch": round(culled / launches, 1), "avg_launch_us": round(st.ms_extend * 1e3 / launches, 3),
+         "algorithmic_bytes_per_ray": round(bytes_ray, 1), "algorithmic_bytes_per_launch": round(bytes_ray * walked / launches, 1),
          "note": "SURVEY 8d prices a fused variant by the wavefront design's algorithmic bytes (40 extend + 104 shade + 96 per path / mean path length) so that designs "
-                 "compare: the kernel moves none of them -- see traffic / frac_counted for what HBM sees and binding_bound for the bound that binds (VALU issue)"}
+                 "compare: the kernel moves none of them -- see traffic / frac_counted for what HBM sees and binding_bound for the bound that binds (VALU issue).  "
+                 "Only WALKED rays are priced (rays_walked_per_launch): rays_culled_per_launch are camera rays of pixels that cannot see the scene, finished without a walk"}
     prof = os.path.join(REPO, "profiles", PMC_RECORD_FUSED.get(kernel, ""))
     if os.path.isfile(prof):
         try:
             pmc = json.load(open(prof))
             per64 = pmc["valu_wave_instr_per_64_rays"]
-            rays_per_s = st.rays / (st.ms_extend * 1e-3)
+            rays_per_s = walked / (st.ms_extend * 1e-3)
             r["binding_bound"] = {"kind": "valu_issue", "valu_wave_instr_per_64_rays": round(per64, 1),
                                   "valu_active_lanes_per_instr": round(pmc.get("valu_active_lanes_per_instr", 0.0), 1),
                                   "wave_instr_per_s": round(per64 / 64.0 * rays_per_s, 1), "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
                                   "frac": round(per64 / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4),
-                                  "source": f"SQ_INSTS_VALU per ray of {os.path.relpath(prof, REPO)} x this run's rays per second / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op)"}
-            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * st.rays / launches, 1)
-            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+                                  "source": f"SQ_INSTS_VALU per WALKED ray of {os.path.relpath(prof, REPO)} x this run's walked rays per second / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op)"}
+            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * walked / launches, 1)
+            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * walked / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
         except Exception:
             pass
     return r
@@ -895,6 +901,10 @@ def main():
             "reps": len(reps), "value_min": min(values), "value_max": max(values), "values": values,
             "timed_seconds_total": round(sum(r[0] for r in reps), 4),
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
+            # (rank 0's share) camera rays of pixels outside the scene box's projection: counted in `value` -- the reference traces them, raygen.rgen:62 --
+            # and finished by the fused kernel without a walk (pt_tuning.fused_cull); value_walked_only prices the step by the walked rays alone
+            "rays_culled_rank0": int(getattr(st, "rays_culled", 0)),
+            "value_walked_only": round((st.rays - int(getattr(st, "rays_culled", 0))) / max(st.rays, 1) * rays_total / dt / 1e6, 2),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "workspace_bytes": st.workspace_bytes,
             "bvh": {"triangles": info.n_tris, "nodes": info.n_nodes, "height": info.bvh_height,
@@ -980,15 +990,19 @@ def main():
             pt.render_prepare(scene, film, exact)
             pt.render(scene, film, exact)                          # warm-up of this shape
             film.clear()
-            ctx.reset_stats()
             torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            pt.render(scene, film, exact)
-            d2 = time.perf_counter() - t0
+            d2s = []
+            for _ in range(5):                                     # (frame 0 starts the film over: the same two frames five times, the median call)
+                ctx.reset_stats()
+                t0 = time.perf_counter()
+                pt.render(scene, film, exact)
+                d2s.append(time.perf_counter() - t0)
             s2 = ctx.stats()
+            d2 = sorted(d2s)[len(d2s) // 2]
             out["c2_exact"] = {"workload": f"BASELINE config C2 exactly: {W}x{H}, 64 spp = 2 frames x 32, {args.depth} bounces, one pt_render",
                                "mrays_per_s": round(s2.rays / d2 / 1e6, 2), "ms_total": round(d2 * 1e3, 3), "ms_per_frame": round(d2 * 1e3 / 2, 3),
-                               "rays": s2.rays, "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups,
+                               "ms_total_calls": [round(x * 1e3, 3) for x in d2s],
+                               "rays": s2.rays, "frames_in_flight": s2.frames_in_flight, "sample_groups": s2.sample_groups, "tail_samples": s2.tail_samples,
                                "pipeline": pt.PIPELINE_NAMES.get(s2.pipeline) + " (PT_PIPELINE_AUTO, what pt_params_default gives a caller)"}
             one = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, frame_count=1)
             pt.render_prepare(scene, film, pt.default_params(frame=0, **one))
@@ -1005,7 +1019,7 @@ def main():
             out["latency_ms_1frame"] = round(lat[len(lat) // 2], 3)
             out["latency_1frame"] = {"median_ms": round(lat[len(lat) // 2], 3), "min_ms": round(lat[0], 3), "max_ms": round(lat[-1], 3),
                                      "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 2), "frames": len(lat),
-                                     "sample_groups": s1.sample_groups, "workspace_bytes": s1.workspace_bytes,
+                                     "sample_groups": s1.sample_groups, "tail_samples": s1.tail_samples, "workspace_bytes": s1.workspace_bytes,
                                      "pipeline": pt.PIPELINE_NAMES.get(s1.pipeline) + " (PT_PIPELINE_AUTO, what pt_params_default gives a caller)",
                                      "shape": "K = 1: one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle, main.cpp:656-683)"}
             if ran == "wavefront" and scene_config == "c2":

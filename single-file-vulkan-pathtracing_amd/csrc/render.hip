@@ -654,7 +654,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     if (have_rect && ctx->tune.fused_cull != 0 && std::isfinite(p->env[0]) && std::isfinite(p->env[1]) && std::isfinite(p->env[2])) {
         rc.cull_on = 1u;
         std::copy(rect, rect + 4, rc.cull);
-        const uint32_t n = sh.tail ? rc.head_samples : p->spp_per_frame;
+        const uint32_t n = p->spp_per_frame;  // (also with head + tail slots: the head of such a pixel stands for all its samples)
         for (int k = 0; k < 3; k++) {
             volatile float c = 0.0f;  // (volatile: one rounded float add per sample, nothing folded)
             for (uint32_t i = 0; i < n; i++) c = c + 1.0f * p->env[k];

@@ -465,7 +465,9 @@ __global__ __launch_bounds__(TB) void k_resolve(RenderConst rc, const uint32_t *
         if (rc.groups == 1u) {
             c = rad.color[(size_t)f * rc.slots_per_lane + local];
         }
-        if (rc.groups > 1u || rc.tail) {  // replay the groups' (or, behind a head slot's accumulator, the one-sample tail slots') term logs in sample order: the reference's sequence of adds
+        // (head + tail with the cull: the head slot of a pixel outside the rectangle holds all its samples, its tail slots were never written)
+        const bool no_tails = rc.tail && rc.cull_on && ((int32_t)px < rc.cull[0] || (int32_t)px > rc.cull[2] || (int32_t)py < rc.cull[1] || (int32_t)py > rc.cull[3]);
+        if ((rc.groups > 1u || rc.tail) && !no_tails) {  // replay the groups' (or, behind a head slot's accumulator, the one-sample tail slots') term logs in sample order: the reference's sequence of adds
             const uint32_t n_logs = rc.tail ? rc.tail : rc.groups;
             const size_t log_slots = rc.tail ? rc.n_tail : rc.n_slots;
             for (uint32_t g = 0; g < n_logs; g++) {

@@ -66,7 +66,8 @@ struct RenderConst {
     // PT_PIPELINE_FUSED, single-level scenes: camera rays that cannot reach the scene.  cull_on: every primary ray of a pixel OUTSIDE the pixel
     // rectangle cull = {x0, y0, x1, y1} (the projection of the scene's box, a pixel of slack: render.hip fused_subject_rect) misses the box and
     // with it every triangle, so such a slot is finished where it is handed out: each of its samples is one ray (counted) whose miss adds
-    // 1 * env (raygen.rgen:59, 76; miss.rmiss:10) -- cull_sum = that add done head_samples (head + tail) or spp times, what a slot without a log stores.
+    // 1 * env (raygen.rgen:59, 76; miss.rmiss:10) -- cull_sum = that add done spp times, what a slot without a log stores (head + tail: the head slot
+    // stands for all spp samples of such a pixel and k_resolve skips its tail logs; several groups: every group logs its samples' terms).
     uint32_t cull_on;
     int32_t cull[4];
     float cull_sum[3];
