@@ -38,6 +38,8 @@ pl = lambda c: e.get(c + "_per_launch", 0.0)
 blocks = [bench.get(k) for k in ("roofline", "roofline_extend", "roofline_shade", "roofline_wavefront") if isinstance(bench.get(k), dict)]
 mine = next((b for b in blocks if str(b.get("kernel", "")).startswith(prefix.split("<")[0])), blocks[0])
 rays_per_launch = bench["rays"] / mine["launches"]   # (a shade launch handles the rays of the extend launch before it)
+if mine.get("rays_walked_per_launch"):               # the fused kernel: per WALKED ray (camera rays of pixels that cannot see the scene are finished without a walk)
+    rays_per_launch = mine["rays_walked_per_launch"]
 avg_us = kt["avg_ns"] / 1e3
 rec = {
     "kernel": name, "config": cfg,

@@ -23,6 +23,8 @@ extern "C" int pt_debug_fused_hist(void *device_u32_2x8192x16)
 }
 #endif
 
+#include "fused_cull.h"
+
 namespace {
 using namespace ptw;
 #include "fused_kernel.h"

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
     const int lane = threadIdx.x & 63;
 
     bool have = false, path = false, out_of_slots = false, in_blas = false;
-    uint32_t n_rays_wave = 0;
+    uint32_t n_rays_wave = 0, n_cull_wave = 0;
     uint32_t w_next = 0, w_end = 0, w_base = 0;
     uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;
     const uint32_t part_len = ((n_slots + PT_FUSED_PARTS - 1) / PT_FUSED_PARTS + 63u) & ~63u;
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                 }
                 const uint32_t take = min((uint32_t)__popcll(m_want), w_end - w_next);
                 const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
+                uint32_t cull_n = 0u;  // samples of a slot that is finished here: its pixel cannot see the scene (fused_cull.h)
                 if (in_blk && !path && rank < take) {
                     const uint32_t mine = w_next + rank;
                     slot = slot_base + mine;
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     const uint32_t tw = s_wtile[(mine - w_base) >> 6];
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
                     const uint32_t sample0 = g * rc.group_size;
-                    if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
+                    const bool in_image = px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp;
+                    if (in_image && ptc::pixel_culled(rc, px, py)) {
+                        cull_n = GROUPED ? ptc::finish_group(rc, rad, slot, g) : ptc::finish_plain(rc, rad, slot);
+                    } else if (in_image) {
                         pxy = px | (py << 16);
                         ctr = sample0;
                         my_state[FS_A * FITB] = 0u;
@@ -292,6 +296,11 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     }
                 }
                 w_next += take;
+                if (rc.cull_on) {
+                    const uint32_t n_c = ptc::rays_finished<GROUPED>(rc, cull_n);
+                    n_rays_wave += n_c;
+                    n_cull_wave += n_c;
+                }
             }
             // (3) camera ray of a slot's next (or first) sample
             if (need_primary) {
@@ -422,4 +431,5 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
         }
     }
     if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);
+    if (lane == 0 && n_cull_wave) atomicAdd(stats + 19, (unsigned long long)n_cull_wave);  // (pt_stats.rays_culled)
 }

@@ -346,19 +346,12 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     const uint32_t px = (tw & 0xFFFFu) * 8u + (local & 7u), py = (tw >> 16) * 8u + ((local >> 3) & 7u);
                     const uint32_t sample0 = (HYB && w_tails) ? rc.head_samples + g : g * rc.group_size;
                     const bool in_image = px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp;
-                    if (in_image && rc.cull_on && ((int32_t)px < rc.cull[0] || (int32_t)px > rc.cull[2] || (int32_t)py < rc.cull[1] || (int32_t)py > rc.cull[3])) {
-                        // every sample of the slot: one camera ray, a miss, color += 1 * env -- without the walk that would find nothing
-                        if (GROUPED) {
-                            const float4 e = make_float4(rc.env[0], rc.env[1], rc.env[2], 0.f);
-                            cull_n = min(rc.spp, (g + 1u) * rc.group_size) - sample0;
-                            for (uint32_t k = 0; k < cull_n; k++) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), e);  // (cull_n <= group_size <= term_pcap)
-                            rad.nterm[slot] = cull_n;
-                        } else if (!(HYB && w_tails)) {
-                            // (head + tail: the head slot stands for ALL spp samples of such a pixel -- the same adds in the same order -- and its
-                            // tail slots are nothing: k_resolve does not replay the logs of a pixel outside the rectangle)
-                            cull_n = rc.spp;
-                            rad.color[slot] = make_float4(rc.cull_sum[0], rc.cull_sum[1], rc.cull_sum[2], 0.f);
-                        }
+                    if (in_image && ptc::pixel_culled(rc, px, py)) {
+                        // every sample of the slot: one camera ray, a miss, color += 1 * env -- without the walk that would find nothing (fused_cull.h)
+                        if (GROUPED) cull_n = ptc::finish_group(rc, rad, slot, g);
+                        else if (!(HYB && w_tails)) cull_n = ptc::finish_plain(rc, rad, slot);
+                        // (head + tail: the head slot stands for ALL spp samples of such a pixel -- the same adds in the same order -- and its
+                        // tail slots are nothing: k_resolve does not replay the logs of a pixel outside the rectangle)
                     } else if (in_image) {
                         pxy = px | (py << 16);
                         ctr = sample0;
@@ -377,9 +370,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 }
                 w_next += take;
                 if (rc.cull_on) {  // (wave-uniform: the rays of the slots finished above, counted as the rays they are)
-                    const uint32_t n_a = HYB ? rc.spp : rc.group_size;
-                    uint32_t n_c = (uint32_t)__popcll(__ballot(cull_n == n_a)) * n_a;
-                    if (GROUPED) n_c += (uint32_t)__popcll(__ballot(cull_n != 0u && cull_n != n_a)) * (rc.spp - (rc.groups - 1u) * rc.group_size);
+                    const uint32_t n_c = ptc::rays_finished<GROUPED>(rc, cull_n);
                     n_rays_wave += n_c;
                     n_cull_wave += n_c;
                 }

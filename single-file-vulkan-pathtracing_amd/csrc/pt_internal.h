@@ -128,6 +128,7 @@ struct pt_scene {
     uint4 *d_tlas16 = nullptr;
     uint32_t n_tlas16 = 0, tlas16_levels = 0;
     float tlas_norm_c[3]{}, tlas_norm_s[3]{1.f, 1.f, 1.f}, tlas_norm_rs[3]{1.f, 1.f, 1.f};
+    float tlas_bmin[3]{}, tlas_bmax[3]{};  // the union of the instances' world boxes (k_inst_boxes): what no ray outside of can hit
 };
 
 struct pt_film {

@@ -496,7 +496,7 @@ uint32_t fused_slots_x32(const pt_ctx *ctx, const pt_film *f, const pt_params *p
     return (uint32_t)std::min<uint64_t>(heads * 32ull / grid_lanes, 1u << 24);
 }
 
-void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan &, const int32_t rect[4], pt_params &q)
+void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan &fp, const int32_t rect[4], pt_params &q)
 {
     q = *p;
     if (q.frames_in_flight == 0) {
@@ -514,6 +514,11 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
         uint32_t g = 1;
         if (x32 < 36u || (q.frames_in_flight < 2u && x32 <= 324u))
             while (g < p->spp_per_frame && (g < 32u || p->spp_per_frame % g)) g++;
+        // two-level scenes have no head + tail form: up to four walked slots per lane their slots are cut in eight (the smallest divisor of spp
+        // that is >= 8).  The 10 000-instance grid, ms per frame with 1 / 8 / 32 groups: 2 frames 12.90 / 11.57 / 11.76, 4 frames 11.18 / 11.28 /
+        // 11.60 (profiles/r05zk_c4_shapes.log)
+        else if (fp.inst && x32 <= 130u)
+            while (g < p->spp_per_frame && (g < 8u || p->spp_per_frame % g)) g++;
         q.sample_groups = g;
     }
 }
@@ -547,17 +552,17 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
 // raygen.rgen:51-57 shoots from cam_origin through (target.x + dx, target.y + dy, target.z), dx, dy in [-1, 1] across the image: a point P in
 // front of the origin lands at dx = o.x + (P.x - o.x) (t.z - o.z) / (P.z - o.z) - t.x.  A box is convex, so its image lies inside the bounding
 // rectangle of its corners' images.  No rectangle (x1 < x0) when a corner is not in front of the origin (the camera is inside or beside the
-// box) and for two-level scenes (no world box kept).  Used twice: as a guess about cost (the hand-out order) and as a proof (the cull below):
+// box).  Used twice: as a guess about cost (the hand-out order) and as a proof (the cull below):
 // the pixel of slack on every side is far above the rounding of this projection and of raygen's own.
 void fused_subject_rect(const pt_scene *s, const pt_params *p, const FusedPlan &fp, int32_t rect[4])
 {
     rect[0] = rect[1] = 0; rect[2] = rect[3] = -1;
-    if (fp.inst || s->n_inst) return;
+    const float *bmin = s->n_inst ? s->tlas_bmin : s->bmin, *bmax = s->n_inst ? s->tlas_bmax : s->bmax;  // (two-level: the union of the instances' world boxes)
     const float den = p->cam_target[2] - p->cam_origin[2];
     if (!(std::fabs(den) > 0.f)) return;
     float lo[2] = { 3.0e38f, 3.0e38f }, hi[2] = { -3.0e38f, -3.0e38f };
     for (int c = 0; c < 8; c++) {
-        const float P[3] = { (c & 1) ? s->bmax[0] : s->bmin[0], (c & 2) ? s->bmax[1] : s->bmin[1], (c & 4) ? s->bmax[2] : s->bmin[2] };
+        const float P[3] = { (c & 1) ? bmax[0] : bmin[0], (c & 2) ? bmax[1] : bmin[1], (c & 4) ? bmax[2] : bmin[2] };
         const float a = (P[2] - p->cam_origin[2]) / den;  // how far along the view axis the corner is, in units of the image plane's distance
         if (!(a > 1.0e-4f)) return;
         for (int k = 0; k < 2; k++) {

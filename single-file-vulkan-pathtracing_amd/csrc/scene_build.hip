@@ -634,6 +634,7 @@ pt_status ptb_set_instances(pt_scene *s, const float *xforms3x4, uint32_t n)
     s->tlas_area_lbvh = o.area_lbvh; s->tlas_area_ploc = o.area_ploc;
     s->d_tlas16 = o.d_wide16t; s->n_tlas16 = o.n_wide16t; s->tlas16_levels = o.levels4t;
     for (int k = 0; k < 3; k++) { s->tlas_norm_c[k] = o.norm_c[k]; s->tlas_norm_s[k] = o.norm_s[k]; s->tlas_norm_rs[k] = o.norm_rs[k]; }
+    for (int k = 0; k < 3; k++) { s->tlas_bmin[k] = o.bmin[k]; s->tlas_bmax[k] = o.bmax[k]; }
     if (rc != PT_OK) { ptb_free_instances(s); return rc; }
     PT_HIP(ctx, hipMalloc((void **)&s->d_inst6, sizeof(float4) * 6 * (size_t)n));
     // (the emitters' world-space copies for the NEE pipeline are made on that pipeline's first render: ptb_ensure_inst_lights)
