@@ -173,7 +173,13 @@ def count_visits(pt, ctx, scene, W, H, common, frames=1, frame0=False):
     shipped kernels for the film / ray-count comparison."""
     scratch = pt.Film(ctx, W, H)
     ctx.reset_stats()
-    pt.render(scene, scratch, pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_COUNT_VISITS, **common))
+    # (an instrumented render walks every ray unless pt_tuning.cull = 1 says otherwise: here the counts have to be those of the rays the TIMED
+    # kernels walk -- cst.rays still holds every ray, walked_rays(cst) the walked ones)
+    old = ctx.set_tuning(cull=1)
+    try:
+        pt.render(scene, scratch, pt.default_params(frame=0, frame_count=frames, flags=pt.FLAG_COUNT_VISITS, **common))
+    finally:
+        ctx.set_tuning(**old)
     cst = ctx.stats()
     film, rays0 = None, None
     if frame0:
@@ -200,14 +206,21 @@ def valu_model(cst, kernel):
         total += waves * b["valu"]
         lanes += ln * b["valu"]
         counts[name] = {"waves": waves, "lanes_per_wave": round(ln / waves, 1) if waves else None, "valu": b["valu"]}
-    return {"wave_instr": total, "per_64_rays": total / max(cst.rays, 1) * 64.0, "lanes_per_instr": lanes / max(total, 1.0),
+    return {"wave_instr": total, "per_64_rays": total / max(walked_rays(cst), 1) * 64.0, "lanes_per_instr": lanes / max(total, 1.0),
             "revision": m.get("revision"), "blocks": counts}
+
+
+def walked_rays(st):
+    """Rays of a render that a kernel walked: pt_stats.rays less the camera rays of pixels that cannot see the scene, which every pipeline finishes
+    without a walk (pt_stats.rays_culled; counted in `value` because the reference traces them, raygen.rgen:62).  The roofline blocks price only
+    these, with per-ray averages of an instrumented run that walks the same rays (count_visits)."""
+    return st.rays - int(getattr(st, "rays_culled", 0) or 0)
 
 
 def roofline_block(pt, st, cst, info, config, note):
     """`roofline` for the dominant kernel (the closest-hit traversal) of a leg: every number from this run."""
-    nodes_per_ray = cst.nodes_visited / max(cst.rays, 1)
-    tris_per_ray = cst.tris_tested / max(cst.rays, 1)
+    nodes_per_ray = cst.nodes_visited / max(walked_rays(cst), 1)   # (per WALKED ray: count_visits instruments the walked rays only)
+    tris_per_ray = cst.tris_tested / max(walked_rays(cst), 1)
     node_occ = cst.nodes_visited / (64.0 * cst.node_steps) if cst.node_steps else None
     leaf_occ = cst.leaf_lanes / (64.0 * cst.tri_steps) if cst.tri_steps else None
     scene_bytes = info.device_bytes
@@ -217,15 +230,16 @@ def roofline_block(pt, st, cst, info, config, note):
     node_bytes = 64.0
     gather = (nodes_per_ray * node_bytes + tris_per_ray * 36.0) if scene_bytes > (32 << 20) else 0.0
     bytes_extend = BYTES_EXTEND + gather
-    gbs = bytes_extend * st.rays / (st.ms_extend * 1e-3) / 1e9
+    gbs = bytes_extend * walked_rays(st) / (st.ms_extend * 1e-3) / 1e9
     kernel = extend_kernel_name(pt, st, info, config)
     r = {
         "bound": "hbm", "kernel": kernel,
         "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
         "traffic": None,
-        "launches": st.launches_extend, "rays_per_launch": round(st.rays / st.launches_extend, 1),
+        "launches": st.launches_extend, "rays_per_launch": round(walked_rays(st) / st.launches_extend, 1),
+        "rays_culled_per_launch": round((st.rays - walked_rays(st)) / st.launches_extend, 1),   # (finished by k_generate, never queued: not priced here)
         "avg_launch_us": round(st.ms_extend * 1e3 / st.launches_extend, 3),
-        "algorithmic_bytes_per_launch": round(bytes_extend * st.rays / st.launches_extend, 1),
+        "algorithmic_bytes_per_launch": round(bytes_extend * walked_rays(st) / st.launches_extend, 1),
         "algorithmic_bytes_per_ray": round(bytes_extend, 1),
         "gather": {"bvh_nodes_per_ray": round(nodes_per_ray, 2), "node_bytes": node_bytes, "tris_per_ray": round(tris_per_ray, 2),
                    "bytes_per_ray": round(gather, 1), "scene_device_bytes": scene_bytes,
@@ -243,10 +257,10 @@ def roofline_block(pt, st, cst, info, config, note):
     if os.path.exists(prof):
         try:
             pmc = json.load(open(prof))
-            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * st.rays / st.launches_extend, 1)
+            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * walked_rays(st) / st.launches_extend, 1)
             # the counter side of `frac`: counted HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE: MALL hits included) instead of
             # algorithmic ones over the same launch time -- what "rocprof HBM GB/s against the chip's peak" reads
-            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * st.rays / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * walked_rays(st) / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             r["pmc_profile"] = {k: (round(pmc[k], 3) if isinstance(pmc[k], float) else pmc[k]) for k in
                                 ("hbm_bytes_per_ray", "hbm_read_requests_per_ray", "valu_issue_frac", "valu_wave_instr_per_64_rays",
                                  "valu_active_lanes_per_instr", "wait_any_fraction_of_wave_cycles", "l2_hit_rate", "rocprof_avg_launch_us") if k in pmc}
@@ -255,7 +269,7 @@ def roofline_block(pt, st, cst, info, config, note):
             pass
     vm = valu_model(cst, kernel)
     if vm:
-        rays_per_s = st.rays / (st.ms_extend * 1e-3)   # the kernel's own rate (its launches overlap the other pipeline's shade)
+        rays_per_s = walked_rays(st) / (st.ms_extend * 1e-3)   # the kernel's own rate (its launches overlap the other pipeline's shade)
         r["valu_wave_instr_per_64_rays"] = round(vm["per_64_rays"], 1)
         r["valu_active_lanes_per_instr"] = round(vm["lanes_per_instr"], 1)
         r["valu_frac"] = round(vm["per_64_rays"] / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4)
@@ -356,14 +370,14 @@ def roofline_shade_block(st, config):
     committed PMC pass x this run's rays per launch, like the traversal kernel's."""
     if not st.launches_shade or not st.ms_shade:
         return None
-    rays_per_launch = st.rays / st.launches_shade
+    rays_per_launch = walked_rays(st) / st.launches_shade
     avg_us = st.ms_shade * 1e3 / st.launches_shade
     gbs = BYTES_SHADE * rays_per_launch / (avg_us * 1e-6) / 1e9
     r = {"bound": "hbm", "kernel": "k_shade", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
          "traffic": None, "launches": st.launches_shade, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_us": round(avg_us, 3),
          "algorithmic_bytes_per_ray": BYTES_SHADE, "algorithmic_bytes_per_launch": round(BYTES_SHADE * rays_per_launch, 1),
          # the same bytes over the device time of the whole timed region (the launches of the pipelines overlap)
-         "frac_all_launches_over_device_time": round(BYTES_SHADE * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+         "frac_all_launches_over_device_time": round(BYTES_SHADE * walked_rays(st) / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
          "pipelines": st.pipelines, "shade_ms": round(st.ms_shade, 3),
          "note": "memory-latency bound: dense coalesced queue streams in and out + the scattered radiance term log; see pmc_profile"}
     prof = os.path.join(REPO, "profiles", PMC_RECORD_SHADE.format(config=config))
@@ -386,7 +400,7 @@ def wavefront_roofline_blocks(pt, st, cst, info, config, note, mean_len):
     """(`roofline` of the traversal kernel, `roofline_shade`) of a timed wavefront render: every factor from that render's per-launch events."""
     r = roofline_block(pt, st, cst, info, config, note)
     bytes_extend = r["algorithmic_bytes_per_ray"]
-    pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * st.rays
+    pipeline_bytes = (bytes_extend + BYTES_SHADE + BYTES_PER_PATH / mean_len) * walked_rays(st)
     r["pipeline_algorithmic_GBps"] = round(pipeline_bytes / (st.ms_total * 1e-3) / 1e9, 2)
     # SURVEY 8d's canonical whole-pipeline figure: (extend + 104 shade + 96 per path / mean length) B per ray over the
     # device time of the timed region, of the HBM peak
@@ -395,7 +409,7 @@ def wavefront_roofline_blocks(pt, st, cst, info, config, note, mean_len):
     # with three pipelines a launch carries a third of the rays and lasts about as long as one of two did.  The same
     # algorithmic bytes over the device time of the timed region do not depend on how the work is cut into launches
     r["pipelines"] = st.pipelines
-    r["frac_all_launches_over_device_time"] = round(bytes_extend * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    r["frac_all_launches_over_device_time"] = round(bytes_extend * walked_rays(st) / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     return r, roofline_shade_block(st, config)
 
 
@@ -586,7 +600,7 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False
         apply_live_traffic(r["roofline"] if "roofline" in r else r, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
         # the same bytes over the DEVICE time of the leg (its pipelines' launches overlap, so the sum of launch durations exceeds it): what the
         # fabric carried for this kernel per second of the frame, of the 8 TB/s peak
-        r["frac_all_launches_over_device_time"] = round(r["algorithmic_bytes_per_ray"] * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        r["frac_all_launches_over_device_time"] = round(r["algorithmic_bytes_per_ray"] * walked_rays(st) / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if lt and lt.get("k_extend"):
             r["frac_counted_over_device_time"] = round(lt["k_extend"]["hbm_bytes_per_ray"] * st.rays / (st.ms_total * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     if oracle_walk:
@@ -902,7 +916,7 @@ def main():
             "timed_seconds_total": round(sum(r[0] for r in reps), 4),
             "rays": rays_total, "paths": paths_total, "rays_per_path": round(mean_len, 4),
             # (rank 0's share) camera rays of pixels outside the scene box's projection: counted in `value` -- the reference traces them, raygen.rgen:62 --
-            # and finished by the fused kernel without a walk (pt_tuning.fused_cull); value_walked_only prices the step by the walked rays alone
+            # and finished by the fused kernel without a walk (pt_tuning.cull); value_walked_only prices the step by the walked rays alone
             "rays_culled_rank0": int(getattr(st, "rays_culled", 0)),
             "value_walked_only": round((st.rays - int(getattr(st, "rays_culled", 0))) / max(st.rays, 1) * rays_total / dt / 1e6, 2),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),

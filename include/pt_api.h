@@ -83,8 +83,9 @@ typedef struct pt_tuning {
                                tail slots handed out after every head slot (spp - S samples) -- a launch with few slots per lane ends with short
                                work.  0 = never; -1: by the launch's slots per lane (render.hip fused_tail_samples); clamped to spp - 1.      */
     int32_t fused_subject;  /* fused pipeline: 0 = hand the tiles out centre first only; -1 / 1: the tiles the scene's box projects to first (render.hip) */
-    int32_t fused_cull;     /* fused pipeline, single-level scenes: 0 = walk every camera ray; -1 / 1: the slots of pixels outside the projection of the
-                               scene's box are finished without a walk -- each of their samples is one counted ray that misses (pt_stats.rays_culled) */
+    int32_t cull;           /* 0 = walk every camera ray; -1 / 1: the slots of pixels outside the projection of the scene's box (two-level: of the instances'
+                               boxes) are finished without a walk -- each of their samples is one counted ray that misses (pt_stats.rays_culled).
+                               Every pipeline; with PT_FLAG_COUNT_VISITS (the walk of every ray is measured) only when set to 1             */
     int32_t reserved[2];
 } pt_tuning;
 pt_status pt_ctx_get_tuning(const pt_ctx *ctx, pt_tuning *out);
@@ -336,8 +337,8 @@ typedef struct pt_stats {
     uint64_t workspace_bytes;
     uint32_t pipeline;         /* (API version 5) PT_PIPELINE_* the last pt_render / pt_render_prepare ran (never PT_PIPELINE_AUTO) */
     uint32_t tail_samples;     /* fused pipeline: samples per pixel and frame traced as one-sample tail slots behind a head slot (0: none) */
-    uint64_t rays_culled;      /* of `rays`: camera rays of pixels outside the projection of the scene's box, which the fused kernel resolves as the
-                                * misses they are without a walk (pt_tuning.fused_cull); the reference traces them (raygen.rgen:62), so they count */
+    uint64_t rays_culled;      /* of `rays`: camera rays of pixels outside the projection of the scene's box, which are resolved as the misses they
+                                * are without a walk (pt_tuning.cull); the reference traces them (raygen.rgen:62), so they count */
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);

@@ -37,9 +37,9 @@ pl = lambda c: e.get(c + "_per_launch", 0.0)
 # the bench line's block of THIS kernel (round 5: `roofline` is the kernel with the most time of the timed region, the others sit beside it)
 blocks = [bench.get(k) for k in ("roofline", "roofline_extend", "roofline_shade", "roofline_wavefront") if isinstance(bench.get(k), dict)]
 mine = next((b for b in blocks if str(b.get("kernel", "")).startswith(prefix.split("<")[0])), blocks[0])
-rays_per_launch = bench["rays"] / mine["launches"]   # (a shade launch handles the rays of the extend launch before it)
-if mine.get("rays_walked_per_launch"):               # the fused kernel: per WALKED ray (camera rays of pixels that cannot see the scene are finished without a walk)
-    rays_per_launch = mine["rays_walked_per_launch"]
+# per WALKED ray: camera rays of pixels that cannot see the scene are finished without a walk (pt_stats.rays_culled) and never reach these kernels --
+# bench.py's blocks carry the walked rays per launch (the fused block beside all rays, the wavefront blocks as rays_per_launch)
+rays_per_launch = mine.get("rays_walked_per_launch") or mine.get("rays_per_launch") or bench["rays"] / mine["launches"]
 avg_us = kt["avg_ns"] / 1e3
 rec = {
     "kernel": name, "config": cfg,

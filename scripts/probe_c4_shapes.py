@@ -11,7 +11,7 @@ for K in (1, 2, 4, 8, 16):
     for cull in (0, 1):
         row = []
         for G in (0, 1, 2, 4, 8, 32):
-            ctx.set_tuning(fused_cull=cull)
+            ctx.set_tuning(cull=cull)
             film = pt.Film(ctx, W, H)
             p = pt.default_params(frame=0, frame_count=K, width=W, height=H, spp_per_frame=32, max_depth=8, pipeline=pt.PIPELINE_FUSED, sample_groups=G)
             pt.render(sc, film, p)

@@ -1,4 +1,4 @@
-"""dev probe: pt_tuning.fused_cull (slots of pixels that cannot see the scene are finished without a walk) off / on, per shape: ms per call at
+"""dev probe: pt_tuning.cull (slots of pixels that cannot see the scene are finished without a walk) off / on, per shape: ms per call at
 1080p, 32 spp, depth 8, K frames per call; g1 = one group, g32 = every sample a slot, S = head + tail with S tail samples, lib = the library's rule."""
 import importlib, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ for K in Ks:
         for name, tune, shape in shapes:
             if K > 4 and name in ("g32", "S16", "S20"):
                 continue
-            ctx.set_tuning(fused_tail=tune, fused_cull=cull)
+            ctx.set_tuning(fused_tail=tune, cull=cull)
             film = pt.Film(ctx, W, H)
             p = pt.default_params(frame=0, frame_count=K, width=W, height=H, spp_per_frame=spp, max_depth=8, pipeline=pt.PIPELINE_FUSED, **shape)
             pt.render(sc, film, p)

@@ -85,7 +85,7 @@ class Stats(C.Structure):
 
 TUNING_NAMES = ["refill", "lds_stack", "extend_blocks", "pipes", "stagger", "sort_bits", "pair_leaves", "pair_kernel", "topdown4",
                 "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield", "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb",
-                "hbm8", "ploc_radius", "leaf_min", "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail", "fused_subject", "fused_cull"]
+                "hbm8", "ploc_radius", "leaf_min", "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail", "fused_subject", "cull"]
 
 
 class Tuning(C.Structure):

@@ -34,7 +34,7 @@ static const char *const k_tune_names[] = { "refill", "lds_stack", "extend_block
                                             "pair_kernel", "topdown4", "rec64", "inst16", "inst16_blocks", "enter_min", "node_yield",
                                             "tlas_lds_kb", "term_ocap", "term_spill", "mem_budget_mb", "hbm8", "ploc_radius", "leaf_min",
                                             "tri_enter", "tri_stay", "inst_frames", "tlas_ploc", "ploc_adopt_pct", "fail_rebuild", "fused_tail",
-                                            "fused_subject", "fused_cull" };
+                                            "fused_subject", "cull" };
 constexpr int k_tune_count = (int)(sizeof(k_tune_names) / sizeof(k_tune_names[0]));
 static_assert(sizeof(pt_tuning) == sizeof(int32_t) * (k_tune_count + 2), "pt_tuning: names and fields out of step");
 
@@ -443,7 +443,7 @@ pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
     ctx->stats.wave_finishes = h[11]; ctx->stats.wave_iterations = h[12];
     ctx->stats.leaf_lanes = h[13]; ctx->stats.pop_lanes = h[14]; ctx->stats.hit_lanes = h[15];
     ctx->stats.enter_steps = h[16]; ctx->stats.enter_lanes = h[17];
-    ctx->stats.rays_culled = h[19];  // (h[18]: the fused pipeline's ray counter before a launch, render.hip)
+    ctx->stats.rays_culled = h[19];  // (h[18], h[20]: the ray counters before a launch whose term logs may overflow, render.hip)
     *out = ctx->stats;
     return PT_OK;
 }

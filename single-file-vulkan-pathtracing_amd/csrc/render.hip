@@ -110,6 +110,56 @@ Radiance job_radiance(const Job &j)
     return { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, j.d_spill_count, j.spill_cap, j.d_overflow };
 }
 
+// The pixel rectangle the scene's box projects to (film_work.hip ptw_tiles_subject_first: its tiles are handed out first).  The camera of
+// raygen.rgen:51-57 shoots from cam_origin through (target.x + dx, target.y + dy, target.z), dx, dy in [-1, 1] across the image: a point P in
+// front of the origin lands at dx = o.x + (P.x - o.x) (t.z - o.z) / (P.z - o.z) - t.x.  A box is convex, so its image lies inside the bounding
+// rectangle of its corners' images.  No rectangle (x1 < x0) when a corner is not in front of the origin (the camera is inside or beside the
+// box).  Used twice: as a guess about cost (the hand-out order) and as a proof (the cull below):
+// the pixel of slack on every side is far above the rounding of this projection and of raygen's own.
+void subject_rect(const pt_scene *s, const pt_params *p, int32_t rect[4])
+{
+    rect[0] = rect[1] = 0; rect[2] = rect[3] = -1;
+    const float *bmin = s->n_inst ? s->tlas_bmin : s->bmin, *bmax = s->n_inst ? s->tlas_bmax : s->bmax;  // (two-level: the union of the instances' world boxes)
+    const float den = p->cam_target[2] - p->cam_origin[2];
+    if (!(std::fabs(den) > 0.f)) return;
+    float lo[2] = { 3.0e38f, 3.0e38f }, hi[2] = { -3.0e38f, -3.0e38f };
+    for (int c = 0; c < 8; c++) {
+        const float P[3] = { (c & 1) ? bmax[0] : bmin[0], (c & 2) ? bmax[1] : bmin[1], (c & 4) ? bmax[2] : bmin[2] };
+        const float a = (P[2] - p->cam_origin[2]) / den;  // how far along the view axis the corner is, in units of the image plane's distance
+        if (!(a > 1.0e-4f)) return;
+        for (int k = 0; k < 2; k++) {
+            const float d = p->cam_origin[k] + (P[k] - p->cam_origin[k]) / a - p->cam_target[k];
+            lo[k] = std::min(lo[k], d); hi[k] = std::max(hi[k], d);
+        }
+    }
+    const float size[2] = { (float)p->width, (float)p->height };
+    int32_t r[4];
+    for (int k = 0; k < 2; k++) {  // dx -> pixel (raygen.rgen:52-53 inverted), one pixel of slack, clamped to the image
+        const float a = (lo[k] + 1.0f) * 0.5f * size[k] - 1.0f, b = (hi[k] + 1.0f) * 0.5f * size[k] + 1.0f;
+        if (!(a == a) || !(b == b) || b < 0.f || a > size[k]) return;  // (NaN, or the box is off the image: no subject to put first)
+        r[k] = (int32_t)std::max(a, 0.f);
+        r[k + 2] = (int32_t)std::min(b, size[k] - 1.0f);
+    }
+    std::copy(r, r + 4, rect);
+}
+
+// Pixels outside the rectangle cannot see the scene: their slots are finished where they are handed out / generated (wavefront_types.h
+// RenderConst::cull, fused_cull.h; pt_tuning.cull = 0: every camera ray is walked; an instrumented render measures the walk of every ray unless
+// pt_tuning.cull = 1 asks for the walked ones only).  The sum a slot without a log stores is the reference's sequence of adds (raygen.rgen:76 with weight 1 and miss.rmiss:10), done here.
+void apply_cull(const pt_ctx *ctx, const pt_params *p, const int32_t rect[4], RenderConst &rc)
+{
+    rc.cull_on = 0u;
+    if (rect[2] < rect[0] || rect[3] < rect[1] || ctx->tune.cull == 0 || ((p->flags & PT_FLAG_COUNT_VISITS) && ctx->tune.cull != 1)) return;
+    if (!std::isfinite(p->env[0]) || !std::isfinite(p->env[1]) || !std::isfinite(p->env[2])) return;
+    rc.cull_on = 1u;
+    std::copy(rect, rect + 4, rc.cull);
+    for (int k = 0; k < 3; k++) {
+        volatile float c = 0.0f;  // (volatile: one rounded float add per sample, nothing folded)
+        for (uint32_t i = 0; i < p->spp_per_frame; i++) c = c + 1.0f * p->env[k];
+        rc.cull_sum[k] = c;
+    }
+}
+
 // ---- once per call: kernel plan, shape + workspace, number of pipelines, ray-sort scratch, shadow queue -----------------
 pt_status job_setup(Job &j)
 {
@@ -125,6 +175,11 @@ pt_status job_setup(Job &j)
     if (ctx->tune.term_spill >= 0) j.spill_cap = std::min<uint32_t>(j.spill_cap, (uint32_t)ctx->tune.term_spill);  // tests
     j.rad = job_radiance(j);
     j.rc = ptw_render_const(p, w, j.sh);
+    {
+        int32_t rect[4];
+        subject_rect(s, p, rect);
+        apply_cull(ctx, p, rect, j.rc);
+    }
     j.profile = !j.nested && (p->flags & PT_FLAG_PROFILE) != 0;  // (a redo would re-record the pooled events of its caller)
     j.count_visits = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
     j.async = (p->flags & PT_FLAG_ASYNC) != 0;
@@ -220,6 +275,7 @@ pt_status batch_begin(Job &j, Pipe *pipe, int &pipes_now, unsigned long long &ra
     if (j.sh.bounded) {  // the exact ray counter as it is before this batch, should the batch have to be redone
         PT_HIP(ctx, hipStreamSynchronize(st));
         PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
+        PT_HIP(ctx, hipMemcpy(ctx->d_stats + 20, ctx->d_stats + 19, sizeof(unsigned long long), hipMemcpyDeviceToDevice));  // (rays_culled before the batch)
     }
     PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 2 * PT_MAX_PIPES, st));
     if (j.sh.bounded) PT_HIP(ctx, hipMemsetAsync(j.d_spill_count, 0, sizeof(unsigned long long), st));
@@ -247,7 +303,7 @@ pt_status batch_begin(Job &j, Pipe *pipe, int &pipes_now, unsigned long long &ra
     }
     for (int k = 0; k < pipes_now; k++) {
         Pipe &pp = pipe[k];
-        ptw_launch_generate(j.rc, w.d_tiles, pp.slot_begin, pp.n_slots, j.rad, pp.qv[0], &pp.count[0], ctx->num_cus, pp.st);
+        ptw_launch_generate(j.rc, w.d_tiles, pp.slot_begin, pp.n_slots, j.rad, pp.qv[0], &pp.count[0], ctx->d_stats, ctx->num_cus, pp.st);
         ctx->stats.launches_other++;
     }
     return PT_OK;
@@ -410,6 +466,7 @@ pt_status batch_finish(Job &j, int pipes_now, unsigned long long rays_before)
     // the flag and render the same frames with one slot per (frame, pixel) -- the plain accumulator needs no log -- then return
     // to this call's workspace shape.
     PT_HIP(ctx, hipMemcpy(ctx->d_stats, &rays_before, sizeof(rays_before), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_stats + 19, ctx->d_stats + 20, sizeof(unsigned long long), hipMemcpyDeviceToDevice));
     PT_HIP(ctx, hipMemset(j.d_overflow, 0, sizeof(unsigned long long)));
     ctx->stats.redone_batches++;
     pt_params q = *p;
@@ -488,7 +545,7 @@ pt_status render_wavefront(pt_scene *s, pt_film *f, const pt_params *p, const Ex
 uint32_t fused_slots_x32(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames, const int32_t rect[4])
 {
     uint64_t tiles = (uint64_t)((f->w + 7) / 8) * ((f->h + 7) / 8);
-    if (rect[2] >= rect[0] && rect[3] >= rect[1] && ctx->tune.fused_cull != 0)
+    if (rect[2] >= rect[0] && rect[3] >= rect[1] && ctx->tune.cull != 0)
         tiles = (uint64_t)(rect[2] / 8 - rect[0] / 8 + 1) * (uint64_t)(rect[3] / 8 - rect[1] / 8 + 1);
     const uint64_t world = std::max(p->world, 1u);
     const uint64_t heads = (uint64_t)frames * 64ull * ((tiles + world - 1) / world);
@@ -548,39 +605,6 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
     return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }
 
-// The pixel rectangle the scene's box projects to (film_work.hip ptw_tiles_subject_first: its tiles are handed out first).  The camera of
-// raygen.rgen:51-57 shoots from cam_origin through (target.x + dx, target.y + dy, target.z), dx, dy in [-1, 1] across the image: a point P in
-// front of the origin lands at dx = o.x + (P.x - o.x) (t.z - o.z) / (P.z - o.z) - t.x.  A box is convex, so its image lies inside the bounding
-// rectangle of its corners' images.  No rectangle (x1 < x0) when a corner is not in front of the origin (the camera is inside or beside the
-// box).  Used twice: as a guess about cost (the hand-out order) and as a proof (the cull below):
-// the pixel of slack on every side is far above the rounding of this projection and of raygen's own.
-void fused_subject_rect(const pt_scene *s, const pt_params *p, const FusedPlan &fp, int32_t rect[4])
-{
-    rect[0] = rect[1] = 0; rect[2] = rect[3] = -1;
-    const float *bmin = s->n_inst ? s->tlas_bmin : s->bmin, *bmax = s->n_inst ? s->tlas_bmax : s->bmax;  // (two-level: the union of the instances' world boxes)
-    const float den = p->cam_target[2] - p->cam_origin[2];
-    if (!(std::fabs(den) > 0.f)) return;
-    float lo[2] = { 3.0e38f, 3.0e38f }, hi[2] = { -3.0e38f, -3.0e38f };
-    for (int c = 0; c < 8; c++) {
-        const float P[3] = { (c & 1) ? bmax[0] : bmin[0], (c & 2) ? bmax[1] : bmin[1], (c & 4) ? bmax[2] : bmin[2] };
-        const float a = (P[2] - p->cam_origin[2]) / den;  // how far along the view axis the corner is, in units of the image plane's distance
-        if (!(a > 1.0e-4f)) return;
-        for (int k = 0; k < 2; k++) {
-            const float d = p->cam_origin[k] + (P[k] - p->cam_origin[k]) / a - p->cam_target[k];
-            lo[k] = std::min(lo[k], d); hi[k] = std::max(hi[k], d);
-        }
-    }
-    const float size[2] = { (float)p->width, (float)p->height };
-    int32_t r[4];
-    for (int k = 0; k < 2; k++) {  // dx -> pixel (raygen.rgen:52-53 inverted), one pixel of slack, clamped to the image
-        const float a = (lo[k] + 1.0f) * 0.5f * size[k] - 1.0f, b = (hi[k] + 1.0f) * 0.5f * size[k] + 1.0f;
-        if (!(a == a) || !(b == b) || b < 0.f || a > size[k]) return;  // (NaN, or the box is off the image: no subject to put first)
-        r[k] = (int32_t)std::max(a, 0.f);
-        r[k + 2] = (int32_t)std::min(b, size[k] - 1.0f);
-    }
-    std::copy(r, r + 4, rect);
-}
-
 pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const ExtendPlan &pl, bool nested, bool prepare_only)
 {
     pt_ctx *ctx = s->ctx;
@@ -593,7 +617,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     pt_status rc_ = ptw_plan_fused(s, pl, p_in->tmin, fp);
     if (rc_ != PT_OK) return rc_;
     int32_t rect[4];
-    fused_subject_rect(s, p_in, fp, rect);
+    subject_rect(s, p_in, rect);
     const bool have_rect = rect[2] >= rect[0] && rect[3] >= rect[1];
     pt_params q;
     fused_shape_defaults(f, p_in, fp, rect, q);
@@ -654,18 +678,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);
     Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
     RenderConst rc = ptw_render_const(p, w, sh);
-    // Pixels outside the rectangle cannot see the scene: their slots are finished where they are handed out (wavefront_types.h RenderConst::cull;
-    // pt_tuning.fused_cull = 0: every camera ray is walked).  The sum a slot without a log stores is the reference's sequence of adds, done here.
-    if (have_rect && ctx->tune.fused_cull != 0 && std::isfinite(p->env[0]) && std::isfinite(p->env[1]) && std::isfinite(p->env[2])) {
-        rc.cull_on = 1u;
-        std::copy(rect, rect + 4, rc.cull);
-        const uint32_t n = p->spp_per_frame;  // (also with head + tail slots: the head of such a pixel stands for all its samples)
-        for (int k = 0; k < 3; k++) {
-            volatile float c = 0.0f;  // (volatile: one rounded float add per sample, nothing folded)
-            for (uint32_t i = 0; i < n; i++) c = c + 1.0f * p->env[k];
-            rc.cull_sum[k] = c;
-        }
-    }
+    apply_cull(ctx, p, rect, rc);
     const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;
     ctx->stats.extend_variant = pl.variant;
     ctx->stats.pipelines = 1;
@@ -682,6 +695,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
         unsigned long long *const d_rays_before = ctx->d_stats + 18;
         if (sh.bounded) {
             PT_HIP(ctx, hipMemcpyAsync(d_rays_before, ctx->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+            PT_HIP(ctx, hipMemcpyAsync(ctx->d_stats + 20, ctx->d_stats + 19, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));  // (rays_culled)
             PT_HIP(ctx, hipMemsetAsync(d_spill_count, 0, sizeof(unsigned long long), st));
         }
         PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * PTW_COUNT_WORDS, st));  // the slot counters (fused_kernel.h: eight, 128 B apart)
@@ -708,6 +722,7 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
         }
         if (redo) {  // a slot filled its term log: the same frames once more with one group
             PT_HIP(ctx, hipMemcpy(ctx->d_stats, d_rays_before, sizeof(unsigned long long), hipMemcpyDeviceToDevice));
+            PT_HIP(ctx, hipMemcpy(ctx->d_stats + 19, ctx->d_stats + 20, sizeof(unsigned long long), hipMemcpyDeviceToDevice));
             PT_HIP(ctx, hipMemset(d_overflow, 0, sizeof(unsigned long long)));
             ctx->stats.redone_batches++;
             pt_params r = *p;

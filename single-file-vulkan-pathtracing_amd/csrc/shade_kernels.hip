@@ -12,13 +12,16 @@
 
 #include <algorithm>
 
+#include "fused_cull.h"
+
 namespace {
 using namespace ptw;
 
 // ---- generate: sample 0 of every (frame, pixel) slot of the batch ----------------------------
 __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t *__restrict__ tiles, uint32_t slot_base,
-                                                 uint32_t n_slots, Radiance rad, QueueView out, uint32_t *count_out)
+                                                 uint32_t n_slots, Radiance rad, QueueView out, uint32_t *count_out, unsigned long long *stats)
 {
+    uint32_t n_culled = 0;  // camera rays of the slots this thread finished without a walk (RenderConst::cull, fused_cull.h)
     // four slots per thread and ONE queue-tail atomic per 1024 slots, as in k_shade: with one atomic per 256 slots
     // the 133 M slots of 16 frames x 4 sample groups spent 2.9 ms per launch on the ~88 atomics/us a single word takes
     constexpr int GEN_ITEMS = 4;
@@ -46,9 +49,15 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
                 const uint32_t sample0 = g * rc.group_size;
                 o_sample[it] = sample0;
                 if (px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp) {
-                    alive[it] = true;
-                    o_seed[it] = ptm::make_seed(px, py, sample0, rc.frame_base + (int32_t)f, rc.spp);
-                    ptm::primary_ray(rc.cam, px, py, o_seed[it], o_org[it], o_dir[it]);
+                    if (ptc::pixel_culled(rc, px, py)) {
+                        // the pixel cannot see the scene: each of the slot's samples is one camera ray (counted) that misses and adds 1 * env -- the
+                        // slot never enters the queues
+                        n_culled += rc.groups == 1u ? ptc::finish_plain(rc, rad, slot) : ptc::finish_group(rc, rad, slot, g);
+                    } else {
+                        alive[it] = true;
+                        o_seed[it] = ptm::make_seed(px, py, sample0, rc.frame_base + (int32_t)f, rc.spp);
+                        ptm::primary_ray(rc.cam, px, py, o_seed[it], o_org[it], o_dir[it]);
+                    }
                 }
             }
         }
@@ -62,6 +71,13 @@ __global__ __launch_bounds__(TB) void k_generate(RenderConst rc, const uint32_t 
                 ptm::st_stream<PT_NT_GEN>(out.rayA + dst[it], make_float4(o_org[it].x, o_org[it].y, o_org[it].z, o_dir[it].x));
                 ptm::st_stream<PT_NT_GEN>(out.rayB + dst[it], make_float2(o_dir[it].y, o_dir[it].z));
             }
+        }
+    }
+    if (rc.cull_on) {  // (uniform: every thread of the block is here)
+        for (int o = 32; o > 0; o >>= 1) n_culled += (uint32_t)__shfl_xor((int)n_culled, o, 64);
+        if ((threadIdx.x & 63u) == 0u && n_culled) {
+            atomicAdd(stats, (unsigned long long)n_culled);        // pt_stats.rays
+            atomicAdd(stats + 19, (unsigned long long)n_culled);   // pt_stats.rays_culled
         }
     }
 }
@@ -540,10 +556,10 @@ __global__ __launch_bounds__(TB) void k_hits_to_api(const float4 *__restrict__ h
 
 // ---- launchers (the scheduler lives in render.hip) ---------------------------------------------------------------------
 void ptw_launch_generate(const ptw::RenderConst &rc, const uint32_t *tiles, uint32_t slot_base, uint32_t n_slots, const ptw::Radiance &rad,
-                         const ptw::QueueView &out, uint32_t *count_out, int num_cus, hipStream_t st)
+                         const ptw::QueueView &out, uint32_t *count_out, unsigned long long *stats, int num_cus, hipStream_t st)
 {
     const int grid = (int)std::min<uint32_t>((n_slots + 4 * TB - 1) / (4 * TB), (uint32_t)num_cus * 16u);
-    k_generate<<<grid, TB, 0, st>>>(rc, tiles, slot_base, n_slots, rad, out, count_out);
+    k_generate<<<grid, TB, 0, st>>>(rc, tiles, slot_base, n_slots, rad, out, count_out, stats);
 }
 
 void ptw_launch_shade(const ShadeLaunch &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)

@@ -67,8 +67,9 @@ struct ShadeLaunch {
     uint32_t *sq_count = nullptr;
 };
 void ptw_launch_shade(const ShadeLaunch &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+// (stats: the context's counters -- k_generate counts the camera rays of the slots it finishes without a walk, RenderConst::cull)
 void ptw_launch_generate(const ptw::RenderConst &rc, const uint32_t *tiles, uint32_t slot_base, uint32_t n_slots, const ptw::Radiance &rad,
-                         const ptw::QueueView &out, uint32_t *count_out, int num_cus, hipStream_t st);
+                         const ptw::QueueView &out, uint32_t *count_out, unsigned long long *stats, int num_cus, hipStream_t st);
 void ptw_launch_shadow_add(const ptw::RenderConst &rc, const ptw::Radiance &rad, const float4 *sq_hit, const float4 *contrib,
                            const uint32_t *slot, const uint32_t *count, int grid, hipStream_t st);
 // (skip_if_set: a device word; the kernel leaves the film alone when it is non-zero -- the fused pipeline's overflow flag, read by the host afterwards)

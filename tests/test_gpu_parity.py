@@ -2309,7 +2309,7 @@ def test_fused_subject_first_order_changes_no_bit(pt, orc, gpu_ctx, cornell_gpu,
     far away, off the image, and with the camera inside or behind the box (no rectangle), the film, the rgba8 image and the ray count are the
     oracle's with and without it, for the plain, the all-groups and the head + tail shape, and when the view changes between calls on one film.
     The same rectangle is a proof: a pixel outside it (by a pixel of slack) cannot see the scene, and the kernel finishes its slots where it hands
-    them out -- every sample one counted ray whose miss adds the environment (pt_tuning.fused_cull, pt_stats.rays_culled).  Same bits, same rays."""
+    them out -- every sample one counted ray whose miss adds the environment (pt_tuning.cull, pt_stats.rays_culled).  Same bits, same rays."""
     w, h, spp = 136, 72, 4
     views = [dict(), dict(cam_origin=(1.1, -1.0, 5.0), cam_target=(1.1, -1.0, 2.0)), dict(cam_origin=(1.0, -0.2, 5.0), cam_target=(1.0, -0.2, 2.0)),
              dict(cam_origin=(0.0, -1.0, 9.0), cam_target=(0.0, -1.0, 6.0)), dict(cam_origin=(3.5, -1.0, 5.0), cam_target=(3.5, -1.0, 2.0)),
@@ -2324,7 +2324,7 @@ def test_fused_subject_first_order_changes_no_bit(pt, orc, gpu_ctx, cornell_gpu,
         for subject, cull in ((1, 1), (0, 1), (-1, -1), (1, 0), (0, 0)):
             for knobs, shape in ((dict(fused_tail=0), dict(sample_groups=1)), (dict(fused_tail=0), dict(sample_groups=spp)), (dict(fused_tail=0), dict(sample_groups=3)),
                                  (dict(fused_tail=2), dict())):
-                old = gpu_ctx.set_tuning(fused_subject=subject, fused_cull=cull, **knobs)
+                old = gpu_ctx.set_tuning(fused_subject=subject, cull=cull, **knobs)
                 try:
                     film.clear()
                     gpu_ctx.reset_stats()
@@ -2366,7 +2366,7 @@ def test_fused_cull_on_two_level_scenes(pt, orc, gpu_ctx, cornell_arrays):
         seen = set()
         for cull in (1, 0):
             for shape in (dict(), dict(sample_groups=1), dict(sample_groups=4), dict(sample_groups=spp, frames_in_flight=2)):
-                old = gpu_ctx.set_tuning(fused_cull=cull)
+                old = gpu_ctx.set_tuning(cull=cull)
                 try:
                     film = pt.Film(gpu_ctx, w, h)
                     gpu_ctx.reset_stats()
