@@ -827,7 +827,9 @@ def main():
     pt.render_prepare(scene, film, timed)
     shape = ctx.stats()
     ran = pt.PIPELINE_NAMES.get(shape.pipeline, str(shape.pipeline))     # what PT_PIPELINE_AUTO resolved to for this scene and call
-    common.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups, pipeline=shape.pipeline)
+    # (the shape the library chose is named in the timed call -- except a head + tail shape, which only the library's own rule gives: naming
+    # sample_groups = 1 would turn it into the plain one-group shape)
+    common.update(frames_in_flight=shape.frames_in_flight, sample_groups=0 if shape.tail_samples else shape.sample_groups, pipeline=shape.pipeline)
     timed = pt.default_params(frame=0, frame_count=args.steps, flags=flags, **common)
     # ... then W untimed warm-up frames run through the same kernels
     if args.warmup > 0:
@@ -909,7 +911,7 @@ def main():
                        "pipeline": ran, "pipeline_requested": args.pipeline,
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
-                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "pipelines": st.pipelines,
+                       "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "tail_samples": shape.tail_samples, "pipelines": st.pipelines,
                        "sort_rays": args.sort_rays},
             # the timed region repeated: value / ms_per_step are the median repetition
             "reps": len(reps), "value_min": min(values), "value_max": max(values), "values": values,

@@ -40,6 +40,8 @@ if has lines; then
   timeout 600 python bench.py --steps 1 --no-extra-legs --no-cpu-baseline > $O/${TAG}_bench_k1.json 2>> $O/${TAG}_bench_k2.err
   timeout 600 python bench.py --config c4 --steps 8 --no-cpu-baseline > $O/${TAG}_bench_c4.json 2> $O/${TAG}_bench_c4.err
   timeout 600 python bench.py --config c4 --steps 8 --pipeline wavefront --no-extra-legs --no-cpu-baseline > $O/${TAG}_bench_c4_wavefront.json 2>> $O/${TAG}_bench_c4.err
+  timeout 600 python bench.py --config c4 --steps 8 --pipeline fused --no-extra-legs --no-cpu-baseline > $O/${TAG}_bench_c4_fused.json 2>> $O/${TAG}_bench_c4.err
+  timeout 600 python bench.py --config c4 --steps 16 --no-extra-legs --no-cpu-baseline > $O/${TAG}_bench_c4_k16.json 2>> $O/${TAG}_bench_c4.err
   for c in c5 c5x; do timeout 900 python bench.py --config $c --steps 4 > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err; done
 fi
 if has pmc; then
@@ -56,7 +58,7 @@ if has pmc; then
   python scripts/make_pmc_json.py $O/prof_${TAG}_c2 $O/${TAG}_pmc_shade_c2.json "--pipeline wavefront --steps 16" --kernel=k_shade > /dev/null || echo "pmc json (shade) failed"
   rm -rf $O/prof_${TAG}_c2
   unset PMC_EXTRA
-  prof fused_c4 k_fused_inst fused_c4 --config c4 --steps 8
+  prof fused_c4 k_fused_inst fused_c4 --config c4 --steps 8 --pipeline fused
   rm -rf $O/prof_${TAG}_fused_c4
   prof c4 k_extend extend_c4 --config c4 --pipeline wavefront --steps 8
   rm -rf $O/prof_${TAG}_c4

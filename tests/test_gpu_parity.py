@@ -1984,14 +1984,15 @@ def test_full_size_frames_equal_the_oracle_known_answers(pt, gpu_ctx, config):
         variants += [dict(pipeline=pt.PIPELINE_FUSED, frames_in_flight=1, sample_groups=1), dict(pipeline=pt.PIPELINE_FUSED)]
     if config == "c5":
         variants += [dict(flags=pt.FLAG_SORT_RAYS), dict(extend=pt.EXTEND_HBM8)]
-    # what a caller gets from pt_params_default (PT_PIPELINE_AUTO): the fused kernels for C2 / C4, the wavefront queues for the soup
+    # what a caller gets from pt_params_default (PT_PIPELINE_AUTO): the fused kernel for C2, the wavefront queues for the soup and -- a single
+    # frame per call -- for the two-level scene
     variants += [dict(pipeline=pt.PIPELINE_AUTO)]
     for kw in variants:
         film.clear()
         gpu_ctx.reset_stats()
         pt.render(scene, film, pt.default_params(**base, **kw))
         if kw.get("pipeline") == pt.PIPELINE_AUTO:
-            assert gpu_ctx.stats().pipeline == (pt.PIPELINE_WAVEFRONT if config == "c5" else pt.PIPELINE_FUSED), config
+            assert gpu_ctx.stats().pipeline == (pt.PIPELINE_FUSED if config == "c2" else pt.PIPELINE_WAVEFRONT), config
         assert gpu_ctx.stats().rays == gold["rays"], (config, kw)
         got = film.read_f32()
         assert got.shape == (h, w, 3)
@@ -2140,10 +2141,19 @@ def test_auto_pipeline_picks_fused_where_it_applies_and_wavefront_elsewhere(pt, 
     oi = orc.Scene(*pt.load_obj(pt.ASSET_CORNELL))
     oi.set_instances(xf)
     of_, _, ri = _render_oracle(orc, oi, 1, **kw)
+    # (two-level scenes: the queues up to 8 frames per launch -- the faster pipeline there since the cull -- and k_fused_inst above)
     film.clear()
     gpu_ctx.reset_stats()
     pt.render(inst, film, pt.library_default_params(frame=0, frame_count=1, **kw))
-    assert gpu_ctx.stats().pipeline == pt.PIPELINE_FUSED and gpu_ctx.stats().rays == ri and film.read_f32().tobytes() == of_.tobytes()
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_WAVEFRONT and gpu_ctx.stats().rays == ri and film.read_f32().tobytes() == of_.tobytes()
+    of9, _, r9 = _render_oracle(orc, oi, 9, **kw)
+    film.clear()
+    gpu_ctx.reset_stats()
+    pt.render(inst, film, pt.library_default_params(frame=0, frame_count=9, **kw))
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_FUSED and gpu_ctx.stats().rays == r9 and film.read_f32().tobytes() == of9.tobytes()
+    film.clear()
+    pt.render(inst, film, pt.library_default_params(frame=0, frame_count=9, frames_in_flight=3, **kw))
+    assert gpu_ctx.stats().pipeline == pt.PIPELINE_WAVEFRONT and film.read_f32().tobytes() == of9.tobytes()
     inst.set_instances(xf[:1])      # one instance: the general two-level kernel, wavefront only
     film.clear()
     pt.render(inst, film, pt.library_default_params(frame=0, frame_count=1, **kw))
