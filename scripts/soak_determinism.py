@@ -9,7 +9,10 @@ cases = [dict(frame_count=8), dict(frame_count=8, sample_groups=4, frames_in_fli
          dict(frame_count=5, frames_in_flight=1, sample_groups=1),
          # the fused single-kernel pipeline: dynamic slot hand-out, work stealing between the eight counters, term logs
          dict(frame_count=8, pipeline=pt.PIPELINE_FUSED), dict(frame_count=2, pipeline=pt.PIPELINE_FUSED),
-         dict(frame_count=3, rank=1, world=3, pipeline=pt.PIPELINE_FUSED), dict(frame_count=1, sample_groups=32, pipeline=pt.PIPELINE_FUSED)]
+         dict(frame_count=3, rank=1, world=3, pipeline=pt.PIPELINE_FUSED), dict(frame_count=1, sample_groups=32, pipeline=pt.PIPELINE_FUSED),
+         # the library default (head + tail slots at one and two frames per call, the cull), and an off-centre view
+         dict(frame_count=1, pipeline=pt.PIPELINE_AUTO), dict(frame_count=2, pipeline=pt.PIPELINE_AUTO),
+         dict(frame_count=4, pipeline=pt.PIPELINE_AUTO, cam_origin=(1.0, -0.2, 5.0), cam_target=(1.0, -0.2, 2.0))]
 t0 = time.time()
 for c in cases:
     hashes = set(); rays = set()

@@ -266,10 +266,10 @@ int main(int argc, char **argv)
     }
     if (!o.pfm.empty() && pth_write_pfm(o.pfm.c_str(), image_f32.data(), o.width, o.height) != 0) die("cannot write " + o.pfm);
 
-    unsigned long long rays = 0, paths = 0, rays_min = ~0ull, rays_max = 0;
+    unsigned long long rays = 0, paths = 0, rays_min = ~0ull, rays_max = 0, rays_culled = 0;
     double render_ms = 0.0, present_ms = 0.0;
     for (const RankResult &r : res) {
-        rays += r.st.rays; paths += r.st.paths;
+        rays += r.st.rays; paths += r.st.paths; rays_culled += r.st.rays_culled;
         rays_min = std::min<unsigned long long>(rays_min, r.st.rays);
         rays_max = std::max<unsigned long long>(rays_max, r.st.rays);
         render_ms = std::max(render_ms, r.render_ms);
@@ -283,10 +283,12 @@ int main(int argc, char **argv)
                 "\"bvh_build_ms\": %.3f, \"width\": %u, \"height\": %u, \"frames\": %u, \"spp_per_frame\": %u, "
                 "\"max_depth\": %u, \"ranks\": %u, \"rccl_ranks\": %u, \"rays\": %llu, \"paths\": %llu, "
                 "\"rays_per_rank_min\": %llu, \"rays_per_rank_max\": %llu, \"rounds\": %u, \"ms_total\": %.3f, "
-                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f, \"selftest_wrong_pixels\": %lld}\n",
+                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f, \"selftest_wrong_pixels\": %lld, "
+                "\"pipeline\": %u, \"sample_groups\": %u, \"tail_samples\": %u, \"rays_culled\": %llu}\n",
                 o.obj.c_str(), info.n_tris, info.n_nodes, info.bvh_height, load_ms, info.build_ms, o.width, o.height, o.frames, o.spp,
                 o.depth, o.ranks, res[0].rccl_ranks, rays, paths, rays_min, rays_max, st.rounds, ms, present_ms, wall_ms,
-                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0, res[0].selftest_wrong);
+                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0, res[0].selftest_wrong,
+                st.pipeline, st.sample_groups, st.tail_samples, rays_culled);  // (rays_culled: camera rays finished without a walk, counted in rays)
     pth_free_scene(&hs);
     return 0;
 }
