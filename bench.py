@@ -920,6 +920,9 @@ def main():
             # (rank 0's share) camera rays of pixels outside the scene box's projection: counted in `value` -- the reference traces them, raygen.rgen:62 --
             # and finished by the fused kernel without a walk (pt_tuning.cull); value_walked_only prices the step by the walked rays alone
             "rays_culled_rank0": int(getattr(st, "rays_culled", 0)),
+            "rays_note": "`rays` (and `value`) count every ray the reference dispatches (raygen.rgen:62), as the CPU oracle does; rays_culled_rank0 of them are camera rays of "
+                         "pixels outside the projection of the scene's box, which every pipeline finishes as the misses they are without walking the tree "
+                         "(bit-identical film; pt_tuning.cull = 0 walks them); value_walked_only = the same time priced by the walked rays alone; roofline blocks price walked rays only",
             "value_walked_only": round((st.rays - int(getattr(st, "rays_culled", 0))) / max(st.rays, 1) * rays_total / dt / 1e6, 2),
             "rounds": st.rounds, "device_ms_rank0": round(st.ms_total, 3),
             "workspace_bytes": st.workspace_bytes,
