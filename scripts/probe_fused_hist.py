@@ -38,6 +38,7 @@ for a in sys.argv[1:] or ["1:-1", "1:0:1", "1:0:32", "2:-1", "2:0:1"]:
     step = max(1, n // 32)
     print(f"   percent of best-tenth rate per {50 * step} us: " + " ".join(f"{100 * all_[i:i + step].mean() / peak:.0f}" for i in range(0, n, step)))
     print("   of which on tail slots:                 " + " ".join(f"{100 * tail[i:i + step].mean() / peak:.0f}" for i in range(0, n, step)))
+    print(f"   absolute Grays/s per {50 * step} us: " + " ".join(f"{all_[i:i + step].mean() / 50e-6 / 1e9:.1f}" for i in range(0, n, step)))
     print("   Mrays per 50 us, first 24 buckets: " + " ".join(f"{x / 1e6:.2f}" for x in all_[:24]))
     print("   Mrays per 50 us, last 40 buckets:  " + " ".join(f"{x / 1e6:.2f}" for x in all_[-40:]))
     film.close()
