@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define PT_API_VERSION 5  /* 5: PT_PIPELINE_AUTO (what pt_params_default returns); pt_stats.pipeline (appended).  4: PT_PIPELINE_FUSED; pt_tuning.tlas_ploc / ploc_adopt_pct / fail_rebuild */
+#define PT_API_VERSION 5  /* 5: PT_PIPELINE_AUTO (what pt_params_default returns); pt_stats.pipeline / .tail_samples / .rays_culled (appended); pt_tuning.fused_tail /
+                           *    .fused_subject / .cull (from the reserved words); pt_device_write.  4: PT_PIPELINE_FUSED; pt_tuning.tlas_ploc / ploc_adopt_pct / fail_rebuild */
 
 typedef enum pt_status {
     PT_OK = 0,
