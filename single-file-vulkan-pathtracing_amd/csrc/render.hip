@@ -590,8 +590,10 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
 //   best S                 3.07 (S 24)     3.39 (S 20)     5.72 (S 20)     6.29 (S 16)      11.92 (S 12)     17.35 (S 8)      22.9 (S 4)
 //   with the cull          .               .               .               7.11 / 6.15 (16) 12.37 / 11.67 (12) 17.39 / 16.94 (8) 22.70 / 22.32 (4)
 // (a rank of world 8 at 16 frames, 6.1: 12.38 -> 12.19; of 4 at 8 frames: 12.38 -> 12.06; 8 and 16 frames: S 2 .. 4 within 0.3 % of none.)
-// So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 3 spp / 8; to 10.1 -> spp / 4; to
-// 13.5 -> spp / 8; above -> 0.  pt_tuning.fused_tail >= 0 overrides.
+// In single steps with the cull (r05zr_tail_fine.log): one frame S 15 .. 16, two frames S 10 (11.51 against 11.55 at 12), three S 8, four S 6
+// (22.11 against 22.22 at 4).
+// So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 5 spp / 16; to 10.1 -> spp / 4; to
+// 13.5 -> 3 spp / 16; above -> 0.  pt_tuning.fused_tail >= 0 overrides.
 uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames, const int32_t rect[4])
 {
     const uint32_t spp = p->spp_per_frame;
@@ -599,8 +601,8 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
     int t = ctx->tune.fused_tail;
     if (t < 0) {
         const uint32_t x = fused_slots_x32(ctx, f, p, frames, rect);
-        t = x < 36u ? 0 : x <= 81u ? (int)(spp * 5u / 8u) : x <= 144u ? (int)(spp / 2u) : x <= 252u ? (int)(spp * 3u / 8u) : x <= 324u ? (int)(spp / 4u)
-                                   : x <= 432u ? (int)(spp / 8u) : 0;
+        t = x < 36u ? 0 : x <= 81u ? (int)(spp * 5u / 8u) : x <= 144u ? (int)(spp / 2u) : x <= 252u ? (int)(spp * 5u / 16u) : x <= 324u ? (int)(spp / 4u)
+                                   : x <= 432u ? (int)(spp * 3u / 16u) : 0;
     }
     return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }

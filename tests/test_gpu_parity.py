@@ -2404,7 +2404,7 @@ def test_fused_cull_on_two_level_scenes(pt, orc, gpu_ctx, cornell_arrays):
 
 def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cornell_gpu):
     """The library's own head + tail rule (render.hip fused_tail_samples: by head slots per lane of the grid) at 1920x1080, 32 spp: one frame
-    per call takes spp / 2 tail samples, two frames 3 spp / 8, four frames spp / 8 -- and each call's film is the oracle's known answer
+    per call takes spp / 2 tail samples, two frames 5 spp / 16, four frames 3 spp / 16 -- and each call's film is the oracle's known answer
     (tests/golden/fullsize_hashes.json: C2's frame 0, C3 after frames 1 and 3) whatever the shape."""
     import hashlib
     import json
@@ -2425,19 +2425,19 @@ def test_fused_tail_rule_at_full_size_against_the_known_answers(pt, gpu_ctx, cor
         gpu_ctx.reset_stats()
         pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=2, **kw))
         st, m = gpu_ctx.stats(), g3["after_frame"]["1"]
-        assert st.tail_samples == spp * 3 // 8 and st.frames_in_flight == 2 and st.rays == m["rays_so_far"]
+        assert st.tail_samples == spp * 5 // 16 and st.frames_in_flight == 2 and st.rays == m["rays_so_far"]
         assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
     if g3 is not None:
         film.clear()
         gpu_ctx.reset_stats()
         pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=4, **kw))
         st, m = gpu_ctx.stats(), g3["after_frame"]["3"]
-        assert st.tail_samples == spp // 8 and st.rays == m["rays_so_far"] and st.rays_culled == 4 * 901676 * spp
+        assert st.tail_samples == spp * 3 // 16 and st.rays == m["rays_so_far"] and st.rays_culled == 4 * 901676 * spp
         assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == m["film_sha256"]
         # a rank of world 8 with 16 frames in flight holds as many slots as two whole frames: the same rule
         film.clear()
         pt.render(cornell_gpu, film, pt.library_default_params(frame=0, frame_count=16, rank=3, world=8, **kw))
-        assert gpu_ctx.stats().tail_samples == spp * 3 // 8
+        assert gpu_ctx.stats().tail_samples == spp * 5 // 16
     film.close()
 
 
