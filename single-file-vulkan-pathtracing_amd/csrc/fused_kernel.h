@@ -61,6 +61,15 @@ enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS
 // MODE 0: one sample group (a slot is a pixel's whole frame; radiance added in LDS); 1: several groups (every slot logs its radiance terms);
 // 2: HEAD + TAIL (wavefront_types.h RenderConst::tail) -- head slots like mode 0 for samples [0, head_samples), handed out first, then one-sample tail
 // slots like mode 1: what a launch of few frames ends with is short work, and only the tail's terms go through the log
+// The node loop of a pass ends once fewer than B / A of the wave's tracing lanes still descend (the others hold a leaf or are done).  1080p Cornell,
+// 16 / 4 frames per call, ms: 1/2 85.7 / 22.4, 2/5 85.2 / 22.2, 1/3 84.4 / 22.0, 2/7 84.3 / 22.0, 1/4 84.0 / 21.9, 1/5 84.3 / 22.0, 1/6 (rounds 4 - 5)
+// 84.8 / 22.1, 1/8 85.7 / 22.4, 1/12 86.9 / 22.7, never (1/64) 96.1 / 24.9 (profiles/r05zs_node_exit.log)
+#ifndef PT_FUSED_NODE_EXIT
+#define PT_FUSED_NODE_EXIT 4
+#endif
+#ifndef PT_FUSED_NODE_EXIT_B
+#define PT_FUSED_NODE_EXIT_B 1
+#endif
 template <int MODE, bool PAIRS>
 __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
                                                               const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, pop);
             do_node = !(cur & LEAF_BIT);
             const int n_cont = __popcll(__ballot(do_node));
-            if (n_cont * 6 < n_have) break;
+            if (n_cont * PT_FUSED_NODE_EXIT < n_have * PT_FUSED_NODE_EXIT_B) break;  // (the node loop ends once fewer than 1 / PT_FUSED_NODE_EXIT of the tracing lanes still descend)
         }
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
         if (have) {
