@@ -1,5 +1,5 @@
 """dev tool: randomized render parity -- random film sizes (ragged), spp, depth, frame ranges, frames in flight,
-sample groups, tail samples, rank/world splits, extend variants, both pipelines, cameras -- GPU film vs the oracle's, bit for bit."""
+sample groups, tail samples, the cull and the hand-out order on / off, rank/world splits, extend variants, both pipelines, cameras -- GPU film vs the oracle's, bit for bit."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,7 +56,8 @@ for k in range(N):
             gk.update(pipeline=pt.PIPELINE_WAVEFRONT)
         else:            # PT_PIPELINE_AUTO (what pt_params_default returns): fused where the call allows it, else wavefront
             gk.update(pipeline=pt.PIPELINE_AUTO)
-        ctx.set_tuning(fused_tail=int(rng.choice([-1, -1, 0, 1, 2, 3, 7])))   # (the fused kernel's head + tail slots: the library's rule, never, S)
+        # the fused kernel's head + tail slots (the library's rule, never, S); the cull of pixels that cannot see the scene and the subject-first order (on, on, off)
+        ctx.set_tuning(fused_tail=int(rng.choice([-1, -1, 0, 1, 2, 3, 7])), cull=int(rng.choice([-1, 1, 0])), fused_subject=int(rng.choice([-1, 1, 0])))
         if f0:
             pt.render(sc, film, pt.default_params(frame=0, frame_count=f0, **gk))
         pt.render(sc, film, pt.default_params(frame=f0, frame_count=nf, **gk))
