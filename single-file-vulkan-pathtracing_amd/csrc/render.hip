@@ -593,7 +593,8 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
 // In single steps with the cull (r05zr_tail_fine.log): one frame S 15 .. 16, two frames S 10 (11.51 against 11.55 at 12), three S 8, four S 6
 // (22.11 against 22.22 at 4).
 // So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 5 spp / 16; to 10.1 -> spp / 4; to
-// 13.5 -> 3 spp / 16; above -> 0.  pt_tuning.fused_tail >= 0 overrides.
+// 13.5 -> 3 spp / 16; to 21.9 -> spp / 8 (5 / 6 / 7 frames and a rank of world 4 at 20 frames: -1.2 / -1.2 / -0.8 / -0.9 %, r05zzb_tail_mid_k.log);
+// above -> 0 (8 frames: -0.1 %).  pt_tuning.fused_tail >= 0 overrides.
 uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames, const int32_t rect[4])
 {
     const uint32_t spp = p->spp_per_frame;
@@ -602,7 +603,7 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
     if (t < 0) {
         const uint32_t x = fused_slots_x32(ctx, f, p, frames, rect);
         t = x < 36u ? 0 : x <= 81u ? (int)(spp * 5u / 8u) : x <= 144u ? (int)(spp / 2u) : x <= 252u ? (int)(spp * 5u / 16u) : x <= 324u ? (int)(spp / 4u)
-                                   : x <= 432u ? (int)(spp * 3u / 16u) : 0;
+                                   : x <= 432u ? (int)(spp * 3u / 16u) : x <= 700u ? (int)(spp / 8u) : 0;
     }
     return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }
