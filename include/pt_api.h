@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define PT_API_VERSION 5  /* 5: PT_PIPELINE_AUTO (what pt_params_default returns); pt_stats.pipeline / .tail_samples / .rays_culled (appended); pt_tuning.fused_tail /
+#define PT_API_VERSION 6  /* 6: pt_get_block_counts (PT_FLAG_COUNT_VISITS on PT_PIPELINE_FUSED: the instrumented single-level fused kernel).
+                           * 5: PT_PIPELINE_AUTO (what pt_params_default returns); pt_stats.pipeline / .tail_samples / .rays_culled (appended); pt_tuning.fused_tail /
                            *    .fused_subject / .cull (from the reserved words); pt_device_write.  4: PT_PIPELINE_FUSED; pt_tuning.tlas_ploc / ploc_adopt_pct / fail_rebuild */
 
 typedef enum pt_status {
@@ -343,6 +344,35 @@ typedef struct pt_stats {
 } pt_stats;
 pt_status pt_get_stats(pt_ctx *ctx, pt_stats *stats);
 pt_status pt_reset_stats(pt_ctx *ctx);
+/* (API version 6) Where the fused kernel's instructions go.  A render with pipeline = PT_PIPELINE_FUSED and PT_FLAG_COUNT_VISITS (single-level
+ * scenes with pair leaves; never timed) runs the instrumented twin of the kernel: every block of its loop -- the restatement of raygen.rgen:41-91 --
+ * counts how often a WAVE executed it and how many LANES were inside.  waves_lanes receives 2 * n_blocks words {wave executions, lanes} in the
+ * order of pt_fused_block, summed since pt_reset_stats.  With the blocks' instruction counts in the shipped ISA (scripts/isa_regions.py,
+ * profiles/isa_valu_model.json) these give the kernel's VALU wave-instructions and its active lanes per instruction block by block.          */
+enum pt_fused_block {
+    PT_FB_ITER = 0,  /* one pass of the outer loop                                              */
+    PT_FB_SHADE,     /* the shade block ran (lanes: with a finished ray, or asking for a slot)  */
+    PT_FB_HIT,       /* ... state loads of the lanes with a hit record                          */
+    PT_FB_MISS,      /* ... miss.rmiss:8-12                                                     */
+    PT_FB_SURFACE,   /* ... closesthit.rchit:33-41, 50-53: material, emission                   */
+    PT_FB_ADD,       /* ... raygen.rgen:76 color += weight * emission                           */
+    PT_FB_BOUNCE,    /* ... closesthit.rchit:56-57 + raygen.rgen:77-80                          */
+    PT_FB_NEXT,      /* ... path ended: next sample or slot complete (raygen.rgen:43, 62, 81)   */
+    PT_FB_DONE,      /* ... the slot's radiance goes to memory                                  */
+    PT_FB_HANDOUT,   /* slot hand-out ran (lanes: asking for a slot)                            */
+    PT_FB_DRAW,      /* ... the wave drew a batch of slots                                      */
+    PT_FB_TAKE,      /* ... lanes that took a slot                                              */
+    PT_FB_CULLED,    /* ... of them: finished here, the pixel cannot see the scene              */
+    PT_FB_PRIMARY,   /* camera ray (raygen.rgen:45-60)                                          */
+    PT_FB_SETUP,     /* state to LDS, ray set-up for the walk                                   */
+    PT_FB_NODE,      /* one BVH4 node step                                                      */
+    PT_FB_POP,       /* one iteration of the stack-pop loop                                     */
+    PT_FB_LEAF,      /* one leaf step (a triangle or a fan pair)                                */
+    PT_FB_DIV,       /* ... its divide block                                                    */
+    PT_FB_FINISH,    /* a walk ended                                                            */
+    PT_FB_COUNT
+};
+pt_status pt_get_block_counts(pt_ctx *ctx, uint64_t *waves_lanes, uint32_t n_blocks /* <= 32 */);
 
 #ifdef __cplusplus
 }

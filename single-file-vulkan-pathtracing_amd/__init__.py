@@ -98,6 +98,9 @@ class HostScene(C.Structure):
                 ("n_tris", C.c_uint32), ("faces", C.POINTER(C.c_float))]
 
 
+# include/pt_api.h pt_fused_block, in order
+FUSED_BLOCKS = ["ITER", "SHADE", "HIT", "MISS", "SURFACE", "ADD", "BOUNCE", "NEXT", "DONE", "HANDOUT", "DRAW", "TAKE", "CULLED", "PRIMARY", "SETUP",
+                "NODE", "POP", "LEAF", "DIV", "FINISH"]
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("inst", "<u4")])
 
 # every symbol include/pt_api.h and include/pt_host.h declare
@@ -106,7 +109,7 @@ API_SYMBOLS = ["pt_ctx_create", "pt_ctx_destroy", "pt_last_error", "pt_sync", "p
                "pt_scene_get_info", "pt_scene_read_bvh", "pt_scene_read_bvh4", "pt_scene_read_bvh8", "pt_film_create", "pt_film_create_external", "pt_film_clear",
                "pt_film_read_f32", "pt_film_read_bgra8", "pt_film_destroy", "pt_params_default", "pt_render",
                "pt_render_prepare", "pt_trace",
-               "pt_get_stats", "pt_reset_stats",
+               "pt_get_stats", "pt_reset_stats", "pt_get_block_counts",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_ranks", "pt_comm_destroy", "pt_film_present",
                "pt_film_tile_count", "pt_film_pack_tiles", "pt_film_unpack_tiles",
                "pt_device_alloc", "pt_device_free", "pt_device_read", "pt_device_write", "pt_ctx_get_tuning", "pt_ctx_set_tuning"]
@@ -165,6 +168,8 @@ def lib_amd():
         L.pt_trace.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_uint32, vp]
         L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.pt_reset_stats.argtypes = [vp]
+        if hasattr(L, "pt_get_block_counts"):   # (API version 6; dev A/B runs load older builds through PT_LIB_AMD)
+            L.pt_get_block_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint32]
         L.pt_comm_unique_id.argtypes = [vp]
         L.pt_comm_create.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.pt_comm_ranks.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -340,6 +345,13 @@ class Context:
 
     def reset_stats(self):
         self._check(lib_amd().pt_reset_stats(self.h))
+
+    def block_counts(self):
+        """{block: (wave executions, lanes inside)} of the instrumented fused kernel since reset_stats (pt_get_block_counts; render with
+        pipeline=PIPELINE_FUSED, flags=FLAG_COUNT_VISITS)."""
+        a = (C.c_uint64 * (2 * len(FUSED_BLOCKS)))()
+        self._check(lib_amd().pt_get_block_counts(self.h, a, len(FUSED_BLOCKS)))
+        return {n: (int(a[2 * i]), int(a[2 * i + 1])) for i, n in enumerate(FUSED_BLOCKS)}
 
     def close(self):
         if self.h:

@@ -27,8 +27,11 @@ extern "C" int pt_debug_fused_hist(void *device_u32_2x8192x16)
 
 namespace {
 using namespace ptw;
+#include "fused_dev.h"
 #include "fused_kernel.h"
 #include "fused_inst_kernel.h"
+constexpr size_t FUSED_COUNT_LDS = sizeof(uint32_t) * 2 * FB_N * (FTB / 64);  // the instrumented twin's per-wave block counters, behind the product plan
+static_assert((int)FB_N == (int)PT_FB_COUNT && FB_N <= PT_N_BLOCKS, "fused_kernel.h FusedBlock mirrors include/pt_api.h pt_fused_block");
 
 // two-level scenes: k_extend_inst16's class (extend_launch.hip: both levels in 15-bit child codes, BLAS in LDS, pair leaves)
 pt_status plan_fused_inst(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPlan &fp)
@@ -101,6 +104,9 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     int per_cu = ctx->fused_per_cu[0];
     const size_t key0 = (fp.smem << 1) | (pl.pairs ? 1u : 0u);
     if (ctx->fused_smem[0] != key0 || per_cu <= 0) {
+        for (const void *fn : { reinterpret_cast<const void *>(k_fused_count<0, true>), reinterpret_cast<const void *>(k_fused_count<1, true>),
+                                 reinterpret_cast<const void *>(k_fused_count<2, true>) })
+            PT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fp.smem + FUSED_COUNT_LDS)));
         for (const void *fn : { reinterpret_cast<const void *>(k_fused<0, true>), reinterpret_cast<const void *>(k_fused<1, true>),
                                  reinterpret_cast<const void *>(k_fused<0, false>), reinterpret_cast<const void *>(k_fused<1, false>),
                                  reinterpret_cast<const void *>(k_fused<2, true>), reinterpret_cast<const void *>(k_fused<2, false>) })
@@ -143,11 +149,17 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
     }
     FastDiv div_frames;  // one group: the hand-out order is tile-major (fused_kernel.h), chunk -> (tile, frame) by this
     div_frames.init(std::max(rc.lanes_active, 1u));
-#define PT_LAUNCH_FUSED(G, P)                                                                                                              \
-    hipExtLaunchKernelGGL((k_fused<G, P>), dim3(fp.grid), dim3(FTB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4, \
+#define PT_LAUNCH_FUSED_K(K, G, P)                                                                                                         \
+    hipExtLaunchKernelGGL((K<G, P>), dim3(fp.grid), dim3(FTB), (uint32_t)(fp.smem + (fp.count ? FUSED_COUNT_LDS : 0)), st, ev0, ev1, 0u, rc, tiles, rad, s->d_wide, s->d_tri4,       \
                           s->d_shade4, s->d_frame4, s->n_wide, s->n_tris, 0u, n_slots, next_slot, stats, fp.refill, tmin, tmax, fp.lds_stack, div_frames)
+#define PT_LAUNCH_FUSED(G, P) PT_LAUNCH_FUSED_K(k_fused, G, P)
     const int mode = rc.tail ? 2 : (grouped ? 1 : 0);
+    if (fp.count) {  // the instrumented twins (pair-leaf trees: what the compact class gets by default)
+        if (mode == 2) PT_LAUNCH_FUSED_K(k_fused_count, 2, true); else if (mode == 1) PT_LAUNCH_FUSED_K(k_fused_count, 1, true); else PT_LAUNCH_FUSED_K(k_fused_count, 0, true);
+        return;
+    }
     if (fp.pairs) { if (mode == 2) PT_LAUNCH_FUSED(2, true); else if (mode == 1) PT_LAUNCH_FUSED(1, true); else PT_LAUNCH_FUSED(0, true); }
     else { if (mode == 2) PT_LAUNCH_FUSED(2, false); else if (mode == 1) PT_LAUNCH_FUSED(1, false); else PT_LAUNCH_FUSED(0, false); }
 #undef PT_LAUNCH_FUSED
+#undef PT_LAUNCH_FUSED_K
 }

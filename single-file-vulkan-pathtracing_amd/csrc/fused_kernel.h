@@ -10,8 +10,8 @@
 //   * traversal: the compact walk of extend_kernel.h (`extend_body<true, false, false, PAIRS>`; pair leaves: one-dword stack
 //     entries in LDS, key-sorted children, fan pairs tested together), restated here operation for operation -- the hot
 //     instantiation of that template is register-allocated to the last VGPR and must not grow a second use;
-//   * a lane whose ray is finished WAITS with its hit in registers until a quarter of the wave's live lanes wait too
-//     (`refill`), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
+//   * a lane whose ray is finished WAITS with its hit in registers until `refill` / 64 of the wave's live lanes wait too
+//     (40 / 64: fused.hip), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
 //     raygen.rgen:76-83, the next sample's camera ray (raygen.rgen:45-60), or the first sample of a NEW slot -- and set up
 //     their next ray; the same operations in the same order as k_shade, so the film is the wavefront pipeline's bit for bit;
 //   * slots (frame, sample group, pixel) are handed out in order by device-scope counters -- eight, one per XCD's share of the
@@ -70,13 +70,39 @@ enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS
 #ifndef PT_FUSED_NODE_EXIT_B
 #define PT_FUSED_NODE_EXIT_B 1
 #endif
-template <int MODE, bool PAIRS>
-__global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
-                                                              const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
-                                                              const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
-                                                              uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
-                                                              uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
-                                                              float tmax, int lds_stack, FastDiv div_frames)
+// COUNT (PT_FLAG_COUNT_VISITS on the fused pipeline; never timed): every block of the loop counts its wave executions and the lanes inside them
+// (FusedBlock below) -- with the blocks' instruction counts in the shipped ISA (scripts/isa_regions.py) that is where the kernel's VALU
+// instructions go and which block runs at how many of its 64 lanes.  The product instantiations (COUNT = false) carry none of it.
+enum FusedBlock : int {
+    FB_ITER = 0,   // one pass of the outer loop (its head: the ballots that decide what runs)
+    FB_SHADE,      // the shade block ran (lanes: those inside it, with a hit or asking for a slot)
+    FB_HIT,        // (1) state loads of the lanes with a hit record
+    FB_MISS,       // ... miss.rmiss: weight * env
+    FB_SURFACE,    // ... closesthit.rchit: the triangle's shading record, weight * Ke
+    FB_ADD,        // ... color += (LDS accumulator or term log)
+    FB_BOUNCE,     // ... position, tangent frame, direction, brdf * cos / pdf (raygen.rgen:77-80)
+    FB_NEXT,       // ... path ended: next sample of the slot, or the slot is complete
+    FB_DONE,       // ... the slot's radiance goes to memory
+    FB_HANDOUT,    // (2) the wave-uniform slot hand-out ran (lanes: those asking for a slot)
+    FB_DRAW,       // ... the wave drew a batch of slots (the atomic and the tile words)
+    FB_TAKE,       // ... lanes that took a slot (decode slot -> frame, pixel)
+    FB_CULLED,     // ... of them: the pixel cannot see the scene, the slot is finished here
+    FB_PRIMARY,    // (3) camera ray of a sample (raygen.rgen:45-60)
+    FB_SETUP,      // (4) state back to LDS, ray set-up for the walk
+    FB_NODE,       // one BVH4 node step
+    FB_POP,        // one iteration of the stack-pop loop (inside node steps and behind leaf steps)
+    FB_LEAF,       // one leaf step (a triangle or a fan pair)
+    FB_DIV,        // ... its divide block (a lane is inside a triangle's edges)
+    FB_FINISH,     // a walk ended (cur == DONE)
+    FB_N
+};
+template <int MODE, bool PAIRS, bool COUNT>
+__device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+                                           const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
+                                           const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
+                                           uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
+                                           uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
+                                           float tmax, int lds_stack, FastDiv div_frames)
 {
     constexpr uint32_t LEAF_BIT = 0x2000u, DONE = 0x3FFFu;
     constexpr bool GROUPED = MODE == 1, HYB = MODE == 2;
@@ -114,14 +140,19 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
     const int lane = threadIdx.x & 63;
 
-#ifdef PT_FUSED_TIMELINE  // dev build (scripts/probe_fused_timeline.py): per wave {start, out of slots, end, rays} in device clock ticks
-    unsigned long long tl_start = wall_clock64(), tl_oos = 0ull;
-    unsigned long long tl_slot_t0 = 0ull, tl_last_t0 = 0ull, tl_last_t1 = 0ull;  // per lane: when its current slot began; its last completed slot
-    uint32_t tl_last_slot = 0xFFFFFFFFu, tl_n_slots = 0u;
-#endif
-#ifdef PT_FUSED_HIST
-    uint32_t tl_hb = 0xFFFFFFFFu, tl_hn = 0u, tl_ht = 0u, tl_pass = 0u;  // the histogram bucket being counted, rays started in it (all / on tail slots)
-#endif
+    FusedDev dev;  // (fused_dev.h: empty in the product build)
+    dev.kernel_begin();
+    // COUNT: {wave executions, lanes inside} of every block, kept per wave in LDS behind the product kernel's plan (no registers: the walk keeps
+    // its allocation) and added by the first active lane of the moment
+    lds_u32 *s_fb = (lds_u32 *)reinterpret_cast<uint32_t *>(s_frame + 2 * (size_t)n_tris) + FS_FIELDS * FTB + (FTB / 64) * PT_FUSED_WTILES + (threadIdx.x >> 6) * (2 * FB_N);
+    if constexpr (COUNT) {
+        if (lane < 2 * FB_N) s_fb[lane] = 0u;
+    }
+#define PT_FB(B)                                                                                        \
+    if constexpr (COUNT) {                                                                              \
+        const unsigned long long m_fb = __ballot(1);                                                    \
+        if (lane == __ffsll((long long)m_fb) - 1) { s_fb[2 * (B)] += 1u; s_fb[2 * (B) + 1] += (uint32_t)__popcll(m_fb); } \
+    }
     bool have = false;          // the lane traces a ray
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
@@ -149,6 +180,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
 
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
+            PT_FB(FB_POP)
             sp--;
             const uint32_t e = my_stack32[sp * FTB];
             if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
@@ -157,6 +189,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
     };
 
     for (;;) {
+        PT_FB(FB_ITER)
         // ---- shade block: the lanes that wait with a hit (or with nothing, while slots are left) -- once enough of them do
         const unsigned long long m_have = __ballot(have);
         const bool in_blk = !have && (path || !out_of_slots);
@@ -166,8 +199,10 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             float wr = 0.f, wg = 0.f, wb = 0.f;
             ptm::f3 org{}, dir{};
             bool got_ray = false, need_primary = false;
+            if (in_blk) { PT_FB(FB_SHADE) }
             // (1) the hit of the ray that just ended: radiance, then bounce / next sample / slot complete
             if (in_blk && path) {
+                PT_FB(FB_HIT)
                 slot = my_state[FS_SLOT * FTB]; ctr = my_state[FS_CTR * FTB]; seed = my_state[FS_SEED * FTB];
                 wr = __uint_as_float(my_state[FS_WR * FTB]); wg = __uint_as_float(my_state[FS_WG * FTB]); wb = __uint_as_float(my_state[FS_WB * FTB]);
                 pxy = my_state[FS_PXY * FTB];
@@ -179,10 +214,12 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 const uint32_t pos = best_pos;
                 float4 s0{}, s1{};
                 if (pos == PT_MISS) {  // miss.rmiss:10-11 then raygen.rgen:76, 81-83
+                    PT_FB(FB_MISS)
                     er = wr * rc.env[0]; eg = wg * rc.env[1]; eb = wb * rc.env[2];
                     add = true;
                     terminated = true;
                 } else {
+                    PT_FB(FB_SURFACE)
                     s0 = s_shade[3 * pos + 0]; s1 = s_shade[3 * pos + 1];
                     const float4 s2 = s_shade[3 * pos + 2];
                     er = wr * s1.z; eg = wg * s1.w; eb = wb * s2.x;
@@ -194,16 +231,15 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 const uint32_t lslot = HYB ? slot - rc.n_head : slot;     // ... its place in the log arrays
                 const uint32_t lstride = HYB ? rc.n_tail : rc.n_slots;
                 if (add) {
+                    PT_FB(FB_ADD)
                     if (!logs) {
                         my_state[FS_A * FTB] = __float_as_uint(__uint_as_float(my_state[FS_A * FTB]) + er);
                         my_state[FS_B * FTB] = __float_as_uint(__uint_as_float(my_state[FS_B * FTB]) + eg);
                         my_state[FS_C * FTB] = __float_as_uint(__uint_as_float(my_state[FS_C * FTB]) + eb);
                     } else {  // the ordered term log of add_radiance (wavefront_types.h), the count kept in LDS
                         const uint32_t k = my_state[FS_A * FTB];
-#ifdef PT_DBG_NO_TERMS  // timing experiment only (wrong images): what the term log's stores cost
-                        if (k == 0xFFFFFFFFu)
-#endif
-                        if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * lstride + lslot), make_float4(er, eg, eb, 0.f));
+                        if (dbg_no_terms && k != 0xFFFFFFFFu) {}  // (fused_dev.h: false in the product build)
+                        else if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * lstride + lslot), make_float4(er, eg, eb, 0.f));
                         else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)lslot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
                         else {
                             const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
@@ -219,6 +255,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     }
                 }
                 if (!terminated) {
+                    PT_FB(FB_BOUNCE)
                     // closesthit.rchit:56-57 position from the barycentrics; raygen.rgen:77-80 the bounce
                     const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
                     float hu, hv;
@@ -236,6 +273,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     wr = wr * fr; wg = wg * fg; wb = wb * fb;
                     got_ray = true;
                 } else {
+                    PT_FB(FB_NEXT)
                     sample++;
                     depth = 0;
                     bool more;
@@ -249,15 +287,12 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     if (more) {
                         need_primary = true;  // the slot's next sample: raygen.rgen:45-60
                     } else {  // the slot is complete
+                        PT_FB(FB_DONE)
                         if (!logs) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FTB]), __uint_as_float(my_state[FS_B * FTB]),
                                                                    __uint_as_float(my_state[FS_C * FTB]), 0.f);
-#ifndef PT_DBG_NO_NTERM
-                        else rad.nterm[lslot] = my_state[FS_A * FTB];
-#endif
+                        else if (!dbg_no_nterm) rad.nterm[lslot] = my_state[FS_A * FTB];
                         path = false;
-#ifdef PT_FUSED_TIMELINE
-                        tl_last_slot = slot; tl_last_t0 = tl_slot_t0; tl_last_t1 = wall_clock64(); tl_n_slots++;
-#endif
+                        dev.slot_end(slot);
                     }
                 }
                 ctr = sample | (depth << 16);
@@ -267,7 +302,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             // paid once per batch -- per lane and shade block, as the first version did, they were 3/4 of the kernel's time.
             const unsigned long long m_want = __ballot(in_blk && !path);
             if (m_want && !out_of_slots) {
+                if (in_blk && !path) { PT_FB(FB_HANDOUT) }
                 if (w_next >= w_end) {
+                    PT_FB(FB_DRAW)
                     // The slots are cut into PT_FUSED_PARTS contiguous parts with a counter each, 128 B apart; a wave starts on part
                     // blockIdx % 8 -- workgroups go to the eight XCDs round-robin, so the waves of one XCD share a word -- and moves
                     // on to the next part when its own is exhausted (work stealing, in ring order) until all eight are.  One word takes
@@ -315,9 +352,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                             break;
                         }
                     }
-#ifdef PT_FUSED_TIMELINE
-                    if (out_of_slots) tl_oos = wall_clock64();
-#endif
+                    if (out_of_slots) dev.out_of_slots();
                     if (!out_of_slots && (uint32_t)lane < (w_end - w_base + 63u) / 64u) {
                         if (GROUPED || (HYB && w_tails)) {
                             const uint32_t c = slot_base + w_base + 64u * (uint32_t)lane;   // a 64-aligned chunk of slots = one 8x8 tile
@@ -332,6 +367,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
                 uint32_t cull_n = 0u;  // samples of a slot that is finished here: its pixel cannot see the scene (RenderConst::cull)
                 if (in_blk && !path && rank < take) {
+                    PT_FB(FB_TAKE)
                     const uint32_t mine = w_next + rank;
                     uint32_t f, g, local;
                     if (HYB && w_tails) {  // tail slot `mine` of the launch: (frame lane, tail j, pixel); sample head_samples + j
@@ -356,6 +392,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                     const uint32_t sample0 = (HYB && w_tails) ? rc.head_samples + g : g * rc.group_size;
                     const bool in_image = px < rc.width && py < rc.height && f < rc.lanes_active && sample0 < rc.spp;
                     if (in_image && ptc::pixel_culled(rc, px, py)) {
+                        PT_FB(FB_CULLED)
                         // every sample of the slot: one camera ray, a miss, color += 1 * env -- without the walk that would find nothing (fused_cull.h)
                         if (GROUPED) cull_n = ptc::finish_group(rc, rad, slot, g);
                         else if (!(HYB && w_tails)) cull_n = ptc::finish_plain(rc, rad, slot);
@@ -368,9 +405,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                         if (!GROUPED) { my_state[FS_B * FTB] = 0u; my_state[FS_C * FTB] = 0u; }
                         path = true;
                         need_primary = true;
-#ifdef PT_FUSED_TIMELINE
-                        tl_slot_t0 = wall_clock64();
-#endif
+                        dev.slot_begin();
                     } else if (GROUPED) {
                         rad.nterm[slot] = 0u;  // (a slot outside the image or the batch: k_resolve never reads it, kept defined anyway)
                     } else if (HYB && w_tails) {
@@ -386,6 +421,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             }
             // (3) camera ray of a slot's next (or first) sample
             if (need_primary) {
+                PT_FB(FB_PRIMARY)
                 const uint32_t f = (HYB && slot >= rc.n_head) ? rc.div_tail.div(rc.div_spl.div(slot - rc.n_head)) : rc.div_groups.div(rc.div_spl.div(slot));
                 const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
                 seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
@@ -395,6 +431,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
             }
             // (4) state back to LDS, ray set-up (the refill block of extend_body<true, false, false, true>)
             if (got_ray) {
+                PT_FB(FB_SETUP)
                 my_state[FS_SLOT * FTB] = slot; my_state[FS_CTR * FTB] = ctr; my_state[FS_SEED * FTB] = seed;
                 my_state[FS_WR * FTB] = __float_as_uint(wr); my_state[FS_WG * FTB] = __float_as_uint(wg); my_state[FS_WB * FTB] = __float_as_uint(wb);
                 my_state[FS_PXY * FTB] = pxy;
@@ -412,26 +449,9 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 sp = 0;
                 have = true;
             }
-            n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));  // (wave-uniform control flow here: every lane keeps the same count)
-#ifdef PT_FUSED_HIST
-            {   // dev build (scripts/probe_fused_hist.py): rays started per 50 us of device clock (100 MHz), [bucket][16 words by block]; the second
-                // half: those of waves drawing tail slots.  Counted in registers; the clock is read on every 8th pass only (a scalar memory read the
-                // wave waits for) and a bucket's count is flushed when the bucket changes: one atomic per wave and bucket, spread over 16 words
-                const uint32_t tl_n = (uint32_t)__popcll(__ballot(got_ray));
-                if ((tl_pass++ & 7u) == 0u) {
-                    const uint32_t b = (uint32_t)(wall_clock64() / 5000ull) & 8191u;
-                    if (b != tl_hb) {
-                        if (lane == 0 && g_fused_hist && tl_hn) {
-                            atomicAdd(g_fused_hist + tl_hb * 16u + (blockIdx.x & 15u), tl_hn);
-                            if (tl_ht) atomicAdd(g_fused_hist + (8192u + tl_hb) * 16u + (blockIdx.x & 15u), tl_ht);
-                        }
-                        tl_hb = b; tl_hn = 0u; tl_ht = 0u;
-                    }
-                }
-                tl_hn += tl_n;
-                if (HYB && w_tails) tl_ht += tl_n;
-            }
-#endif
+            const uint32_t n_started = (uint32_t)__popcll(__ballot(got_ray));  // (wave-uniform control flow here: every lane keeps the same count)
+            n_rays_wave += n_started;
+            dev.rays_started(n_started, HYB && w_tails, lane);
         }
         if (__ballot(have) == 0ull) {
             if (__ballot(path) == 0ull && out_of_slots) break;
@@ -442,6 +462,7 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         bool do_node = have && !(cur & LEAF_BIT);
         const int n_have = __popcll(__ballot(have));
         while (do_node) {
+            PT_FB(FB_NODE)
             cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, pop);
             do_node = !(cur & LEAF_BIT);
             const int n_cont = __popcll(__ballot(do_node));
@@ -450,13 +471,14 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
         if (have) {
             if (cur != DONE && (cur & LEAF_BIT)) {
+                PT_FB(FB_LEAF)
                 if (PAIRS) {
                     const uint32_t first = cur & 0x7FFu;
                     ptl::pair_leaf_test(tri4, (size_t)tri_base + 3 * (size_t)first, ((cur >> 11) & 3u) != 0u, first, pre, orgp, tmin, tmax,
                                         [&](float t, float V, float W, float det, uint32_t pos, uint32_t) {
                                             ptl::closer_single_level(tri4, tri_base, t, V, W, det, pos, best_t, best_V, best_W, best_det, best_pos);
                                         },
-                                        [] {});
+                                        [&] { PT_FB(FB_DIV) });
                 } else {
                     const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
                     for (uint32_t k = 0; k < cnt; k++) {
@@ -474,25 +496,42 @@ __global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, c
                 }
                 cur = pop();
             }
-            if (cur == DONE) have = false;  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block
+            if (cur == DONE) {  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block
+                PT_FB(FB_FINISH)
+                have = false;
+            }
         }
     }
     if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);
     if (lane == 0 && n_cull_wave) atomicAdd(stats + 19, (unsigned long long)n_cull_wave);  // (pt_stats.rays_culled)
-#ifdef PT_FUSED_HIST
-    if (lane == 0 && g_fused_hist && tl_hn) {
-        atomicAdd(g_fused_hist + (tl_hb & 8191u) * 16u + (blockIdx.x & 15u), tl_hn);
-        if (tl_ht) atomicAdd(g_fused_hist + (8192u + (tl_hb & 8191u)) * 16u + (blockIdx.x & 15u), tl_ht);
+    dev.kernel_end(lane, n_rays_wave, FTB);
+    if constexpr (COUNT) {  // (pt_get_block_counts: stats[PT_N_STATS + 2 * block] wave executions, [+ 1] lanes inside them)
+        if (lane < 2 * FB_N) atomicAdd(stats + PT_N_STATS + lane, (unsigned long long)s_fb[lane]);
     }
-#endif
-#ifdef PT_FUSED_TIMELINE
-    if (lane == 0 && g_fused_timeline) {
-        unsigned long long *o = g_fused_timeline + 4 * (size_t)(blockIdx.x * (FTB / 64) + (threadIdx.x >> 6));
-        o[0] = tl_start; o[1] = tl_oos; o[2] = wall_clock64(); o[3] = n_rays_wave;
-    }
-    if (g_fused_timeline) {  // per lane, after the per-wave records: {last slot | slots done << 32, its start, its end}
-        unsigned long long *o = g_fused_timeline + 4 * (size_t)(gridDim.x * (FTB / 64)) + 3 * (size_t)(blockIdx.x * FTB + threadIdx.x);
-        o[0] = (unsigned long long)tl_last_slot | ((unsigned long long)tl_n_slots << 32); o[1] = tl_last_t0; o[2] = tl_last_t1;
-    }
-#endif
+#undef PT_FB
+}
+
+template <int MODE, bool PAIRS>
+__global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+                                                              const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
+                                                              const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
+                                                              uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
+                                                              uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
+                                                              float tmax, int lds_stack, FastDiv div_frames)
+{
+    fused_body<MODE, PAIRS, false>(rc, tiles, rad, g_wide, g_tri4, g_shade4, g_frame4, n_wide, n_tris, slot_base, n_slots, next_slot, stats, refill, tmin,
+                                   tmax, lds_stack, div_frames);
+}
+// the instrumented twin (PT_FLAG_COUNT_VISITS): the same LDS plan and block size, so a wave holds what it holds in the timed kernel; the counters
+// cost registers (spills), so it is slower and never timed
+template <int MODE, bool PAIRS>
+__global__ __launch_bounds__(FTB, PT_FUSED_WAVES) void k_fused_count(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+                                                                    const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
+                                                                    const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
+                                                                    uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
+                                                                    uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
+                                                                    float tmax, int lds_stack, FastDiv div_frames)
+{
+    fused_body<MODE, PAIRS, true>(rc, tiles, rad, g_wide, g_tri4, g_shade4, g_frame4, n_wide, n_tris, slot_base, n_slots, next_slot, stats, refill, tmin,
+                                  tmax, lds_stack, div_frames);
 }

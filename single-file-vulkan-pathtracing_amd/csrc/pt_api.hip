@@ -133,8 +133,8 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     }
     if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return fail("hipEventCreate", e);
-    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * PT_N_STATS)) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * PT_N_STATS_ALL)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS_ALL)) != hipSuccess) return fail("hipMemset", e);
     *out = ctx;
     return PT_OK;
 }
@@ -448,11 +448,20 @@ pt_status pt_get_stats(pt_ctx *ctx, pt_stats *out)
     return PT_OK;
 }
 
+pt_status pt_get_block_counts(pt_ctx *ctx, uint64_t *waves_lanes, uint32_t n_blocks)
+{
+    if (!ctx) return PT_ERR_INVALID_ARG;
+    if (!waves_lanes || n_blocks > (uint32_t)PT_N_BLOCKS) { ctx->err = "pt_get_block_counts: null array or more than 32 blocks"; return PT_ERR_INVALID_ARG; }
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(waves_lanes, ctx->d_stats + PT_N_STATS, sizeof(unsigned long long) * 2 * n_blocks, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 pt_status pt_reset_stats(pt_ctx *ctx)
 {
     if (!ctx) return PT_ERR_INVALID_ARG;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS));
+    PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS_ALL));
     ctx->stats = pt_stats{};
     return PT_OK;
 }

@@ -19,7 +19,9 @@
 //            as halves (2 dwords each), child[4]                                                      64 B
 //   wide   : BVH4 collapsed from it, 8 x float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
 //            hi.z[4] child[4] spare; leaf child = LEAF | (count-1)<<28 | first sorted position     128 B
-constexpr int PT_N_STATS = 24;  // u64 slots of pt_ctx::d_stats
+constexpr int PT_N_STATS = 24;  // u64 slots of pt_ctx::d_stats that pt_get_stats reads ...
+constexpr int PT_N_BLOCKS = 32;  // ... followed by {wave executions, lanes} of up to this many kernel blocks (pt_get_block_counts; fused_kernel.h FusedBlock)
+constexpr int PT_N_STATS_ALL = PT_N_STATS + 2 * PT_N_BLOCKS;
 constexpr int PT_MAX_PIPES = 4;  // concurrent wavefront pipelines (streams) per pt_render
 
 struct pt_ctx {

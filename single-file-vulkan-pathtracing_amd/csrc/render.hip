@@ -29,8 +29,8 @@ pt_status check_params(pt_scene *s, pt_film *f, const pt_params *p)
     }
     if (p->frame < 0 || p->frame_count == 0) { ctx->err = "frame must be >= 0 and frame_count >= 1"; return PT_ERR_INVALID_ARG; }
     if (p->pipeline > PT_PIPELINE_AUTO) { ctx->err = "unknown pipeline"; return PT_ERR_UNSUPPORTED; }
-    if (p->pipeline == PT_PIPELINE_FUSED && (p->flags & (PT_FLAG_ASYNC | PT_FLAG_COUNT_VISITS))) {
-        ctx->err = "the fused pipeline has no asynchronous and no instrumented form";
+    if (p->pipeline == PT_PIPELINE_FUSED && (p->flags & PT_FLAG_ASYNC)) {
+        ctx->err = "the fused pipeline has no asynchronous form";
         return PT_ERR_UNSUPPORTED;
     }
     if (p->pipeline == PT_PIPELINE_WAVEFRONT_NEE) {
@@ -619,9 +619,15 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     FusedPlan fp;
     pt_status rc_ = ptw_plan_fused(s, pl, p_in->tmin, fp);
     if (rc_ != PT_OK) return rc_;
+    if (p_in->flags & PT_FLAG_COUNT_VISITS) {  // the instrumented twin of the single-level kernel (wave-level block counts: pt_get_block_counts)
+        if (fp.inst || !fp.pairs) {
+            ctx->err = "PT_FLAG_COUNT_VISITS on the fused pipeline: single-level scenes with pair leaves only (the two-level kernel has no instrumented form)";
+            return PT_ERR_UNSUPPORTED;
+        }
+        fp.count = true;
+    }
     int32_t rect[4];
     subject_rect(s, p_in, rect);
-    const bool have_rect = rect[2] >= rect[0] && rect[3] >= rect[1];
     pt_params q;
     fused_shape_defaults(f, p_in, fp, rect, q);
     const pt_params *p = &q;

@@ -85,6 +85,7 @@ struct FusedPlan {
     size_t smem = 0;
     int grid = 0, block = 0, lds_stack = 0, refill = 40;
     bool pairs = true;                   // single-level: the pair-leaf instantiation (ExtendPlan::pairs)
+    bool count = false;                  // PT_FLAG_COUNT_VISITS: the instrumented twin (single-level scenes; wave-level block counts)
     bool inst = false;                   // two-level scene: k_fused_inst (fused_inst_kernel.h) around k_extend_inst16's walk
     uint32_t n_tlas_lds = 0;             // ... its TLAS nodes staged in LDS
     uint32_t *spill = nullptr;           // ... its stack entries beyond lds_stack: [levels][grid * block] dwords of the context's spill area

@@ -2577,7 +2577,7 @@ def test_fused_pipeline_shards_term_log_tiers_and_refusals(pt, orc, gpu_ctx, cor
         finally:
             gpu_ctx.set_tuning(**old)
     film = pt.Film(gpu_ctx, w, h)
-    for bad in (dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_ASYNC), dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_COUNT_VISITS),
+    for bad in (dict(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_ASYNC),
                 dict(pipeline=pt.PIPELINE_FUSED, extend=pt.EXTEND_HBM), dict(pipeline=pt.PIPELINE_FUSED, tmin=0.0), dict(pipeline=4)):
         with pytest.raises(pt.PtError) as e:
             pt.render(cornell_gpu, film, pt.default_params(**{**kw, **bad}))
@@ -2683,3 +2683,41 @@ def test_sah_device_builder_makes_its_committed_trees(pt, gpu_ctx):
         got = sc.read_bvh4()
         assert got.shape == g[name].shape and got.tobytes() == g[name].tobytes(), name
         sc.close()
+
+
+def test_fused_block_counts_instrumented_twin_is_bit_exact_and_consistent(pt, gpu_ctx, cornell_gpu):
+    """PT_FLAG_COUNT_VISITS on the fused pipeline (API v6): the instrumented twin of k_fused renders the same film and ray count as the product
+    kernel, through its three forms (one group, several groups, head + tail), and its wave-level block counts (pt_get_block_counts) are
+    consistent with the ray count: every walked ray is set up once and finished once, every shaded hit is a miss or a surface hit, a camera ray
+    per sample.  Two-level scenes have no instrumented fused form."""
+    w, h = 200, 120
+    kw = dict(width=w, height=h, spp_per_frame=8, max_depth=8, frame=0, frame_count=3)
+    for shape in (dict(sample_groups=1), dict(sample_groups=4), dict()):
+        old = gpu_ctx.set_tuning(cull=1)
+        try:
+            film = pt.Film(gpu_ctx, w, h)
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, **shape, **kw))
+            want, rays, culled = film.read_f32(), gpu_ctx.stats().rays, gpu_ctx.stats().rays_culled
+            film.clear()
+            gpu_ctx.reset_stats()
+            pt.render(cornell_gpu, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_COUNT_VISITS, **shape, **kw))
+            st = gpu_ctx.stats()
+            bc = gpu_ctx.block_counts()
+        finally:
+            gpu_ctx.set_tuning(**old)
+        assert film.read_f32().tobytes() == want.tobytes() and st.rays == rays and st.rays_culled == culled, shape
+        film.close()
+        walked = rays - culled
+        assert bc["SETUP"][1] == walked and bc["FINISH"][1] == walked, (shape, bc, walked)
+        assert bc["HIT"][1] == walked and bc["MISS"][1] + bc["SURFACE"][1] == walked
+        assert bc["BOUNCE"][1] + bc["PRIMARY"][1] == walked                      # every walked ray is a bounce ray or a camera ray
+        assert bc["NODE"][0] > 0 and bc["LEAF"][1] >= bc["DIV"][1] > 0 and bc["ITER"][0] >= bc["SHADE"][0] > 0
+        assert all(wv <= ln <= 64 * wv for wv, ln in bc.values())
+    inst = pt.Scene(gpu_ctx, *pt.load_obj(pt.ASSET_CORNELL))
+    inst.set_instances(pt.cornell_grid_instances()[:16])
+    film = pt.Film(gpu_ctx, w, h)
+    with pytest.raises(pt.PtError) as e:
+        pt.render(inst, film, pt.default_params(pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_COUNT_VISITS, **kw))
+    assert e.value.status == 5
+    film.close(); inst.close()

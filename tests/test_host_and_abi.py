@@ -249,7 +249,7 @@ def test_struct_layouts_match_header(pt, tmp_path):
     subprocess.check_call([shutil.which("gcc") or "gcc", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert got == [C.sizeof(pt.Tuning), C.sizeof(pt.Params), C.sizeof(pt.Stats), C.sizeof(pt.SceneInfo), pt.Params.sample_groups.offset,
-                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.tree_area_ploc.offset, pt.Stats.pipeline.offset, 5], got
+                   pt.Stats.workspace_bytes.offset, pt.Stats.wave_refills.offset, pt.SceneInfo.tree_area_ploc.offset, pt.Stats.pipeline.offset, 6], got
     assert C.sizeof(pt.Tuning) == 4 * 32 and pt.PIPELINE_FUSED == 2 and pt.PIPELINE_AUTO == 3
     assert C.sizeof(pt.Params) == 4 * 8 + 4 * 9 + 4 * 7
     p = pt.library_default_params()   # (pt_params_default itself; the suite's own pt.default_params names the wavefront pipeline, conftest.py)
