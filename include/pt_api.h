@@ -363,13 +363,17 @@ enum pt_fused_block {
     PT_FB_DRAW,      /* ... the wave drew a batch of slots                                      */
     PT_FB_TAKE,      /* ... lanes that took a slot                                              */
     PT_FB_CULLED,    /* ... of them: finished here, the pixel cannot see the scene              */
-    PT_FB_PRIMARY,   /* camera ray (raygen.rgen:45-60)                                          */
+    PT_FB_PRIMARY,   /* camera ray: the sample's seed (raygen.rgen:47-48)                       */
     PT_FB_SETUP,     /* state to LDS, ray set-up for the walk                                   */
     PT_FB_NODE,      /* one BVH4 node step                                                      */
     PT_FB_POP,       /* one iteration of the stack-pop loop                                     */
     PT_FB_LEAF,      /* one leaf step (a triangle or a fan pair)                                */
     PT_FB_DIV,       /* ... its divide block                                                    */
     PT_FB_FINISH,    /* a walk ended                                                            */
+    PT_FB_TRACE,     /* (no code of its own) once per pass with a walk: the lanes that trace    */
+    PT_FB_SPAWN,     /* the steps a bounce and a camera ray share: two rand, one square root    */
+    PT_FB_PTARGET,   /* camera ray: pixel + jitter -> target - origin (raygen.rgen:51-56)       */
+    PT_FB_PDIR,      /* camera ray: normalize (raygen.rgen:57)                                  */
     PT_FB_COUNT
 };
 pt_status pt_get_block_counts(pt_ctx *ctx, uint64_t *waves_lanes, uint32_t n_blocks /* <= 32 */);

@@ -50,7 +50,7 @@ if __name__ == "__main__":
     print(f"{'block':9s} {'waves/64 rays':>14s} {'lanes':>6s} {'VALU':>5s} {'VALU/64 rays':>13s} {'share':>6s} {'lane-instr/ray':>15s}")
     for n, r in t["blocks"].items():
         li = r["valu_per_64_rays"] / 64.0 * (r["lanes"] or 0)
-        print(f"{n:9s} {r['waves_per_64_rays']:14.3f} {str(r['lanes']):>6s} {r['valu']:5d} {r['valu_per_64_rays']:13.1f} "
+        print(f"{n:9s} {r['waves_per_64_rays']:14.3f} {str(r['lanes']):>6s} {r['valu']:5.0f} {r['valu_per_64_rays']:13.1f} "
               f"{100.0 * r['valu_per_64_rays'] / t['valu_wave_instr_per_64_rays']:5.1f}% {li:15.1f}")
     print(f"model: {t['valu_wave_instr_per_64_rays']} VALU wave-instructions per 64 walked rays at {t['valu_active_lanes_per_instr']} lanes "
           f"(PMC of round 5: 1508 at 34.4)")

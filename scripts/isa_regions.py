@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "single-file-vulkan-pathtracing_amd", "csrc")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
 BLOCKS = ["ITER", "SHADE", "HIT", "MISS", "SURFACE", "ADD", "BOUNCE", "NEXT", "DONE", "HANDOUT", "DRAW", "TAKE", "CULLED", "PRIMARY", "SETUP",
-          "NODE", "POP", "LEAF", "DIV", "FINISH"]
+          "NODE", "POP", "LEAF", "DIV", "FINISH", "TRACE", "SPAWN", "PTARGET", "PDIR"]
 
 
 def compile_s(extra, debug):
@@ -90,6 +90,8 @@ def marker_regions(path):
         if l.lstrip().startswith("#define"):
             continue
         for m in re.finditer(r"PT_FB\(FB_(\w+)\)", l):
+            if m.group(1) == "TRACE":   # (a count without code of its own)
+                continue
             e = enclosing(i)
             # a marker in a one-line block `if (c) { PT_FB(X) }` or in the body of a one-line lambda speaks for the block around that line
             marks.append((m.group(1), e))

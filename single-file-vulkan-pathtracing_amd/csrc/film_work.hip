@@ -367,7 +367,10 @@ ptw::RenderConst ptw_render_const(const pt_params *p, const pt_film::Work &w, co
 {
     ptw::RenderConst rc{};
     rc.cam = { p->cam_origin[0], p->cam_origin[1], p->cam_origin[2], p->cam_target[0], p->cam_target[1], p->cam_target[2],
-               (float)p->width, (float)p->height };
+               (float)p->width, (float)p->height,
+               // (pt_math.h primary_target: the reciprocals of the launch size by the host's correctly rounded divide, for sizes the three-FMA
+               // quotient is proven for)
+               p->width <= (1u << 20) ? 1.0f / (float)p->width : 0.0f, p->height <= (1u << 20) ? 1.0f / (float)p->height : 0.0f };
     for (int k = 0; k < 3; k++) rc.env[k] = p->env[k];
     rc.tmin = p->tmin; rc.tmax = p->tmax;
     rc.width = p->width; rc.height = p->height; rc.tiles_x = (p->width + 7) / 8;

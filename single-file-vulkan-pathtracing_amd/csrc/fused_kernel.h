@@ -54,8 +54,10 @@ constexpr int FTB = PT_FUSED_TB;
 #define PT_FUSED_PART_STRIDE 32   // ... in dwords: one 128-B line each
 
 // path state in LDS, [field][thread]
-enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS_B, FS_C, FS_FIELDS };
+enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS_B, FS_C, FS_MB, FS_FIELDS };
 // FS_A..C: the slot's colour (one sample group) | FS_A: its term count (several groups)
+// FS_MB: maxSamples * frame + 1 of the slot's frame (raygen.rgen:47: the seed's multiplier less the sample number), kept so that a
+// sample's camera ray does not decode slot -> frame again (two divisions by run-time constants, at the ten lanes of that block)
 
 // PAIRS: every leaf is one triangle or one fan pair (k_extend_lds7p's trees); else leaves of up to four triangles (k_extend_lds7's)
 // MODE 0: one sample group (a slot is a pixel's whole frame; radiance added in LDS); 1: several groups (every slot logs its radiance terms);
@@ -94,6 +96,10 @@ enum FusedBlock : int {
     FB_LEAF,       // one leaf step (a triangle or a fan pair)
     FB_DIV,        // ... its divide block (a lane is inside a triangle's edges)
     FB_FINISH,     // a walk ended (cur == DONE)
+    FB_TRACE,      // (no code of its own) once per pass with a walk: the lanes that trace
+    FB_SPAWN,      // the steps a bounce and a camera ray share: two rand, one square root
+    FB_PTARGET,    // camera ray: pixel + jitter -> target - origin, its squared length (raygen.rgen:51-56)
+    FB_PDIR,       // camera ray: the normalisation's three quotients (raygen.rgen:57)
     FB_N
 };
 template <int MODE, bool PAIRS, bool COUNT>
@@ -198,7 +204,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
             uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
             float wr = 0.f, wg = 0.f, wb = 0.f;
             ptm::f3 org{}, dir{};
-            bool got_ray = false, need_primary = false;
+            bool got_ray = false, need_primary = false, bounce = false;
             if (in_blk) { PT_FB(FB_SHADE) }
             // (1) the hit of the ray that just ended: radiance, then bounce / next sample / slot complete
             if (in_blk && path) {
@@ -212,7 +218,6 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                 float er, eg, eb;
                 bool terminated, add;
                 const uint32_t pos = best_pos;
-                float4 s0{}, s1{};
                 if (pos == PT_MISS) {  // miss.rmiss:10-11 then raygen.rgen:76, 81-83
                     PT_FB(FB_MISS)
                     er = wr * rc.env[0]; eg = wg * rc.env[1]; eb = wb * rc.env[2];
@@ -220,8 +225,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                     terminated = true;
                 } else {
                     PT_FB(FB_SURFACE)
-                    s0 = s_shade[3 * pos + 0]; s1 = s_shade[3 * pos + 1];
-                    const float4 s2 = s_shade[3 * pos + 2];
+                    const float4 s1 = s_shade[3 * pos + 1], s2 = s_shade[3 * pos + 2];
                     er = wr * s1.z; eg = wg * s1.w; eb = wb * s2.x;
                     add = !(er == 0.f && eg == 0.f && eb == 0.f);
                     depth++;
@@ -255,23 +259,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                     }
                 }
                 if (!terminated) {
-                    PT_FB(FB_BOUNCE)
-                    // closesthit.rchit:56-57 position from the barycentrics; raygen.rgen:77-80 the bounce
-                    const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
-                    float hu, hv;
-                    ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
-                    const float b0 = (1.0f - hu) - hv;
-                    org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
-                    const ptm::f3 nrm = { s0.x, s0.y, s0.z };
-                    const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
-                    const float r2 = ptm::rnd(seed);
-                    const float4 f0 = s_frame[2 * pos + 0], f1 = s_frame[2 * pos + 1];
-                    dir = ptm::sample_direction_frame(r1, r2, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
-                    const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
-                    float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
-                    ptm::div3_by_pdf(fr, fg, fb);
-                    wr = wr * fr; wg = wg * fg; wb = wb * fb;
-                    got_ray = true;
+                    bounce = true;  // (the bounce itself: step (3), beside the camera rays)
                 } else {
                     PT_FB(FB_NEXT)
                     sample++;
@@ -279,6 +267,8 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                     bool more;
                     if (HYB) {
                         more = !logs && sample < rc.head_samples;  // (a tail slot is one sample)
+                    } else if (!GROUPED) {
+                        more = sample < rc.spp;  // (one group: the slot is the pixel's whole frame)
                     } else {
                         const uint32_t lane_slot = rc.div_spl.div(slot);  // = frame lane * groups + sample group (slot_pixel)
                         const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
@@ -403,6 +393,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                         ctr = sample0;
                         my_state[FS_A * FTB] = 0u;  // colour.r = +0.0f | term count = 0
                         if (!GROUPED) { my_state[FS_B * FTB] = 0u; my_state[FS_C * FTB] = 0u; }
+                        my_state[FS_MB * FTB] = (uint32_t)((int32_t)rc.spp * (rc.frame_base + (int32_t)f)) + 1u;
                         path = true;
                         need_primary = true;
                         dev.slot_begin();
@@ -419,14 +410,52 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                     n_cull_wave += n_c;
                 }
             }
-            // (3) camera ray of a slot's next (or first) sample
+            // (3) the new ray: a bounce (closesthit.rchit:56-57, raygen.rgen:77-80) or the camera ray of a slot's next / first sample
+            // (raygen.rgen:45-60).  Both draw two rand and take one square root -- sqrt(1 - r1^2) of the hemisphere sample, the length of the
+            // camera ray's direction -- and those steps run ONCE for both kinds of lanes: the camera rays are a fifth of the rays, so a block of
+            // their own ran in every shade block at ten lanes of 64 (the block table of round 6: 11 % of the kernel's instructions).  Same
+            // operations on the same operands in the same order per lane: same bits.
             if (need_primary) {
                 PT_FB(FB_PRIMARY)
-                const uint32_t f = (HYB && slot >= rc.n_head) ? rc.div_tail.div(rc.div_spl.div(slot - rc.n_head)) : rc.div_groups.div(rc.div_spl.div(slot));
-                const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
-                seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
-                ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                const uint32_t m = (ctr & 0xFFFFu) + my_state[FS_MB * FTB];  // = sample + maxSamples * frame + 1 (ptm::make_seed)
+                const uint2 sd = ptm::pcg2d(make_uint2((pxy & 0xFFFFu) * m, (pxy >> 16) * m));
+                seed = sd.x + sd.y;
                 wr = wg = wb = 1.0f;  // raygen.rgen:59
+            }
+            if (bounce || need_primary) {
+                PT_FB(FB_SPAWN)
+                const float r1 = ptm::rnd(seed);  // bounce: cos(theta) first, azimuth second; camera ray: x jitter first, then y
+                const float r2 = ptm::rnd(seed);
+                float vx = 0.f, vy = 0.f, vz = 0.f, sq_arg;
+                if (need_primary) {
+                    PT_FB(FB_PTARGET)
+                    ptm::primary_target(rc.cam, pxy & 0xFFFFu, pxy >> 16, r1, r2, vx, vy, vz);
+                    sq_arg = (vx * vx + vy * vy) + vz * vz;
+                } else {
+                    sq_arg = 1.0f - r1 * r1;
+                }
+                const float sq = ptm::fsqrt(sq_arg);
+                if (need_primary) {
+                    PT_FB(FB_PDIR)
+                    org = { rc.cam.ox, rc.cam.oy, rc.cam.oz };
+                    ptm::div3_dominant(vx, vy, vz, sq, dir.x, dir.y, dir.z);
+                } else {
+                    PT_FB(FB_BOUNCE)
+                    const uint32_t pos = best_pos;
+                    const float4 s0 = s_shade[3 * pos + 0], s1 = s_shade[3 * pos + 1];
+                    const ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                    const float4 f0 = s_frame[2 * pos + 0], f1 = s_frame[2 * pos + 1];
+                    dir = ptm::sample_direction_frame_sq(r1, r2, sq, nrm, { f0.x, f0.y, f0.z }, { f0.w, f1.x, f1.y });
+                    const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
+                    float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
+                    ptm::div3_by_pdf(fr, fg, fb);
+                    wr = wr * fr; wg = wg * fg; wb = wb * fb;
+                    const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
+                    float hu, hv;
+                    ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
+                    const float b0 = (1.0f - hu) - hv;
+                    org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
+                }
                 got_ray = true;
             }
             // (4) state back to LDS, ray set-up (the refill block of extend_body<true, false, false, true>)
@@ -461,6 +490,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
         // ---- node phase (extend_body, LDS_SCENE && COMPACT): every lane descends until it holds a leaf
         bool do_node = have && !(cur & LEAF_BIT);
         const int n_have = __popcll(__ballot(have));
+        if (have) { PT_FB(FB_TRACE) }
         while (do_node) {
             PT_FB(FB_NODE)
             cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, pop);

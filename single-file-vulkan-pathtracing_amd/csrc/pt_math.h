@@ -175,20 +175,38 @@ struct Camera {
     float ox, oy, oz;   // raygen.rgen:55
     float tx, ty, tz;   // raygen.rgen:56: target = (d.x + tx, d.y + ty, tz)
     float w, h;         // float(gl_LaunchSizeEXT.xy)
+    float rw, rh;       // RN(1 / w), RN(1 / h) (the host's IEEE divide), or 0: the divides by the launch size take the IEEE expansion
 };
 
+// raygen.rgen:51-56 for given jitters: the un-normalised direction target - origin of the camera ray through pixel (px, py)
+__device__ __forceinline__ void primary_target(const Camera &cam, uint32_t px, uint32_t py, float jx, float jy, float &vx, float &vy, float &vz)
+{
+    const float sx = (float)px + jx;
+    const float sy = (float)py + jy;
+    // screenPos / size (raygen.rgen:52) is a true divide.  The divisor is the same for every ray, so its correctly rounded reciprocal comes with
+    // the launch constants and the quotient is quot_rn's three instructions instead of the ten of the IEEE expansion -- the IEEE quotient bit for
+    // bit under that sequence's proven conditions (above): divisor in [1, 2^20] (the host passes 0 as the reciprocal otherwise), dividend no
+    // larger than the divisor (pixel + jitter <= size) and either +0 -- q0 = +0, residual fma(-b, +0, +0) = +0, result +0, the IEEE 0 / b -- or
+    // at least 2^-32 (a pixel >= 1, or rand's smallest non-zero value alone).
+    float qx, qy;
+    if (cam.rw != 0.0f && cam.rh != 0.0f) {  // (uniform)
+        qx = quot_rn(sx, cam.w, cam.rw); qy = quot_rn(sy, cam.h, cam.rh);
+    } else {
+        qx = fdiv(sx, cam.w); qy = fdiv(sy, cam.h);
+    }
+    const float dx = qx * 2.0f - 1.0f;  // no aspect-ratio correction (kept)
+    const float dy = qy * 2.0f - 1.0f;
+    vx = (dx + cam.tx) - cam.ox;
+    vy = (dy + cam.ty) - cam.oy;
+    vz = cam.tz - cam.oz;
+}
 __device__ __forceinline__ void primary_ray(const Camera &cam, uint32_t px, uint32_t py, uint32_t &seed,
                                             f3 &org, f3 &dir)  // raygen.rgen:51-57
 {
     const float jx = rnd(seed);  // x first, then y
     const float jy = rnd(seed);
-    const float sx = (float)px + jx;
-    const float sy = (float)py + jy;
-    const float dx = fdiv(sx, cam.w) * 2.0f - 1.0f;  // no aspect-ratio correction (kept)
-    const float dy = fdiv(sy, cam.h) * 2.0f - 1.0f;
-    const float vx = (dx + cam.tx) - cam.ox;
-    const float vy = (dy + cam.ty) - cam.oy;
-    const float vz = cam.tz - cam.oz;
+    float vx, vy, vz;
+    primary_target(cam, px, py, jx, jy, vx, vy, vz);
     const float len = fsqrt((vx * vx + vy * vy) + vz * vz);
     org = { cam.ox, cam.oy, cam.oz };
     div3_dominant(vx, vy, vz, len, dir.x, dir.y, dir.z);
@@ -225,6 +243,16 @@ __device__ __forceinline__ f3 sample_direction(float r1, float r2, const f3 n)
     const f3 T = { bx ? ql : zl, bx ? zl : -ql, bx ? -pl : pl };
     const f3 B = { n.y * T.z - n.z * T.y, n.z * T.x - n.x * T.z, n.x * T.y - n.y * T.x };
     const float sq = fsqrt(1.0f - r1 * r1);  // uniform hemisphere, pdf 1/(2*pi)
+    const float phi = 6.2831854820251465f * r2;
+    float sn, cs;
+    sincos_2pi(phi, sn, cs);
+    const float dx = cs * sq, dy = sn * sq, dz = r1;
+    return { (T.x * dx + B.x * dy) + n.x * dz, (T.y * dx + B.y * dy) + n.y * dz,
+             (T.z * dx + B.z * dy) + n.z * dz };
+}
+// ... with sq = sqrt(1 - r1 * r1) given (the fused kernel takes that root beside the camera rays' length)
+__device__ __forceinline__ f3 sample_direction_frame_sq(float r1, float r2, float sq, const f3 n, const f3 T, const f3 B)
+{
     const float phi = 6.2831854820251465f * r2;
     float sn, cs;
     sincos_2pi(phi, sn, cs);
