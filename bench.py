@@ -413,15 +413,52 @@ def wavefront_roofline_blocks(pt, st, cst, info, config, note, mean_len):
     return r, roofline_shade_block(st, config)
 
 
-PMC_RECORD_FUSED = {"k_fused": "r05_pmc_fused_c2.json", "k_fused_inst": "r05_pmc_fused_c4.json"}
+PMC_RECORD_FUSED = {"k_fused": "r06_pmc_fused_c2.json", "k_fused_inst": "r06_pmc_fused_c4.json"}
 
 
-def fused_roofline_block(st, mean_len, config, kernel):
-    """`roofline` of the fused kernel (PT_PIPELINE_FUSED / what PT_PIPELINE_AUTO runs for scenes that live in LDS).  By the contract ("a fused
-    variant that keeps path state in registers moves fewer bytes -- still divide by the ALGORITHMIC bytes so designs are comparable, and say which
-    variant ran") `achieved` / `frac` price the kernel by the wavefront design's algorithmic bytes per ray over its launch time; they are a comparison
-    device, not traffic: `traffic` / `frac_counted` are what HBM really sees (live counters), and the bound that binds this kernel is VALU issue
-    (`binding_bound`: wave-instructions per 64 rays of the committed SQ_INSTS_VALU pass x this run's ray rate / the chip's 2-cycle issue peak)."""
+def fused_block_model(pt, ctx, scene, W, H, frames, spp, depth, rank=0, world=1):
+    """Where k_fused's VALU instructions go, from THIS run: the same `frames` frames once more, untimed, through the kernel's instrumented twin
+    (PT_FLAG_COUNT_VISITS on PT_PIPELINE_FUSED: wave executions and lanes of every block of its loop, include/pt_api.h pt_fused_block) x the blocks'
+    VALU instruction counts in the shipped ISA (profiles/isa_valu_model.json "k_fused": scripts/isa_regions.py attributes every instruction of the
+    product kernel's listing to a block by its .loc).  -> None when the scene / build has no instrumented form."""
+    model = (ISA_VALU_MODEL or {}).get("k_fused")
+    if not model or not hasattr(ctx, "block_counts"):
+        return None
+    film = pt.Film(ctx, W, H)
+    old = ctx.set_tuning(cull=1)   # (an instrumented render walks every ray unless told otherwise: count what the timed kernel walks)
+    try:
+        ctx.reset_stats()
+        pt.render(scene, film, pt.default_params(frame=0, frame_count=frames, width=W, height=H, spp_per_frame=spp, max_depth=depth, rank=rank, world=world,
+                                                 pipeline=pt.PIPELINE_FUSED, flags=pt.FLAG_COUNT_VISITS))
+        st, bc = ctx.stats(), ctx.block_counts()
+    except Exception:
+        return None
+    finally:
+        ctx.set_tuning(**old)
+        film.close()
+    walked = max(walked_rays(st), 1)
+    rows, tot, lanes = {}, 0.0, 0.0
+    for name, (waves, ln) in bc.items():
+        v = model["blocks"].get(name, {}).get("valu", 0.0)
+        tot += waves * v
+        lanes += ln * v
+        if waves:
+            rows[name] = {"waves_per_64_rays": round(waves / walked * 64.0, 3), "lanes": round(ln / waves, 1), "valu": v, "valu_per_64_rays": round(waves * v / walked * 64.0, 1)}
+    return {"per_64_rays": tot / walked * 64.0, "lanes_per_instr": lanes / max(tot, 1.0), "blocks": rows, "isa_revision": model.get("revision"),
+            "tracing_lanes_per_pass": rows.get("TRACE", {}).get("lanes"),
+            "source": "live: the timed frames once more through the instrumented twin (PT_FLAG_COUNT_VISITS, pt_get_block_counts) x VALU instructions per block of the "
+                      "shipped ISA (profiles/isa_valu_model.json, scripts/isa_regions.py); fallback paths of the guarded three-FMA quotients priced at zero executions"}
+
+
+def fused_roofline_block(st, mean_len, config, kernel, model=None):
+    """`roofline` of the fused kernel (PT_PIPELINE_FUSED / what PT_PIPELINE_AUTO runs for scenes that live in LDS).  The kernel moves 0.2 B per ray
+    through HBM; what binds it is VALU ISSUE, so that is the roofline the block states: `achieved` = wave64 VALU instructions per second
+    -- the instructions per 64 walked rays from the live block model (fused_block_model; for the two-level kernel, which has no instrumented twin,
+    the round's committed SQ_INSTS_VALU pass) x this run's walked rays per second of kernel time -- against `peak` = 256 CUs x 4 SIMDs x 2.4 GHz / 2
+    cycles per wave64 op (an add / mul / mov / 2-source fma; min / max / compare / select / 3-source ops issue at ~4.3 cycles:
+    profiles/r05q_valu_rate_ubench_sdwa.txt, so a real instruction mix saturates the SIMD well below 1.0).  `lanes` = active lanes per VALU
+    instruction of 64.  The contract's form for a fused variant ("still divide by the ALGORITHMIC bytes of the wavefront design so
+    designs are comparable") is kept as `frac_contract_8d` -- a comparison device, not traffic; `traffic` / `frac_counted` are what HBM really sees."""
     bytes_ray = BYTES_EXTEND + BYTES_SHADE + BYTES_PER_PATH / mean_len
     launches = max(st.launches_extend, 1)
     # rays the kernel WALKS: camera rays of pixels outside the scene box's projection are finished where their slot is handed out (pt_stats.rays_culled;
@@ -429,29 +466,47 @@ def fused_roofline_block(st, mean_len, config, kernel):
     culled = int(getattr(st, "rays_culled", 0))
     walked = st.rays - culled
     gbs = bytes_ray * walked / (st.ms_extend * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": kernel, "variant": "fused: traversal and shading in one persistent kernel, path state in LDS / registers; HBM sees 16 B per slot (or per logged term)",
-         "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+    rays_per_s = walked / (st.ms_extend * 1e-3)
+    r = {"bound": "valu_issue", "kernel": kernel,
+         "variant": "fused: traversal and shading in one persistent kernel, path state in LDS / registers; HBM sees 16 B per slot (or per logged term)",
+         "achieved": None, "peak": round(VALU_PEAK_WAVE_INSTR / 1e9, 1), "unit": "G wave64 VALU instr/s", "frac": None, "traffic": None,
+         "lanes": None, "instr_per_64_rays": None,
          "launches": st.launches_extend, "rays_per_launch": round(st.rays / launches, 1), "rays_walked_per_launch": round(walked / launches, 1),
          "rays_culled_per_launch": round(culled / launches, 1), "avg_launch_us": round(st.ms_extend * 1e3 / launches, 3),
+         "frac_contract_8d": round(gbs / HBM_PEAK_GBS, 5), "achieved_contract_8d_GBps": round(gbs, 2), "peak_contract_8d_GBps": HBM_PEAK_GBS,
          "algorithmic_bytes_per_ray": round(bytes_ray, 1), "algorithmic_bytes_per_launch": round(bytes_ray * walked / launches, 1),
-         "note": "SURVEY 8d prices a fused variant by the wavefront design's algorithmic bytes (40 extend + 104 shade + 96 per path / mean path length) so that designs "
-                 "compare: the kernel moves none of them -- see traffic / frac_counted for what HBM sees and binding_bound for the bound that binds (VALU issue).  "
-                 "Only WALKED rays are priced (rays_walked_per_launch): rays_culled_per_launch are camera rays of pixels that cannot see the scene, finished without a walk"}
+         "note": "bound = VALU issue (the kernel walks LDS).  frac_contract_8d prices the WALKED rays by the wavefront design's algorithmic bytes (40 extend + 104 shade + "
+                 "96 per path / mean path length) over the kernel's launch time against 8 TB/s, as SURVEY 8d prescribes for a fused variant: a comparison device -- the kernel "
+                 "moves none of those bytes (traffic / frac_counted).  rays_culled_per_launch are camera rays of pixels that cannot see the scene, finished without a walk"}
+    per64 = lanes = None
+    src = None
+    if model:
+        per64, lanes, src = model["per_64_rays"], model["lanes_per_instr"], model["source"]
+        r["blocks"] = model["blocks"]
+        r["isa_revision"] = model["isa_revision"]
+        r["tracing_lanes_per_pass"] = model["tracing_lanes_per_pass"]
     prof = os.path.join(REPO, "profiles", PMC_RECORD_FUSED.get(kernel, ""))
+    pmc = None
     if os.path.isfile(prof):
         try:
             pmc = json.load(open(prof))
-            per64 = pmc["valu_wave_instr_per_64_rays"]
-            rays_per_s = walked / (st.ms_extend * 1e-3)
-            r["binding_bound"] = {"kind": "valu_issue", "valu_wave_instr_per_64_rays": round(per64, 1),
-                                  "valu_active_lanes_per_instr": round(pmc.get("valu_active_lanes_per_instr", 0.0), 1),
-                                  "wave_instr_per_s": round(per64 / 64.0 * rays_per_s, 1), "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
-                                  "frac": round(per64 / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4),
-                                  "source": f"SQ_INSTS_VALU per WALKED ray of {os.path.relpath(prof, REPO)} x this run's walked rays per second / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op)"}
-            r["traffic"] = round(pmc["hbm_bytes_per_ray"] * walked / launches, 1)
-            r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * walked / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
         except Exception:
-            pass
+            pmc = None
+    if pmc:
+        r["pmc_check"] = {"valu_wave_instr_per_64_rays": round(pmc["valu_wave_instr_per_64_rays"], 1), "valu_active_lanes_per_instr": round(pmc.get("valu_active_lanes_per_instr", 0.0), 1),
+                          "source": os.path.relpath(prof, REPO) + " (SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU of the round's committed rocprofv3 pass: what the live model has to agree with)"}
+        if per64 is None:
+            per64, lanes = pmc["valu_wave_instr_per_64_rays"], pmc.get("valu_active_lanes_per_instr")
+            src = "SQ_INSTS_VALU per WALKED ray of " + os.path.relpath(prof, REPO) + " x this run's walked rays per second"
+        r["traffic"] = round(pmc["hbm_bytes_per_ray"] * walked / launches, 1)
+        r["frac_counted"] = round(pmc["hbm_bytes_per_ray"] * walked / (st.ms_extend * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+    if per64 is not None:
+        r["instr_per_64_rays"] = round(per64, 1)
+        r["lanes"] = round(lanes, 1) if lanes else None
+        r["achieved"] = round(per64 / 64.0 * rays_per_s / 1e9, 2)
+        r["frac"] = round(per64 / 64.0 * rays_per_s / VALU_PEAK_WAVE_INSTR, 4)
+        r["lane_weighted_frac"] = round(r["frac"] * (lanes or 0.0) / 64.0, 4)
+        r["instr_source"] = src
     return r
 
 
@@ -462,6 +517,23 @@ def wavefront_leg(pt, ctx, scene, info, W, H, args, config, note, child_argv):
     kw = dict(width=W, height=H, spp_per_frame=args.spp, max_depth=args.depth, pipeline=pt.PIPELINE_WAVEFRONT)
     film = pt.Film(ctx, W, H)
     timed = pt.default_params(frame=0, frame_count=args.steps, flags=pt.FLAG_PROFILE, **kw)
+    # what the queue design reaches when it may take the memory it wants (69 GB at 20 frames): the library's own 8 GB budget lifted for this leg,
+    # the rate under that budget beside it
+    at_default = None
+    try:
+        pt.render(scene, film, pt.default_params(frame=0, frame_count=args.steps, **kw))
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        pt.render(scene, film, pt.default_params(frame=0, frame_count=args.steps, **kw))
+        d0 = time.perf_counter() - t0
+        s0 = ctx.stats()
+        at_default = {"mem_budget_mb": "library default (8192)", "mrays_per_s": round(s0.rays / d0 / 1e6, 2), "workspace_bytes": s0.workspace_bytes,
+                      "frames_in_flight": s0.frames_in_flight, "sample_groups": s0.sample_groups}
+    except Exception as e:
+        at_default = {"error": repr(e)}
+    film.close()
+    film = pt.Film(ctx, W, H)
+    budget_before = ctx.set_tuning(mem_budget_mb=0)
     pt.render_prepare(scene, film, timed)
     shape = ctx.stats()
     kw.update(frames_in_flight=shape.frames_in_flight, sample_groups=shape.sample_groups)
@@ -489,7 +561,9 @@ def wavefront_leg(pt, ctx, scene, info, W, H, args, config, note, child_argv):
         apply_live_traffic(r, (lt or {}).get("k_extend"), st, st.ms_extend, st.launches_extend)
         if rs:
             apply_live_traffic(rs, (lt or {}).get("k_shade"), st, st.ms_shade, st.launches_shade)
+    ctx.set_tuning(**budget_before)
     return {"pipeline": "PT_PIPELINE_WAVEFRONT (generate / extend / shade queues, compacted per bounce)", "frames": args.steps,
+            "mem_budget_mb": "none (lifted for this leg: pt_tuning.mem_budget_mb = 0)", "at_default_budget": at_default,
             "mrays_per_s": round(st.rays / dt / 1e6, 2), "values": [round(st.rays / x[0] / 1e6, 2) for x in reps], "ms_per_frame": round(dt * 1e3 / args.steps, 4),
             "rays": st.rays, "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "pipelines": st.pipelines,
             "workspace_bytes": st.workspace_bytes, "rounds": st.rounds, "roofline": r, "roofline_shade": rs}
@@ -546,6 +620,28 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False
     sh = LEG_SHAPE[config]
     scene, arrays, name, ingest, tlas_ms = build_scene(pt, ctx, config, sh["tris"], rank, "fast_trace")
     info = scene.info()
+    # what the workspace budget buys (the library plans within 8 GB unless the caller says otherwise): the leg's frames through the wavefront
+    # pipeline's own shapes at 2 / 8 / 32 GB; the roofline block below is measured at 32 GB and says so
+    by_budget = {}
+    for mb in (2048, 8192, 32768):
+        old_b = ctx.set_tuning(mem_budget_mb=mb)
+        try:
+            fb = pt.Film(ctx, W, H)
+            pb = pt.default_params(frame=0, frame_count=frames, width=W, height=H, spp_per_frame=sh["spp"], max_depth=sh["depth"], pipeline=pt.PIPELINE_WAVEFRONT)
+            pt.render(scene, fb, pb)
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            pt.render(scene, fb, pb)
+            db = time.perf_counter() - t0
+            sb = ctx.stats()
+            by_budget[f"{mb // 1024} GB" + (" (library default)" if mb == 8192 else "")] = {
+                "mrays_per_s": round(sb.rays / db / 1e6, 1), "workspace_GB": round(sb.workspace_bytes / 2**30, 2), "frames_in_flight": sb.frames_in_flight, "sample_groups": sb.sample_groups}
+            fb.close()
+        except Exception as e:
+            by_budget[f"{mb // 1024} GB"] = {"error": repr(e)}
+        finally:
+            ctx.set_tuning(**old_b)
+    leg_budget = ctx.set_tuning(mem_budget_mb=32768)
     film = pt.Film(ctx, W, H)
     # (the wavefront pipeline explicitly: the leg is about its traversal kernel; what PT_PIPELINE_AUTO gives a caller of C4 is the `fused` block)
     common = dict(width=W, height=H, spp_per_frame=sh["spp"], max_depth=sh["depth"], pipeline=pt.PIPELINE_WAVEFRONT)
@@ -564,6 +660,7 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False
     cst, _, _ = count_visits(pt, ctx, scene, W, H, common, frames)
     r = roofline_block(pt, st, cst, info, config, NOTES[config])
     out = {"workload": f"{config.upper()}: {name} {W}x{H}, {sh['spp']} spp/frame x {frames} frames, {sh['depth']} bounces",
+           "mem_budget_mb": 32768, "by_budget": by_budget,
            "mrays_per_s": round(st.rays / dt / 1e6, 2), "ms_per_frame": round(dt * 1e3 / frames, 3), "rays": st.rays,
            "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "workspace_bytes": st.workspace_bytes,
            "bvh": {"triangles": info.n_tris, "bvh4_nodes": info.n_wide_nodes, "height": info.bvh_height, "build_ms": round(info.build_ms, 3),
@@ -627,6 +724,7 @@ def extra_leg(pt, ctx, W, H, config, frames, rank, live=False, oracle_walk=False
         except Exception as e:
             r["gather_8d_literal"] = {"error": repr(e)}
     out.update(r)
+    ctx.set_tuning(**leg_budget)
     film.close()
     scene.close()
     return out
@@ -674,6 +772,45 @@ def fused_leg(pt, ctx, scene, film, W, H, spp, depth, steps, wavefront_mrays):
     return out
 
 
+def reference_dispatch_leg(pt, ctx, scene):
+    """The reference's own dispatch, tested and timed: pt_params_default untouched -- 1024 x 1024 (main.cpp:16-17, 659), 32 spp (raygen.rgen:43),
+    depth 8, PT_PIPELINE_AUTO -- (a) as the reference's frame loop issues it, one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle,
+    main.cpp:656-683), frames 1 .. 8 after a warm-up frame 0; (b) 20 frames in one call.  The full-size known answers of this launch (ray counts, film and
+    bgra8 SHA-256 of frames 0 .. 3 from the oracle) are tests/golden/fullsize_hashes.json "ref1024" and the -m gpu test beside them."""
+    import statistics
+    p0 = pt.default_params()
+    W, H = p0.width, p0.height
+    film = pt.Film(ctx, W, H)
+    pt.render(scene, film, pt.default_params(frame=0, frame_count=1))
+    lat = []
+    ctx.reset_stats()
+    for k in range(1, 9):
+        t0 = time.perf_counter()
+        pt.render(scene, film, pt.default_params(frame=k, frame_count=1))
+        lat.append((time.perf_counter() - t0) * 1e3)
+    s1 = ctx.stats()
+    out = {"workload": f"the reference's launch: {W}x{H} (main.cpp:16-17, 659), {p0.spp_per_frame} spp, {p0.max_depth} bounces, pt_params_default (PT_PIPELINE_AUTO -> "
+                       f"{pt.PIPELINE_NAMES.get(s1.pipeline)})",
+           "k1_blocking": {"median_ms": round(statistics.median(lat), 3), "min_ms": round(min(lat), 3), "max_ms": round(max(lat), 3), "frames": len(lat),
+                           "mrays_per_s": round(s1.rays / (sum(lat) * 1e-3) / 1e6, 1), "mrays_per_s_walked": round(walked_rays(s1) / (sum(lat) * 1e-3) / 1e6, 1),
+                           "rays_per_frame": s1.rays // len(lat), "sample_groups": s1.sample_groups, "tail_samples": s1.tail_samples, "workspace_bytes": s1.workspace_bytes}}
+    film.clear()
+    p20 = pt.default_params(frame=0, frame_count=20)
+    pt.render(scene, film, p20)
+    ts = []
+    for _ in range(5):
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        pt.render(scene, film, p20)
+        ts.append(time.perf_counter() - t0)
+    s20 = ctx.stats()
+    d = statistics.median(ts)
+    out["k20"] = {"ms_per_frame": round(d * 1e3 / 20, 3), "mrays_per_s": round(s20.rays / d / 1e6, 1), "mrays_per_s_walked": round(walked_rays(s20) / d / 1e6, 1),
+                  "frames_in_flight": s20.frames_in_flight, "sample_groups": s20.sample_groups, "tail_samples": s20.tail_samples, "workspace_bytes": s20.workspace_bytes}
+    film.close()
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, exactly as
     torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, rendezvous
@@ -713,6 +850,81 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def compact_line(out):
+    """The ONE JSON line of the contract, small enough (<= 1.8 KB) that a log tail keeps it whole: the headline, the roofline of the dominant kernel, the CPU
+    baseline, and the short form of every other leg.  The full blocks are printed before it as `# detail <name>: {json}` lines (not JSON lines themselves,
+    so "the last JSON line" and "the only JSON line" are the same line) and written to gpurun_out/bench_last_full.json when that directory exists."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype") if k in out}
+    c["metric"] = c["metric"].split(" (")[0]
+    c["data"] = "synthetic"
+    w = (out.get("config") or {}).get("workload", "")
+    c["config"] = {"workload": w.split("; step")[0].replace(" (the library default, PT_PIPELINE_AUTO)", " (library default)"), "pipeline": (out.get("config") or {}).get("pipeline")}
+    for k in ("value_walked_only", "rays", "workspace_bytes", "frame0_film_bit_exact", "present_ms", "rccl_ranks"):
+        if out.get(k) is not None:
+            c[k] = out[k]
+    if isinstance(out.get("selftest"), dict):
+        c["selftest_ok"] = out["selftest"].get("ok")
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        c["roofline"] = pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_contract_8d", "frac_counted", "lanes", "instr_per_64_rays",
+                                 "launches", "avg_launch_us"))
+        if c["roofline"].get("unit", "").startswith("G wave64"):
+            c["roofline"]["unit"] = "Gwave-instr/s"
+    b = out.get("cpu_baseline")
+    if isinstance(b, dict):
+        c["cpu_baseline"] = pick(b, ("value", "unit", "cores", "kind", "cpu_model", "single_thread_mrays"))
+        if b.get("sample"):
+            c["cpu_baseline"]["sample"] = str(b["sample"])[:70]
+    if isinstance(out.get("c2_exact"), dict):
+        c["c2_exact"] = pick(out["c2_exact"], ("mrays_per_s", "ms_total"))
+    if isinstance(out.get("latency_1frame"), dict):
+        c["latency_1frame"] = pick(out["latency_1frame"], ("median_ms",))
+    rd = out.get("reference_dispatch")
+    if isinstance(rd, dict) and "k1_blocking" in rd:
+        c["reference_dispatch"] = {"size": "1024x1024x32spp", "k1_ms": rd["k1_blocking"].get("median_ms"), "k1_mrays": rd["k1_blocking"].get("mrays_per_s"),
+                                   "k20_mrays": (rd.get("k20") or {}).get("mrays_per_s")}
+    if isinstance(out.get("wavefront"), dict) and "mrays_per_s" in out["wavefront"]:
+        c["wavefront"] = {"mrays": out["wavefront"]["mrays_per_s"], "extend_frac": (out.get("roofline_wavefront") or {}).get("frac"),
+                          "shade_frac": (out.get("roofline_shade") or {}).get("frac")}
+    for leg in ("c4", "c5", "c5x"):
+        d = out.get("roofline_" + leg)
+        if isinstance(d, dict) and "mrays_per_s" in d:
+            e = {"mrays": d["mrays_per_s"], "kernel": d.get("kernel"), "frac": d.get("frac"), "frac_counted": d.get("frac_counted")}
+            if isinstance(d.get("fused"), dict) and "mrays_per_s" in d["fused"]:
+                e["fused_mrays"] = d["fused"]["mrays_per_s"]
+                e["fused_GB"] = round(d["fused"].get("workspace_bytes", 0) / 2**30, 2)
+            dflt = next((v for k, v in (d.get("by_budget") or {}).items() if "default" in k), None)
+            if isinstance(dflt, dict) and "mrays_per_s" in dflt:
+                e["at_8GB"] = dflt["mrays_per_s"]
+            c[leg] = {k: v for k, v in e.items() if v is not None}
+    return c
+
+
+def emit(out, args):
+    """Rank 0's output: the legs' full blocks first, one `# detail` line each, then the one JSON line of the contract (--full-line: the whole record as that line,
+    for the dev scripts that read single keys of it)."""
+    try:
+        d = os.path.join(REPO, "gpurun_out")
+        if os.path.isdir(d):
+            json.dump(out, open(os.path.join(d, "bench_last_full.json"), "w"))
+    except Exception:
+        pass
+    if args.full_line:
+        print(json.dumps(out), flush=True)
+        return
+    big = ("roofline", "roofline_shade", "roofline_extend", "roofline_wavefront", "wavefront", "c2_exact", "latency_1frame", "reference_dispatch", "c2_fused",
+           "roofline_c4", "roofline_c5", "roofline_c5x", "cpu_baseline", "config", "bvh", "selftest", "frame0_ray_count")
+    for k in big:
+        if out.get(k) is not None:
+            print(f"# detail {k}: " + json.dumps(out[k]), flush=True)
+    rest = {k: v for k, v in out.items() if k not in big}
+    print("# detail headline: " + json.dumps(rest), flush=True)
+    line = json.dumps(compact_line(out), separators=(",", ":"))
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -747,6 +959,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record instead of two nested rocprofv3 passes of this command")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the nested run of live_traffic()
+    ap.add_argument("--full-line", action="store_true", help="print the whole record as the one JSON line (the default prints the legs as `# detail` lines and a compact final line)")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c4 / _c5 / _c5x legs")
     ap.add_argument("--c5-frames", type=int, default=4, help="frames of the roofline_c5 leg")
     ap.add_argument("--c4-frames", type=int, default=8, help="frames of the roofline_c4 leg")
@@ -962,7 +1175,8 @@ def main():
                 scratch.close()
             if st.launches_extend and st.ms_extend > 0:
                 kname = "k_fused_inst" if info.n_instances else "k_fused"
-                out["roofline"] = fused_roofline_block(st, mean_len, scene_config, kname)
+                model = fused_block_model(pt, ctx, scene, W, H, args.steps, args.spp, args.depth, rank, world) if kname == "k_fused" and not args.pmc_child else None
+                out["roofline"] = fused_roofline_block(st, mean_len, scene_config, kname, model)
                 if live:
                     lt = None
                     try:
@@ -1041,6 +1255,12 @@ def main():
                                      "sample_groups": s1.sample_groups, "tail_samples": s1.tail_samples, "workspace_bytes": s1.workspace_bytes,
                                      "pipeline": pt.PIPELINE_NAMES.get(s1.pipeline) + " (PT_PIPELINE_AUTO, what pt_params_default gives a caller)",
                                      "shape": "K = 1: one blocking pt_render per frame (pushConstants + traceRaysKHR + waitIdle, main.cpp:656-683)"}
+            # ---- the reference's OWN launch: WIDTH = HEIGHT = 1024 (main.cpp:16-17), traceRaysKHR(1024, 1024, 1) (main.cpp:659), 32 spp, depth 8 -- exactly
+            # what pt_params_default returns -- as the reference's host issues it (one blocking call per frame, main.cpp:647-685) and as one call of 20 frames
+            try:
+                out["reference_dispatch"] = reference_dispatch_leg(pt, ctx, scene)
+            except Exception as e:
+                out["reference_dispatch"] = {"error": repr(e)}
             if ran == "wavefront" and scene_config == "c2":
                 try:
                     out["c2_fused"] = fused_leg(pt, ctx, scene, film, W, H, args.spp, args.depth, args.steps, st.rays / dt / 1e6)
@@ -1065,7 +1285,7 @@ def main():
                 # float of the film must agree (checker only: none of this is in the timed region)
                 out["frame0_ray_count"] = {"gpu": frame0_rays_gpu, "cpu_oracle": cpu_rays, "equal": frame0_rays_gpu == cpu_rays}
                 out["frame0_film_bit_exact"] = bool(frame0_film_gpu.tobytes() == cpu_img.tobytes())
-        print(json.dumps(out), flush=True)
+        emit(out, args)
 
     if presenter:
         presenter.close()

@@ -69,7 +69,7 @@ typedef struct pt_tuning {
     int32_t tlas_lds_kb;    /* ... KB of TLAS top levels staged in LDS                                                 */
     int32_t term_ocap;      /* tests: cap on the per-slot overflow term log (entries)                                  */
     int32_t term_spill;     /* tests: cap on the shared term pool (entries)                                            */
-    int32_t mem_budget_mb;  /* upper bound on a film's wavefront workspace (also env PT_MEM_BUDGET_MB); 0 = none       */
+    int32_t mem_budget_mb;  /* upper bound on a film's workspace, MB (also env PT_MEM_BUDGET_MB); 0 = none; -1 = 8192  */
     int32_t hbm8;           /* 1: AUTO walks big scenes through the 8-wide compressed nodes (PT_EXTEND_HBM8)           */
     int32_t ploc_radius;    /* PLOC rebuild of big scenes' binary tree: neighbours searched on either side (1..32, 8)  */
     int32_t leaf_min;       /* compact two-level kernel: lanes that wait with a triangle leaf before the leaf step runs */
@@ -220,7 +220,9 @@ enum {
  * return identical bits; AUTO picks by scene size. */
 enum {
     PT_EXTEND_AUTO = 0,
-    PT_EXTEND_FLAT_REMOVED = 1, /* (until API version 4: a brute-force loop over <= 1024 triangles, never AUTO; PT_ERR_UNSUPPORTED now) */
+    PT_EXTEND_FLAT = 1, /* deprecated (until API version 4: a brute-force loop over <= 1024 triangles, never AUTO): the name still compiles, pt_render /
+                         * pt_trace return PT_ERR_UNSUPPORTED for it.  The CPU oracle (oracle/, tests only) is the brute-force reference since. */
+    PT_EXTEND_FLAT_REMOVED = PT_EXTEND_FLAT,
     PT_EXTEND_LDS = 2,  /* BVH4 + triangles staged in LDS (scenes <= 24 KB by AUTO), lane refill             */
     PT_EXTEND_HBM = 3,  /* BVH4 + triangles read through L1/L2/MALL from HBM, LDS short stack + HBM spill    */
     PT_EXTEND_HBM8 = 4  /* 8-wide tree: 64-B nodes with byte planes, one stack entry per node (AUTO only with pt_tuning.hbm8) */

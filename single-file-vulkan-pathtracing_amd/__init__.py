@@ -35,7 +35,8 @@ FLAG_COUNT_VISITS = 2
 FLAG_ASYNC = 4
 FLAG_SORT_RAYS = 8
 FLAG_NO_SORT_RAYS = 16
-EXTEND_AUTO, EXTEND_LDS, EXTEND_HBM, EXTEND_HBM8 = 0, 2, 3, 4   # (1 was PT_EXTEND_FLAT, removed in API version 5)
+EXTEND_AUTO, EXTEND_LDS, EXTEND_HBM, EXTEND_HBM8 = 0, 2, 3, 4
+EXTEND_FLAT = 1   # deprecated: the brute-force loop was removed in API version 5 (PT_ERR_UNSUPPORTED); the name is kept for source compatibility
 BVH_PREFER_FAST_TRACE, BVH_PREFER_FAST_BUILD = 0, 1
 EXTEND_NAMES = {2: "BVH4, scene staged in LDS", 3: "BVH4, scene in HBM/L2",
                 4: "8-wide tree (64-B nodes with byte planes, one stack entry per node), scene in HBM/L2"}

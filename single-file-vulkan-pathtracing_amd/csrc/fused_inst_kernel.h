@@ -130,7 +130,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
             uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
             float wr = 0.f, wg = 0.f, wb = 0.f;
             ptm::f3 org{}, dir{};
-            bool got_ray = false, need_primary = false;
+            bool got_ray = false, need_primary = false, bounce = false;
             // (1) the hit of the ray that just ended
             if (in_blk && path) {
                 slot = my_state[FS_SLOT * FITB]; ctr = my_state[FS_CTR * FITB]; seed = my_state[FS_SEED * FITB];
@@ -140,14 +140,12 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                 float er, eg, eb;
                 bool terminated, add;
                 const uint32_t pos = best_pos;
-                float4 s0{}, s1{};
                 if (pos == PT_MISS) {  // miss.rmiss:10-11 then raygen.rgen:76, 81-83
                     er = wr * rc.env[0]; eg = wg * rc.env[1]; eb = wb * rc.env[2];
                     add = true;
                     terminated = true;
                 } else {
-                    s0 = s_shade[3 * pos + 0]; s1 = s_shade[3 * pos + 1];
-                    const float4 s2 = s_shade[3 * pos + 2];
+                    const float4 s1 = s_shade[3 * pos + 1], s2 = s_shade[3 * pos + 2];
                     er = wr * s1.z; eg = wg * s1.w; eb = wb * s2.x;
                     add = !(er == 0.f && eg == 0.f && eb == 0.f);
                     depth++;
@@ -176,53 +174,19 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     }
                 }
                 if (!terminated) {
-                    // closesthit.rchit:56-57 position from the barycentrics, in object space; then k_shade<INST>: position by the
-                    // object->world matrix, normal + tangent of the (instance, triangle) pair; raygen.rgen:77-80 the bounce
-                    const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
-                    float hu, hv;
-                    ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
-                    const float b0 = (1.0f - hu) - hv;
-                    org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
-                    ptm::f3 nrm = { s0.x, s0.y, s0.z };
-                    ptm::f3 tng{};
-                    const uint32_t ip = best_ipos;
-                    const float4 m0 = inst6[6 * (size_t)ip + 0], m1 = inst6[6 * (size_t)ip + 1], m2 = inst6[6 * (size_t)ip + 2];
-                    const ptm::f3 pw = { ((m0.x * org.x + m0.y * org.y) + m0.z * org.z) + m0.w,
-                                         ((m1.x * org.x + m1.y * org.y) + m1.z * org.z) + m1.w,
-                                         ((m2.x * org.x + m2.y * org.y) + m2.z * org.z) + m2.w };
-                    org = pw;
-                    if (inst_frame) {
-                        const size_t e = 2 * ((size_t)ip * n_tris + pos);
-                        const float4 f0 = inst_frame[e], f1 = inst_frame[e + 1];
-                        nrm = { f0.x, f0.y, f0.z };
-                        tng = { f0.w, f1.x, f1.y };
-                    } else {
-                        const float4 i0 = inst6[6 * (size_t)ip + 3], i1 = inst6[6 * (size_t)ip + 4], i2 = inst6[6 * (size_t)ip + 5];
-                        const float nx = (i0.x * nrm.x + i1.x * nrm.y) + i2.x * nrm.z;
-                        const float ny = (i0.y * nrm.x + i1.y * nrm.y) + i2.y * nrm.z;
-                        const float nz = (i0.z * nrm.x + i1.z * nrm.y) + i2.z * nrm.z;
-                        const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
-                        nrm = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
-                    }
-                    const float r1 = ptm::rnd(seed);  // cos(theta) first, azimuth second
-                    const float r2 = ptm::rnd(seed);
-                    if (inst_frame) {  // bitangent = the cross product of tangent_frame, same operands
-                        const ptm::f3 btg = { nrm.y * tng.z - nrm.z * tng.y, nrm.z * tng.x - nrm.x * tng.z, nrm.x * tng.y - nrm.y * tng.x };
-                        dir = ptm::sample_direction_frame(r1, r2, nrm, tng, btg);
-                    } else {
-                        dir = ptm::sample_direction(r1, r2, nrm);  // raygen.rgen:78
-                    }
-                    const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
-                    float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
-                    ptm::div3_by_pdf(fr, fg, fb);
-                    wr = wr * fr; wg = wg * fg; wb = wb * fb;
-                    got_ray = true;
+                    bounce = true;  // (the bounce itself: step (3), beside the camera rays -- fused_kernel.h explains)
                 } else {
                     sample++;
                     depth = 0;
-                    const uint32_t lane_slot = rc.div_spl.div(slot);
-                    const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
-                    if (sample < min(rc.spp, (g + 1u) * rc.group_size)) {
+                    bool more;
+                    if (!GROUPED) {
+                        more = sample < rc.spp;  // (one group: the slot is the pixel's whole frame)
+                    } else {
+                        const uint32_t lane_slot = rc.div_spl.div(slot);
+                        const uint32_t g = lane_slot - rc.div_groups.div(lane_slot) * rc.groups;
+                        more = sample < min(rc.spp, (g + 1u) * rc.group_size);
+                    }
+                    if (more) {
                         need_primary = true;  // the slot's next sample: raygen.rgen:45-60
                     } else {  // the slot is complete
                         if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FITB]), __uint_as_float(my_state[FS_B * FITB]),
@@ -289,6 +253,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                         ctr = sample0;
                         my_state[FS_A * FITB] = 0u;
                         if (!GROUPED) { my_state[FS_B * FITB] = 0u; my_state[FS_C * FITB] = 0u; }
+                        my_state[FS_MB * FITB] = (uint32_t)((int32_t)rc.spp * (rc.frame_base + (int32_t)f)) + 1u;
                         path = true;
                         need_primary = true;
                     } else if (GROUPED) {
@@ -302,13 +267,70 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     n_cull_wave += n_c;
                 }
             }
-            // (3) camera ray of a slot's next (or first) sample
+            // (3) the new ray: a bounce or the camera ray of a slot's next / first sample; their two rand and their square root -- sqrt(1 - r1^2) of the
+            // hemisphere sample, the length of the camera ray's direction -- run once for both kinds of lanes (fused_kernel.h has the measurement)
             if (need_primary) {
-                const uint32_t f = rc.div_groups.div(rc.div_spl.div(slot));
-                const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
-                seed = ptm::make_seed(px, py, ctr & 0xFFFFu, rc.frame_base + (int32_t)f, rc.spp);
-                ptm::primary_ray(rc.cam, px, py, seed, org, dir);
+                const uint32_t m = (ctr & 0xFFFFu) + my_state[FS_MB * FITB];  // = sample + maxSamples * frame + 1 (ptm::make_seed)
+                const uint2 sd = ptm::pcg2d(make_uint2((pxy & 0xFFFFu) * m, (pxy >> 16) * m));
+                seed = sd.x + sd.y;
                 wr = wg = wb = 1.0f;  // raygen.rgen:59
+            }
+            if (bounce || need_primary) {
+                const float r1 = ptm::rnd(seed);  // bounce: cos(theta) first, azimuth second; camera ray: x jitter first, then y
+                const float r2 = ptm::rnd(seed);
+                float vx = 0.f, vy = 0.f, vz = 0.f, sq_arg;
+                if (need_primary) {
+                    ptm::primary_target(rc.cam, pxy & 0xFFFFu, pxy >> 16, r1, r2, vx, vy, vz);
+                    sq_arg = (vx * vx + vy * vy) + vz * vz;
+                } else {
+                    sq_arg = 1.0f - r1 * r1;
+                }
+                const float sq = ptm::fsqrt(sq_arg);
+                if (need_primary) {
+                    org = { rc.cam.ox, rc.cam.oy, rc.cam.oz };
+                    ptm::div3_dominant(vx, vy, vz, sq, dir.x, dir.y, dir.z);
+                } else {
+                    // closesthit.rchit:56-57 position from the barycentrics, in object space; then k_shade<INST>: position by the
+                    // object->world matrix, normal + tangent of the (instance, triangle) pair; raygen.rgen:77-80 the bounce
+                    const uint32_t pos = best_pos;
+                    const float4 s0 = s_shade[3 * pos + 0], s1 = s_shade[3 * pos + 1];
+                    const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
+                    float hu, hv;
+                    ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
+                    const float b0 = (1.0f - hu) - hv;
+                    org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
+                    ptm::f3 nrm = { s0.x, s0.y, s0.z };
+                    ptm::f3 tng{};
+                    const uint32_t ip = best_ipos;
+                    const float4 m0 = inst6[6 * (size_t)ip + 0], m1 = inst6[6 * (size_t)ip + 1], m2 = inst6[6 * (size_t)ip + 2];
+                    const ptm::f3 pw = { ((m0.x * org.x + m0.y * org.y) + m0.z * org.z) + m0.w,
+                                         ((m1.x * org.x + m1.y * org.y) + m1.z * org.z) + m1.w,
+                                         ((m2.x * org.x + m2.y * org.y) + m2.z * org.z) + m2.w };
+                    org = pw;
+                    if (inst_frame) {
+                        const size_t e = 2 * ((size_t)ip * n_tris + pos);
+                        const float4 f0 = inst_frame[e], f1 = inst_frame[e + 1];
+                        nrm = { f0.x, f0.y, f0.z };
+                        tng = { f0.w, f1.x, f1.y };
+                        // bitangent = the cross product of tangent_frame, same operands
+                        const ptm::f3 btg = { nrm.y * tng.z - nrm.z * tng.y, nrm.z * tng.x - nrm.x * tng.z, nrm.x * tng.y - nrm.y * tng.x };
+                        dir = ptm::sample_direction_frame_sq(r1, r2, sq, nrm, tng, btg);
+                    } else {
+                        const float4 i0 = inst6[6 * (size_t)ip + 3], i1 = inst6[6 * (size_t)ip + 4], i2 = inst6[6 * (size_t)ip + 5];
+                        const float nx = (i0.x * nrm.x + i1.x * nrm.y) + i2.x * nrm.z;
+                        const float ny = (i0.y * nrm.x + i1.y * nrm.y) + i2.y * nrm.z;
+                        const float nz = (i0.z * nrm.x + i1.z * nrm.y) + i2.z * nrm.z;
+                        const float l = ptm::fsqrt((nx * nx + ny * ny) + nz * nz);
+                        nrm = { ptm::fdiv(nx, l), ptm::fdiv(ny, l), ptm::fdiv(nz, l) };
+                        ptm::f3 T, B;
+                        ptm::tangent_frame(nrm, T, B);  // raygen.rgen:14-21 (sample_direction's own first half)
+                        dir = ptm::sample_direction_frame_sq(r1, r2, sq, nrm, T, B);  // raygen.rgen:78
+                    }
+                    const float dt = (dir.x * nrm.x + dir.y * nrm.y) + dir.z * nrm.z;
+                    float fr = s0.w * dt, fg = s1.x * dt, fb = s1.y * dt;
+                    ptm::div3_by_pdf(fr, fg, fb);
+                    wr = wr * fr; wg = wg * fg; wb = wb * fb;
+                }
                 got_ray = true;
             }
             // (4) state back to LDS, ray set-up (the refill block of k_extend_inst16)

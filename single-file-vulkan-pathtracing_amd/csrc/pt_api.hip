@@ -84,9 +84,9 @@ pt_status pt_ctx_set_tuning(pt_ctx *ctx, const pt_tuning *in)
 {
     if (!ctx || !in) return PT_ERR_INVALID_ARG;
     ctx->tune = *in;
-    // mem_budget_mb: > 0 a budget, 0 and -1 (the built-in choice) none -- so writing back what pt_ctx_get_tuning returned
+    // mem_budget_mb: > 0 a budget, 0 none, -1 the built-in choice (PT_DEFAULT_MEM_BUDGET_MB) -- so writing back what pt_ctx_get_tuning returned
     // restores the state it described (pt_ctx_create applies the same rule)
-    ctx->mem_budget = in->mem_budget_mb > 0 ? (size_t)in->mem_budget_mb << 20 : 0;
+    ctx->mem_budget = pt_budget_bytes(in->mem_budget_mb);
     return PT_OK;
 }
 
@@ -123,8 +123,8 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     const char *val[2];
     for (int k = 0; k < 2; k++) val[k] = getenv(env[k]);
     if (val[0] && !tuning_parse(val[0], &ctx->tune, g_create_err)) { pt_ctx_destroy(ctx); return PT_ERR_INVALID_ARG; }
-    if (val[1]) ctx->tune.mem_budget_mb = (int32_t)std::max(0ll, std::min(atoll(val[1]), 1ll << 30));
-    if (ctx->tune.mem_budget_mb > 0) ctx->mem_budget = (size_t)ctx->tune.mem_budget_mb << 20;
+    if (val[1]) ctx->tune.mem_budget_mb = (int32_t)std::max(0ll, std::min(atoll(val[1]), 1ll << 30));  // (0: no bound)
+    ctx->mem_budget = pt_budget_bytes(ctx->tune.mem_budget_mb);
     if (stream) {
         ctx->stream = reinterpret_cast<hipStream_t>(stream);
     } else {

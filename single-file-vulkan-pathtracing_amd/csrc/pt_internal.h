@@ -44,9 +44,9 @@ struct pt_ctx {
     std::vector<hipEvent_t> ev_pool;  // PT_FLAG_PROFILE start/stop events, reused across pt_render calls
     void *d_spill = nullptr;   // HBM overflow of the traversal short stack: [level][thread] uint2
     size_t spill_bytes = 0;
-    // Upper bound on the wavefront workspace of a film (0 = what hipMemGetInfo reports as free).  Set from the
-    // environment variable PT_MEM_BUDGET_MB at pt_ctx_create: for processes that share the GPU with another
-    // allocator (torch), and for the out-of-memory tests.
+    // Upper bound on the workspace of a film (0 = what hipMemGetInfo reports as free).  pt_tuning.mem_budget_mb / the environment variable
+    // PT_MEM_BUDGET_MB at pt_ctx_create; left alone (-1) the library plans within PT_DEFAULT_MEM_BUDGET_MB: a scene of 400 MB should not
+    // take 25 GB of the device without being asked (what each GB buys: profiles/r06e_mem_budget.log).
     size_t mem_budget = 0;
     pt_tuning tune;            // include/pt_api.h: defaults (-1) + PT_TUNE, filled once by pt_ctx_create
     // fused.hip: the launch attributes / occupancy of the fused kernels for the last LDS size planned ([0] single-level, [1] two-level):
@@ -54,6 +54,12 @@ struct pt_ctx {
     size_t fused_smem[2] = { 0, 0 };
     int fused_per_cu[2] = { 0, 0 };
 };
+// The workspace budget a context plans within when the caller names none: 8 GB.  Round 6, one MI355X, Grays/s at 2 / 4 / 8 / 16 / 32 GB / no
+// bound: the 10 000-instance grid through the queues 13.6 / 15.0 / 15.0 / 15.1 / 15.4 / 15.3 (the fused kernel 15.5 in 0.6 GB at every budget);
+// the 1 M-triangle soup 2.30 / 2.30 / 3.10 / 3.31 / 3.44 / 3.43; the 8 M-triangle soup 1.89 / 2.96 / 3.18 / 3.29 / 3.27 / 3.28
+// (profiles/r06e_mem_budget.log).  A caller who wants the last 3 .. 10 % on big scenes says so (mem_budget_mb = 32768, or 0 for no bound).
+constexpr int PT_DEFAULT_MEM_BUDGET_MB = 8192;
+inline size_t pt_budget_bytes(int32_t mb) { return mb > 0 ? (size_t)mb << 20 : mb == 0 ? 0 : (size_t)PT_DEFAULT_MEM_BUDGET_MB << 20; }
 // a tuning field with its built-in choice and its valid range
 inline int pt_tuned(int32_t v, int dflt, int lo, int hi) { return v < 0 ? dflt : (v < lo ? lo : (v > hi ? hi : v)); }
 

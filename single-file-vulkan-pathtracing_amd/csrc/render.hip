@@ -275,7 +275,9 @@ pt_status batch_begin(Job &j, Pipe *pipe, int &pipes_now, unsigned long long &ra
     if (j.sh.bounded) {  // the exact ray counter as it is before this batch, should the batch have to be redone
         PT_HIP(ctx, hipStreamSynchronize(st));
         PT_HIP(ctx, hipMemcpy(&rays_before, ctx->d_stats, sizeof(rays_before), hipMemcpyDeviceToHost));
-        PT_HIP(ctx, hipMemcpy(ctx->d_stats + 20, ctx->d_stats + 19, sizeof(unsigned long long), hipMemcpyDeviceToDevice));  // (rays_culled before the batch)
+        // (rays_culled before the batch: ON the stream, ahead of the k_generate launches that add to word 19 -- a plain device-to-device copy runs
+        // on the null stream, which the library's non-blocking streams are not ordered against)
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_stats + 20, ctx->d_stats + 19, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
     }
     PT_HIP(ctx, hipMemsetAsync(w.d_count, 0, sizeof(uint32_t) * 2 * PT_MAX_PIPES, st));
     if (j.sh.bounded) PT_HIP(ctx, hipMemsetAsync(j.d_spill_count, 0, sizeof(unsigned long long), st));
@@ -777,13 +779,17 @@ uint32_t resolve_pipeline(pt_scene *s, const pt_params *p, const ExtendPlan &pl)
     const pt_status rc = ptw_plan_fused(s, pl, p->tmin, fp);
     if (rc != PT_OK) s->ctx->err = keep;  // (not an error of this call: the scene is simply not the fused kernel's)
     if (rc != PT_OK) return PT_PIPELINE_WAVEFRONT;
-    // Two-level scenes: since the cull (round 5) keeps the pixels that look past the instances out of the queues, the wavefront pipeline is the
-    // faster one on launches of few frames -- the 10 000-instance grid at 1080p, ms per frame fused / wavefront: 1 frame 12.02 / 10.39, 2 frames
-    // 11.48 / 11.04, 4 frames 11.14 / 10.59, 8 frames 10.65 / 10.38, 16 frames 10.36 / 10.32 (profiles/r05zm_c4_pipelines.log) -- in 13 .. 37 GB
-    // of workspace against 0.4 .. 5.  Up to 8 frames per launch the queues; above, the fused kernel (the same speed in 1 / 37 of the memory).
+    // Two-level scenes: the fused two-level kernel, in 0.4 .. 5 GB.  With the pixels that look past the instances out of its queues (the cull)
+    // the wavefront pipeline is the faster one on launches of few frames -- the 10 000-instance grid at 1080p, ms per frame fused / wavefront:
+    // 1 frame 11.95 / 10.40, 2 frames 11.41 / 10.98, 4 frames 11.08 / 10.55, 8 frames 10.49 / 10.39, 16 frames 10.21 / 10.30
+    // (profiles/r06d_c4_pipelines.log) -- but it takes 13 .. 37 GB for that, and under the library's own workspace budget (8 GB,
+    // pt_internal.h) its shapes shrink until the fused kernel is ahead at every frame count (8 frames: 15.0 against 15.5 Grays/s,
+    // profiles/r06e_mem_budget.log).  So the queues only where they are >= 15 % ahead AND the caller has raised the budget to what they
+    // take: one frame per launch with >= 16 GB.
     if (fp.inst) {
         const uint32_t per_launch = p->frames_in_flight ? std::min(p->frames_in_flight, p->frame_count) : std::min(p->frame_count, 32u);
-        if (per_launch <= 8u) return PT_PIPELINE_WAVEFRONT;
+        const size_t budget = s->ctx->mem_budget;
+        if (per_launch == 1u && (budget == 0 || budget >= ((size_t)16 << 30))) return PT_PIPELINE_WAVEFRONT;
     }
     return PT_PIPELINE_FUSED;
 }

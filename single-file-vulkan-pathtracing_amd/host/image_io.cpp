@@ -8,13 +8,26 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "../../include/pt_host.h"
+
+namespace {
+// what the try / catch wrappers of the C-ABI need so that an exception (std::bad_alloc of a row buffer) leaks neither a FILE nor a malloc block
+struct FileCloser { void operator()(FILE *f) const { if (f) std::fclose(f); } };
+using File = std::unique_ptr<FILE, FileCloser>;
+struct Freer { void operator()(void *p) const { std::free(p); } };
+template <class T> using Block = std::unique_ptr<T, Freer>;
+// the explicit close whose result the writers report (the guard then holds nothing)
+int close_checked(File &f) { return std::fclose(f.release()) == 0 ? 0 : 3; }
+}  // namespace
 
 extern "C" int pth_write_ppm_bgra8(const char *path, const uint8_t *bgra, uint32_t w, uint32_t h)
 try {
     if (!path || !bgra || !w || !h) return 1;
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return 2;
+    File fg(std::fopen(path, "wb"));
+    if (!fg) return 2;
+    FILE *f = fg.get();
     std::fprintf(f, "P6\n%u %u\n255\n", w, h);
     std::vector<uint8_t> row(3 * (size_t)w);
     for (uint32_t y = 0; y < h; y++) {
@@ -26,7 +39,7 @@ try {
         }
         std::fwrite(row.data(), 1, row.size(), f);
     }
-    return std::fclose(f) == 0 ? 0 : 3;
+    return close_checked(fg);
 } catch (...) {
     return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }
@@ -34,11 +47,12 @@ try {
 extern "C" int pth_write_pfm(const char *path, const float *rgb, uint32_t w, uint32_t h)
 try {
     if (!path || !rgb || !w || !h) return 1;
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return 2;
+    File fg(std::fopen(path, "wb"));
+    if (!fg) return 2;
+    FILE *f = fg.get();
     std::fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
     for (uint32_t y = h; y-- > 0;) std::fwrite(rgb + 3 * (size_t)y * w, sizeof(float), 3 * (size_t)w, f);
-    return std::fclose(f) == 0 ? 0 : 3;
+    return close_checked(fg);
 } catch (...) {
     return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }
@@ -81,10 +95,12 @@ extern "C" int pth_make_soup(uint32_t n_tris, uint32_t seed, pth_scene *out)
 try {
     if (!out || !n_tris || n_tris > 0x0FFFFFFFu) return 1;
     *out = pth_scene{};
-    float *vert = static_cast<float *>(std::malloc(sizeof(float) * 9 * (size_t)n_tris));
-    uint32_t *idx = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * 3 * (size_t)n_tris));
-    float *faces = static_cast<float *>(std::malloc(sizeof(float) * 6 * (size_t)n_tris));
-    if (!vert || !idx || !faces) { std::free(vert); std::free(idx); std::free(faces); return 2; }
+    Block<float> vert_g(static_cast<float *>(std::malloc(sizeof(float) * 9 * (size_t)n_tris)));
+    Block<uint32_t> idx_g(static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * 3 * (size_t)n_tris)));
+    Block<float> faces_g(static_cast<float *>(std::malloc(sizeof(float) * 6 * (size_t)n_tris)));
+    if (!vert_g || !idx_g || !faces_g) return 2;
+    float *vert = vert_g.get(), *faces = faces_g.get();
+    uint32_t *idx = idx_g.get();
     Pcg rng{ seed };
     for (uint32_t i = 0; i < n_tris; i++) {
         float v[3][3];
@@ -102,7 +118,7 @@ try {
             faces[6 * (size_t)i + 3 + a] = light ? kSoupLightKe[a] : 0.f;
         }
     }
-    out->vertices = vert; out->n_verts = 3u * n_tris; out->indices = idx; out->n_tris = n_tris; out->faces = faces;
+    out->vertices = vert_g.release(); out->n_verts = 3u * n_tris; out->indices = idx_g.release(); out->n_tris = n_tris; out->faces = faces_g.release();
     return 0;
 } catch (...) {
     return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
@@ -216,14 +232,16 @@ try {
     }
     const size_t nt = o.faces.size() / 6;
     if (nt == 0 || nt > 0x0FFFFFFFu) return 1;
-    float *vert = static_cast<float *>(std::malloc(sizeof(float) * o.vert.size()));
-    uint32_t *idx = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * 3 * nt));
-    float *faces = static_cast<float *>(std::malloc(sizeof(float) * o.faces.size()));
-    if (!vert || !idx || !faces) { std::free(vert); std::free(idx); std::free(faces); return 2; }
+    Block<float> vert_g(static_cast<float *>(std::malloc(sizeof(float) * o.vert.size())));
+    Block<uint32_t> idx_g(static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * 3 * nt)));
+    Block<float> faces_g(static_cast<float *>(std::malloc(sizeof(float) * o.faces.size())));
+    if (!vert_g || !idx_g || !faces_g) return 2;
+    float *vert = vert_g.get(), *faces = faces_g.get();
+    uint32_t *idx = idx_g.get();
     std::memcpy(vert, o.vert.data(), sizeof(float) * o.vert.size());   // (already in loaded space: y negated by StadiumOut::tri)
     std::memcpy(faces, o.faces.data(), sizeof(float) * o.faces.size());
     for (size_t i = 0; i < 3 * nt; i++) idx[i] = (uint32_t)i;
-    out->vertices = vert; out->n_verts = (uint32_t)(3 * nt); out->indices = idx; out->n_tris = (uint32_t)nt; out->faces = faces;
+    out->vertices = vert_g.release(); out->n_verts = (uint32_t)(3 * nt); out->indices = idx_g.release(); out->n_tris = (uint32_t)nt; out->faces = faces_g.release();
     return 0;
 } catch (...) {
     return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
@@ -240,17 +258,19 @@ try {
     std::string mtl = obj.size() > 4 && obj.substr(obj.size() - 4) == ".obj" ? obj.substr(0, obj.size() - 4) + ".mtl" : obj + ".mtl";
     const size_t slash = mtl.find_last_of('/');
     const std::string mtl_name = slash == std::string::npos ? mtl : mtl.substr(slash + 1);
-    FILE *fm = std::fopen(mtl.c_str(), "w");
-    if (!fm) return 2;
+    File fmg(std::fopen(mtl.c_str(), "w"));
+    if (!fmg) return 2;
+    FILE *fm = fmg.get();
     const char *const *names = kSoupNames;
     const float (&kd)[8][3] = kSoupKd;
     for (int i = 0; i < 8; i++) std::fprintf(fm, "newmtl %s\nKd %g %g %g\nKe 0 0 0\n\n", names[i], kd[i][0], kd[i][1], kd[i][2]);
     std::fprintf(fm, "newmtl light\nKd 0.78 0.78 0.78\nKe 17 12 4\n");
-    std::fclose(fm);
+    if (close_checked(fmg)) return 3;
 
-    FILE *f = std::fopen(obj.c_str(), "w");
-    if (!f) return 2;
-    std::vector<char> buf(1 << 20);
+    std::vector<char> buf(1 << 20);   // (declared before the FILE that uses it as its buffer: destroyed after the FILE is closed)
+    File fg(std::fopen(obj.c_str(), "w"));
+    if (!fg) return 2;
+    FILE *f = fg.get();
     std::setvbuf(f, buf.data(), _IOFBF, buf.size());
     std::fprintf(f, "# synthetic triangle soup, %u triangles, seed %u\nmtllib %s\n", n_tris, seed, mtl_name.c_str());
     Pcg rng{ seed };
@@ -266,7 +286,7 @@ try {
         for (int k = 0; k < 3; k++) std::fprintf(f, "v %.9g %.9g %.9g\n", v[k][0], v[k][1], v[k][2]);
         std::fprintf(f, "f -3 -2 -1\n");
     }
-    return std::fclose(f) == 0 ? 0 : 3;
+    return close_checked(fg);
 } catch (...) {
     return 3;  // (std::bad_alloc and the like: nothing leaves the C-ABI as an exception)
 }

@@ -9,6 +9,13 @@ LIVE oracle run inside its cpu_baseline leg; the numbers agree: C2 224 112 445 r
     python tests/golden/make_fullsize_hashes.py [c2 c4 c5]      # ~2 min for C2+C4, ~10 min for C5 on 8 cores
     python tests/golden/make_fullsize_hashes.py c3              # ~20 min on 8 cores
 
+    python tests/golden/make_fullsize_hashes.py ref1024         # ~2 min on 8 cores
+
+`ref1024` is the REFERENCE'S OWN launch (main.cpp:16-17 WIDTH = HEIGHT = 1024, main.cpp:659 traceRaysKHR(WIDTH, HEIGHT, 1), 32 spp, depth 8: exactly
+what pt_params_default returns), frames 0..3 blended progressively as its frame loop does (main.cpp:647-685, raygen.rgen:88-90): the exact ray count of
+every frame and the SHA-256 of the float film and of the bgra8 storage image after each of them; `test_reference_dispatch_1024_*` issues the same four
+blocking calls on the GPU through PT_PIPELINE_AUTO and requires all of it to the bit.
+
 `c3` is BASELINE config C3 at its size: the Cornell box, 1920x1080, 1024 spp = frames 0..31 of 32 spp (seed multipliers
 m = 1..1024, raygen.rgen:47), depth 8, blended progressively as raygen.rgen:88-90 does -- the float film AND the reference's rgba8
 storage image.  Recorded: the exact ray count of every frame (their sum is the 8-GPU job's total), the SHA-256 of the float
@@ -76,9 +83,36 @@ def make_c3(res):
     print("c3", {k: v for k, v in res["c3"].items() if k != "rays_per_frame"}, flush=True)
 
 
+def make_ref1024(res):
+    import numpy as np
+    osc = orc.Scene(*pt.load_obj(os.path.join(REPO, "assets", "CornellBox-Original.obj")))
+    p0 = orc.default_params()
+    w, h = int(p0.width), int(p0.height)
+    assert (w, h, int(p0.spp_per_frame), int(p0.max_depth)) == (1024, 1024, 32, 8), "the oracle's defaults are the reference's constants"
+    film = np.zeros((h, w, 3), np.float32)
+    bgra = np.zeros((h, w, 4), np.uint8)
+    frames = []
+    t0 = time.perf_counter()
+    for frame in range(4):
+        img, rays, _, _ = osc.render_frame(orc.default_params(frame=frame), mode=1, nthreads=os.cpu_count() or 1)
+        orc.accumulate_f32(film, img, frame)
+        orc.accumulate_bgra8(bgra, img, frame)
+        frames.append({"frame": frame, "rays": int(rays), "film_sha256": hashlib.sha256(film.astype("<f4").tobytes()).hexdigest(),
+                       "bgra8_sha256": hashlib.sha256(bgra.tobytes()).hexdigest()})
+        print("ref1024 frame", frame, rays, round(time.perf_counter() - t0, 1), "s", flush=True)
+    res["ref1024"] = {"width": w, "height": h, "spp_per_frame": 32, "max_depth": 8, "frames": frames, "rays": int(sum(f["rays"] for f in frames)),
+                      "film_sum_f64": float(film.astype("float64").sum()), "scene": "CornellBox-Original.obj",
+                      "what": "the reference's own dispatch (main.cpp:16-17, 659), one blocking launch per frame (main.cpp:647-685)",
+                      "oracle_seconds": round(time.perf_counter() - t0, 1)}
+
+
 def main():
     want = sys.argv[1:] or list(CONFIGS)
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    if "ref1024" in want:
+        make_ref1024(res)
+        json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+        want = [x for x in want if x != "ref1024"]
     if "c3" in want:
         make_c3(res)
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)

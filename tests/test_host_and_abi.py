@@ -325,7 +325,7 @@ def test_bench_gpus_n_needs_no_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PT_BENCH_EMULATE")}
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--reps", "1",
-                        "--width", "64", "--height", "64", "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True,
+                        "--width", "64", "--height", "64", "--no-cpu-baseline", "--no-extra-legs", "--full-line"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert "must be launched with" not in r.stderr
     assert time.time() - t0 < 240
