@@ -594,6 +594,9 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
 // (a rank of world 8 at 16 frames, 6.1: 12.38 -> 12.19; of 4 at 8 frames: 12.38 -> 12.06; 8 and 16 frames: S 2 .. 4 within 0.3 % of none.)
 // In single steps with the cull (r05zr_tail_fine.log): one frame S 15 .. 16, two frames S 10 (11.51 against 11.55 at 12), three S 8, four S 6
 // (22.11 against 22.22 at 4).
+// Round 6, the rule against hand-picked shapes at sizes it was not fitted on (1280 x 720, 1024 x 1024 -- the reference's own launch --, 2560 x 1440,
+// 3840 x 2160; K = 1, 2, 20; scripts/probe_shape_rules.py, profiles/r06h_shape_rules.log): within 1 % of the best of twelve shapes everywhere (S 24 against
+// the rule's S 20 on one small frame: 2.82 / 2.85 and 2.85 / 2.83 ms in two passes -- noise); nothing changed.
 // So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 5 spp / 16; to 10.1 -> spp / 4; to
 // 13.5 -> 3 spp / 16; to 21.9 -> spp / 8 (5 / 6 / 7 frames and a rank of world 4 at 20 frames: -1.2 / -1.2 / -0.8 / -0.9 %, r05zzb_tail_mid_k.log);
 // above -> 0 (8 frames: -0.1 %).  pt_tuning.fused_tail >= 0 overrides.
