@@ -1,0 +1,24 @@
+"""dev probe: config C4 (10 000 instances, 1080p) through the fused two-level kernel, ms per frame at 8 and 16 frames per call; one process per build (PT_LIB_AMD) / tuning."""
+import importlib, os, statistics, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pt = importlib.import_module("single-file-vulkan-pathtracing_amd")
+ctx = pt.Context(0)
+for a in sys.argv[1:]:
+    k, v = a.split("=")
+    ctx.set_tuning(**{k: int(v)})
+sc = pt.Scene(ctx, *pt.load_obj(pt.ASSET_CORNELL))
+sc.set_instances(pt.cornell_grid_instances())
+W, H = 1920, 1080
+row = []
+for K in (8, 16):
+    film = pt.Film(ctx, W, H)
+    p = pt.default_params(frame=0, frame_count=K, width=W, height=H, spp_per_frame=32, max_depth=8, pipeline=pt.PIPELINE_FUSED)
+    pt.render(sc, film, p)
+    ts = []
+    for _ in range(5):
+        ctx.reset_stats()
+        t0 = time.perf_counter(); pt.render(sc, film, p); ts.append(time.perf_counter() - t0)
+    st = ctx.stats()
+    row.append(f"K {K}: {statistics.median(ts) * 1e3 / K:.3f} ms/frame ({st.rays / statistics.median(ts) / 1e9:.2f} Grays/s)")
+    film.close()
+print(os.environ.get("PT_LIB_AMD", "product"), " ".join(sys.argv[1:]), " | ".join(row), flush=True)

@@ -3,7 +3,7 @@
 // (Round 1 built the same tree on the host; that builder is gone -- tests/test_gpu_parity.py checks this one's trees
 // structurally and through the hit records.)  Primitives = triangles or fan pairs, binary surface-area sweep over every split position of all three centroid
 // orders, cost area(L) n(L) + area(R) n(R) in binary64, first minimum in (cost, axis, position) order, median split below
-// depth 24; then the BVH4 by opening the internal child of largest area, rows in the same format and order.
+// depth 24; then the BVH4 as the cut of that tree with the least sum of internal-node areas (k_sah_emit), rows in the same format and order.
 //
 // Scenes of <= 2048 triangles; the Cornell box has 18 primitives.  No sorting: for a node
 // of m primitives each of the 3m candidates (axis a, primitive j) is "everything whose (centroid_a, id) key is <= j's
@@ -420,10 +420,17 @@ __global__ __launch_bounds__(TBD) void k_sah_node_boxes(const SahNode *__restric
     ntris[i] = n_tri;
 }
 
-// BVH4 rows + leaf order from the binary tree: one thread opens, per wide node, the internal child of largest area.  The walk is a
-// chain of dependent reads, so everything it BRANCHES on -- links, ranges, areas, triangle counts, the primitives -- is staged in LDS by
-// the whole workgroup first (<= 96 KB for 2048 primitives), and all it writes per row is which binary node sits in which slot and the slot's
-// child word: k_sah_rows then fills the 128-B rows (boxes, words, padding) in parallel.  2047 triangles: scene build 10.3 -> 8.6 ms (profiles/r04aj_times.txt).
+// BVH4 rows + leaf order from the binary tree.  Which binary nodes become BVH4 nodes is a CUT of the binary tree, and the cut is chosen to
+// minimise what a walk pays for: the sum of the areas of the BVH4's internal nodes (the surface-area estimate of node visits per ray; the
+// leaves are the binary tree's and cost the same under every cut).  Dynamic programming over the binary tree (Ylitie, Karras, Laine 2017,
+// section 3): F(n, k) = the least area sum that covers subtree n with at most k slots of its parent = min(area(n) + S(n, 4) -- n becomes a
+// node --, S(n, k) -- n is opened --) with S(n, k) = min over j of F(left, j) + F(right, k - j); a leaf costs 0.  Until round 6 the cut was
+// greedy (open the internal child of largest area until the row is full), which left the Cornell box with a child of the root that spans
+// the whole room -- three walls -- and is visited by every ray: 8 nodes, 3.46 expected node visits per ray (3.41 measured) against the
+// optimum's 7 nodes and 2.97 (2.87 in a simulation of the walk over path-traced rays, leaf visits 1.39 -> 1.40).  One thread does both passes;
+// everything it BRANCHES on -- links, ranges, areas, triangle counts, the primitives, the tables -- is staged in LDS by the whole
+// workgroup first (<= 143 KB for 2048 primitives), and all it writes per row is which binary node sits in which slot and the slot's child
+// word: k_sah_rows then fills the 128-B rows (boxes, words, padding) in parallel.
 constexpr uint32_t ROW_EMPTY = 0xFFFFFFFFu;
 __global__ __launch_bounds__(TBD) void k_sah_emit(const SahNode *__restrict__ nodes, const uint32_t *__restrict__ n_nodes, const uint32_t *__restrict__ ids,
                                                   const uint32_t *__restrict__ prim_first, const uint8_t *__restrict__ prim_tris, uint32_t np,
@@ -437,6 +444,8 @@ __global__ __launch_bounds__(TBD) void k_sah_emit(const SahNode *__restrict__ no
     uint32_t *s_fc = s_lr + nn;                                             // [nn]: first | count << 16
     uint32_t *s_nt = s_fc + nn;                                             // [nn]: triangles below the node
     uint32_t *s_prim = s_nt + nn;                                           // [np]: first triangle | triangles << 16 of the primitive at that place of the order
+    float *s_f = reinterpret_cast<float *>(s_prim + np);                    // [nn][3]: F(n, 1 .. 3)
+    uint8_t *s_ch = reinterpret_cast<uint8_t *>(s_f + 3 * (size_t)nn);      // [nn]: bit 0 F(n,2) opens n, bit 1 F(n,3) opens n, bit 2 j of S(n,3) - 1, bits 3-4 j of S(n,4) - 1
     __shared__ uint2 s_todo[SAH_STACK * 3];                                 // {binary node, row}: <= 3 pushed per level
     for (uint32_t i = threadIdx.x; i < nn; i += TBD) {
         const SahNode &k = nodes[i];
@@ -453,26 +462,69 @@ __global__ __launch_bounds__(TBD) void k_sah_emit(const SahNode *__restrict__ no
     if (threadIdx.x != 0) return;
     uint32_t n_rows = 0, n_order = 0, sp = 0;
     auto is_leaf = [&](uint32_t n) { return (s_lr[n] & 0xFFFFu) == 0xFFFFu; };
+    // ---- pass 1: the tables, children before parents (an explicit post-order walk; s_todo.y: 0 = first visit, 1 = children done)
+    s_todo[sp++] = make_uint2(0u, 0u);
+    while (sp > 0) {
+        const uint2 it = s_todo[sp - 1];
+        const uint32_t n = it.x;
+        if (is_leaf(n)) {
+            s_f[3 * n + 0] = s_f[3 * n + 1] = s_f[3 * n + 2] = 0.f;
+            s_ch[n] = 0u;
+            sp--;
+            continue;
+        }
+        const uint32_t l = s_lr[n] & 0xFFFFu, r = s_lr[n] >> 16;
+        if (it.y == 0u) {
+            s_todo[sp - 1].y = 1u;
+            s_todo[sp++] = make_uint2(l, 0u);
+            s_todo[sp++] = make_uint2(r, 0u);
+            continue;
+        }
+        sp--;
+        auto F = [&](uint32_t m, uint32_t k) { return s_f[3 * m + (k - 1u)]; };   // k = 1 .. 3
+        // S(n, k): the best split of k slots between the two children (first minimum in j)
+        const float s2 = F(l, 1) + F(r, 1);
+        float s3 = F(l, 1) + F(r, 2);
+        uint32_t j3 = 1u;
+        if (F(l, 2) + F(r, 1) < s3) { s3 = F(l, 2) + F(r, 1); j3 = 2u; }
+        float s4 = F(l, 1) + F(r, 3);
+        uint32_t j4 = 1u;
+        if (F(l, 2) + F(r, 2) < s4) { s4 = F(l, 2) + F(r, 2); j4 = 2u; }
+        if (F(l, 3) + F(r, 1) < s4) { s4 = F(l, 3) + F(r, 1); j4 = 3u; }
+        const float as_node = (float)s_area[n] + s4;
+        s_f[3 * n + 0] = as_node;
+        // (equal cost: open the node -- the same estimate with a row less)
+        const bool open2 = s2 <= as_node, open3 = s3 <= as_node;
+        s_f[3 * n + 1] = open2 ? s2 : as_node;
+        s_f[3 * n + 2] = open3 ? s3 : as_node;
+        s_ch[n] = (uint8_t)((open2 ? 1u : 0u) | (open3 ? 2u : 0u) | ((j3 - 1u) << 2) | ((j4 - 1u) << 3));
+    }
+    // ---- pass 2: the rows.  A row's slots = the cut below its binary node: S(n, 4) at the top, then the tables' choices, left before right
+    sp = 0;
     s_todo[sp++] = make_uint2(0u, n_rows++);
     while (sp > 0) {
         const uint2 it = s_todo[--sp];
         uint32_t kids[4];
         int m = 0;
-        if (is_leaf(it.x)) kids[m++] = it.x;  // the whole scene is one leaf
-        else { kids[m++] = s_lr[it.x] & 0xFFFFu; kids[m++] = s_lr[it.x] >> 16; }
-        while (m < 4) {
-            int pick = -1;
-            double pa = -1.0;
-            for (int j = 0; j < m; j++) {
-                if (is_leaf(kids[j])) continue;
-                const double a = s_area[kids[j]];
-                if (a > pa) { pa = a; pick = j; }
+        if (is_leaf(it.x)) {
+            kids[m++] = it.x;  // the whole scene is one leaf
+        } else {
+            uint2 ex[8];       // {binary node, slots it may take}; popped left first
+            int xs = 0;
+            {
+                const uint32_t j4 = ((s_ch[it.x] >> 3) & 3u) + 1u;
+                ex[xs++] = make_uint2(s_lr[it.x] >> 16, 4u - j4);
+                ex[xs++] = make_uint2(s_lr[it.x] & 0xFFFFu, j4);
             }
-            if (pick < 0) break;
-            const uint32_t lr = s_lr[kids[pick]];
-            for (int j = m; j > pick + 1; j--) kids[j] = kids[j - 1];
-            kids[pick] = lr & 0xFFFFu; kids[pick + 1] = lr >> 16;
-            m++;
+            while (xs > 0) {
+                const uint2 e = ex[--xs];
+                const uint32_t n = e.x, k = e.y;
+                const bool open = !is_leaf(n) && k >= 2u && ((s_ch[n] >> (k - 2u)) & 1u);
+                if (!open) { kids[m++] = n; continue; }
+                const uint32_t j = k == 2u ? 1u : ((s_ch[n] >> 2) & 1u) + 1u;   // (k = 3; k = 4 only at the top)
+                ex[xs++] = make_uint2(s_lr[n] >> 16, k - j);
+                ex[xs++] = make_uint2(s_lr[n] & 0xFFFFu, j);
+            }
         }
         for (int j = 0; j < 4; j++) {
             uint32_t kid = ROW_EMPTY, word = ROW_EMPTY;
@@ -576,7 +628,7 @@ pt_status pt_sah_build_bvh4_device(pt_ctx *ctx, const float *tlo, const float *t
                                                                    d_narea.p, d_ntris.p);
     Buf<uint32_t> d_row_kid, d_row_word;
     PT_HIP(ctx, d_row_kid.alloc(4 * (2 * (size_t)np + 1))); PT_HIP(ctx, d_row_word.alloc(4 * (2 * (size_t)np + 1)));
-    const size_t emit_smem = (sizeof(double) + 3 * sizeof(uint32_t)) * (2 * (size_t)np + 1) + sizeof(uint32_t) * (size_t)np;  // <= 88 KB for 2048 primitives
+    const size_t emit_smem = (sizeof(double) + 3 * sizeof(uint32_t) + 3 * sizeof(float) + 1) * (2 * (size_t)np + 1) + sizeof(uint32_t) * (size_t)np + 16;  // <= 143 KB for 2048 primitives
     if (emit_smem > 48 * 1024)
         PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sah_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_smem));
     k_sah_emit<<<1, TBD, emit_smem, st>>>(d_nodes.p, d_nn.p, d_ids.p, d_first.p, d_tris.p, np, d_narea.p, d_ntris.p, d_row_kid.p, d_row_word.p, d_order.p, d_counts.p);
