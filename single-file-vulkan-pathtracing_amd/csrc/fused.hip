@@ -121,8 +121,10 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
     fp.block = FTB;
     // of 64: the share of a wave's live lanes that must wait with a finished ray before the shade block runs for them.  The block
     // is ~4x a node step, so it pays to run it fuller than k_extend's refill (16): 8 / 16 / 24 / 32 / 40 -> 33.9 / 34.1 / 34.6 /
-    // 35.7 / 36.3 Grays/s on the Cornell box at 1080p (profiles/r04b_fused_refill_sweep.txt)
-    fp.refill = pt_tuned(ctx->tune.refill, 40, 1, 64);
+    // 35.7 / 36.3 Grays/s on the Cornell box at 1080p (profiles/r04b_fused_refill_sweep.txt).  Round 6, after the shade block lost a fifth of
+    // its instructions (the shared spawn steps) and the tree a node: 32 / 36 / 40 / 44 / 48 -> 73.1 / 73.1 / 73.8 / 75.1 / 76.1 ms per 16 frames,
+    // one blocking frame 5.48 / 5.45 / 5.43 / 5.47 / 5.52 (profiles/r06l_refill_exit_resweep.log): 36
+    fp.refill = pt_tuned(ctx->tune.refill, 36, 1, 64);
     return PT_OK;
 }
 
@@ -134,8 +136,10 @@ void ptw_launch_fused(const FusedPlan &fp, bool grouped, const ptw::RenderConst 
         const NormBox nbt = { s->tlas_norm_c[0], s->tlas_norm_c[1], s->tlas_norm_c[2], s->tlas_norm_s[0], s->tlas_norm_s[1], s->tlas_norm_s[2],
                               s->tlas_norm_rs[0], s->tlas_norm_rs[1], s->tlas_norm_rs[2] };
         const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
-        // the waiting rules of k_extend_inst16 (extend_launch.hip has the measurements)
-        const int enter_min = pt_tuned(s->ctx->tune.enter_min, 16, 1, 64), leaf_min = pt_tuned(s->ctx->tune.leaf_min, 8, 1, 64);
+        // the waiting rules of k_extend_inst16 (extend_launch.hip has the measurements), re-swept for this kernel in round 6 on the tree with the
+        // least-area cut (leaves are reached a node earlier): a leaf step waits for 14 lanes (8 / 10 / 12 / 14 / 20 / 24: 16.42 / 16.60 / 16.72 / 16.76 /
+        // 16.52 / 16.32 Grays/s on the 10 000-instance grid at 16 frames), an instance entry for 12 (profiles/r06m_c4_fused_knobs.log)
+        const int enter_min = pt_tuned(s->ctx->tune.enter_min, 12, 1, 64), leaf_min = pt_tuned(s->ctx->tune.leaf_min, 14, 1, 64);
         const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
 #define PT_LAUNCH_FUSED_INST(G, P)                                                                                                     \
     hipExtLaunchKernelGGL((k_fused_inst<G, P>), dim3(fp.grid), dim3(FITB), (uint32_t)fp.smem, st, ev0, ev1, 0u, rc, tiles, rad, s->d_tlas16, nbt, \

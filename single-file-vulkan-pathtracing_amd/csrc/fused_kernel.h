@@ -11,7 +11,7 @@
 //     entries in LDS, key-sorted children, fan pairs tested together), restated here operation for operation -- the hot
 //     instantiation of that template is register-allocated to the last VGPR and must not grow a second use;
 //   * a lane whose ray is finished WAITS with its hit in registers until `refill` / 64 of the wave's live lanes wait too
-//     (40 / 64: fused.hip), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
+//     (36 / 64: fused.hip), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
 //     raygen.rgen:76-83, the next sample's camera ray (raygen.rgen:45-60), or the first sample of a NEW slot -- and set up
 //     their next ray; the same operations in the same order as k_shade, so the film is the wavefront pipeline's bit for bit;
 //   * slots (frame, sample group, pixel) are handed out in order by device-scope counters -- eight, one per XCD's share of the
