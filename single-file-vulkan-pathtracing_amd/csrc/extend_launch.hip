@@ -221,7 +221,9 @@ void ptw_launch_extend(const ExtendPlan &pl, pt_scene *s, const float4 *rayA, co
                               s->tlas_norm_rs[0], s->tlas_norm_rs[1], s->tlas_norm_rs[2] };
         const NormBox nbb = { s->norm_c[0], s->norm_c[1], s->norm_c[2], s->norm_s[0], s->norm_s[1], s->norm_s[2], s->norm_rs[0], s->norm_rs[1], s->norm_rs[2] };
         const int enter_min = pt_tuned(s->ctx->tune.enter_min, 16, 1, 64);  // lanes that wait to enter an instance together (8, 16, 24 measured alike within 1 %)
-        const int leaf_min = pt_tuned(s->ctx->tune.leaf_min, 8, 1, 64);    // ... and lanes that wait with a triangle leaf (extend_inst16.h)
+        // ... and lanes that wait with a triangle leaf (extend_inst16.h): 8 until round 6; on the BLAS with the least-area cut 8 / 12 / 14 / 20 -> 16.12 / 16.33 /
+        // 16.34 / 16.19 Grays/s on the 10 000-instance grid (profiles/r06o_c4_wavefront_knobs.log)
+        const int leaf_min = pt_tuned(s->ctx->tune.leaf_min, 14, 1, 64);
         // the node loop yields to the lanes waiting with a leaf once fewer than 1/6 of the wave's rays still descend
         // (C4 11.7 -> 12.2 Grays/s; 2, 3, 4, 8 measured within 1 % of it, 0 = never: profiles/r02i_ab_c4_node_yield.log)
         const int node_yield = pt_tuned(s->ctx->tune.node_yield, 6, 0, 64);
