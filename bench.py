@@ -66,8 +66,8 @@ BYTES_PER_PATH = 96.0
 _MODEL = os.path.join(REPO, "profiles", "isa_valu_model.json")
 ISA_VALU_MODEL = json.load(open(_MODEL)) if os.path.exists(_MODEL) else None
 # which PMC record (scripts/make_pmc_json.py) carries the HBM-side traffic of a config's traversal kernel
-PMC_RECORD = "r05_pmc_extend_{config}.json"
-PMC_RECORD_SHADE = "r05_pmc_shade_{config}.json"
+PMC_RECORD = "r06_pmc_extend_{config}.json"
+PMC_RECORD_SHADE = "r06_pmc_shade_{config}.json"
 
 
 def cpu_model():
@@ -959,6 +959,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record instead of two nested rocprofv3 passes of this command")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the nested run of live_traffic()
+    ap.add_argument("--mem-budget-mb", type=int, default=None, help="pt_tuning.mem_budget_mb for the headline's context: the workspace budget the shapes are planned within "
+                                                                    "(default: the library's own 8192; 0 = none).  The extra legs name their own budgets")
     ap.add_argument("--full-line", action="store_true", help="print the whole record as the one JSON line (the default prints the legs as `# detail` lines and a compact final line)")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only: no c2_exact / latency / roofline_c4 / _c5 / _c5x legs")
     ap.add_argument("--c5-frames", type=int, default=4, help="frames of the roofline_c5 leg")
@@ -1017,6 +1019,8 @@ def main():
         args.depth = args.depth or 8
     stream = torch.cuda.current_stream(dev)
     ctx = pt.Context(local_rank, stream=stream.cuda_stream)
+    if args.mem_budget_mb is not None:
+        ctx.set_tuning(mem_budget_mb=args.mem_budget_mb)
     scene, arrays, scene_name, ingest, tlas_ms = build_scene(pt, ctx, scene_config, args.soup_tris, rank, args.bvh_quality)
     info = scene.info()
     film_t = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)   # this rank's accumulation film (torch owns the memory)
@@ -1125,7 +1129,8 @@ def main():
                        "pixel_sharding": f"8x8 tiles interleaved over {world} rank(s)" +
                                          (f", {presenter.describe()}" if presenter else ""),
                        "frames_in_flight": shape.frames_in_flight, "sample_groups": shape.sample_groups, "tail_samples": shape.tail_samples, "pipelines": st.pipelines,
-                       "sort_rays": args.sort_rays},
+                       "sort_rays": args.sort_rays,
+                       "mem_budget_mb": args.mem_budget_mb if args.mem_budget_mb is not None else "library default (8192)"},
             # the timed region repeated: value / ms_per_step are the median repetition
             "reps": len(reps), "value_min": min(values), "value_max": max(values), "values": values,
             "timed_seconds_total": round(sum(r[0] for r in reps), 4),
@@ -1162,7 +1167,7 @@ def main():
         frame0_rays_gpu = frame0_film_gpu = None
         cst = None
         live = world == 1 and not (args.no_extra_legs or args.no_live_pmc or args.pmc_child)
-        child_common = ["--pmc-child", "--config", args.config, "--steps", str(args.steps), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
+        child_common = (["--mem-budget-mb", str(args.mem_budget_mb)] if args.mem_budget_mb is not None else []) + ["--pmc-child", "--config", args.config, "--steps", str(args.steps), "--warmup", "0", "--reps", "1", "--no-cpu-baseline", "--no-extra-legs",
                         "--width", str(W), "--height", str(H), "--spp", str(args.spp), "--depth", str(args.depth), "--extend", args.extend,
                         "--frames-in-flight", str(args.frames_in_flight), "--sample-groups", str(args.sample_groups), "--sort-rays", args.sort_rays,
                         "--bvh-quality", args.bvh_quality] + (["--soup-tris", str(args.soup_tris)] if args.soup_tris else [])
