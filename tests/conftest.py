@@ -99,3 +99,10 @@ def cornell_gpu(pt, gpu_ctx, cornell_arrays):
     sc = pt.Scene(gpu_ctx, *cornell_arrays)
     yield sc
     sc.close()
+
+
+@pytest.fixture(params=["wavefront", "auto"])
+def any_pipeline(request, pt):
+    """tests that are not ABOUT the queues run through both the wavefront pipeline (what `pt.default_params` names in this suite) and what a
+    caller of pt_params_default really gets (PT_PIPELINE_AUTO: the fused kernels for the scenes that live in LDS).  -> the `pipeline=` value."""
+    return pt.PIPELINE_WAVEFRONT if request.param == "wavefront" else pt.PIPELINE_AUTO
