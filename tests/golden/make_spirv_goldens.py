@@ -11,6 +11,8 @@ correctly rounded sqrt, the evaluation order of dot/cross/normalize, and the uno
 image.  Everything else is the reference's instruction stream.
 
 Usage (repo root):  python tests/golden/make_spirv_goldens.py                  (spirv_pixels.npz, canonical driver)
+                    python tests/golden/make_spirv_goldens.py --ref1024        (spirv_ref1024.npz: the reference's OWN launch,
+                                                                                WIDTH = HEIGHT = 1024, main.cpp:16-17, 659 -- frames 0..3)
                     python tests/golden/make_spirv_goldens.py --independent    (spirv_independent.npz: a driver that shares
                                                                                 no code with oracle/, see IndependentDriver)
 """
@@ -254,8 +256,41 @@ def main():
     np.savez_compressed(os.path.join(REPO, "tests", "golden", "spirv_pixels.npz"), **out)
 
 
+def main_ref1024():
+    """tests/golden/spirv_ref1024.npz: the reference's own dispatch -- traceRaysKHR(1024, 1024, 1) (main.cpp:16-17, 659), push constant frame = 0, 1, 2,
+    3 (main.cpp:656-658), the image blended in place (raygen.rgen:88-90) -- executed by the reference's compiled shaders for a 64 x 48 rectangle that holds the
+    tall box's front, its coincident duplicate and the light's reflection, and for a scattered pixel set (corners, row / column 0, the emitter, a jittered
+    grid); a sixth of the scattered set also through the rgba8 storage image."""
+    t0 = time.time()
+    out = {}
+    W = H = 1024
+    NF = 4
+    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+        x0, y0, rw, rh = 480, 488, 64, 48
+        res = pool.map(run_pixel, [(x0 + x, y0 + y, W, H, NF, False) for y in range(rh) for x in range(rw)], chunksize=16)
+        out["launch"] = np.array([W, H], np.int32)
+        out["rect"] = np.array([x0, y0, rw, rh], np.int32)
+        out["rect_texels"] = np.array([r[0] for r in res], np.float32).reshape(rh, rw, NF, 4).transpose(2, 0, 1, 3)   # [frame][y][x][rgba]
+        out["rect_traces"] = np.array([r[1] for r in res], np.int64).reshape(rh, rw, NF).transpose(2, 0, 1)
+        print("ref1024 rect", rw, "x", rh, "x", NF, "frames, traces", out["rect_traces"].sum(axis=(1, 2)), "%.0f s" % (time.time() - t0), flush=True)
+        px = pixel_set(W, H, 16, 16, 3)
+        res = pool.map(run_pixel, [(int(x), int(y), W, H, NF, False) for x, y in px], chunksize=4)
+        out["pixels"] = px
+        out["texels"] = np.array([r[0] for r in res], np.float32).transpose(1, 0, 2)    # [frame][pixel][rgba]
+        out["traces"] = np.array([r[1] for r in res], np.int64).T
+        print("ref1024", len(px), "pixels x", NF, "frames, traces", out["traces"].sum(), "%.0f s" % (time.time() - t0), flush=True)
+        pxb = px[::6]
+        res = pool.map(run_pixel, [(int(x), int(y), W, H, NF, True) for x, y in pxb], chunksize=2)
+        out["pixels_rgba8"] = pxb
+        out["rgba8"] = np.array([r[0] for r in res], np.uint8).transpose(1, 0, 2)        # component order r,g,b,a
+        print("ref1024 rgba8", len(pxb), "pixels %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", "spirv_ref1024.npz"), **out)
+
+
 if __name__ == "__main__":
-    if "--independent" in sys.argv:
+    if "--ref1024" in sys.argv:
+        main_ref1024()
+    elif "--independent" in sys.argv:
         main_independent()
     elif "--all" in sys.argv:
         main()

@@ -2771,3 +2771,30 @@ def test_reference_dispatch_1024_four_blocking_frames_equal_the_oracle_known_ans
         assert hashlib.sha256(film.read_f32().astype("<f4").tobytes()).hexdigest() == last["film_sha256"], kw
         assert hashlib.sha256(film.read_bgra8().tobytes()).hexdigest() == last["bgra8_sha256"], kw
     film.close()
+
+
+def test_reference_dispatch_1024_equals_the_references_own_shaders(pt, gpu_ctx, cornell_gpu):
+    """The reference's own launch against the reference's own compiled shaders (tests/golden/spirv_ref1024.npz: shaders/*.spv executed by oracle/spirv_vm.py for a
+    64 x 48 rectangle and a scattered pixel set of the 1024 x 1024 launch, frames 0 .. 3): pt_params_default untouched, one blocking call per frame through the
+    library default (PT_PIPELINE_AUTO -> the fused kernel), and after every frame the film's texels -- and, for a sixth of the set, the bgra8 image -- are the
+    shaders' bit for bit.  (test_reference_dispatch_1024_four_blocking_frames_* checks the WHOLE frames against the oracle's SHA-256.)"""
+    path = os.path.join(HERE, "golden", "spirv_ref1024.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/spirv_ref1024.npz not generated")
+    g = np.load(path)
+    w, h = [int(v) for v in g["launch"]]
+    p0 = pt.library_default_params()
+    assert (p0.width, p0.height, p0.spp_per_frame, p0.max_depth) == (w, h, 32, 8)
+    x0, y0, rw, rh = [int(v) for v in g["rect"]]
+    film = pt.Film(gpu_ctx, w, h)
+    for frame in range(g["rect_texels"].shape[0]):
+        pt.render(cornell_gpu, film, pt.library_default_params(frame=frame, frame_count=1))
+        assert gpu_ctx.stats().pipeline == pt.PIPELINE_FUSED
+        got = film.read_f32()
+        assert np.ascontiguousarray(got[y0:y0 + rh, x0:x0 + rw]).tobytes() == np.ascontiguousarray(g["rect_texels"][frame, :, :, :3]).tobytes(), frame
+        px = g["pixels"]
+        assert np.ascontiguousarray(got[px[:, 1], px[:, 0]]).tobytes() == np.ascontiguousarray(g["texels"][frame, :, :3]).tobytes(), frame
+        bg = film.read_bgra8()
+        pb = g["pixels_rgba8"]
+        assert np.ascontiguousarray(bg[pb[:, 1], pb[:, 0]][:, [2, 1, 0, 3]]).tobytes() == np.ascontiguousarray(g["rgba8"][frame]).tobytes(), frame
+    film.close()

@@ -72,6 +72,39 @@ def test_oracle_golden_crop_equals_reference_shaders(orc):
     assert [int(r) for r in g["rays"]] == [int(r) for r in G["d_traces"].sum(axis=(1, 2))]
 
 
+def _ref1024():
+    path = os.path.join(HERE, "golden", "spirv_ref1024.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/spirv_ref1024.npz not generated (tests/golden/make_spirv_goldens.py --ref1024)")
+    return np.load(path)
+
+
+def test_oracle_equals_reference_shaders_at_the_references_own_launch(orc, cornell_oracle):
+    """The reference's OWN dispatch -- traceRaysKHR(1024, 1024, 1) (main.cpp:16-17, 659), push constant frame = 0 .. 3 (main.cpp:656-658), the image blended
+    in place (raygen.rgen:88-90) -- as its compiled shaders produce it (tests/golden/spirv_ref1024.npz, oracle/spirv_vm.py): a 64 x 48 rectangle through the
+    tall box's front and a scattered pixel set, every texel and every trace count after every frame; a sixth of the set through the rgba8 storage image."""
+    g = _ref1024()
+    w, h = [int(v) for v in g["launch"]]
+    assert (w, h) == (orc.default_params().width, orc.default_params().height) == (1024, 1024)
+    x0, y0, rw, rh = [int(v) for v in g["rect"]]
+    film = np.zeros((rh, rw, 3), np.float32)
+    for frame in range(g["rect_texels"].shape[0]):
+        col, rays = orc.render_rect(cornell_oracle, orc.default_params(frame=frame), x0, y0, rw, rh, mode=1, nthreads=4)
+        orc.accumulate_f32(film, col, frame)
+        assert film.tobytes() == np.ascontiguousarray(g["rect_texels"][frame, :, :, :3]).tobytes(), frame
+        assert rays == int(g["rect_traces"][frame].sum()), frame
+    for k, (x, y) in enumerate(g["pixels"]):
+        f1, rays = _progressive(orc, cornell_oracle, w, h, int(x), int(y), g["texels"].shape[0])
+        assert f1.tobytes() == np.ascontiguousarray(g["texels"][:, k, :3]).tobytes(), (x, y)
+        assert rays == list(g["traces"][:, k]), (x, y)
+    for k, (x, y) in enumerate(g["pixels_rgba8"]):
+        bgra = np.zeros((1, 4), np.uint8)
+        for frame in range(g["rgba8"].shape[0]):
+            col, _ = orc.render_rect(cornell_oracle, orc.default_params(frame=frame), int(x), int(y), 1, 1, nthreads=1)
+            orc.accumulate_bgra8(bgra, col, frame)
+            assert list(bgra[0, [2, 1, 0, 3]]) == list(g["rgba8"][frame, k]), (x, y, frame)
+
+
 @pytest.mark.skipif(not os.path.exists(REF_SHADERS + "raygen.rgen.spv"), reason="needs /root/reference (build container only)")
 def test_fixture_is_reproducible_from_the_reference_binaries(orc, cornell_oracle):
     """Re-executes the reference's SPIR-V here for a few pixels: the committed fixture is what the binaries give,
