@@ -376,6 +376,7 @@ enum pt_fused_block {
     PT_FB_SPAWN,     /* the steps a bounce and a camera ray share: two rand, one square root    */
     PT_FB_PTARGET,   /* camera ray: pixel + jitter -> target - origin (raygen.rgen:51-56)       */
     PT_FB_PDIR,      /* camera ray: normalize (raygen.rgen:57)                                  */
+    PT_FB_POPTOP,    /* a node step without a hit child takes the stack's top entry from a register */
     PT_FB_COUNT
 };
 pt_status pt_get_block_counts(pt_ctx *ctx, uint64_t *waves_lanes, uint32_t n_blocks /* <= 32 */);

@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "single-file-vulkan-pathtracing_amd", "csrc")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
 BLOCKS = ["ITER", "SHADE", "HIT", "MISS", "SURFACE", "ADD", "BOUNCE", "NEXT", "DONE", "HANDOUT", "DRAW", "TAKE", "CULLED", "PRIMARY", "SETUP",
-          "NODE", "POP", "LEAF", "DIV", "FINISH", "TRACE", "SPAWN", "PTARGET", "PDIR"]
+          "NODE", "POP", "LEAF", "DIV", "FINISH", "TRACE", "SPAWN", "PTARGET", "PDIR", "POPTOP"]
 
 
 def compile_s(extra, debug):

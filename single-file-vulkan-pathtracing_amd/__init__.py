@@ -101,7 +101,7 @@ class HostScene(C.Structure):
 
 # include/pt_api.h pt_fused_block, in order
 FUSED_BLOCKS = ["ITER", "SHADE", "HIT", "MISS", "SURFACE", "ADD", "BOUNCE", "NEXT", "DONE", "HANDOUT", "DRAW", "TAKE", "CULLED", "PRIMARY", "SETUP",
-                "NODE", "POP", "LEAF", "DIV", "FINISH", "TRACE", "SPAWN", "PTARGET", "PDIR"]
+                "NODE", "POP", "LEAF", "DIV", "FINISH", "TRACE", "SPAWN", "PTARGET", "PDIR", "POPTOP"]
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("inst", "<u4")])
 
 # every symbol include/pt_api.h and include/pt_host.h declare
