@@ -597,9 +597,11 @@ void fused_shape_defaults(const pt_film *f, const pt_params *p, const FusedPlan 
 // Round 6, the rule against hand-picked shapes at sizes it was not fitted on (1280 x 720, 1024 x 1024 -- the reference's own launch --, 2560 x 1440,
 // 3840 x 2160; K = 1, 2, 20; scripts/probe_shape_rules.py, profiles/r06h_shape_rules.log): within 1 % of the best of twelve shapes everywhere (S 24 against
 // the rule's S 20 on one small frame: 2.82 / 2.85 and 2.85 / 2.83 ms in two passes -- noise); nothing changed.
-// So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 5 spp / 16; to 10.1 -> spp / 4; to
-// 13.5 -> 3 spp / 16; to 21.9 -> spp / 8 (5 / 6 / 7 frames and a rank of world 4 at 20 frames: -1.2 / -1.2 / -0.8 / -0.9 %, r05zzb_tail_mid_k.log);
-// above -> 0 (8 frames: -0.1 %).  pt_tuning.fused_tail >= 0 overrides.
+// So by walked slots per lane: under 1.1 -> 0 (all groups); to 2.5 -> 5 spp / 8; to 4.5 -> spp / 2; to 7.9 -> 5 spp / 16; to 10.1 -> spp / 4;
+// above -> 0.  (Round 5 had two more steps, 3 spp / 16 up to 13.5 and spp / 8 up to 21.9 per lane: on round 6's kernel -- 17 % faster, its launches end
+// sooner -- they cost what they gained or more: 4 / 5 / 6 / 7 frames with S 6 / 4 / 4 / 4 against none 19.43 / 23.89 / 28.51 / 33.10 against 19.44 / 23.62 /
+// 28.02 / 32.39 ms, a rank of world 8 at 32 frames 19.69 against 19.15, of world 4 at 16 frames 19.52 against 19.19: profiles/r06u_tail_rule_refit.log.)
+// pt_tuning.fused_tail >= 0 overrides.
 uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params *p, uint32_t frames, const int32_t rect[4])
 {
     const uint32_t spp = p->spp_per_frame;
@@ -607,8 +609,7 @@ uint32_t fused_tail_samples(const pt_ctx *ctx, const pt_film *f, const pt_params
     int t = ctx->tune.fused_tail;
     if (t < 0) {
         const uint32_t x = fused_slots_x32(ctx, f, p, frames, rect);
-        t = x < 36u ? 0 : x <= 81u ? (int)(spp * 5u / 8u) : x <= 144u ? (int)(spp / 2u) : x <= 252u ? (int)(spp * 5u / 16u) : x <= 324u ? (int)(spp / 4u)
-                                   : x <= 432u ? (int)(spp * 3u / 16u) : x <= 700u ? (int)(spp / 8u) : 0;
+        t = x < 36u ? 0 : x <= 81u ? (int)(spp * 5u / 8u) : x <= 144u ? (int)(spp / 2u) : x <= 252u ? (int)(spp * 5u / 16u) : x <= 324u ? (int)(spp / 4u) : 0;
     }
     return (uint32_t)std::max(0, std::min<int>(t, (int)spp - 1));
 }
