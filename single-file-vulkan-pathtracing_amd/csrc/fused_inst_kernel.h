@@ -207,14 +207,6 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                         if (lane == 0) {
                             uint32_t *cnt = next_slot + w_part * (uint32_t)PT_FUSED_PART_STRIDE;
                             size = (uint32_t)(GROUPED ? PT_FUSED_BATCH : PT_FUSED_BATCH1);
-#if PT_FUSED_BATCH1 > 64  // (guided self-scheduling of bigger one-group batches: what is left / (2 x the waves that share the part), down to one tile)
-                            if (!GROUPED) {
-                                const uint32_t seen = __atomic_load_n(cnt, __ATOMIC_RELAXED);
-                                const uint32_t left = part_begin + seen < part_end ? part_end - part_begin - seen : 0u;
-                                const uint32_t share = left / max(2u * gridDim.x * (uint32_t)(FITB / 64) / (uint32_t)PT_FUSED_PARTS, 1u);
-                                size = min((uint32_t)PT_FUSED_BATCH1, max(64u, share & ~63u));
-                            }
-#endif
                             rel = atomicAdd(cnt, size);
                         }
                         rel = __builtin_amdgcn_readfirstlane(rel);

@@ -313,14 +313,6 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                         if (lane == 0) {
                             uint32_t *cnt = next_slot + (w_part + ((HYB && w_tails) ? (uint32_t)PT_FUSED_PARTS : 0u)) * (uint32_t)PT_FUSED_PART_STRIDE;
                             size = (uint32_t)(grp ? PT_FUSED_BATCH : PT_FUSED_BATCH1);
-#if PT_FUSED_BATCH1 > 64  // (guided self-scheduling of bigger one-group batches: what is left / (2 x the waves that share the part), down to one tile)
-                            if (!GROUPED) {
-                                const uint32_t seen = __atomic_load_n(cnt, __ATOMIC_RELAXED);
-                                const uint32_t left = part_begin + seen < part_end ? part_end - part_begin - seen : 0u;
-                                const uint32_t share = left / max(2u * gridDim.x * (uint32_t)(FTB / 64) / (uint32_t)PT_FUSED_PARTS, 1u);
-                                size = min((uint32_t)PT_FUSED_BATCH1, max(64u, share & ~63u));
-                            }
-#endif
                             rel = atomicAdd(cnt, size);
                         }
                         rel = __builtin_amdgcn_readfirstlane(rel);
