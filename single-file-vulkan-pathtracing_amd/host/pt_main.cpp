@@ -283,12 +283,12 @@ int main(int argc, char **argv)
                 "\"bvh_build_ms\": %.3f, \"width\": %u, \"height\": %u, \"frames\": %u, \"spp_per_frame\": %u, "
                 "\"max_depth\": %u, \"ranks\": %u, \"rccl_ranks\": %u, \"rays\": %llu, \"paths\": %llu, "
                 "\"rays_per_rank_min\": %llu, \"rays_per_rank_max\": %llu, \"rounds\": %u, \"ms_total\": %.3f, "
-                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f, \"selftest_wrong_pixels\": %lld, "
+                "\"present_ms\": %.3f, \"wall_ms_all_ranks\": %.3f, \"ms_per_frame\": %.3f, \"mrays_per_s\": %.1f, \"mrays_per_s_walked\": %.1f, \"selftest_wrong_pixels\": %lld, "
                 "\"pipeline\": %u, \"sample_groups\": %u, \"tail_samples\": %u, \"rays_culled\": %llu}\n",
                 o.obj.c_str(), info.n_tris, info.n_nodes, info.bvh_height, load_ms, info.build_ms, o.width, o.height, o.frames, o.spp,
                 o.depth, o.ranks, res[0].rccl_ranks, rays, paths, rays_min, rays_max, st.rounds, ms, present_ms, wall_ms,
-                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0, res[0].selftest_wrong,
-                st.pipeline, st.sample_groups, st.tail_samples, rays_culled);  // (rays_culled: camera rays finished without a walk, counted in rays)
+                ms / o.frames, ms > 0 ? (double)rays / (ms * 1e3) : 0.0, ms > 0 ? (double)(rays - rays_culled) / (ms * 1e3) : 0.0, res[0].selftest_wrong,
+                st.pipeline, st.sample_groups, st.tail_samples, rays_culled);  // (rays_culled: camera rays finished without a walk, counted in rays and in mrays_per_s; mrays_per_s_walked prices the same time without them)
     pth_free_scene(&hs);
     return 0;
 }
