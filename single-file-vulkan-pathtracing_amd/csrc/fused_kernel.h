@@ -13,7 +13,8 @@
 //   * a lane whose ray is finished WAITS with its hit in registers until `refill` / 64 of the wave's live lanes wait too
 //     (36 / 64: fused.hip), then all of them run the shade block -- closesthit.rchit:50-65 / miss.rmiss:8-12, the bounce of
 //     raygen.rgen:76-83, the next sample's camera ray (raygen.rgen:45-60), or the first sample of a NEW slot -- and set up
-//     their next ray; the same operations in the same order as k_shade, so the film is the wavefront pipeline's bit for bit;
+//     their next ray; the same operations on the same operands as k_shade, per lane in the same order, so the film is the wavefront pipeline's bit
+//     for bit.  The steps a bounce and a camera ray share (two rand, one square root) run once for both kinds of lanes (step (3) below);
 //   * slots (frame, sample group, pixel) are handed out in order by device-scope counters -- eight, one per XCD's share of the
 //     workgroups, with work stealing between them -- PT_FUSED_BATCH at a time per wave, so a wave that drew cheap border
 //     pixels simply takes more of them: no tail beyond the last batch's own length;
@@ -24,10 +25,10 @@
 // complete (one sample group), or the ordered term logs that k_resolve replays (several groups) -- k_resolve is shared.
 #pragma once
 
-// Block shape: the scene tables (10.5 KB for the Cornell box) are per block, the stack and the path state (19 KB per 256 threads) per
-// thread, so bigger blocks leave more of the 160 KB to waves: 256 threads = 30 KB = 5 blocks = 5 waves per SIMD; 512 threads =
-// 49.6 KB = 3 blocks = 6 waves per SIMD at 80 VGPRs (2 / 7 dwords spilled).  Same box, interleaved: 36.2 -> 38.1 Grays/s
-// (profiles/r04d_ab_fused_tb.log); 4 waves: 31.4.
+// Block shape: the scene tables (9.2 KB for the Cornell box) are per block, the stack and the path state (20 dwords) per
+// thread, so bigger blocks leave more of the 160 KB to waves: 256 threads = 5 blocks = 5 waves per SIMD; 512 threads =
+// 50.2 KB = 3 blocks = 6 waves per SIMD at 80 VGPRs (1 - 2 dwords spilled).  Same box, interleaved: 36.2 -> 38.1 Grays/s
+// (profiles/r04d_ab_fused_tb.log); 4 waves: 31.4.  Round 6's kernel: 768 x 6 waves -1 %, 256 -7 %, 384 -14 % (profiles/r06q_fused_block_size.log).
 #ifndef PT_FUSED_WAVES
 #define PT_FUSED_WAVES 6
 #endif
