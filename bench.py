@@ -857,7 +857,6 @@ def compact_line(out):
     def pick(d, keys):
         return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
     c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype") if k in out}
-    c["metric"] = c["metric"].split(" (")[0]
     c["data"] = "synthetic"
     w = (out.get("config") or {}).get("workload", "")
     c["config"] = {"workload": w.split("; step")[0].replace(" (the library default, PT_PIPELINE_AUTO)", " (library default)"), "pipeline": (out.get("config") or {}).get("pipeline")}
