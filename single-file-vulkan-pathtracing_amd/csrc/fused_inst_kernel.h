@@ -278,17 +278,20 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     sq_arg = 1.0f - r1 * r1;
                 }
                 const float sq = ptm::fsqrt(sq_arg);
+                // (one set of quotients by a common divisor for both kinds of lanes: direction = (target - origin) / length, barycentrics = (V, W) / det --
+                // fused_kernel.h)
+                float q1, q2, q3;
+                ptm::div3_dominant(need_primary ? vx : best_V, need_primary ? vy : best_W, need_primary ? vz : best_W, need_primary ? sq : best_det, q1, q2, q3);
                 if (need_primary) {
                     org = { rc.cam.ox, rc.cam.oy, rc.cam.oz };
-                    ptm::div3_dominant(vx, vy, vz, sq, dir.x, dir.y, dir.z);
+                    dir = { q1, q2, q3 };
                 } else {
                     // closesthit.rchit:56-57 position from the barycentrics, in object space; then k_shade<INST>: position by the
                     // object->world matrix, normal + tangent of the (instance, triangle) pair; raygen.rgen:77-80 the bounce
                     const uint32_t pos = best_pos;
                     const float4 s0 = s_shade[3 * pos + 0], s1 = s_shade[3 * pos + 1];
                     const float4 a = verts[3 * pos + 0], b = verts[3 * pos + 1], c = verts[3 * pos + 2];
-                    float hu, hv;
-                    ptm::div2_dominant(best_V, best_W, best_det, hu, hv);
+                    const float hu = q1, hv = q2;
                     const float b0 = (1.0f - hu) - hv;
                     org = { (a.x * b0 + b.x * hu) + c.x * hv, (a.y * b0 + b.y * hu) + c.y * hv, (a.z * b0 + b.z * hu) + c.z * hv };
                     ptm::f3 nrm = { s0.x, s0.y, s0.z };
