@@ -97,8 +97,10 @@ pt_status ptw_plan_fused(pt_scene *s, const ExtendPlan &pl, float tmin, FusedPla
                    "kernels' class: <= 2047 triangles in <= 24 KB, stack bound <= 16, tmin > 0)";
         return PT_ERR_UNSUPPORTED;
     }
-    fp.lds_stack = pl.lds_stack;
-    fp.smem = (size_t)pl.lds_stack * FTB * sizeof(uint32_t) + (pl.smem - (size_t)pl.lds_stack * TB * sizeof(uint32_t)) + tables +
+    // (one stack level more than the walk needs: level -1, never written, is what the node step's read of the stack's top entry lands on when the stack is
+    // empty -- fused_kernel.h)
+    fp.lds_stack = pl.lds_stack + 1;
+    fp.smem = (size_t)fp.lds_stack * FTB * sizeof(uint32_t) + (pl.smem - (size_t)pl.lds_stack * TB * sizeof(uint32_t)) + tables +
               sizeof(uint32_t) * FS_FIELDS * FTB + sizeof(uint32_t) * (FTB / 64) * PT_FUSED_WTILES;
     fp.pairs = pl.pairs;
     int per_cu = ctx->fused_per_cu[0];

@@ -145,7 +145,9 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
     const float4 *wide = s_wide, *tri4 = s_tri;
     const float4 *verts = s_tri + 6 * (size_t)n_tris;
 
-    lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(smem) + threadIdx.x;
+    // (the stack's level 0 is the SECOND of the lds_stack levels: the first, never written, is where the node step's read of the top entry lands
+    // when the stack is empty -- an address without a compare and a select)
+    lds_u32 *my_stack32 = (lds_u32 *)reinterpret_cast<uint32_t *>(smem) + FTB + threadIdx.x;
     const int lane = threadIdx.x & 63;
 
     FusedDev dev;  // (fused_dev.h: empty in the product build)
@@ -493,7 +495,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
             PT_FB(FB_NODE)
             // The stack's top entry is read WITH the node's planes: a step whose four children all miss pushed nothing, so that entry is what its
             // pop would load first -- the ~3 lanes such a step leaves behind take it from a register instead of starting a loop on an LDS round trip
-            const uint32_t e_top = my_stack32[(sp > 0 ? sp - 1 : 0) * FTB];
+            const uint32_t e_top = my_stack32[(sp - 1) * FTB];
             cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
                 if (sp == 0) return DONE;
                 PT_FB(FB_POPTOP)
