@@ -346,10 +346,14 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
             }
             n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));
         }
+#ifdef PT_FUSED_CONTINUE
         if (__ballot(have) == 0ull) {
             if (__ballot(path) == 0ull && out_of_slots) break;
             continue;
         }
+#else
+        if (__ballot(have) == 0ull && __ballot(path) == 0ull && out_of_slots) break;  // (no `continue`: fused_kernel.h, one way back to the loop's head)
+#endif
 
         // ---- node phase, either level (k_extend_inst16)
         const int n_have = __popcll(__ballot(have));

@@ -482,10 +482,17 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
             n_rays_wave += n_started;
             dev.rays_started(n_started, HYB && w_tails, lane);
         }
+        // Nobody tracing, but hits pending or slots left: the shade block runs in the next pass.  The pass FALLS THROUGH the two phases (no lane
+        // enters either) instead of `continue`: a second way back to the loop's head kept the hit record's old registers alive across the leaf
+        // phase, and the compiler copied the five of them at every block boundary of it -- ~30 v_mov per pass (profiles/r06x_one_latch.log)
+#ifdef PT_FUSED_CONTINUE
         if (__ballot(have) == 0ull) {
             if (__ballot(path) == 0ull && out_of_slots) break;
-            continue;  // (lanes with a pending hit, or slots left, and nobody tracing: the shade block runs in the next iteration)
+            continue;
         }
+#else
+        if (__ballot(have) == 0ull && __ballot(path) == 0ull && out_of_slots) break;
+#endif
 
         // ---- node phase (extend_body, LDS_SCENE && COMPACT): every lane descends until it holds a leaf
         bool do_node = have && !(cur & LEAF_BIT);
