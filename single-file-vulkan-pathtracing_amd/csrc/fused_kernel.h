@@ -520,7 +520,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                 PT_FB(FB_LEAF)
                 if (PAIRS) {
                     const uint32_t first = cur & 0x7FFu;
-                    ptl::pair_leaf_test(tri4, (size_t)tri_base + 3 * (size_t)first, ((cur >> 11) & 3u) != 0u, first, pre, orgp, tmin, tmax,
+                    ptl::pair_leaf_test<true>(tri4, (size_t)tri_base + 3 * (size_t)first, ((cur >> 11) & 3u) != 0u, first, pre, orgp, tmin, tmax,
                                         [&](float t, float V, float W, float det, uint32_t pos, uint32_t) {
                                             ptl::closer_single_level(tri4, tri_base, t, V, W, det, pos, best_t, best_V, best_W, best_det, best_pos);
                                         },

@@ -13,11 +13,19 @@ namespace ptl {
 // tri4: the permuted triangle records in LDS -- {v0, id} {v1} {v2} per triangle, a pair's second triangle behind the first, so the pair's
 // fourth vertex is record 5 (.w = the second triangle's gl_PrimitiveID); ti: index of the first record; first: the leaf's first position.
 // accept(t, V, W, det, pos, prim_bits): a hit inside the range, in primitive order (first half first); hit_block(): once per divide block.
-template <class Accept, class HitBlock>
+template <bool LOAD_D_FIRST = false, class Accept, class HitBlock>
 __device__ __forceinline__ void pair_leaf_test(const float4 *tri4, size_t ti, bool two, uint32_t first, const ptm::RayPre &pre,
                                                const ptm::f3 &orgp, float tmin, float tmax, Accept &&accept, HitBlock &&hit_block)
 {
     const float4 a = tri4[ti + 0], b = tri4[ti + 1], c = tri4[ti + 2];
+    // LOAD_D_FIRST: the pair's fourth vertex is read WITH the first three instead of behind `two` -- one LDS round trip per leaf step instead of
+    // two (k_fused: -0.5 %, profiles/r06y_leaf_fourth_vertex_first.log).  A single triangle's step then reads 16 bytes of the record behind it:
+    // only for callers whose triangle records are followed by more of their own LDS (the fused kernel: its shade table).
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LOAD_D_FIRST) {
+        d = tri4[ti + 5];
+        asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));  // (keeps the load here: the compiler sinks it back behind the branch)
+    }
     // the sheared vertices and the products of the edge v0-v2 serve both halves (ptm::tri_test_perm, same operands in the same order:
     // bit-identical numerators)
     const float Az_ = a.z - orgp.z, Bz_ = b.z - orgp.z, Cz_ = c.z - orgp.z;
@@ -43,7 +51,7 @@ __device__ __forceinline__ void pair_leaf_test(const float4 *tri4, size_t ti, bo
     uint32_t primB = 0u;
     bool inB = false;
     if (two) {
-        const float4 d = tri4[ti + 5];  // third vertex of the second half; .w = its primitive id (k_pack)
+        if (!LOAD_D_FIRST) d = tri4[ti + 5];  // third vertex of the second half; .w = its primitive id (k_pack)
         Dz_ = d.z - orgp.z;
         const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
         // (v0, v2, v3): U = Dx*Cy - Dy*Cx, V = Ax*Dy - Ay*Dx, W = Cx*Ay - Cy*Ax = qAC - pAC
