@@ -28,13 +28,28 @@ constexpr int FITB = PT_FUSEDI_TB;
 // PAIRS: every BLAS leaf is one triangle or one fan pair (tested with shared vertex work); else leaves of up to four triangles
 template <bool GROUPED, bool PAIRS>
 __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
-    RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad, const uint4 *__restrict__ tlas16, NormBox nbt,
-    const uint4 *__restrict__ g_blas16, NormBox nbb, const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
-    uint32_t n_blas_wide, uint32_t n_tris, const float4 *__restrict__ inst6, const uint32_t *__restrict__ inst_id,
-    const float4 *__restrict__ inst_frame, uint32_t slot_base, uint32_t n_slots, uint32_t *next_slot, unsigned long long *stats,
-    uint32_t *__restrict__ spill, uint32_t spill_stride, int refill, float tmin, float tmax, int lds_stack, int enter_min,
-    int leaf_min, int node_yield, uint32_t n_tlas_lds)
+    RenderConst rc_arg, const uint32_t *__restrict__ tiles_arg, Radiance rad_arg, const uint4 *__restrict__ tlas16_arg, NormBox nbt_arg,
+    const uint4 *__restrict__ g_blas16, NormBox nbb_arg, const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
+    uint32_t n_blas_wide, uint32_t n_tris, const float4 *__restrict__ inst6_arg, const uint32_t *__restrict__ inst_id_arg,
+    const float4 *__restrict__ inst_frame_arg, uint32_t slot_base_arg, uint32_t n_slots_arg, uint32_t *next_slot_arg, unsigned long long *stats_arg,
+    uint32_t *__restrict__ spill_arg, uint32_t spill_stride_arg, int refill_arg, float tmin_arg, float tmax_arg, int lds_stack, int enter_min_arg,
+    int leaf_min_arg, int node_yield_arg, uint32_t n_tlas_lds_arg)
 {
+    // (everything the persistent loop reads: a scalar register of its own -- ptm::own_sgprs)
+    const RenderConst rc = ptm::own_sgprs(rc_arg);
+    const Radiance rad = ptm::own_sgprs(rad_arg);
+    const NormBox nbt = ptm::own_sgprs(nbt_arg), nbb = ptm::own_sgprs(nbb_arg);
+    const uint32_t *tiles = ptm::own_sgprs(static_cast<const uint32_t *>(tiles_arg));
+    const uint4 *tlas16 = ptm::own_sgprs(static_cast<const uint4 *>(tlas16_arg));
+    const float4 *inst6 = ptm::own_sgprs(static_cast<const float4 *>(inst6_arg)), *inst_frame = ptm::own_sgprs(static_cast<const float4 *>(inst_frame_arg));
+    const uint32_t *inst_id = ptm::own_sgprs(static_cast<const uint32_t *>(inst_id_arg));
+    uint32_t *next_slot = ptm::own_sgprs(next_slot_arg), *spill = ptm::own_sgprs(static_cast<uint32_t *>(spill_arg));
+    unsigned long long *stats = ptm::own_sgprs(stats_arg);
+    const uint32_t slot_base = ptm::own_sgprs(slot_base_arg), n_slots = ptm::own_sgprs(n_slots_arg), spill_stride = ptm::own_sgprs(spill_stride_arg),
+                   n_tlas_lds = ptm::own_sgprs(n_tlas_lds_arg);
+    const int refill = ptm::own_sgprs(refill_arg), enter_min = ptm::own_sgprs(enter_min_arg), leaf_min = ptm::own_sgprs(leaf_min_arg),
+              node_yield = ptm::own_sgprs(node_yield_arg);
+    const float tmin = ptm::own_sgprs(tmin_arg), tmax = ptm::own_sgprs(tmax_arg);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS: stack | BLAS nodes + the TLAS's top levels | three permuted triangle copies | shade4 | path state | tile words
     uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem);  // [lds_stack][FITB]
@@ -159,15 +174,16 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     } else {  // the ordered term log of add_radiance (wavefront_types.h), the count kept in LDS
                         const uint32_t k = my_state[FS_A * FITB];
                         if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * rc.n_slots + slot), make_float4(er, eg, eb, 0.f));
-                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
+                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.dev->terms_over + ((size_t)slot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));  // (rad.dev: wavefront_types.h)
                         else {
-                            const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
-                            if (idx < rad.spill_cap) {
+                            const Radiance rr = *rad.dev;
+                            const unsigned long long idx = atomicAdd(rr.spill_count, 1ull);
+                            if (idx < rr.spill_cap) {
                                 // (the slot's first pool entry ends its chain: no per-slot initialisation of the heads)
-                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rad.spill_head[slot]));
-                                rad.spill_head[slot] = (uint32_t)idx;
+                                rr.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rr.spill_head[slot]));
+                                rr.spill_head[slot] = (uint32_t)idx;
                             } else {
-                                *rad.overflow = 1ull;
+                                *rr.overflow = 1ull;
                             }
                         }
                         my_state[FS_A * FITB] = k + 1u;

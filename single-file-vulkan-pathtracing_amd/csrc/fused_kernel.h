@@ -105,15 +105,25 @@ enum FusedBlock : int {
     FB_N
 };
 template <int MODE, bool PAIRS, bool COUNT>
-__device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__restrict__ tiles, Radiance rad,
+__device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *__restrict__ tiles_arg, Radiance rad_arg,
                                            const float4 *__restrict__ g_wide, const float4 *__restrict__ g_tri4,
                                            const float4 *__restrict__ g_shade4, const float4 *__restrict__ g_frame4,
-                                           uint32_t n_wide, uint32_t n_tris, uint32_t slot_base, uint32_t n_slots,
-                                           uint32_t *next_slot, unsigned long long *stats, int refill, float tmin,
-                                           float tmax, int lds_stack, FastDiv div_frames)
+                                           uint32_t n_wide, uint32_t n_tris, uint32_t slot_base_arg, uint32_t n_slots_arg,
+                                           uint32_t *next_slot_arg, unsigned long long *stats_arg, int refill_arg, float tmin_arg,
+                                           float tmax_arg, int lds_stack, FastDiv div_frames_arg)
 {
     constexpr uint32_t LEAF_BIT = 0x2000u, DONE = 0x3FFFu;
     constexpr bool GROUPED = MODE == 1, HYB = MODE == 2;
+    // (everything the persistent loop reads: a scalar register of its own -- own_sgprs)
+    const RenderConst rc = ptm::own_sgprs(rc_arg);
+    const Radiance rad = ptm::own_sgprs(rad_arg);
+    const FastDiv div_frames = ptm::own_sgprs(div_frames_arg);
+    const uint32_t *tiles = ptm::own_sgprs(static_cast<const uint32_t *>(tiles_arg));
+    uint32_t *next_slot = ptm::own_sgprs(next_slot_arg);
+    unsigned long long *stats = ptm::own_sgprs(stats_arg);
+    const uint32_t slot_base = ptm::own_sgprs(slot_base_arg), n_slots = ptm::own_sgprs(n_slots_arg);
+    const int refill = ptm::own_sgprs(refill_arg);
+    const float tmin = ptm::own_sgprs(tmin_arg), tmax = ptm::own_sgprs(tmax_arg);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS: stack | BVH4 nodes | three permuted triangle copies | shade4 | tangent frames | path state
     float4 *s_wide = reinterpret_cast<float4 *>(smem + (size_t)lds_stack * FTB * sizeof(uint32_t));
@@ -163,7 +173,8 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
         const unsigned long long m_fb = __ballot(1);                                                    \
         if (lane == __ffsll((long long)m_fb) - 1) { s_fb[2 * (B)] += 1u; s_fb[2 * (B) + 1] += (uint32_t)__popcll(m_fb); } \
     }
-    bool have = false;          // the lane traces a ray
+    // (a lane traces a ray <=> cur != DONE: the shade block sets cur = 0 with the new ray, the walk ends with cur == DONE.  No flag is kept: a
+    // loop-carried bool lives in a lane mask, and every ballot of one costs a v_cndmask + v_cmp to clear its inactive lanes -- a compare does not)
     bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
@@ -188,19 +199,26 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
     uint32_t cur = DONE;
     int sp = 0;
 
+    // (a loop on the WAVE's condition: the lanes that are served sit out behind one exec mask -- see the node loop)
     auto pop = [&]() -> uint32_t {
-        while (sp > 0) {
-            PT_FB(FB_POP)
-            sp--;
-            const uint32_t e = my_stack32[sp * FTB];
-            if (__uint_as_float(e & 0xFFFFC000u) <= best_t) return e & 0x3FFFu;
+        constexpr uint32_t PENDING = 0xFFFFFFFFu;
+        uint32_t r = sp > 0 ? PENDING : DONE;
+        while (__ballot(r == PENDING)) {
+            if (r == PENDING) {
+                PT_FB(FB_POP)
+                sp--;
+                const uint32_t e = my_stack32[sp * FTB];
+                if (__uint_as_float(e & 0xFFFFC000u) <= best_t) r = e & 0x3FFFu;
+                else if (sp == 0) r = DONE;
+            }
         }
-        return DONE;
+        return r;
     };
 
     for (;;) {
         PT_FB(FB_ITER)
         // ---- shade block: the lanes that wait with a hit (or with nothing, while slots are left) -- once enough of them do
+        const bool have = cur != DONE;
         const unsigned long long m_have = __ballot(have);
         const bool in_blk = !have && (path || !out_of_slots);
         const int n_work = __popcll(__ballot(in_blk));
@@ -248,15 +266,16 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                         const uint32_t k = my_state[FS_A * FTB];
                         if (dbg_no_terms && k != 0xFFFFFFFFu) {}  // (fused_dev.h: false in the product build)
                         else if (k < rc.term_pcap) ptm::st_stream<true>(rad.terms + ((size_t)k * lstride + lslot), make_float4(er, eg, eb, 0.f));
-                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.terms_over + ((size_t)lslot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));
+                        else if (k < rc.term_cap) ptm::st_stream<true>(rad.dev->terms_over + ((size_t)lslot * (rc.term_cap - rc.term_pcap) + (k - rc.term_pcap)), make_float4(er, eg, eb, 0.f));  // (rad.dev: wavefront_types.h)
                         else {
-                            const unsigned long long idx = atomicAdd(rad.spill_count, 1ull);
-                            if (idx < rad.spill_cap) {
+                            const Radiance rr = *rad.dev;
+                            const unsigned long long idx = atomicAdd(rr.spill_count, 1ull);
+                            if (idx < rr.spill_cap) {
                                 // (the slot's first pool entry ends its chain: no per-slot initialisation of the heads)
-                                rad.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rad.spill_head[lslot]));
-                                rad.spill_head[lslot] = (uint32_t)idx;
+                                rr.spill[idx] = make_float4(er, eg, eb, __uint_as_float(k == rc.term_cap ? SPILL_NONE : rr.spill_head[lslot]));
+                                rr.spill_head[lslot] = (uint32_t)idx;
                             } else {
-                                *rad.overflow = 1ull;
+                                *rr.overflow = 1ull;
                             }
                         }
                         my_state[FS_A * FTB] = k + 1u;
@@ -476,7 +495,6 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
                 best_pos = PT_MISS;
                 cur = 0u;
                 sp = 0;
-                have = true;
             }
             const uint32_t n_started = (uint32_t)__popcll(__ballot(got_ray));  // (wave-uniform control flow here: every lane keeps the same count)
             n_rays_wave += n_started;
@@ -485,37 +503,38 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
         // Nobody tracing, but hits pending or slots left: the shade block runs in the next pass.  The pass FALLS THROUGH the two phases (no lane
         // enters either) instead of `continue`: a second way back to the loop's head kept the hit record's old registers alive across the leaf
         // phase, and the compiler copied the five of them at every block boundary of it -- ~30 v_mov per pass (profiles/r06x_one_latch.log)
-#ifdef PT_FUSED_CONTINUE
-        if (__ballot(have) == 0ull) {
-            if (__ballot(path) == 0ull && out_of_slots) break;
-            continue;
-        }
-#else
-        if (__ballot(have) == 0ull && __ballot(path) == 0ull && out_of_slots) break;
-#endif
+        const bool tracing = cur != DONE;
+        const unsigned long long m_tracing = __ballot(tracing);
+        if (m_tracing == 0ull && __ballot(path) == 0ull && out_of_slots) break;
 
         // ---- node phase (extend_body, LDS_SCENE && COMPACT): every lane descends until it holds a leaf
-        bool do_node = have && !(cur & LEAF_BIT);
-        const int n_have = __popcll(__ballot(have));
-        if (have) { PT_FB(FB_TRACE) }
-        while (do_node) {
-            PT_FB(FB_NODE)
-            // The stack's top entry is read WITH the node's planes: a step whose four children all miss pushed nothing, so that entry is what its
-            // pop would load first -- the ~3 lanes such a step leaves behind take it from a register instead of starting a loop on an LDS round trip
-            const uint32_t e_top = my_stack32[(sp - 1) * FTB];
-            cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
-                if (sp == 0) return DONE;
-                PT_FB(FB_POPTOP)
-                sp--;
-                if (__uint_as_float(e_top & 0xFFFFC000u) <= best_t) return e_top & 0x3FFFu;
-                return pop();
-            });  // (without it: +1.8 %, profiles/r06r_speculative_pop.log)
-            do_node = !(cur & LEAF_BIT);
-            const int n_cont = __popcll(__ballot(do_node));
-            if (n_cont * PT_FUSED_NODE_EXIT < n_have * PT_FUSED_NODE_EXIT_B) break;  // (the node loop ends once fewer than 1 / PT_FUSED_NODE_EXIT of the tracing lanes still descend)
+        const int n_have = __popcll(m_tracing);
+        if (tracing) { PT_FB(FB_TRACE) }
+        // The loop's condition is the WAVE's: lanes that hold a leaf sit out a pass behind one exec mask instead of leaving a divergent loop, whose
+        // bookkeeping of the lanes that left cost ~15 scalar instructions per step (the scalar unit is one per CU, and this kernel kept it 70 % busy:
+        // scripts/ubench/salu_rate.hip, profiles/r06z_*).  cur of a lane without a ray is DONE, which carries the leaf bit: the mask of the lanes
+        // that step is one compare.  The vote comes BEFORE each step, the first too (after it, the first step unconditional: +4.5 %).
+        const int n_thr = n_have > 0 ? n_have * PT_FUSED_NODE_EXIT_B : 1;
+        for (;;) {
+            const bool dn = !(cur & LEAF_BIT);
+            // (the node loop ends once fewer than PT_FUSED_NODE_EXIT_B / PT_FUSED_NODE_EXIT of the tracing lanes still descend; n_thr >= 1: a wave without a stepping lane leaves)
+            if (__popcll(__ballot(dn)) * PT_FUSED_NODE_EXIT < n_thr) break;
+            if (dn) {
+                PT_FB(FB_NODE)
+                // The stack's top entry is read WITH the node's planes: a step whose four children all miss pushed nothing, so that entry is what its
+                // pop would load first -- the ~3 lanes such a step leaves behind take it from a register instead of starting a loop on an LDS round trip
+                const uint32_t e_top = my_stack32[(sp - 1) * FTB];
+                cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
+                    if (sp == 0) return DONE;
+                    PT_FB(FB_POPTOP)
+                    sp--;
+                    if (__uint_as_float(e_top & 0xFFFFC000u) <= best_t) return e_top & 0x3FFFu;
+                    return pop();
+                });  // (without it: +1.8 %, profiles/r06r_speculative_pop.log)
+            }
         }
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
-        if (have) {
+        if (tracing) {
             if (cur != DONE && (cur & LEAF_BIT)) {
                 PT_FB(FB_LEAF)
                 if (PAIRS) {
@@ -544,7 +563,6 @@ __device__ __forceinline__ void fused_body(RenderConst rc, const uint32_t *__res
             }
             if (cur == DONE) {  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block
                 PT_FB(FB_FINISH)
-                have = false;
             }
         }
     }

@@ -34,16 +34,18 @@ __device__ __forceinline__ void pair_leaf_test(const float4 *tri4, size_t ti, bo
     const float Cx = (c.x - orgp.x) - pre.Sx * Cz_, Cy = (c.y - orgp.y) - pre.Sy * Cz_;
     const float pAC = Ax * Cy, qAC = Ay * Cx;
     // edge test of one half: inside (no strictly negative AND strictly positive edge function) and not edge-on
+    // (no short-circuit evaluation: each `&&` was a branch -- exec-mask bookkeeping on the scalar unit for instructions the wave runs anyway)
     auto inside = [](float U, float V, float W) {
-        return !((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) && ((U + V) + W) != 0.0f;
+        const bool neg = fminf(fminf(U, V), W) < 0.0f, pos = fmaxf(fmaxf(U, V), W) > 0.0f, nz = ((U + V) + W) != 0.0f;
+        return bool(!(neg & pos) & nz);
     };
     auto finish = [&](float U, float V, float W, float z0, float z1, float z2, uint32_t pos, uint32_t prim) {
         const float det = (U + V) + W;
         hit_block();
         const float T = (U * (pre.Sz * z0) + V * (pre.Sz * z1)) + W * (pre.Sz * z2);
         const float t = ptm::fdiv(T, det);
-        if (!(t > tmin && t < tmax)) return;
-        accept(t, V, W, det, pos, prim);
+        // outside the range: a NaN goes on, which is neither closer than nor equal to anything (one select instead of two branches)
+        accept(((t > tmin) & (t < tmax)) ? t : __builtin_nanf(""), V, W, det, pos, prim);
     };
     const float UA = Cx * By - Cy * Bx, VA = pAC - qAC, WA = Bx * Ay - By * Ax;
     const bool inA = inside(UA, VA, WA);
@@ -76,10 +78,15 @@ __device__ __forceinline__ bool closer_single_level(const float4 *tri4, uint32_t
                                                     float &best_t, float &best_V, float &best_W, float &best_det, uint32_t &best_pos)
 {
     bool closer = t < best_t;
-    if (!closer && t == best_t)
-        closer = best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
-                                            __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w);
-    if (closer) { best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos; }
+    if (closer) {
+        best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos;
+    } else if (t == best_t) {  // (rare, and apart from the common path: merged into `closer` it cost every divide block seven scalar instructions)
+        if (best_pos == PT_MISS || __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)pos + 2].w) <
+                                       __float_as_uint(tri4[(size_t)tri_base + 3 * (size_t)best_pos + 2].w)) {
+            best_t = t; best_V = V; best_W = W; best_det = det; best_pos = pos;
+            closer = true;
+        }
+    }
     return closer;
 }
 

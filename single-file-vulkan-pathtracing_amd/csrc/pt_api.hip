@@ -135,6 +135,8 @@ pt_status pt_ctx_create(int device, void *stream, pt_ctx **out)
     if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->d_stats, sizeof(unsigned long long) * PT_N_STATS_ALL)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * PT_N_STATS_ALL)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMalloc(&ctx->d_rad, sizeof(ctx->h_rad))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(ctx->d_rad, 0, sizeof(ctx->h_rad))) != hipSuccess) return fail("hipMemset", e);
     *out = ctx;
     return PT_OK;
 }
@@ -144,6 +146,7 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_rad) (void)hipFree(ctx->d_rad);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);

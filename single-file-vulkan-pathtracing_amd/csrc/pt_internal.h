@@ -32,6 +32,8 @@ struct pt_ctx {
     std::string err;
     // statistics block in device memory (u64 x 8): [0] rays, [1] unused, [2] BVH4 nodes visited, [3] triangles tested, [4] wave steps of the node code, [5] of the triangle code, [6] term-log overflow flag, [7] term pool fill, [8..12] wave executions of refill / pop iteration / hit block / finish / outer iteration, [13] lanes in leaf steps, [14] lanes in pop iterations, [15] lanes in divide blocks, [16] wave executions of the instance entry, [17] lanes in them
     unsigned long long *d_stats = nullptr;
+    void *d_rad = nullptr;                 // ptw::Radiance of the fused launch in device memory (wavefront_types.h: Radiance::dev) ...
+    unsigned char h_rad[128] = {};         // ... and what it holds (uploaded when it changes: the film's buffers only move when they grow)
     pt_stats stats{};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     hipStream_t pipe_stream[PT_MAX_PIPES] = {};  // extra pipelines of pt_render ([0] unused: that is `stream`)

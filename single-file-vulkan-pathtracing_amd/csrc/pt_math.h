@@ -34,6 +34,28 @@ struct f3 { float x, y, z; };
 
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
 
+// A kernel argument (a record of dwords) copied dword by dword into scalar registers of their own.  The compiler fetches kernel arguments eight or sixteen
+// dwords at a time and keeps such a group as ONE register tuple; this kernel holds more scalar values than there are scalar registers, and a tuple
+// spilled to vector lanes comes back whole -- eight v_readlane_b32 for `term_pcap`.  Unused copies are dead code; a used one is one s_mov_b32 per launch.
+template <class T>
+__device__ __forceinline__ T own_sgprs(const T &x)
+{
+    static_assert(sizeof(T) % 4 == 0, "a record of dwords");
+    T r;
+    if constexpr (alignof(T) >= 8 && sizeof(T) % 8 == 0) {  // (records of pointers: pairs, as an address operand wants them)
+        const unsigned long long *src = (const unsigned long long *)(const void *)&x;
+        unsigned long long *dst = (unsigned long long *)(void *)&r;
+#pragma unroll
+        for (size_t i = 0; i < sizeof(T) / 8; i++) asm("s_mov_b64 %0, %1" : "=s"(dst[i]) : "s"(src[i]));
+    } else {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&x);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+        for (size_t i = 0; i < sizeof(T) / 4; i++) asm("s_mov_b32 %0, %1" : "=s"(dst[i]) : "s"(src[i]));
+    }
+    return r;
+}
+
 // x / (1/(2 pi)) for three values at once (raygen.rgen:79-80 divides by the pdf as a true division).
 // For THIS divisor, q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c) equals the
 // correctly rounded quotient for every float with 2^-100 <= |x| <= 2^120: proven by enumerating all of

@@ -11,6 +11,7 @@
 // documented where it is applied.  PT_PIPELINE_FUSED replaces rounds by one persistent kernel per batch (fused.hip).
 #include "wavefront_host.h"
 
+#include <cstring>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -107,7 +108,7 @@ struct Job {
 Radiance job_radiance(const Job &j)
 {
     const pt_film::Work &w = j.f->work;
-    return { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, j.d_spill_count, j.spill_cap, j.d_overflow };
+    return { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, j.d_spill_count, j.spill_cap, j.d_overflow, nullptr };
 }
 
 // The pixel rectangle the scene's box projects to (film_work.hip ptw_tiles_subject_first: its tiles are handed out first).  The camera of
@@ -691,7 +692,19 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
     unsigned long long *const d_overflow = ctx->d_stats + 6, *const d_spill_count = ctx->d_stats + 7;
     uint32_t spill_cap = sh.bounded ? SPILL_POOL_ENTRIES : 0u;
     if (ctx->tune.term_spill >= 0) spill_cap = std::min<uint32_t>(spill_cap, (uint32_t)ctx->tune.term_spill);
-    Radiance rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+    static_assert(sizeof(Radiance) <= sizeof(pt_ctx::h_rad), "pt_ctx::h_rad holds a Radiance");
+    // (the record the kernel gets by value, and the same in device memory for the ends of the log it rarely takes: Radiance::dev)
+    Radiance rad{};
+    auto set_rad = [&]() -> pt_status {
+        rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow, static_cast<const Radiance *>(ctx->d_rad) };
+        if (std::memcmp(ctx->h_rad, &rad, sizeof(rad)) != 0) {
+            std::memcpy(ctx->h_rad, &rad, sizeof(rad));
+            PT_HIP(ctx, hipMemcpyAsync(ctx->d_rad, ctx->h_rad, sizeof(rad), hipMemcpyHostToDevice, st));
+        }
+        return PT_OK;
+    };
+    rc_ = set_rad();
+    if (rc_ != PT_OK) return rc_;
     RenderConst rc = ptw_render_const(p, w, sh);
     apply_cull(ctx, p, rect, rc);
     const bool profile = !nested && (p->flags & PT_FLAG_PROFILE) != 0;
@@ -746,7 +759,8 @@ pt_status render_fused(pt_scene *s, pt_film *f, const pt_params *p_in, const Ext
             if (rc_ != PT_OK) return rc_;
             rc_ = ptw_ensure_work(f, p->rank, p->world, sh.lanes, sh.groups, sh.term_cap, sh.term_pcap, false, sh.tail);
             if (rc_ != PT_OK) return rc_;
-            rad = { w.d_color, w.d_terms, w.d_terms_over, w.d_nterm, w.d_spill, w.d_spill_head, d_spill_count, spill_cap, d_overflow };
+            rc_ = set_rad();
+            if (rc_ != PT_OK) return rc_;
         }
     }
     if (!nested) PT_HIP(ctx, hipEventRecord(ctx->ev_b, st));

@@ -90,6 +90,11 @@ struct Radiance {
     unsigned long long *spill_count;
     uint32_t spill_cap;
     unsigned long long *overflow;  // set when the pool is full too: the host re-renders the batch with groups == 1
+    // This record once more, in device memory (pt_ctx::d_rad; null for the wavefront kernels).  The fused kernels read the log's rarely taken ends
+    // (terms_over, the pool) from it where they take them, so that those six pointers are not live in scalar registers through the persistent
+    // loop -- with them the head + tail kernel spilled 170 scalar values into vector lanes and read them back with a v_readlane each, 64 of them
+    // in the block that logs a term (one blocking frame -4 %, profiles/r06z_*)
+    const Radiance *dev;
 };
 constexpr uint32_t SPILL_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SPILL_POOL_ENTRIES = 4u << 20;  // 64 MB
