@@ -3,7 +3,7 @@ tag=r06z; mkdir -p gpurun_out/$tag
 V=${VARIANTS}; OUT=${OUT:-ab.txt}
 for v in $V; do
   echo "== parity $v" >> gpurun_out/$tag/$OUT
-  ( PT_LIB_AMD=build/variants/$v/libpt_amd.so timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "fused and not bench" 2>&1 | tail -2 ) >> gpurun_out/$tag/$OUT
+  ( PT_LIB_AMD=build/variants/$v/libpt_amd.so timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "${KEXPR:-fused and not bench}" 2>&1 | tail -2 ) >> gpurun_out/$tag/$OUT
 done
 for r in 1 2 3; do
   for v in "" $V; do

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
     const float INF = __builtin_inff();
     const int lane = threadIdx.x & 63;
 
-    bool have = false, path = false, out_of_slots = false, in_blas = false;
+    // (a lane traces a ray <=> cur != I16_DONE: no flag is kept, fused_kernel.h)
+    bool path = false, out_of_slots = false, in_blas = false;
     uint32_t n_rays_wave = 0, n_cull_wave = 0;
     uint32_t w_next = 0, w_end = 0, w_base = 0;
     uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;
@@ -114,17 +115,25 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
         else my_spill[(size_t)(sp - lds_stack) * spill_stride] = e;
         sp++;
     };
-    auto pop = [&]() -> uint32_t {
-        while (sp > 0) {
-            if (in_blas && sp == sp_exit) in_blas = false;  // the instance is done: back to the world-space ray and the TLAS
-            sp--;
-            uint32_t e;
-            if (sp < lds_stack) e = my_stack[sp * FITB];
-            else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if (__uint_as_float(e & 0xFFFF0000u) <= best_t) return e & 0xFFFFu;
+    auto pop = [&]() -> uint32_t {  // (a loop on the WAVE's condition, fused_kernel.h)
+        constexpr uint32_t PENDING = 0xFFFFFFFFu;
+        uint32_t r = PENDING;
+        while (__ballot(r == PENDING)) {
+            if (r == PENDING) {
+                if (sp > 0) {
+                    if (in_blas && sp == sp_exit) in_blas = false;  // the instance is done: back to the world-space ray and the TLAS
+                    sp--;
+                    uint32_t e;
+                    if (sp < lds_stack) e = my_stack[sp * FITB];
+                    else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
+                    if (__uint_as_float(e & 0xFFFF0000u) <= best_t) r = e & 0xFFFFu;
+                } else {
+                    in_blas = false;
+                    r = I16_DONE;
+                }
+            }
         }
-        in_blas = false;
-        return I16_DONE;
+        return r;
     };
     auto pop_and_restore = [&]() -> uint32_t {
         const bool was_in = in_blas;
@@ -138,6 +147,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
 
     for (;;) {
         // ---- shade block (fused_kernel.h, with k_shade<INST>'s hit shading)
+        const bool have = cur != I16_DONE;
         const unsigned long long m_have = __ballot(have);
         const bool in_blk = !have && (path || !out_of_slots);
         const int n_work = __popcll(__ballot(in_blk));
@@ -358,23 +368,20 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                 best_pos = PT_MISS; best_prim = PT_MISS; best_ipos = PT_MISS; best_iid = PT_MISS;
                 cur = 0u;  // TLAS root
                 sp = 0;
-                have = true;
             }
             n_rays_wave += (uint32_t)__popcll(__ballot(got_ray));
         }
-#ifdef PT_FUSED_CONTINUE
-        if (__ballot(have) == 0ull) {
-            if (__ballot(path) == 0ull && out_of_slots) break;
-            continue;
-        }
-#else
-        if (__ballot(have) == 0ull && __ballot(path) == 0ull && out_of_slots) break;  // (no `continue`: fused_kernel.h, one way back to the loop's head)
-#endif
+        const bool tracing = cur != I16_DONE;
+        const unsigned long long m_tracing = __ballot(tracing);
+        if (m_tracing == 0ull && __ballot(path) == 0ull && out_of_slots) break;  // (no `continue`: fused_kernel.h, one way back to the loop's head)
 
         // ---- node phase, either level (k_extend_inst16)
-        const int n_have = __popcll(__ballot(have));
-        bool do_node = have && !(cur & I16_LEAF);
-        while (do_node) {
+        // (a loop on the WAVE's condition, fused_kernel.h; the first step is unconditional here: the leaf phase's waiting rules rely on every lane that
+        // holds a node taking a step per pass)
+        const int n_have = __popcll(m_tracing);
+        bool do_node = !(cur & I16_LEAF);  // (I16_DONE carries the leaf bit)
+        if (__ballot(do_node) != 0ull) for (;;) {
+            if (do_node) {
             uint4 q0, q1, q2, cw;
             if (in_blas || cur < n_tlas_lds) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -413,18 +420,20 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
             if (k2 < KINF) push(k2);
             if (k1 < KINF) push(k1);
             cur = k0 < KINF ? (k0 & 0xFFFFu) : pop_and_restore();
+            }
             do_node = !(cur & I16_LEAF);
-            if (node_yield > 0 && __popcll(__ballot(do_node)) * node_yield < n_have) break;
+            const int n_cont = __popcll(__ballot(do_node));
+            if (n_cont == 0 || (node_yield > 0 && n_cont * node_yield < n_have)) break;
         }
         // ---- leaf phase: a BLAS leaf (one triangle or one fan pair) or a TLAS leaf (enter the instance)
-        const bool at_leaf = have && (cur & I16_LEAF) && cur != I16_DONE;
+        const bool at_leaf = (cur & I16_LEAF) && cur != I16_DONE;
         const int n_enter = __popcll(__ballot(at_leaf && !in_blas));
         const int n_leaf = __popcll(__ballot(at_leaf && in_blas));
-        const bool descending = __ballot(have && !(cur & I16_LEAF)) != 0ull;
+        const bool descending = __ballot(!(cur & I16_LEAF)) != 0ull;
         const bool do_leaf = n_leaf >= leaf_min || !(descending || n_enter >= enter_min);
         const bool others = descending || (do_leaf && n_leaf > 0);
         const bool do_enter = n_enter >= enter_min || !others;
-        if (have) {
+        if (tracing) {
             if (at_leaf && in_blas && do_leaf) {
                 const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
                 auto accept = [&](float t, float V, float W, float det, uint32_t pos, uint32_t prim) {
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                 in_blas = true;
                 cur = 0u;  // BLAS root
             }
-            if (cur == I16_DONE) have = false;  // the hit (best_pos, best_V, best_W, best_det, best_ipos) waits in registers for the shade block
+            // (cur == I16_DONE: the hit (best_pos, best_V, best_W, best_det, best_ipos) waits in registers for the shade block
         }
     }
     if (lane == 0 && n_rays_wave) atomicAdd(stats, (unsigned long long)n_rays_wave);

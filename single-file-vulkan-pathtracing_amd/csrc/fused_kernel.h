@@ -513,24 +513,27 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
         // The loop's condition is the WAVE's: lanes that hold a leaf sit out a pass behind one exec mask instead of leaving a divergent loop, whose
         // bookkeeping of the lanes that left cost ~15 scalar instructions per step (the scalar unit is one per CU, and this kernel kept it 70 % busy:
         // scripts/ubench/salu_rate.hip, profiles/r06z_*).  cur of a lane without a ray is DONE, which carries the leaf bit: the mask of the lanes
-        // that step is one compare.  The vote comes BEFORE each step, the first too (after it, the first step unconditional: +4.5 %).
-        const int n_thr = n_have > 0 ? n_have * PT_FUSED_NODE_EXIT_B : 1;
-        for (;;) {
-            const bool dn = !(cur & LEAF_BIT);
-            // (the node loop ends once fewer than PT_FUSED_NODE_EXIT_B / PT_FUSED_NODE_EXIT of the tracing lanes still descend; n_thr >= 1: a wave without a stepping lane leaves)
-            if (__popcll(__ballot(dn)) * PT_FUSED_NODE_EXIT < n_thr) break;
-            if (dn) {
-                PT_FB(FB_NODE)
-                // The stack's top entry is read WITH the node's planes: a step whose four children all miss pushed nothing, so that entry is what its
-                // pop would load first -- the ~3 lanes such a step leaves behind take it from a register instead of starting a loop on an LDS round trip
-                const uint32_t e_top = my_stack32[(sp - 1) * FTB];
-                cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
-                    if (sp == 0) return DONE;
-                    PT_FB(FB_POPTOP)
-                    sp--;
-                    if (__uint_as_float(e_top & 0xFFFFC000u) <= best_t) return e_top & 0x3FFFu;
-                    return pop();
-                });  // (without it: +1.8 %, profiles/r06r_speculative_pop.log)
+        // that step is one compare.  The node loop ends once fewer than PT_FUSED_NODE_EXIT_B / PT_FUSED_NODE_EXIT of the tracing lanes still descend;
+        // the first step is unconditional (the vote before every step: +0.5 %; as a `for` with a first-pass flag: +4.5 %, the compiler peels it).
+        {
+            bool dn = !(cur & LEAF_BIT);
+            if (__ballot(dn) != 0ull) {
+                int n_cont;
+                do {
+                    if (dn) {
+                        PT_FB(FB_NODE)
+                        const uint32_t e_top = my_stack32[(sp - 1) * FTB];
+                        cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
+                            if (sp == 0) return DONE;
+                            PT_FB(FB_POPTOP)
+                            sp--;
+                            if (__uint_as_float(e_top & 0xFFFFC000u) <= best_t) return e_top & 0x3FFFu;
+                            return pop();
+                        });
+                    }
+                    dn = !(cur & LEAF_BIT);
+                    n_cont = __popcll(__ballot(dn));
+                } while (n_cont * PT_FUSED_NODE_EXIT >= n_have * PT_FUSED_NODE_EXIT_B && n_cont != 0);
             }
         }
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
