@@ -199,21 +199,23 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
     uint32_t cur = DONE;
     int sp = 0;
 
-    // (a loop on the WAVE's condition: the lanes that are served sit out behind one exec mask -- see the node loop)
-    auto pop = [&]() -> uint32_t {
-        constexpr uint32_t PENDING = 0xFFFFFFFFu;
-        uint32_t r = sp > 0 ? PENDING : DONE;
+    // The stack's pop with the cull against best_t: a loop on the WAVE's condition -- the lanes that are served sit out behind one exec mask (see the
+    // node loop) -- with selects inside, not branches (two more vector instructions for eight fewer scalar ones per pass).  r: PENDING for the lanes
+    // that still look for an entry
+    constexpr uint32_t PENDING = 0xFFFFFFFFu;
+    auto pop_pending = [&](uint32_t r) -> uint32_t {
         while (__ballot(r == PENDING)) {
             if (r == PENDING) {
                 PT_FB(FB_POP)
                 sp--;
                 const uint32_t e = my_stack32[sp * FTB];
-                if (__uint_as_float(e & 0xFFFFC000u) <= best_t) r = e & 0x3FFFu;
-                else if (sp == 0) r = DONE;
+                const uint32_t miss = sp == 0 ? DONE : PENDING;
+                r = __uint_as_float(e & 0xFFFFC000u) <= best_t ? (e & 0x3FFFu) : miss;
             }
         }
         return r;
     };
+    auto pop = [&]() -> uint32_t { return pop_pending(sp > 0 ? PENDING : DONE); };
 
     for (;;) {
         PT_FB(FB_ITER)
@@ -524,16 +526,18 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                         PT_FB(FB_NODE)
                         const uint32_t e_top = my_stack32[(sp - 1) * FTB];
                         cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
-                            if (sp == 0) return DONE;
                             PT_FB(FB_POPTOP)
-                            sp--;
-                            if (__uint_as_float(e_top & 0xFFFFC000u) <= best_t) return e_top & 0x3FFFu;
-                            return pop();
+                            // (the top entry as the pop's first candidate, by selects: empty stack -> DONE; entry within best_t -> taken; else the loop)
+                            const bool any = sp > 0;
+                            sp -= any ? 1 : 0;
+                            const uint32_t below = sp > 0 ? PENDING : DONE;
+                            const uint32_t top = __uint_as_float(e_top & 0xFFFFC000u) <= best_t ? (e_top & 0x3FFFu) : below;
+                            return pop_pending(any ? top : DONE);
                         });
                     }
                     dn = !(cur & LEAF_BIT);
                     n_cont = __popcll(__ballot(dn));
-                } while (n_cont * PT_FUSED_NODE_EXIT >= n_have * PT_FUSED_NODE_EXIT_B && n_cont != 0);
+                } while (n_cont * PT_FUSED_NODE_EXIT >= n_have * PT_FUSED_NODE_EXIT_B);  // (n_have >= 1 in here: no lane left ends it too)
             }
         }
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
