@@ -126,7 +126,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                     uint32_t e;
                     if (sp < lds_stack) e = my_stack[sp * FITB];
                     else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-                    if (__uint_as_float(e & 0xFFFF0000u) <= best_t) r = e & 0xFFFFu;
+                    r = __uint_as_float(e & 0xFFFF0000u) <= best_t ? (e & 0xFFFFu) : PENDING;  // (a select, not a branch: fused_kernel.h)
                 } else {
                     in_blas = false;
                     r = I16_DONE;

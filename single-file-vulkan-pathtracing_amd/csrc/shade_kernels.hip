@@ -156,17 +156,26 @@ __global__ __launch_bounds__(TB) void k_shadow_add(RenderConst rc, Radiance rad,
 #endif
 // INST: the scene is instanced (position and normal go to world space per hit; the single-level instantiations carry none of that code)
 template <int SH_ITEMS, bool LDS_TABLES, bool NEE = false, bool INST = false>
-__global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE_WAVES) void k_shade(RenderConst rc, const uint32_t *__restrict__ tiles,
+__global__ __launch_bounds__(TB, NEE ? 4 : INST ? PT_SHADE_WAVES_INST : PT_SHADE_WAVES) void k_shade(RenderConst rc_arg, const uint32_t *__restrict__ tiles,
                                               const float4 *__restrict__ g_tri4, const float4 *__restrict__ g_shade4,
-                                              uint32_t n_tris,
-                                              const float4 *__restrict__ hit, Radiance rad, QueueView in,
-                                              QueueView out, const uint32_t *__restrict__ count_in, uint32_t *count_out,
+                                              uint32_t n_tris_arg,
+                                              const float4 *__restrict__ hit, Radiance rad_arg, QueueView in_arg,
+                                              QueueView out_arg, const uint32_t *__restrict__ count_in, uint32_t *count_out_arg,
                                               const float4 *__restrict__ inst6, const uint32_t *__restrict__ hit_inst,
                                               const float4 *__restrict__ shade64, const float4 *__restrict__ ke4,
-                                              const float4 *__restrict__ lights, uint32_t n_lights, float light_area,
-                                              ShadowQueue sq, uint32_t *sq_count, const float4 *__restrict__ g_frame4,
+                                              const float4 *__restrict__ lights, uint32_t n_lights_arg, float light_area_arg,
+                                              ShadowQueue sq_arg, uint32_t *sq_count_arg, const float4 *__restrict__ g_frame4,
                                               const float4 *__restrict__ inst_frame)
 {
+    // (the records and scalars the slot loop reads: scalar registers of their own -- ptm::own_sgprs; with the argument tuples as the compiler
+    // fetches them the instanced variants reloaded 212 .. 270 spilled scalars per pass, a v_readlane_b32 each)
+    const RenderConst rc = ptm::own_sgprs(rc_arg);
+    const Radiance rad = ptm::own_sgprs(rad_arg);
+    const QueueView in = ptm::own_sgprs(in_arg), out = ptm::own_sgprs(out_arg);
+    const ShadowQueue sq = ptm::own_sgprs(sq_arg);
+    const uint32_t n_tris = ptm::own_sgprs(n_tris_arg), n_lights = ptm::own_sgprs(n_lights_arg);
+    const float light_area = ptm::own_sgprs(light_area_arg);
+    uint32_t *count_out = ptm::own_sgprs(count_out_arg), *sq_count = ptm::own_sgprs(sq_count_arg);
     __shared__ uint32_t s_wcnt[SH_ITEMS][4];
     __shared__ uint32_t s_base;
     // Under two pipelines the shade launches run back to back -- their durations add up to the wall clock -- while the VALU-bound
