@@ -110,33 +110,10 @@ __device__ __forceinline__ uint32_t compact_node_step(const float4 *wide, uint32
     const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wide) + __umul24(cur, 16u * LDS_NODE_F4));
     PT_NODE_LOAD(nd)
     const uint32_t w0 = __float_as_uint(cw.x), w1 = __float_as_uint(cw.y), w2 = __float_as_uint(cw.z), w3 = __float_as_uint(cw.w);
-#ifdef PT_SLAB_SCALAR_FMA
     PT_SLAB4(t0, x)
     PT_SLAB4(t1, y)
     PT_SLAB4(t2, z)
     PT_SLAB4(t3, w)
-#else
-    {   // the 24 plane distances as 12 v_pk_fma_f32 (two children per instruction, the ray's slope and origin term broadcast): the same roundings,
-        // 4.8 cycles per pair against 2 x 2.8 (profiles/r05q_valu_rate_ubench_sdwa.txt)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        auto fma2 = [](float a0, float a1, float m, float c) -> f2 { return __builtin_elementwise_fma((f2){ a0, a1 }, (f2){ m, m }, (f2){ c, c }); };
-        const f2 nxa = fma2(nx.x, nx.y, inv.x, on.x), nxb = fma2(nx.z, nx.w, inv.x, on.x), nya = fma2(ny.x, ny.y, inv.y, on.y), nyb = fma2(ny.z, ny.w, inv.y, on.y),
-                 nza = fma2(nz.x, nz.y, inv.z, on.z), nzb = fma2(nz.z, nz.w, inv.z, on.z);
-        const f2 fxa = fma2(fx.x, fx.y, invf.x, of.x), fxb = fma2(fx.z, fx.w, invf.x, of.x), fya = fma2(fy.x, fy.y, invf.y, of.y), fyb = fma2(fy.z, fy.w, invf.y, of.y),
-                 fza = fma2(fz.x, fz.y, invf.z, of.z), fzb = fma2(fz.z, fz.w, invf.z, of.z);
-#define PT_SLAB_T(T, NX, NY, NZ, FX, FY, FZ)                                                     \
-        {                                                                                        \
-            const float tn = fmaxf(fmaxf(NX, NY), max_raw_s(NZ, tmin));                          \
-            const float tf = fminf(fminf(FX, FY), min_raw(FZ, best_t));                          \
-            T = tn <= tf ? tn : INF;                                                             \
-        }
-        PT_SLAB_T(t0, nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x)
-        PT_SLAB_T(t1, nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y)
-        PT_SLAB_T(t2, nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x)
-        PT_SLAB_T(t3, nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y)
-#undef PT_SLAB_T
-    }
-#endif
     uint32_t k0 = (__float_as_uint(t0) & 0xFFFFC000u) | w0, k1 = (__float_as_uint(t1) & 0xFFFFC000u) | w1,
              k2 = (__float_as_uint(t2) & 0xFFFFC000u) | w2, k3 = (__float_as_uint(t3) & 0xFFFFC000u) | w3;
 #define PT_KSWAP(A, B) { const uint32_t lo_ = min(A, B), hi_ = max(A, B); A = lo_; B = hi_; }
