@@ -151,7 +151,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
         const unsigned long long m_have = __ballot(have);
         const bool in_blk = !have && (path || !out_of_slots);
         const int n_work = __popcll(__ballot(in_blk));
-        if (n_work && (m_have == 0ull || n_work * 64 >= refill * (n_work + __popcll(m_have)))) {
+        if (n_work && n_work * 64 >= refill * (n_work + __popcll(m_have))) {  // (refill <= 64: a wave without a tracing lane always passes)
             uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
             float wr = 0.f, wg = 0.f, wb = 0.f;
             ptm::f3 org{}, dir{};
