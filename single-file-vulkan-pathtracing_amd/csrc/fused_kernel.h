@@ -67,8 +67,10 @@ enum : int { FS_SLOT = 0, FS_CTR, FS_SEED, FS_WR, FS_WG, FS_WB, FS_PXY, FS_A, FS
 // The node loop of a pass ends once fewer than B / A of the wave's tracing lanes still descend (the others hold a leaf or are done).  1080p Cornell,
 // 16 / 4 frames per call, ms: 1/2 85.7 / 22.4, 2/5 85.2 / 22.2, 1/3 84.4 / 22.0, 2/7 84.3 / 22.0, 1/4 84.0 / 21.9, 1/5 84.3 / 22.0, 1/6 (rounds 4 - 5)
 // 84.8 / 22.1, 1/8 85.7 / 22.4, 1/12 86.9 / 22.7, never (1/64) 96.1 / 24.9 (profiles/r05zs_node_exit.log)
+// Round 6, with the loops on the wave's condition (a pass of the node loop got cheaper than a pass of the outer loop): 1/2 64.4, 2/5 63.95, 1/3 63.85, 1/4 64.1,
+// 1/5 64.5, 1/8 66.0 ms per 16 frames (profiles/r06z_ab_node_exit.log): 1/3
 #ifndef PT_FUSED_NODE_EXIT
-#define PT_FUSED_NODE_EXIT 4
+#define PT_FUSED_NODE_EXIT 3
 #endif
 #ifndef PT_FUSED_NODE_EXIT_B
 #define PT_FUSED_NODE_EXIT_B 1
