@@ -19,7 +19,11 @@
 //     workgroups, with work stealing between them -- PT_FUSED_BATCH at a time per wave, so a wave that drew cheap border
 //     pixels simply takes more of them: no tail beyond the last batch's own length;
 //   * path state that only the shade block touches (slot, sample | depth, seed, weight, pixel, the slot's colour or its
-//     term count) lives in LDS, [field][thread]: the traversal loop keeps the registers it has in k_extend_lds7p.
+//     term count) lives in LDS, [field][thread]: the traversal loop keeps the registers it has in k_extend_lds7p;
+//   * control flow is written for the CU's ONE scalar unit (round 6: it was as busy as the vector units -- DESIGN.md section 6): the loops inside
+//     the persistent loop (node steps, pops) run on the WAVE's condition, with the lanes that are served behind one exec mask; no `continue`
+//     (one way back to the loop's head); selects instead of short-circuit branches where the wave runs both sides anyway; no loop-carried
+//     flag where a register says the same (`cur != DONE`); every kernel argument in a scalar register of its own (ptm::own_sgprs).
 //
 // Radiance goes where the wavefront pipeline puts it (struct Radiance): one accumulator per slot written when the slot is
 // complete (one sample group), or the ordered term logs that k_resolve replays (several groups) -- k_resolve is shared.
