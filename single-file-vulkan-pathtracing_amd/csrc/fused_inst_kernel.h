@@ -86,7 +86,8 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
     const int lane = threadIdx.x & 63;
 
     // (a lane traces a ray <=> cur != I16_DONE: no flag is kept, fused_kernel.h)
-    bool path = false, out_of_slots = false, in_blas = false;
+    // (... and owns a live path <=> sp >= 0: a lane without one holds sp = -1, fused_kernel.h)
+    bool out_of_slots = false, in_blas = false;
     uint32_t n_rays_wave = 0, n_cull_wave = 0;
     uint32_t w_next = 0, w_end = 0, w_base = 0;
     uint32_t w_part = blockIdx.x % (uint32_t)PT_FUSED_PARTS, w_tried = 0;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS, best_prim = PT_MISS, best_ipos = PT_MISS, best_iid = PT_MISS;
     uint32_t cur = I16_DONE, cur_ipos = 0, cur_iid = 0;
-    int sp = 0, sp_exit = 0;
+    int sp = -1, sp_exit = 0;
 
     auto level_setup = [&](const ptm::f3 o, const ptm::f3 d, const NormBox &nb) {
         const ptm::f3 on_ = { (o.x - nb.cx) * nb.rsx, (o.y - nb.cy) * nb.rsy, (o.z - nb.cz) * nb.rsz };
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
 
     for (;;) {
         // ---- shade block (fused_kernel.h, with k_shade<INST>'s hit shading)
-        const bool have = cur != I16_DONE;
-        const unsigned long long m_have = __ballot(have);
+        const bool have = cur != I16_DONE, path = sp >= 0;
+        const unsigned long long m_have = __ballot(have), m_path = __ballot(path);
+        const unsigned long long m_in_blk = ~m_have & (out_of_slots ? m_path : ~0ull);  // (waves are whole: FITB is a multiple of 64)
         const bool in_blk = !have && (path || !out_of_slots);
-        const int n_work = __popcll(__ballot(in_blk));
+        const int n_work = __popcll(m_in_blk);
         if (n_work && n_work * 64 >= refill * (n_work + __popcll(m_have))) {  // (refill <= 64: a wave without a tracing lane always passes)
             uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
             float wr = 0.f, wg = 0.f, wb = 0.f;
@@ -218,13 +220,13 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                         if (!GROUPED) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FITB]), __uint_as_float(my_state[FS_B * FITB]),
                                                                    __uint_as_float(my_state[FS_C * FITB]), 0.f);
                         else rad.nterm[slot] = my_state[FS_A * FITB];
-                        path = false;
+                        sp = -1;  // (no path)
                     }
                 }
                 ctr = sample | (depth << 16);
             }
             // (2) new slots for the lanes without a path: the batches, counters and tile words of k_fused (fused_kernel.h explains)
-            const unsigned long long m_want = __ballot(in_blk && !path);
+            const unsigned long long m_want = __ballot(in_blk && sp < 0);
             if (m_want && !out_of_slots) {
                 if (w_next >= w_end) {
                     for (;;) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                 const uint32_t take = min((uint32_t)__popcll(m_want), w_end - w_next);
                 const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
                 uint32_t cull_n = 0u;  // samples of a slot that is finished here: its pixel cannot see the scene (fused_cull.h)
-                if (in_blk && !path && rank < take) {
+                if (in_blk && sp < 0 && rank < take) {
                     const uint32_t mine = w_next + rank;
                     slot = slot_base + mine;
                     const uint32_t lane_slot = rc.div_spl.div(slot);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
                         my_state[FS_A * FITB] = 0u;
                         if (!GROUPED) { my_state[FS_B * FITB] = 0u; my_state[FS_C * FITB] = 0u; }
                         my_state[FS_MB * FITB] = (uint32_t)((int32_t)rc.spp * (rc.frame_base + (int32_t)f)) + 1u;
-                        path = true;
+                        sp = 0;  // (a path)
                         need_primary = true;
                     } else if (GROUPED) {
                         rad.nterm[slot] = 0u;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
         }
         const bool tracing = cur != I16_DONE;
         const unsigned long long m_tracing = __ballot(tracing);
-        if (m_tracing == 0ull && __ballot(path) == 0ull && out_of_slots) break;  // (no `continue`: fused_kernel.h, one way back to the loop's head)
+        if (m_tracing == 0ull && __ballot(sp >= 0) == 0ull && out_of_slots) break;  // (no `continue`: fused_kernel.h, one way back to the loop's head)
 
         // ---- node phase, either level (k_extend_inst16)
         // (a loop on the WAVE's condition, fused_kernel.h; the first step is unconditional here: the leaf phase's waiting rules rely on every lane that

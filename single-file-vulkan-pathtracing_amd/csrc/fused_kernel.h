@@ -181,7 +181,9 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
     }
     // (a lane traces a ray <=> cur != DONE: the shade block sets cur = 0 with the new ray, the walk ends with cur == DONE.  No flag is kept: a
     // loop-carried bool lives in a lane mask, and every ballot of one costs a v_cndmask + v_cmp to clear its inactive lanes -- a compare does not)
-    bool path = false;          // the lane owns a live path (its state is in LDS); !have && path: a hit record awaits shading
+    // (the lane owns a live path -- its state is in LDS; not tracing: a hit record awaits shading -- <=> sp >= 0: a lane without a path holds sp = -1.
+    // No flag for that either: the loop's head asks for three wave masks of it per pass, and a ballot of a flag is two vector instructions, of a
+    // compare one; the masks are combined as 64-bit integers on the scalar unit)
     bool out_of_slots = false;  // wave-uniform: the slot counter ran past the end
     uint32_t n_rays_wave = 0;   // wave-uniform: rays this wave started
     uint32_t n_cull_wave = 0;   // ... of them camera rays of pixels that cannot see the scene, resolved without a walk
@@ -203,7 +205,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
     float best_t = tmax, best_V = 0.f, best_W = 0.f, best_det = 1.f;
     uint32_t best_pos = PT_MISS;
     uint32_t cur = DONE;
-    int sp = 0;
+    int sp = -1;
 
     // The stack's pop with the cull against best_t: a loop on the WAVE's condition -- the lanes that are served sit out behind one exec mask (see the
     // node loop) -- with selects inside, not branches (two more vector instructions for eight fewer scalar ones per pass).  r: PENDING for the lanes
@@ -226,10 +228,11 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
     for (;;) {
         PT_FB(FB_ITER)
         // ---- shade block: the lanes that wait with a hit (or with nothing, while slots are left) -- once enough of them do
-        const bool have = cur != DONE;
-        const unsigned long long m_have = __ballot(have);
+        const bool have = cur != DONE, path = sp >= 0;
+        const unsigned long long m_have = __ballot(have), m_path = __ballot(path);
+        const unsigned long long m_in_blk = ~m_have & (out_of_slots ? m_path : ~0ull);  // (waves are whole: FTB is a multiple of 64)
         const bool in_blk = !have && (path || !out_of_slots);
-        const int n_work = __popcll(__ballot(in_blk));
+        const int n_work = __popcll(m_in_blk);
         if (n_work && n_work * 64 >= refill * (n_work + __popcll(m_have))) {  // (refill <= 64: a wave without a tracing lane always passes)
             uint32_t slot = 0, ctr = 0, seed = 0, pxy = 0;
             float wr = 0.f, wg = 0.f, wb = 0.f;
@@ -312,7 +315,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                         if (!logs) rad.color[slot] = make_float4(__uint_as_float(my_state[FS_A * FTB]), __uint_as_float(my_state[FS_B * FTB]),
                                                                    __uint_as_float(my_state[FS_C * FTB]), 0.f);
                         else if (!dbg_no_nterm) rad.nterm[lslot] = my_state[FS_A * FTB];
-                        path = false;
+                        sp = -1;  // (no path)
                         dev.slot_end(slot);
                     }
                 }
@@ -321,9 +324,9 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
             // (2) new slots for the lanes without a path (wave-uniform part).  A wave draws PT_FUSED_BATCH consecutive slots per
             // atomic and the tile words that give them their pixels with it: the two dependent round trips to memory (~3 us) are
             // paid once per batch -- per lane and shade block, as the first version did, they were 3/4 of the kernel's time.
-            const unsigned long long m_want = __ballot(in_blk && !path);
+            const unsigned long long m_want = __ballot(in_blk && sp < 0);
             if (m_want && !out_of_slots) {
-                if (in_blk && !path) { PT_FB(FB_HANDOUT) }
+                if (in_blk && sp < 0) { PT_FB(FB_HANDOUT) }
                 if (w_next >= w_end) {
                     PT_FB(FB_DRAW)
                     // The slots are cut into PT_FUSED_PARTS contiguous parts with a counter each, 128 B apart; a wave starts on part
@@ -379,7 +382,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                 const uint32_t take = min((uint32_t)__popcll(m_want), w_end - w_next);
                 const uint32_t rank = (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
                 uint32_t cull_n = 0u;  // samples of a slot that is finished here: its pixel cannot see the scene (RenderConst::cull)
-                if (in_blk && !path && rank < take) {
+                if (in_blk && sp < 0 && rank < take) {
                     PT_FB(FB_TAKE)
                     const uint32_t mine = w_next + rank;
                     uint32_t f, g, local;
@@ -417,7 +420,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                         my_state[FS_A * FTB] = 0u;  // colour.r = +0.0f | term count = 0
                         if (!GROUPED) { my_state[FS_B * FTB] = 0u; my_state[FS_C * FTB] = 0u; }
                         my_state[FS_MB * FTB] = (uint32_t)((int32_t)rc.spp * (rc.frame_base + (int32_t)f)) + 1u;
-                        path = true;
+                        sp = 0;  // (a path)
                         need_primary = true;
                         dev.slot_begin();
                     } else if (GROUPED) {
@@ -513,7 +516,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
         // phase, and the compiler copied the five of them at every block boundary of it -- ~30 v_mov per pass (profiles/r06x_one_latch.log)
         const bool tracing = cur != DONE;
         const unsigned long long m_tracing = __ballot(tracing);
-        if (m_tracing == 0ull && __ballot(path) == 0ull && out_of_slots) break;
+        if (m_tracing == 0ull && __ballot(sp >= 0) == 0ull && out_of_slots) break;
 
         // ---- node phase (extend_body, LDS_SCENE && COMPACT): every lane descends until it holds a leaf
         const int n_have = __popcll(m_tracing);
