@@ -384,8 +384,11 @@ __device__ __forceinline__ bool tri_test(const RayPre &r, const f3 v0, const f3 
 // padded by 2^-18 of the scene scale and the far distance by 4e-7, far more than v_rcp_f32's 1 ulp).
 __device__ __forceinline__ float safe_inv(float d)
 {
-    if (fabsf(d) < 1e-20f) d = copysignf(1e-20f, d);
-    return __builtin_amdgcn_rcpf(d);
+    // (|d| clamped from below with d's sign put back: v_max + v_bfi, a compare and a select less per axis than `if (|d| < 1e-20) d = copysign(1e-20, d)`;
+    // the same value for every d that is not a NaN)
+    float m;  // (the instruction itself: fmaxf() would re-quiet its operand with a v_max x, x first)
+    asm("v_max_f32 %0, |%1|, %2" : "=v"(m) : "v"(d), "s"(1e-20f));
+    return __builtin_amdgcn_rcpf(copysignf(m, d));
 }
 
 // Triangle test on vertices whose components were permuted to (kx, ky, kz) at build time and a ray
