@@ -495,6 +495,9 @@ def fused_roofline_block(st, mean_len, config, kernel, model=None):
     if pmc:
         r["pmc_check"] = {"valu_wave_instr_per_64_rays": round(pmc["valu_wave_instr_per_64_rays"], 1), "valu_active_lanes_per_instr": round(pmc.get("valu_active_lanes_per_instr", 0.0), 1),
                           "source": os.path.relpath(prof, REPO) + " (SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU of the round's committed rocprofv3 pass: what the live model has to agree with)"}
+        if pmc.get("salu_wave_instr_per_64_rays") is not None:  # the CU's one scalar unit beside the vector units
+            r["pmc_check"]["salu_wave_instr_per_64_rays"] = round(pmc["salu_wave_instr_per_64_rays"], 1)
+            r["pmc_check"]["salu_unit_frac"] = round(pmc.get("salu_unit_frac", 0.0), 3)
         if per64 is None:
             per64, lanes = pmc["valu_wave_instr_per_64_rays"], pmc.get("valu_active_lanes_per_instr")
             src = "SQ_INSTS_VALU per WALKED ray of " + os.path.relpath(prof, REPO) + " x this run's walked rays per second"

@@ -64,6 +64,10 @@ rec = {
     "valu_issue_frac": pl("SQ_INSTS_VALU") / (avg_us * 1e-6) / (256 * 4 * 2.4e9 / 2),
     "valu_wave_instr_per_64_rays": pl("SQ_INSTS_VALU") / (rays_per_launch / 64.0),
     "valu_active_lanes_per_instr": pl("SQ_THREAD_CYCLES_VALU") / pl("SQ_INSTS_VALU"),
+    # the scalar unit: ONE per CU, 4.4 cycles per instruction and SIMD when all four SIMDs ask = 1 / 1.1 instructions per cycle and CU
+    # (scripts/ubench/salu_rate.hip, profiles/r06z_salu_rate_ubench.txt); at the chip's nominal 2.4 GHz, like valu_issue_frac
+    "salu_wave_instr_per_64_rays": pl("SQ_INSTS_SALU") / (rays_per_launch / 64.0),
+    "salu_unit_frac": pl("SQ_INSTS_SALU") / (avg_us * 1e-6) / (256 * 2.4e9 / 1.1),
     "wait_any_fraction_of_wave_cycles": pl("SQ_WAIT_ANY") / pl("SQ_WAVE_CYCLES"),
     "lds_bank_conflict_fraction_of_lds_cycles": (pl("SQ_LDS_BANK_CONFLICT") / pl("SQ_LDS_IDX_ACTIVE")) if pl("SQ_LDS_IDX_ACTIVE") else None,
     "l2_hit_rate": pl("TCC_HIT_sum") / pl("TCC_REQ_sum") if pl("TCC_REQ_sum") else None,
