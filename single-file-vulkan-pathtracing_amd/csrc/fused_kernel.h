@@ -533,6 +533,9 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                 do {
                     if (dn) {
                         PT_FB(FB_NODE)
+                        // (the stack's top entry, read WITH the node's planes: a step whose four children all miss pushed nothing, so that entry is what
+                        // its pop looks at first -- from a register instead of behind an LDS round trip: -1.8 %, profiles/r06r_speculative_pop.log.  Level -1,
+                        // never written, is what the read lands on at an empty stack)
                         const uint32_t e_top = my_stack32[(sp - 1) * FTB];
                         cur = compact_node_step<FTB>(wide, cur, inv, invf, on, of, ax, ay, az, tmin, best_t, my_stack32, sp, [&]() -> uint32_t {
                             PT_FB(FB_POPTOP)
