@@ -113,19 +113,28 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
     // C4 -1.6 %, three of three rounds -- the second copy costs more than the test: profiles/r03bo_ab_c4_roomy.log)
     // (an instance visit ends when the stack is back at the height it had on entry, `sp_exit` -- no marker entry under the
     // instance's own entries, which cost the pop loop one iteration per visit for the one or two lanes that met it)
+    // (a loop on the WAVE's condition -- the lanes that are served sit out behind one exec mask -- as in the fused kernels: fused_kernel.h)
     auto pop = [&]() -> uint32_t {
-        while (sp > 0) {
-            PT_COUNT_WAVE(c_pops);
-            if (COUNT) c_pop_lanes++;
-            if (in_blas && sp == sp_exit) in_blas = false;  // the instance is done: back to the world-space ray and the TLAS
-            sp--;
-            uint32_t e;
-            if (sp < lds_stack) e = my_stack[sp * TB];
-            else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
-            if (__uint_as_float(e & 0xFFFF0000u) <= best_t) return e & 0xFFFFu;
+        constexpr uint32_t PENDING = 0xFFFFFFFFu;
+        uint32_t r = PENDING;
+        while (__ballot(r == PENDING)) {
+            if (r == PENDING) {
+                if (sp > 0) {
+                    PT_COUNT_WAVE(c_pops);
+                    if (COUNT) c_pop_lanes++;
+                    if (in_blas && sp == sp_exit) in_blas = false;  // the instance is done: back to the world-space ray and the TLAS
+                    sp--;
+                    uint32_t e;
+                    if (sp < lds_stack) e = my_stack[sp * TB];
+                    else e = my_spill[(size_t)(sp - lds_stack) * spill_stride];
+                    r = __uint_as_float(e & 0xFFFF0000u) <= best_t ? (e & 0xFFFFu) : PENDING;
+                } else {
+                    in_blas = false;
+                    r = I16_DONE;
+                }
+            }
         }
-        in_blas = false;
-        return I16_DONE;
+        return r;
     };
     // ... whose slab constants wait in registers (four blocks per CU leave 128) and come back ONCE after the pop loop, for all
     // lanes that left an instance in it: inside the loop the fifteen moves ran in nearly every one of its 20 iterations per 64
@@ -175,7 +184,8 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
         // leaf -- goes first and the stragglers resume in the next outer iteration, as in the Cornell kernel)
         const int n_have = __popcll(__ballot(have));
         bool do_node = have && !(cur & I16_LEAF);
-        while (do_node) {
+        if (__ballot(do_node) != 0ull) for (;;) {  // (on the wave's condition, the first step unconditional: fused_inst_kernel.h)
+            if (do_node) {
             uint4 q0, q1, q2, cw;
             if (in_blas || cur < n_tlas_lds) {
                 // (LDS-typed pointer: with generic ones the compiler folds the two branches into FLAT loads)
@@ -221,8 +231,10 @@ __global__ __launch_bounds__(TB) void k_extend_inst16(const uint4 *__restrict__ 
             if (k2 < KINF) push(k2);
             if (k1 < KINF) push(k1);
             cur = k0 < KINF ? (k0 & 0xFFFFu) : pop_and_restore();
-            do_node = !(cur & I16_LEAF);
-            if (node_yield > 0 && __popcll(__ballot(do_node)) * node_yield < n_have) break;
+            }
+            do_node = have && !(cur & I16_LEAF);
+            const int n_cont = __popcll(__ballot(do_node));
+            if (n_cont == 0 || (node_yield > 0 && n_cont * node_yield < n_have)) break;
         }
         // ---- leaf phase: a BLAS leaf (triangles) or a TLAS leaf (enter the instance)
         // entering costs ~130 VALU: lanes that want to wait until ENTER_MIN of them do, or no lane has triangle work
