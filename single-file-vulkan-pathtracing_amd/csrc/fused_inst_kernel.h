@@ -381,7 +381,7 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
         // (a loop on the WAVE's condition, fused_kernel.h; the first step is unconditional here: the leaf phase's waiting rules rely on every lane that
         // holds a node taking a step per pass)
         const int n_have = __popcll(m_tracing);
-        bool do_node = !(cur & I16_LEAF);  // (I16_DONE carries the leaf bit)
+        bool do_node = cur < I16_LEAF;  // (an inner node: the codes of leaves and I16_DONE carry the leaf bit -- ONE compare, fused_kernel.h)
         if (__ballot(do_node) != 0ull) for (;;) {
             if (do_node) {
             uint4 q0, q1, q2, cw;
@@ -423,26 +423,26 @@ __global__ __launch_bounds__(FITB, PT_FUSEDI_WAVES) void k_fused_inst(
             if (k1 < KINF) push(k1);
             cur = k0 < KINF ? (k0 & 0xFFFFu) : pop_and_restore();
             }
-            do_node = !(cur & I16_LEAF);
+            do_node = cur < I16_LEAF;
             const int n_cont = __popcll(__ballot(do_node));
             if (n_cont == 0 || (node_yield > 0 && n_cont * node_yield < n_have)) break;
         }
         // ---- leaf phase: a BLAS leaf (one triangle or one fan pair) or a TLAS leaf (enter the instance)
-        const bool at_leaf = (cur & I16_LEAF) && cur != I16_DONE;
+        const bool at_leaf = (uint32_t)(cur - I16_LEAF) < I16_DONE - I16_LEAF;  // (a leaf that is not I16_DONE, as one compare)
         const int n_enter = __popcll(__ballot(at_leaf && !in_blas));
         const int n_leaf = __popcll(__ballot(at_leaf && in_blas));
-        const bool descending = __ballot(!(cur & I16_LEAF)) != 0ull;
+        const bool descending = __ballot(cur < I16_LEAF) != 0ull;
         const bool do_leaf = n_leaf >= leaf_min || !(descending || n_enter >= enter_min);
         const bool others = descending || (do_leaf && n_leaf > 0);
         const bool do_enter = n_enter >= enter_min || !others;
-        if (tracing) {
+        {   // (no `if (tracing)` around it: at_leaf is false for a lane without a ray)
             if (at_leaf && in_blas && do_leaf) {
                 const uint32_t first = cur & 0x7FFu, cnt = ((cur >> 11) & 3u) + 1u;
                 auto accept = [&](float t, float V, float W, float det, uint32_t pos, uint32_t prim) {
                     ptl::closer_instanced(t, V, W, det, pos, prim, cur_ipos, cur_iid, best_t, best_V, best_W, best_det, best_pos, best_prim, best_ipos, best_iid);
                 };
                 if (PAIRS) {
-                    ptl::pair_leaf_test(s_tri, (size_t)tri_base + 3 * (size_t)first, cnt == 2u, first, pre, orgp, tmin, tmax, accept,
+                    ptl::pair_leaf_test<true>(s_tri, (size_t)tri_base + 3 * (size_t)first, cnt == 2u, first, pre, orgp, tmin, tmax, accept,  // (<true>: the triangle records are followed by the shade table in LDS)
                                         [] {});
                 } else {
                     for (uint32_t k = 0; k < cnt; k++) {

@@ -527,7 +527,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
         // that step is one compare.  The node loop ends once fewer than PT_FUSED_NODE_EXIT_B / PT_FUSED_NODE_EXIT of the tracing lanes still descend;
         // the first step is unconditional (the vote before every step: +0.5 %; as a `for` with a first-pass flag: +4.5 %, the compiler peels it).
         {
-            bool dn = !(cur & LEAF_BIT);
+            bool dn = cur < LEAF_BIT;  // (an inner node: the codes of leaves and DONE carry the leaf bit)
             if (__ballot(dn) != 0ull) {
                 int n_cont;
                 do {
@@ -547,14 +547,14 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                             return pop_pending(any ? top : DONE);
                         });
                     }
-                    dn = !(cur & LEAF_BIT);
+                    dn = cur < LEAF_BIT;
                     n_cont = __popcll(__ballot(dn));
                 } while (n_cont * PT_FUSED_NODE_EXIT >= n_have * PT_FUSED_NODE_EXIT_B);  // (n_have >= 1 in here: no lane left ends it too)
             }
         }
         // ---- leaf phase (extend_body, PAIRS): one triangle or one fan pair per leaf
-        if (tracing) {
-            if (cur != DONE && (cur & LEAF_BIT)) {
+        {   // (no `if (tracing)` around it: a lane without a ray holds DONE, and one compare says "a leaf that is not DONE")
+            if ((uint32_t)(cur - LEAF_BIT) < DONE - LEAF_BIT) {
                 PT_FB(FB_LEAF)
                 if (PAIRS) {
                     const uint32_t first = cur & 0x7FFu;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void fused_body(RenderConst rc_arg, const uint32_t *_
                 }
                 cur = pop();
             }
-            if (cur == DONE) {  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block
+            if (tracing && cur == DONE) {  // the hit (best_pos, best_V, best_W, best_det) waits in registers for the shade block
                 PT_FB(FB_FINISH)
             }
         }

@@ -52,14 +52,14 @@ __device__ __forceinline__ void pair_leaf_test(const float4 *tri4, size_t ti, bo
     float UB = 0.f, VB = 0.f, WB = 0.f, Dz_ = 0.f;
     uint32_t primB = 0u;
     bool inB = false;
-    if (two) {
+    if (LOAD_D_FIRST || two) {  // (LOAD_D_FIRST: the second half is computed for every lane -- nearly every wave holds a pair, so the branch only cost its bookkeeping)
         if (!LOAD_D_FIRST) d = tri4[ti + 5];  // third vertex of the second half; .w = its primitive id (k_pack)
         Dz_ = d.z - orgp.z;
         const float Dx = (d.x - orgp.x) - pre.Sx * Dz_, Dy = (d.y - orgp.y) - pre.Sy * Dz_;
         // (v0, v2, v3): U = Dx*Cy - Dy*Cx, V = Ax*Dy - Ay*Dx, W = Cx*Ay - Cy*Ax = qAC - pAC
         UB = Dx * Cy - Dy * Cx; VB = Ax * Dy - Ay * Dx; WB = qAC - pAC;
         primB = __float_as_uint(d.w);
-        inB = inside(UB, VB, WB);
+        inB = bool(two & inside(UB, VB, WB));
     }
     // A wave nearly always holds lanes inside the first half AND lanes inside the second, so two separate divide blocks both ran in 95 %
     // of the steps, each for a handful of lanes.  One block serves both: a lane inside the second half only brings that half's operands;
